@@ -1,0 +1,493 @@
+"""Pins the CPU oracle against the reference's own literal known-answer tests.
+
+Each test cites the reference test it restates (file:line under
+/root/reference/conex/test).  Randomised reference tests (Eigen::MatrixXd::Random
+= libc rand()) are restated as seeded property tests with the same tolerances.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+import oracle_lib as ol
+from oracle_lib import dp, ip
+
+
+# --------------------------------------------------------------------------
+# tree_utils_test.cc:80-104
+# --------------------------------------------------------------------------
+def _spanning_tree(root):
+    # TestGraph(): edges 0-1, 1-2, 0-3, 3-4 ; GetSpanningTree (tree_utils_test.cc:23-50)
+    adj = {0: [1, 3], 1: [0, 2], 2: [1], 3: [0, 4], 4: [3]}
+    parent = [-1] * 5
+    height = [0] * 5
+    parent[root] = root
+    stack = [root]
+    while stack:
+        p = stack.pop()
+        for i in adj[p]:
+            if parent[i] == -1:
+                parent[i] = p
+                height[i] = height[p] + 1
+                stack.append(i)
+    return np.array(parent, dtype=np.int32), np.array(height, dtype=np.int32)
+
+
+def _path(x, y, parent, height, fn):
+    out = np.zeros(16, dtype=np.int32)
+    n = fn(x, y, 5, ip(parent), ip(height), ip(out))
+    return list(out[:n])
+
+
+def _ref_tree_lib():
+    p = os.path.join(ol.ORACLE_DIR, "_ref", "libconex_ref_tree.so")
+    if not os.path.exists(p):
+        return None
+    L = C.CDLL(p)
+    L.ref_path_in_tree.restype = C.c_int
+    L.ref_path_in_tree.argtypes = [C.c_int, C.c_int, C.c_int, ol.c_int_p, ol.c_int_p, ol.c_int_p]
+    return L
+
+
+def test_path_in_tree_literals(oracle):
+    L = oracle.lib()
+    parent, height = _spanning_tree(0)
+    assert _path(4, 0, parent, height, L.cxo_path_in_tree) == [4, 3, 0]
+    assert _path(4, 2, parent, height, L.cxo_path_in_tree) == [4, 2, 3, 1, 0]
+    parent, height = _spanning_tree(4)
+    assert _path(0, 4, parent, height, L.cxo_path_in_tree) == [0, 3, 4]
+    assert _path(2, 4, parent, height, L.cxo_path_in_tree) == [2, 1, 0, 3, 4]
+
+
+def test_path_in_tree_against_compiled_reference(oracle):
+    """oracle/_ref holds conex/tree_utils.cc compiled from the reference itself."""
+    R = _ref_tree_lib()
+    if R is None:
+        pytest.skip("oracle/_ref not built (reference absent)")
+    L = oracle.lib()
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        n = int(rng.integers(2, 40))
+        parent = np.zeros(n, dtype=np.int32)
+        height = np.zeros(n, dtype=np.int32)
+        for i in range(1, n):
+            parent[i] = rng.integers(0, i)
+            height[i] = height[parent[i]] + 1
+        x, y = int(rng.integers(0, n)), int(rng.integers(0, n))
+        o1 = np.zeros(2 * n + 2, dtype=np.int32)
+        o2 = np.zeros(2 * n + 2, dtype=np.int32)
+        n1 = L.cxo_path_in_tree(x, y, n, ip(parent), ip(height), ip(o1))
+        n2 = R.ref_path_in_tree(x, y, n, ip(parent), ip(height), ip(o2))
+        assert n1 == n2 and list(o1[:n1]) == list(o2[:n2])
+
+
+# --------------------------------------------------------------------------
+# clique_ordering_test.cc
+# --------------------------------------------------------------------------
+def _verify_perfect_elimination(cliques_in, expect_fill_in=False):
+    """clique_ordering_test.cc:38-74"""
+    cliques = [sorted(c) for c in cliques_in]
+    n = len(cliques)
+    for root in range(-1, n):
+        order, sn, sep = ol.pick_clique_order(cliques, root)
+        assert sorted(order) == list(range(n))
+        for i in range(n):
+            union = sorted(set(sn[i]) | set(sep[i]))
+            if expect_fill_in:
+                assert len(sn[i]) + len(sep[i]) >= len(cliques[i])
+                assert sorted(set(union) & set(cliques[i])) == cliques[i]
+            else:
+                assert len(sn[i]) + len(sep[i]) == len(cliques[i])
+                assert union == cliques[i]
+        all_sn = sorted(set(x for s in sn for x in s))
+        all_cl = sorted(set(x for c in cliques for x in c))
+        assert all_sn == all_cl
+        # supernodes partition the variables
+        assert sum(len(s) for s in sn) == len(all_cl)
+
+
+def test_perfect_elimination_order_found(oracle):  # :76-81
+    _verify_perfect_elimination([[1, 2, 3, 5], [3, 4, 5], [4, 5, 6, 7], [8, 9], [1, 11]])
+    _verify_perfect_elimination([[0, 2, 3, 5], [3, 4, 5], [4, 5, 6, 7], [0, 11]])
+
+
+def test_small_size(oracle):  # :83-86
+    _verify_perfect_elimination([[0, 1]])
+    _verify_perfect_elimination([[0, 1], [1, 2]])
+
+
+def test_diagonal(oracle):  # :88-103
+    cliques = [[1], [2], [3], [4], [5]]
+    _verify_perfect_elimination(cliques)
+    order, sn, sep = ol.pick_clique_order(cliques, 0)
+    assert all(len(s) == 0 for s in sep)
+
+
+def test_fill_in_literal(oracle):  # :110-124
+    order, sn, sep = ol.pick_clique_order([[0, 1], [1, 2], [0, 3], [2, 3]], 1)
+    assert order[0] == 2
+    assert order[-1] == 1
+    # hand-traced from the reference code
+    assert order == [2, 3, 0, 1]
+    assert sn == [[], [0, 1, 2], [], [3]]
+    assert sep == [[0, 1], [], [0, 3], [0, 2]]
+    _verify_perfect_elimination([[0, 1], [1, 2], [0, 3], [2, 3]], expect_fill_in=True)
+
+
+def test_nonmaximal_literal(oracle):  # :126-141
+    cliques = [[0, 1], [0, 1, 2], [0, 1, 2, 3, 4]]
+    order, sn, sep = ol.pick_clique_order(cliques, 2)
+    assert order == [0, 1, 2]
+    # post_order (clique_ordering.cc:319-332 FindSupernode): first supernode containing separator
+    post = [[] for _ in cliques]
+    for e in sep:
+        if len(e) == 0:
+            continue
+        for j, s in enumerate(sn):
+            if set(e) <= set(s) and len(set(e) & set(s)) == len(e):
+                post[j].append(e)
+                break
+    assert [len(p) for p in post] == [0, 0, 2]
+
+
+def test_symbolic_worked_example(oracle):
+    """SupernodesToData outputs for the 4-cycle through a Program."""
+    p = ol.Program(4)
+    for c in [[0, 1], [1, 2], [0, 3], [2, 3]]:
+        p.add_static(np.eye(2), c)
+    p.initialize()
+    # GetRootNode: first largest clique = 0; so rerun expectation with root 0 is not the 3.6 trace.
+    # Use the explicit root-1 trace through pick_clique_order instead and check SupernodesToData
+    # invariants on the program.
+    perm, pinv = p.permutation()
+    assert sorted(perm) == [0, 1, 2, 3]
+    assert all(pinv[perm[i]] == i for i in range(4))
+    sizes = p.supernode_sizes()
+    assert sizes.sum() == 4 == p.N
+    for e in range(4):
+        cl = p.get_list(0, e)
+        ns = sizes[e]
+        # supernode labels contiguous, separators sorted and later than the supernode
+        if ns:
+            assert list(cl[:ns]) == list(range(cl[0], cl[0] + ns))
+        assert list(cl[ns:]) == sorted(cl[ns:])
+        if ns and len(cl) > ns:
+            assert cl[ns] > cl[ns - 1]
+
+
+# --------------------------------------------------------------------------
+# block_triangular_operations_test.cc / supernodal_solver_test.cc helpers
+# --------------------------------------------------------------------------
+def _running_intersection_closure(path):  # block_triangular_operations_test.cc:13-30
+    n = len(path)
+    if n < 2:
+        return path
+    for i in range(n - 2):
+        for j in range(n - 1, i + 1, -1):
+            temp = sorted(set(path[i]) & set(path[j]))
+            if not temp:
+                continue
+            for k in range(j - 1, i, -1):
+                path[k] = sorted(set(path[k]) | set(temp))
+    return path
+
+
+def _residual_size(path):  # :32-41
+    y = []
+    for j in range(len(path) - 1):
+        y.append(len(path[j]) - len(set(path[j]) & set(path[j + 1])))
+    y.append(len(path[-1]))
+    return y
+
+
+def make_sparse_triangular(cliques):  # :43-50
+    path = [sorted(c) for c in cliques]
+    path = _running_intersection_closure(path)
+    sizes = _residual_size(path)
+    # constructor takes cliques as [supernode vars..., separator vars...]
+    return ol.Workspace(path, sizes)
+
+
+def fill_in_pattern(cliques):  # :52-72
+    w = make_sparse_triangular(cliques)
+    for j in range(w.K - 1, -1, -1):
+        ns = w.supernode_size[j]
+        s = len(w.path[j]) - ns
+        w.slab[w.diag_off[j]:w.diag_off[j] + ns * ns] = 1
+        w.slab[w.offd_off[j]:w.offd_off[j] + ns * s] = 1
+        for idx in w.ss_index(j):
+            w.slab[idx] += 1
+    return w
+
+
+def add_to_diagonals(w, val):
+    for j in range(w.K):
+        ns = w.supernode_size[j]
+        for i in range(ns):
+            w.slab[w.diag_off[j] + i * ns + i] += val
+
+
+@pytest.mark.parametrize("cliques", [
+    [[0, 1, 5], [1, 2, 5], [3, 4, 5]],
+    [[0, 1, 2]],
+    [[0, 1, 2, 4], [3, 4], [5, 6, 7]],
+])
+def test_fill_pattern(oracle, cliques):  # supernodal_solver_test.cc:122-139
+    N = max(max(c) for c in cliques) + 1
+    M = np.zeros((N, N))
+    for c in cliques:
+        for ci in c:
+            for cj in c:
+                M[ci, cj] += 1
+    D = fill_in_pattern(cliques).to_dense()
+    assert np.array_equal(np.tril(M), np.tril(D))
+
+
+@pytest.mark.parametrize("cliques", [
+    [[0, 1, 2], [2]],
+    [[0, 1, 2, 4, 7], [3, 4], [5, 6, 7]],
+    [[0, 1, 5], [1, 2, 5], [3, 4, 5]],
+    [[0, 1, 2], [1, 2, 3], [3, 4, 2]],
+    [[0, 1], [2, 4], [3, 4], [5, 6, 7], [7, 8, 9, 10]],
+])
+def test_block_cholesky_vs_dense(oracle, cliques):  # block_triangular_operations_test.cc:102-125
+    w = fill_in_pattern(cliques)
+    add_to_diagonals(w, 100)
+    X = w.to_dense()
+    X = np.tril(X) + np.tril(X, -1).T
+    Lref = np.linalg.cholesky(X)
+    assert w.cholesky() == 1
+    err = np.tril(w.to_dense() - Lref)
+    assert np.linalg.norm(err) <= 1e-12
+
+
+@pytest.mark.parametrize("cliques", [
+    [[0, 1, 2, 3], [3, 4, 5]],
+    [[0, 1, 2, 3]],
+    [[0, 1, 2, 3], [3, 4], [4, 5, 6]],
+])
+def test_block_inverse(oracle, cliques):  # :127-146
+    w = fill_in_pattern(cliques)
+    add_to_diagonals(w, 10)
+    Lm = np.tril(w.to_dense())
+    b = np.linspace(-1, 1, Lm.shape[0])
+    y = w.forward(b)
+    assert np.linalg.norm(Lm @ y - b) <= 1e-12
+
+
+@pytest.mark.parametrize("cliques", [
+    [[0, 1, 2, 5], [3, 4, 5]],
+    [[0, 1, 2, 5], [3, 4, 5], [5, 6]],
+    [[0, 1, 2, 3]],
+])
+def test_block_inverse_of_transpose(oracle, cliques):  # :148-167
+    w = fill_in_pattern(cliques)
+    add_to_diagonals(w, 10)
+    Lm = np.tril(w.to_dense())
+    b = np.linspace(-1, 1, Lm.shape[0])
+    y = w.backward(b)
+    assert np.linalg.norm(Lm.T @ y - b) <= 1e-12
+
+
+# --------------------------------------------------------------------------
+# assembly_test.cc:196-219  (out-of-order clique variables, exact equality)
+# --------------------------------------------------------------------------
+def test_assemble_variables_out_of_order(oracle):
+    p = ol.Program(4)
+    Q = np.zeros((3, 3))
+    Q[0, 0], Q[2, 2] = 1, 3
+    p.add_static(Q, [1, 0, 3])
+    Q2 = np.zeros((3, 3))
+    Q2[0, 0], Q2[2, 2] = 1, 2
+    p.add_static(Q2, [1, 0, 2])
+    p.initialize()
+    p.assemble()
+    M = p.kkt_matrix()
+    assert np.array_equal(np.diag(M), np.array([0., 2., 2., 3.]))
+    assert np.array_equal(M, np.diag([0., 2., 2., 3.]))
+
+
+# --------------------------------------------------------------------------
+# exponential_map_pade_test.cc:16-37
+# --------------------------------------------------------------------------
+A4 = np.array([[3., 1, 0, 1], [1, 3, 1, 0], [0, 1, 4, 1], [1, 0, 1, 5]])
+
+
+def test_pade_vs_expm(oracle):
+    A = A4 / np.trace(A4)
+    out = np.zeros(16)
+    a = ol.colmajor(A)
+    oracle.lib().cxo_pade(4, dp(a), dp(out))
+    calc = out.reshape(4, 4).T
+    ref = scipy.linalg.expm(A)
+    assert np.max(np.abs(calc - ref)) <= 1e-7
+
+
+# --------------------------------------------------------------------------
+# test/approximate_eigenvalues.cc:16-85
+# --------------------------------------------------------------------------
+def _lanczos_asym(WS, W, r, iters):
+    n = WS.shape[0]
+    e = np.zeros(n + 2)
+    k = ol.lib().cxo_lanczos_asym(n, dp(ol.colmajor(WS)), dp(ol.colmajor(W)), dp(ol.f64(r)),
+                                  iters, dp(e))
+    return np.sort(e[:k])
+
+
+def test_nonsymmetric_from_jacobi_iterations(oracle):  # :16-42
+    n = 4
+    # seeds for which the reference's own early-exit rule (beta^2 < 1e-6,
+    # approximate_eigenvalues.cc:218-222) does not truncate the recurrence
+    for seed in [0, 2, 3, 4, 5]:
+        A = A4 / np.trace(A4)
+        rng = np.random.default_rng(seed)
+        W = rng.uniform(-1, 1, (n, n))
+        W = W @ W.T
+        A = W @ A
+        r0 = np.array([1., 2, 0, 4])
+        eJ = np.zeros(n)
+        k = oracle.lib().cxo_jacobi(n, dp(ol.colmajor(A)), dp(ol.colmajor(W)), dp(r0), n, dp(eJ))
+        assert k == n
+        eJ = np.sort(eJ)
+        eL = _lanczos_asym(A, W, r0, n)
+        assert np.max(np.abs(eL - eJ)) <= 1e-12
+        eA = np.sort(np.linalg.eigvals(A).real)
+        assert np.max(np.abs(eJ - eA)) <= 1e-12
+
+
+def test_truncated_approximation_interlaces(oracle):  # :44-61
+    A = np.diag([.1, 3, 4, 5])
+    r0 = np.array([1., 2, 0, 4])
+    eJ = _lanczos_asym(A, np.eye(4), r0, 2)
+    eA = np.sort(np.linalg.eigvalsh(A))
+    assert eJ[-1] <= eA[-1]
+    assert eJ[0] >= eA[0]
+
+
+def test_lanczos_symmetric(oracle):  # :63-85
+    n = 4
+    A = A4 / np.trace(A4)
+    r0 = np.array([1., 2, 0, 4])
+    eJ = _lanczos_asym(A, np.eye(n), r0, n)
+    eA = np.sort(np.linalg.eigvalsh(A))
+    assert np.max(np.abs(eJ - eA)) <= 1e-12
+    eL = np.zeros(n)
+    oracle.lib().cxo_lanczos_sym(n, dp(ol.colmajor(A)), dp(r0), n, dp(eL))
+    assert np.max(np.abs(np.sort(eL) - eA)) <= 1e-12
+
+
+def test_lanczos_spectral_radius_random(oracle):  # :87-113 (value assertion only)
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        n = 25
+        S = rng.uniform(-1, 1, (n, n))
+        S = S + S.T
+        W = rng.uniform(-1, 1, (n, n))
+        W = W @ W.T
+        WS = W @ S
+        r0 = rng.uniform(-1, 1, n)
+        eJ = _lanczos_asym(WS, W, r0, n // 2)
+        eWS = np.linalg.eigvals(WS).real
+        assert abs(eWS.max() / eJ.max() - 1) <= 1e-2
+
+
+def test_tridiagonal_eigenvalues(oracle):
+    rng = np.random.default_rng(5)
+    for n in [1, 2, 3, 7, 12]:
+        d = rng.normal(size=n)
+        e = rng.normal(size=max(n - 1, 1))
+        T = np.diag(d) + np.diag(e[:n - 1], 1) + np.diag(e[:n - 1], -1)
+        out = np.zeros(n)
+        oracle.lib().cxo_tridiag_eigs(n, dp(d), dp(e), dp(out))
+        assert np.max(np.abs(out - np.linalg.eigvalsh(T))) <= 1e-13 * max(1, np.abs(T).max())
+
+
+# --------------------------------------------------------------------------
+# test_divergence.cc:22-57
+# --------------------------------------------------------------------------
+def test_divergence_bound(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(11)
+    for _ in range(20):
+        gw = np.abs(rng.uniform(-1, 1, 3))
+        p5 = np.array([gw @ gw, gw.sum(), gw.min(), gw.max(), 3.0])
+
+        def divergence(k):
+            d = k * gw - 1
+            return (d @ d) / (1 - np.abs(d).max())
+
+        k_ref = 2.0 / (gw.max() + gw.min()) * .8
+        hub = divergence(k_ref)
+        assert abs(hub - L.cxo_divergence_upper_bound(k_ref, dp(p5))) <= 1e-8
+        k = L.cxo_divergence_upper_bound_inverse(hub, dp(p5))
+        assert abs(hub - divergence(k)) <= 1e-8
+        assert k >= k_ref - 1e-12
+
+        k_ref = 2.0 / (gw.max() + gw.min()) * 1.2
+        hub = divergence(k_ref)
+        assert abs(hub - L.cxo_divergence_upper_bound(k_ref, dp(p5))) <= 1e-8 * max(1, abs(hub))
+        k = L.cxo_divergence_upper_bound_inverse(hub, dp(p5))
+        if k != -1:
+            assert abs(hub - L.cxo_divergence_upper_bound(k, dp(p5))) <= 1e-8 * max(1, abs(hub))
+            assert k >= k_ref - 1e-9
+
+        k_ref = 1000000
+        hub = divergence(k_ref)
+        k = L.cxo_divergence_upper_bound_inverse(hub, dp(p5))
+        assert k == -1
+
+
+# --------------------------------------------------------------------------
+# test_sdp.cc:13-59 (SDP.Mixed literal)
+# --------------------------------------------------------------------------
+def test_sdp_mixed_literal(oracle):
+    A = np.zeros((3, 2, 2))
+    A[0] = [[-1, 0], [0, 0]]
+    A[1] = [[0, -1], [-1, 0]]
+    A[2] = [[0, 0], [0, -1]]
+    Cm = np.zeros((2, 2))
+    b = np.array([-1., 0, -1])
+    p = ol.Program(3)
+    # UpperBound(u): A = I, c = u ; LowerBound(l): A = -I, c = -l (linear_constraint.h:86-116)
+    assert p.add_linear(np.array([[1.0]]), [1.0], [1]) == 0
+    assert p.add_linear(np.array([[-1.0]]), [-1.0], [1]) == 1
+    assert p.add_lmi(A, Cm) == 2
+    cfg = ol.default_config()
+    cfg.max_iterations = 30
+    ok, y = p.solve(b, cfg)
+    S = -sum(y[i] * A[i] for i in range(3))
+    assert np.linalg.norm(S - np.ones((2, 2))) <= 1e-6
+
+
+# --------------------------------------------------------------------------
+# test_lp.cc:16-53 (LP.Dense, divergence-bound branch; seeded restatement)
+# --------------------------------------------------------------------------
+def test_lp_dense_random(oracle):
+    rng = np.random.default_rng(1)
+    cfg = ol.default_config()
+    cfg.prepare_dual_variables = 1
+    cfg.inv_sqrt_mu_max = 5e5
+    cfg.divergence_upper_bound = 1000
+    cfg.dinf_upper_bound = 1.35
+    cfg.final_centering_tolerance = 1
+    eps = 1e-12
+    for i in range(10):
+        nv, nc = 5, 6 + 2 * i
+        A = rng.uniform(-1, 1, (nc, nv))
+        c = np.abs(rng.uniform(-1, 1, nc))
+        x0 = np.abs(rng.uniform(-1, 1, nc))
+        x0 *= 0.01 / np.linalg.norm(x0)
+        b = A.T @ x0
+        p = ol.Program(nv)
+        p.add_linear(A, c)
+        ok, y = p.solve(b, cfg)
+        x = p.dual_variable(0)
+        slack = c - A @ y
+        assert np.linalg.norm(A.T @ x - b) <= 1e-9 * np.linalg.norm(b)
+        assert slack.min() >= -eps
+        assert x.min() >= -eps
+        assert slack @ x >= -eps
+        mu = 1.0 / (cfg.inv_sqrt_mu_max ** 2)
+        assert slack @ x <= (mu + np.sqrt(eps)) * nc
