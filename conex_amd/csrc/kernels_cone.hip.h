@@ -1,0 +1,388 @@
+// Linear (nonnegative orthant) and second-order (spin factor) cone kernels, plus the
+// constant Schur block.  One workgroup per constraint.
+//
+// Reference semantics:
+//   ConstructSchurComplementSystem(LinearConstraint*)  linear_constraint.cc:177-205
+//   PrepareStep/TakeStep/GetWeightedSlackEigenvalues   linear_constraint.cc:108-175
+//   ConstructSchurComplementSystem(SOCConstraint*)     soc_constraint.cc:272-303
+//   Sqrt/Exp/QuadraticRepresentation/NormInf           soc_constraint.cc:14-191
+//   PrepareStep/TakeStep/GetWeightedSlackEigenvalues   soc_constraint.cc:200-270
+//   QuadraticFunction / SupernodalAssemblerStatic      quadratic_cost.cc:46-57
+#pragma once
+#include "device_utils.h"
+#include "kernels_lmi.hip.h"
+
+namespace cxk {
+
+struct VecGroup {  // linear: len = rows ; SOC: len = n + 1
+  int len;
+  int m;
+  int count;
+  const double* A;  // count x (len x m), col-major
+  const double* c;  // count x len
+  double* W;        // count x len   (SOC: W[0] = W0, W[1:] = W1)
+  double* T1;       // count x len   linear temp_1 / SOC d (d0, d1)
+  double* T2;       // count x len   linear temp_2 (d)
+  const int* ids;
+};
+
+// ------------------------------------------------------------------ linear
+__global__ void __launch_bounds__(256) linear_schur(VecGroup g, Arena ar) {
+  __shared__ double red[8];
+  const int r = g.len, m = g.m;
+  const int mem = blockIdx.x, id = g.ids[mem];
+  const double* A = g.A + (size_t)mem * r * m;
+  const double* c = g.c + (size_t)mem * r;
+  const double* w = g.W + (size_t)mem * r;
+  double* G = ar.G + ar.g_off[id];
+  double* AW = ar.AWc + ar.r_off[id];
+  double* AQc = ar.AQcc + ar.r_off[id];
+  for (int idx = threadIdx.x; idx < m * m; idx += blockDim.x) {
+    const int i = idx % m, j = idx / m;
+    double s = 0;
+    for (int k = 0; k < r; k++) {
+      const double wk = w[k];
+      s = fma(wk * A[k + (size_t)i * r], wk * A[k + (size_t)j * r], s);
+    }
+    G[idx] = s;
+  }
+  for (int i = threadIdx.x; i < m; i += blockDim.x) {
+    double a = 0, q = 0;
+    for (int k = 0; k < r; k++) {
+      const double wk = w[k];
+      a = fma(A[k + (size_t)i * r], wk, a);
+      q = fma(wk * A[k + (size_t)i * r], wk * c[k], q);
+    }
+    AW[i] = a;
+    AQc[i] = q;
+  }
+  double s1 = 0, s2 = 0;
+  for (int k = threadIdx.x; k < r; k += blockDim.x) {
+    const double wc = w[k] * c[k];
+    s1 += wc;
+    s2 = fma(wc, wc, s2);
+  }
+  s1 = BlockSum(s1, red);
+  s2 = BlockSum(s2, red);
+  if (threadIdx.x == 0) {
+    ar.sc[2 * id] = s1;
+    ar.sc[2 * id + 1] = s2;
+  }
+}
+
+// mode 0 PrepareStep, mode 1 GetWeightedSlackEigenvalues
+template <int MODE>
+__global__ void __launch_bounds__(256) linear_prepare(VecGroup g, StepArgs sa) {
+  extern __shared__ double lds[];
+  __shared__ double red[8];
+  const int r = g.len, m = g.m;
+  const int mem = blockIdx.x, id = g.ids[mem];
+  const double* A = g.A + (size_t)mem * r * m;
+  const double* c = g.c + (size_t)mem * r;
+  double* w = g.W + (size_t)mem * r;
+  double* T1 = g.T1 + (size_t)mem * r;
+  double* T2 = g.T2 + (size_t)mem * r;
+  double* sy = lds;
+  for (int q = threadIdx.x; q < m; q += blockDim.x) sy[q] = sa.y[sa.cl_perm[sa.cl_ptr[id] + q]];
+  __syncthreads();
+  const double kc = (MODE == 0 && sa.affine) ? 0.0 : sa.c_weight;
+  double mx = 0, mn = 0, s2 = 0, s1 = 0;
+  bool first = true;
+  for (int k = threadIdx.x; k < r; k += blockDim.x) {
+    double s = 0;
+    for (int j = 0; j < m; j++) s = fma(A[k + (size_t)j * r], sy[j], s);
+    s -= c[k] * kc;
+    if (MODE == 0) {
+      if (sa.affine) {  // AffineUpdate: SW = minus_s .* W ; W += W .* SW
+        const double sw = s * w[k];
+        T1[k] = sw;
+        w[k] += w[k] * sw;
+      } else {
+        const double d = s * w[k] + sa.e_weight;
+        T2[k] = d;
+        mx = fmax(mx, fabs(d));
+        s2 = fma(d, d, s2);
+      }
+    } else {
+      const double ws = w[k] * s;
+      mx = first ? ws : fmax(mx, ws);
+      mn = first ? ws : fmin(mn, ws);
+      first = false;
+      s2 = fma(ws, ws, s2);
+      s1 += ws;
+    }
+  }
+  if (MODE == 0 && sa.affine) return;
+  if (MODE == 1) {  // lanes without rows must not disturb min/max
+    if (first) {
+      mx = -1.7976931348623157e308;
+      mn = 1.7976931348623157e308;
+    }
+    mn = -WaveMax(-mn);
+  }
+  mx = WaveMax(mx);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) {
+    red[wave] = mx;
+    red[4 + wave] = mn;
+  }
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  double gmx = red[0], gmn = red[4];
+  for (int q = 1; q < nw; q++) {
+    gmx = fmax(gmx, red[q]);
+    gmn = fmin(gmn, red[4 + q]);
+  }
+  __syncthreads();
+  s2 = BlockSum(s2, red);
+  s1 = BlockSum(s1, red);
+  if (threadIdx.x == 0) {
+    if (MODE == 0) {
+      sa.info[2 * id] = s2;
+      sa.info[2 * id + 1] = gmx;
+    } else {
+      sa.info[4 * id] = -gmx;
+      sa.info[4 * id + 1] = -gmn;
+      sa.info[4 * id + 2] = s2;
+      sa.info[4 * id + 3] = -s1;
+    }
+  }
+}
+
+__global__ void linear_take_step(VecGroup g, StepArgs sa) {
+  const size_t total = (size_t)g.count * g.len;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < total;
+       q += (size_t)gridDim.x * blockDim.x) {
+    double d = g.T2[q];
+    if (sa.step_size != 1) d *= sa.step_size;
+    g.T2[q] = d;
+    g.W[q] *= exp(d);
+  }
+}
+
+__global__ void vec_set_identity(VecGroup g, int soc) {
+  const size_t total = (size_t)g.count * g.len;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < total;
+       q += (size_t)gridDim.x * blockDim.x)
+    g.W[q] = soc ? ((q % g.len) == 0 ? 1.0 : 0.0) : 1.0;
+}
+
+// -------------------------------------------------------------------- SOC
+// z = f(x) through the spin-factor spectral decomposition; op 0 sqrt, 1 exp. Single thread.
+__device__ inline void SocSpectral(int n, double x0, const double* x1, int op, double* z) {
+  double nq = 0;
+  for (int i = 0; i < n; i++) nq = fma(x1[i], x1[i], nq);
+  nq = sqrt(nq);
+  const double e0 = x0 + nq, e1 = x0 - nq;
+  const double f0 = op == 0 ? sqrt(e0) : exp(e0);
+  const double f1 = op == 0 ? sqrt(e1) : exp(e1);
+  z[0] = f0 * .5 + f1 * .5;
+  for (int i = 0; i < n; i++) {
+    const double q = nq > 0 ? x1[i] / nq : 0.0;
+    z[1 + i] = nq > 0 ? f0 * (.5 * q) + f1 * (-.5 * q) : 0.0;
+  }
+}
+
+// out = Q(x) y = 2 (x.y) x - det(x) R y
+__device__ inline void SocQuadRep(int len, const double* x, const double* y, double* out) {
+  double t2 = 0, xy = 0;
+  for (int i = 1; i < len; i++) t2 = fma(x[i], x[i], t2);
+  for (int i = 0; i < len; i++) xy = fma(x[i], y[i], xy);
+  const double det = x[0] * x[0] - t2;
+  for (int i = 0; i < len; i++) out[i] = (2 * xy) * x[i] + (i == 0 ? -det * y[i] : det * y[i]);
+}
+
+__global__ void __launch_bounds__(64) soc_schur(VecGroup g, Arena ar) {
+  extern __shared__ double lds[];
+  const int len = g.len, n = len - 1, m = g.m;
+  const int mem = blockIdx.x, id = g.ids[mem];
+  const double* A = g.A + (size_t)mem * len * m;
+  const double* c = g.c + (size_t)mem * len;
+  const double* W = g.W + (size_t)mem * len;
+  double* wsqrt = lds;            // len
+  double* wc = wsqrt + len;       // len
+  double* WA = wc + len;          // len x m
+  double* G = ar.G + ar.g_off[id];
+  double* AW = ar.AWc + ar.r_off[id];
+  double* AQc = ar.AQcc + ar.r_off[id];
+  if (threadIdx.x == 0) {
+    SocSpectral(n, W[0], W + 1, 0, wsqrt);
+    SocQuadRep(len, wsqrt, c, wc);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < m; i += blockDim.x) SocQuadRep(len, wsqrt, A + (size_t)i * len, WA + i * len);
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < m * m; idx += blockDim.x) {
+    const int i = idx % m, j = idx / m;
+    double s = 0;
+    for (int k = 0; k < len; k++) s = fma(WA[k + i * len], WA[k + j * len], s);
+    G[idx] = 2 * s;
+  }
+  for (int i = threadIdx.x; i < m; i += blockDim.x) {
+    double a = 0, q = 0;
+    for (int k = 0; k < len; k++) {
+      a = fma(A[k + (size_t)i * len], W[k], a);
+      q = fma(WA[k + i * len], wc[k], q);
+    }
+    AW[i] = 2 * a;
+    AQc[i] = 2 * q;
+  }
+  if (threadIdx.x == 0) {
+    double s = 0;
+    for (int k = 0; k < len; k++) s = fma(wc[k], wc[k], s);
+    ar.sc[2 * id] = 2 * wc[0];
+    ar.sc[2 * id + 1] = 2 * s;
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) soc_prepare(VecGroup g, StepArgs sa) {
+  extern __shared__ double lds[];
+  const int len = g.len, n = len - 1, m = g.m;
+  const int mem = blockIdx.x, id = g.ids[mem];
+  const double* A = g.A + (size_t)mem * len * m;
+  const double* c = g.c + (size_t)mem * len;
+  double* W = g.W + (size_t)mem * len;
+  double* D = g.T1 + (size_t)mem * len;
+  double* sy = lds;          // m
+  double* ms = sy + m;       // len
+  double* wsqrt = ms + len;  // len
+  double* d = wsqrt + len;   // len
+  for (int q = threadIdx.x; q < m; q += blockDim.x) sy[q] = sa.y[sa.cl_perm[sa.cl_ptr[id] + q]];
+  __syncthreads();
+  for (int k = threadIdx.x; k < len; k += blockDim.x) {
+    double s = 0;
+    for (int j = 0; j < m; j++) s = fma(A[k + (size_t)j * len], sy[j], s);
+    ms[k] = s - c[k] * sa.c_weight;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    SocSpectral(n, W[0], W + 1, 0, wsqrt);
+    SocQuadRep(len, wsqrt, ms, d);
+    double nq = 0;
+    if (MODE == 0) {
+      for (int k = 0; k < len; k++) W[k] = wsqrt[k];  // PrepareStep leaves w^{1/2} in W
+      d[0] += 1;
+      double s = 0;
+      for (int k = 0; k < len; k++) {
+        D[k] = d[k];
+        s = fma(d[k], d[k], s);
+      }
+      for (int k = 1; k < len; k++) nq = fma(d[k], d[k], nq);
+      nq = sqrt(nq);
+      const double e0 = fabs(d[0] + nq), e1 = fabs(d[0] - nq);
+      sa.info[2 * id] = 2 * s;
+      sa.info[2 * id + 1] = e0 > e1 ? e0 : e1;
+    } else {
+      for (int k = 1; k < len; k++) nq = fma(d[k], d[k], nq);
+      nq = sqrt(nq);
+      const double e0 = d[0] + nq, e1 = d[0] - nq;
+      const double lmax = -fmin(e0, e1), lmin = -fmax(e0, e1);
+      sa.info[4 * id] = lmin;
+      sa.info[4 * id + 1] = lmax;
+      sa.info[4 * id + 2] = lmax * lmax + lmin * lmin;
+      sa.info[4 * id + 3] = lmax + lmin;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) soc_take_step(VecGroup g, StepArgs sa) {
+  extern __shared__ double lds[];
+  const int len = g.len, n = len - 1;
+  const int mem = blockIdx.x;
+  double* W = g.W + (size_t)mem * len;
+  double* D = g.T1 + (size_t)mem * len;
+  double* d = lds;
+  double* ex = d + len;
+  double* wn = ex + len;
+  double* w = wn + len;
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < len; k++) {
+      d[k] = D[k];
+      w[k] = W[k];
+    }
+    if (sa.step_size != 1.0) {
+      for (int k = 0; k < len; k++) d[k] *= sa.step_size;
+      for (int k = 1; k < len; k++) D[k] = d[k];  // the reference scales temp1_1 in place
+    }
+    SocSpectral(n, d[0], d + 1, 1, ex);
+    SocQuadRep(len, w, ex, wn);
+    for (int k = 0; k < len; k++) W[k] = wn[k];
+  }
+}
+
+// ----------------------------------------------------------- constant block
+struct StaticGroup {
+  int m;
+  int count;
+  const double* Gc;  // count x (m x m)
+  const int* ids;
+};
+
+__global__ void static_schur(StaticGroup g, Arena ar) {
+  const int mem = blockIdx.x, id = g.ids[mem], mm = g.m * g.m;
+  const double* src = g.Gc + (size_t)mem * mm;
+  double* G = ar.G + ar.g_off[id];
+  for (int q = threadIdx.x; q < mm; q += blockDim.x) G[q] = src[q];
+  for (int q = threadIdx.x; q < g.m; q += blockDim.x) {
+    ar.AWc[ar.r_off[id] + q] = 0;
+    ar.AQcc[ar.r_off[id] + q] = 0;
+  }
+  if (threadIdx.x == 0) {
+    ar.sc[2 * id] = 0;
+    ar.sc[2 * id + 1] = 0;
+  }
+}
+
+// Fixed-order reduction of the per-constraint step outputs on one workgroup.
+// mode 0: info2 -> {sum normsqrd, max norminfd (init -1)}
+// mode 1: info4 -> {min lambda_min (init 30000), max lambda_max (init -30000), sum frob, sum trace}
+__global__ void __launch_bounds__(256)
+reduce_step_info(int K, int mode, const double* __restrict__ info, const unsigned char* __restrict__ mask,
+                 double* __restrict__ out) {
+  __shared__ double red[8];
+  __shared__ double red2[8];
+  double a = 0, b = (mode == 0) ? -1.0 : 30000.0, c = -30000.0, d = 0;
+  for (int i = threadIdx.x; i < K; i += blockDim.x) {
+    if (!mask[i]) continue;
+    if (mode == 0) {
+      a += info[2 * i];
+      b = fmax(b, info[2 * i + 1]);
+    } else {
+      b = fmin(b, info[4 * i]);
+      c = fmax(c, info[4 * i + 1]);
+      a += info[4 * i + 2];
+      d += info[4 * i + 3];
+    }
+  }
+  a = BlockSum(a, red);
+  d = BlockSum(d, red);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double bm = (mode == 0) ? WaveMax(b) : -WaveMax(-b);
+  double cm = WaveMax(c);
+  __syncthreads();
+  if (lane == 0) {
+    red[wave] = bm;
+    red2[wave] = cm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double B = red[0], C = red2[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
+      B = (mode == 0) ? fmax(B, red[w]) : fmin(B, red[w]);
+      C = fmax(C, red2[w]);
+    }
+    if (mode == 0) {
+      out[0] = a;
+      out[1] = B;
+    } else {
+      out[0] = B;
+      out[1] = C;
+      out[2] = a;
+      out[3] = d;
+    }
+  }
+}
+
+}  // namespace cxk

@@ -1,0 +1,434 @@
+// Dense-LMI (real PSD cone) kernels, LDS-resident formulation for small orders.
+// One 256-thread workgroup per constraint; W, one A_i and two n x n temporaries live in
+// LDS.  These are the shape-generic kernels (any n with 4 n^2 doubles <= LDS budget);
+// kernels_lmi_fused.hip.h holds the register/scalar-operand specialisation used for the
+// benchmark shape.
+//
+// Reference semantics reproduced here:
+//   ConstructSchurComplementSystem(DenseLMIConstraint*)  dense_lmi_constraint.cc:72-103
+//   PrepareStep(PsdConstraint*)                          psd_constraint.cc:45-84
+//   TakeStep / GeodesicUpdate                            psd_constraint.cc:13-28, 86-90
+//   AffineUpdate                                         psd_constraint.cc:33-43
+//   GetWeightedSlackEigenvalues(PsdConstraint*)          psd_constraint.cc:97-128
+//   AsymmetricLanczos                                    approximate_eigenvalues.cc:178-239
+//   ExponentialMapPadeApproximation                      exponential_map_pade.cc:10-32
+#pragma once
+#include "device_utils.h"
+
+namespace cxk {
+
+struct LmiGroup {
+  int n;
+  int m;
+  int count;
+  const double* A;  // count x m x (n*n)
+  const double* C;  // count x (n*n)
+  double* W;        // count x (n*n)
+  double* T1;       // count x (n*n)   temp_1 of WorkspaceDensePSD (WS between Prepare/TakeStep)
+  const int* ids;   // member -> constraint id
+};
+
+struct Arena {
+  double* G;              // per-constraint m x m Schur blocks (lower triangle meaningful)
+  const int64_t* g_off;   // [K]
+  double* AWc;            // per-constraint AW / AQc
+  double* AQcc;
+  const int64_t* r_off;   // [K]
+  double* sc;             // [2K] <w,c>, <c,Qc>
+};
+
+// out(n x n) = X(n x n) * Y(n x n), all in LDS, column-major. Caller syncs.
+__device__ __forceinline__ void LdsGemm(int n, const double* X, const double* Y, double* out) {
+  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+    const int r = idx % n, c = idx / n;
+    double s = 0;
+    for (int k = 0; k < n; k++) s = fma(X[r + k * n], Y[k + c * n], s);
+    out[idx] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256) lmi_schur_generic(LmiGroup g, Arena ar) {
+  extern __shared__ double lds[];
+  const int n = g.n, m = g.m, nn = n * n;
+  double* sW = lds;
+  double* sA = sW + nn;
+  double* sP = sA + nn;
+  double* sX = sP + nn;
+  const int mem = blockIdx.x;
+  const int id = g.ids[mem];
+  const double* A = g.A + (size_t)mem * m * nn;
+  const double* Cm = g.C + (size_t)mem * nn;
+  const double* Wg = g.W + (size_t)mem * nn;
+  double* G = ar.G + ar.g_off[id];
+  double* AW = ar.AWc + ar.r_off[id];
+  double* AQc = ar.AQcc + ar.r_off[id];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+
+  for (int q = threadIdx.x; q < nn; q += blockDim.x) sW[q] = Wg[q];
+  for (int i = 0; i <= m; i++) {
+    const double* M = (i < m) ? A + (size_t)i * nn : Cm;
+    __syncthreads();
+    for (int q = threadIdx.x; q < nn; q += blockDim.x) sA[q] = M[q];
+    __syncthreads();
+    LdsGemm(n, sA, sW, sP);  // AW = A_i * W
+    __syncthreads();
+    LdsGemm(n, sW, sP, sX);  // WAW = W * AW
+    __syncthreads();
+    if (i < m) {
+      for (int task = wave; task <= i + 2; task += nwaves) {
+        double v = 0;
+        if (task <= i) {
+          const double* Aj = A + (size_t)task * nn;
+          for (int q = lane; q < nn; q += 64) v = fma(sX[q], Aj[q], v);
+        } else if (task == i + 1) {
+          for (int r = lane; r < n; r += 64) v += sP[r + r * n];
+        } else {
+          for (int q = lane; q < nn; q += 64) v = fma(Cm[q], sX[q], v);
+        }
+        v = WaveSum(v);
+        if (lane == 0) {
+          if (task <= i)
+            G[i + (size_t)task * m] = v;
+          else if (task == i + 1)
+            AW[i] = v;
+          else
+            AQc[i] = v;
+        }
+      }
+    } else {
+      if (wave == 0) {
+        double v = 0;
+        for (int q = lane; q < nn; q += 64) v = fma(Cm[q], sW[q], v);
+        v = WaveSum(v);
+        if (lane == 0) ar.sc[2 * id] = v;
+      } else if (wave == 1) {
+        double v = 0;
+        for (int q = lane; q < nn; q += 64) v = fma(Cm[q], sX[q], v);
+        v = WaveSum(v);
+        if (lane == 0) ar.sc[2 * id + 1] = v;
+      }
+    }
+  }
+}
+
+// Eigenvalue range of a symmetric tridiagonal (implicit QL); single thread. d,e are clobbered.
+__device__ inline void TridiagMinMax(int n, double* d, double* e, double* mn, double* mx) {
+  e[n - 1] = 0;
+  for (int l = 0; l < n; l++) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; m++) {
+        const double dd = fabs(d[m]) + fabs(d[m + 1]);
+        if (fabs(e[m]) <= 2.2204460492503131e-16 * dd) break;
+      }
+      if (m != l) {
+        if (iter++ == 200) break;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + (g >= 0 ? fabs(r) : -fabs(r)));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; i--) {
+          double f = s * e[i];
+          const double b = c * e[i];
+          r = hypot(f, g);
+          e[i + 1] = r;
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[m] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          p = s * r;
+          d[i + 1] = g + p;
+          g = c * r - b;
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  double lo = d[0], hi = d[0];
+  for (int i = 1; i < n; i++) {
+    lo = fmin(lo, d[i]);
+    hi = fmax(hi, d[i]);
+  }
+  *mn = lo;
+  *mx = hi;
+}
+
+// Two-sided Lanczos on WS with V = [W r, r] run by wave 0; result (min,max eigenvalue of the
+// Jacobi matrix) is left in out[0], out[1] (LDS).  vec: 6n doubles of LDS; ab: 2*num_iter+2.
+__device__ inline void LanczosWave0(int n, const double* sWS, const double* sW, const double* r,
+                                    int num_iter, double* vec, double* ab, double* out) {
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  if (n == 1) {
+    if (lane == 0) out[0] = out[1] = sWS[0];
+    return;
+  }
+  double* V0 = vec;
+  double* V1 = vec + n;
+  double* U0 = vec + 2 * n;
+  double* U1 = vec + 3 * n;
+  double* P0 = vec + 4 * n;
+  double* P1 = vec + 5 * n;
+  double* alpha = ab;
+  double* beta = ab + num_iter + 1;
+  // V.col(1) = r ; V.col(0) = W r
+  for (int i = lane; i < n; i += 64) {
+    V1[i] = r[i];
+    double s = 0;
+    for (int k = 0; k < n; k++) s = fma(sW[i + k * n], r[k], s);
+    V0[i] = s;
+  }
+  double ip = 0;
+  for (int i = lane; i < n; i += 64) ip = fma(V0[i], V1[i], ip);
+  const double nrm = sqrt(WaveSum(ip));
+  for (int i = lane; i < n; i += 64) {
+    V0[i] /= nrm;
+    V1[i] /= nrm;
+    P0[i] = V0[i];
+    P1[i] = V1[i];
+  }
+  int cnt = 0;
+  double beta_prev = 0;
+  for (int j = 0; j < num_iter; j++) {
+    if (j > 0) {
+      double b2 = 0;
+      for (int i = lane; i < n; i += 64) b2 = fma(U0[i], U1[i], b2);
+      b2 = WaveSum(b2);
+      if (b2 < 1e-6) break;
+      beta_prev = sqrt(b2);
+      if (lane == 0) beta[j - 1] = beta_prev;
+      for (int i = lane; i < n; i += 64) {
+        P0[i] = V0[i];
+        P1[i] = V1[i];
+        V0[i] = U0[i] / beta_prev;
+        V1[i] = U1[i] / beta_prev;
+      }
+      cnt++;
+    }
+    // U.col(0) = WS V.col(0) ; U.col(1) = WS^T V.col(1)
+    double a = 0;
+    for (int i = lane; i < n; i += 64) {
+      double s0 = 0, s1 = 0;
+      for (int k = 0; k < n; k++) {
+        s0 = fma(sWS[i + k * n], V0[k], s0);
+        s1 = fma(sWS[k + i * n], V1[k], s1);
+      }
+      U0[i] = s0;
+      U1[i] = s1;
+    }
+    for (int i = lane; i < n; i += 64) a = fma(V0[i], U1[i], a);
+    a = WaveSum(a);
+    if (lane == 0) alpha[j] = a;
+    for (int i = lane; i < n; i += 64) {
+      double u0 = U0[i] - a * V0[i], u1 = U1[i] - a * V1[i];
+      if (j > 0) {
+        u0 -= beta_prev * P0[i];
+        u1 -= beta_prev * P1[i];
+      }
+      U0[i] = u0;
+      U1[i] = u1;
+    }
+  }
+  if (lane == 0) TridiagMinMax(cnt + 1, alpha, beta, &out[0], &out[1]);
+}
+
+struct StepArgs {
+  const double* y;        // permuted Newton direction (device)
+  const int* cl_ptr;      // [K+1] clique pointer
+  const int* cl_perm;     // permuted index of each clique variable
+  double* info;           // per-constraint outputs (2 or 4 doubles each)
+  int affine;
+  double c_weight;
+  double e_weight;
+  double step_size;
+};
+
+// mode 0: PrepareStep ; mode 1: GetWeightedSlackEigenvalues
+template <int MODE>
+__global__ void __launch_bounds__(256) lmi_prepare_generic(LmiGroup g, StepArgs sa) {
+  extern __shared__ double lds[];
+  const int n = g.n, m = g.m, nn = n * n;
+  double* sW = lds;
+  double* sS = sW + nn;
+  double* sWS = sS + nn;
+  double* vec = sWS + nn;           // 6n
+  double* ab = vec + 6 * n;         // 2*(n/2+1)+2
+  double* sy = ab + 2 * (n / 2 + 2);  // m
+  double* red = sy + m;             // 8
+  const int mem = blockIdx.x;
+  const int id = g.ids[mem];
+  const double* A = g.A + (size_t)mem * m * nn;
+  const double* Cm = g.C + (size_t)mem * nn;
+  double* Wg = g.W + (size_t)mem * nn;
+  double* T1 = g.T1 + (size_t)mem * nn;
+
+  for (int q = threadIdx.x; q < m; q += blockDim.x) sy[q] = sa.y[sa.cl_perm[sa.cl_ptr[id] + q]];
+  for (int q = threadIdx.x; q < nn; q += blockDim.x) sW[q] = Wg[q];
+  __syncthreads();
+  // minus_s = sum_i y_i A_i - k C   (dense_lmi_constraint.cc:8-27)
+  for (int q = threadIdx.x; q < nn; q += blockDim.x) {
+    double s = 0;
+    for (int i = 0; i < m; i++) s += sy[i] * A[(size_t)i * nn + q];
+    s -= sa.c_weight * Cm[q];
+    sS[q] = s;
+  }
+  __syncthreads();
+  LdsGemm(n, sW, sS, sWS);  // WS = W * minus_s
+  __syncthreads();
+  if (MODE == 0) {
+    for (int q = threadIdx.x; q < nn; q += blockDim.x) T1[q] = sWS[q];
+    if (sa.affine) {  // AffineUpdate: W = W (1 + w_e) + (WS) W
+      LdsGemm(n, sWS, sW, sS);
+      __syncthreads();
+      for (int q = threadIdx.x; q < nn; q += blockDim.x) {
+        const double w = (sa.e_weight == 0) ? sW[q] : sW[q] * (1 + sa.e_weight);
+        Wg[q] = w + sS[q];
+      }
+      return;
+    }
+  }
+  // index of the first maximal diagonal entry of WS
+  __shared__ int s_index;
+  if (threadIdx.x == 0) {
+    int idx = 0;
+    for (int i = 1; i < n; i++)
+      if (sWS[i + i * n] > sWS[idx + idx * n]) idx = i;
+    s_index = idx;
+  }
+  __syncthreads();
+  // PrepareStep aliases minus_s and WS (both temp_1), so its start vector is WS.col(index);
+  // GetWeightedSlackEigenvalues keeps them apart and starts from minus_s.col(index).
+  const double* r = (MODE == 0 ? sWS : sS) + s_index * n;
+  LanczosWave0(n, sWS, sW, r, n / 2, vec, ab, red + 4);
+  // tr(WS*WS) and tr(WS)
+  double t2 = 0, t1 = 0;
+  for (int q = threadIdx.x; q < nn; q += blockDim.x) {
+    const int a = q % n, b = q / n;
+    t2 = fma(sWS[q], sWS[b + a * n], t2);
+    if (a == b) t1 += sWS[q];
+  }
+  t2 = BlockSum(t2, red);
+  t1 = BlockSum(t1, red);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double mn = red[4], mx = red[5];
+    if (MODE == 0) {
+      const double l1 = fabs(sa.e_weight + mn), l2 = fabs(sa.e_weight + mx);
+      sa.info[2 * id] = t2 + 2 * t1 + n;
+      sa.info[2 * id + 1] = l1 < l2 ? l2 : l1;
+    } else {
+      sa.info[4 * id] = -mx;      // lambda_min
+      sa.info[4 * id + 1] = -mn;  // lambda_max
+      sa.info[4 * id + 2] = t2;
+      sa.info[4 * id + 3] = -t1;
+    }
+  }
+}
+
+// W <- sym( pade33( (WS + e I) * alpha ) * W )
+__global__ void __launch_bounds__(256) lmi_take_step_generic(LmiGroup g, StepArgs sa) {
+  extern __shared__ double lds[];
+  const int n = g.n, nn = n * n;
+  double* sW = lds;
+  double* sX = sW + nn;
+  double* sV = sX + nn;
+  double* aug = sV + nn;  // n x 2n : [denom | numer]
+  __shared__ int s_piv;
+  const int mem = blockIdx.x;
+  double* Wg = g.W + (size_t)mem * nn;
+  const double* T1 = g.T1 + (size_t)mem * nn;
+  for (int q = threadIdx.x; q < nn; q += blockDim.x) {
+    sW[q] = Wg[q];
+    double x = T1[q];
+    if (q % n == q / n) x += sa.e_weight;
+    if (sa.step_size != 1.0) x *= sa.step_size;
+    sX[q] = x;
+  }
+  __syncthreads();
+  LdsGemm(n, sX, sX, sV);  // A^2
+  __syncthreads();
+  // tmp = A^2 + 60 I (in aug[0:nn]) ; U = A * tmp (in aug[nn:2nn])
+  for (int q = threadIdx.x; q < nn; q += blockDim.x) aug[q] = sV[q] + ((q % n == q / n) ? 60.0 : 0.0);
+  __syncthreads();
+  LdsGemm(n, sX, aug, aug + nn);
+  __syncthreads();
+  for (int q = threadIdx.x; q < nn; q += blockDim.x) {
+    const double v = sV[q] * 12.0 + ((q % n == q / n) ? 120.0 : 0.0);
+    const double u = aug[nn + q];
+    aug[q] = -u + v;      // denom
+    aug[nn + q] = u + v;  // numer
+  }
+  __syncthreads();
+  // LU with partial pivoting on denom, carrying the n right-hand sides along.
+  const int n2 = 2 * n;
+  for (int k = 0; k < n; k++) {
+    if (threadIdx.x == 0) {
+      int piv = k;
+      double best = fabs(aug[k + k * n]);
+      for (int i = k + 1; i < n; i++) {
+        const double v = fabs(aug[i + k * n]);
+        if (v > best) {
+          best = v;
+          piv = i;
+        }
+      }
+      s_piv = piv;
+    }
+    __syncthreads();
+    const int piv = s_piv;
+    if (piv != k) {
+      for (int c = threadIdx.x; c < n2; c += blockDim.x) {
+        const double t = aug[k + c * n];
+        aug[k + c * n] = aug[piv + c * n];
+        aug[piv + c * n] = t;
+      }
+      __syncthreads();
+    }
+    const double d = aug[k + k * n];
+    for (int i = k + 1 + threadIdx.x; i < n; i += blockDim.x) aug[i + k * n] /= d;
+    __syncthreads();
+    const int rows = n - k - 1, cols = n2 - k - 1;
+    for (int idx = threadIdx.x; idx < rows * cols; idx += blockDim.x) {
+      const int i = k + 1 + idx % rows, c = k + 1 + idx / rows;
+      aug[i + c * n] -= aug[i + k * n] * aug[k + c * n];
+    }
+    __syncthreads();
+  }
+  // back substitution, one right-hand side per thread
+  for (int c = threadIdx.x; c < n; c += blockDim.x) {
+    double* b = aug + nn + c * n;
+    for (int j = n - 1; j >= 0; j--) {
+      b[j] /= aug[j + j * n];
+      const double bj = b[j];
+      for (int i = 0; i < j; i++) b[i] -= aug[i + j * n] * bj;
+    }
+  }
+  __syncthreads();
+  LdsGemm(n, aug + nn, sW, sV);  // expWS * W
+  __syncthreads();
+  for (int q = threadIdx.x; q < nn; q += blockDim.x) {
+    const int a = q % n, b = q / n;
+    Wg[q] = (sV[q] + sV[b + a * n]) * 0.5;
+  }
+}
+
+__global__ void lmi_set_identity(LmiGroup g) {
+  const int nn = g.n * g.n;
+  const size_t total = (size_t)g.count * nn;
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < total;
+       q += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(q % nn);
+    g.W[q] = (e % g.n == e / g.n) ? 1.0 : 0.0;
+  }
+}
+
+}  // namespace cxk

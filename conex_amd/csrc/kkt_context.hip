@@ -1,0 +1,1119 @@
+// cxk_* C-ABI: device-resident Newton-step KKT path (see include/conex_kkt_hip.h).
+//
+// Host side = structure + launches only.  All fp64 state (A_i, C, W, Schur blocks, the
+// supernodal slab, right-hand sides) lives in HBM for the lifetime of the context; per
+// Newton step only scalars cross PCIe.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/conex_kkt_hip.h"
+#include "kernels_cone.hip.h"
+#include "kernels_kkt.hip.h"
+#include "kernels_lmi.hip.h"
+#include "kernels_lmi_fused.hip.h"
+#include "symbolic.h"
+
+using namespace cxk;
+
+namespace {
+
+struct ConstraintRec {
+  int type = 0, n = 0, m = 0;
+  std::vector<double> A, C;
+  int group = -1, member = -1;
+};
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e == hipSuccess) e = hipMemset(p, 0, count * sizeof(T));
+    return e;
+  }
+  hipError_t upload(const std::vector<T>& v) {
+    hipError_t e = alloc(v.size());
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+  }
+};
+
+struct Group {
+  int type = 0, n = 0, m = 0;
+  std::vector<int> ids;
+  DevBuf<double> A, C, W, T1, T2;
+  DevBuf<int> dids;
+  bool fused = false;
+};
+
+}  // namespace
+
+struct cxk_context {
+  int num_vars = 0;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::vector<ConstraintRec> cons;
+  IntLists cliques, dual_vars;
+  bool finalized = false;
+  int rank = 0, world = 1;
+  MatrixData md;
+  Layout lay;
+  std::vector<Group> groups;
+  std::vector<int64_t> g_off, r_off;
+  std::vector<unsigned char> owned;
+  // levels
+  std::vector<int> level_ptr, level_sn;
+  size_t chol_lds = 0, solve_lds = 0;
+  // device state
+  DevBuf<double> G, AWc, AQcc, sc, slab, y, b, AW, AQc, sys_sc, info, red_out;
+  DevBuf<int64_t> d_g_off, d_r_off, as_dst, as_src, rs_src;
+  DevBuf<int> as_ptr, rs_ptr, cl_ptr, cl_perm, d_level_sn, d_fail, d_pinv;
+  DevBuf<unsigned char> d_mask;
+  DevBuf<int> p_ns, p_nsep, p_start, tg_ptr, tr_ptr, tr_len, fs_ptr, fs_start, fs_len, bs_ptr, bs_c,
+      bs_row;
+  DevBuf<int64_t> p_diag, p_offd, tg_dst, tr_colk, tr_colj, fs_col;
+  int64_t as_T = 0;
+  FactorPlan plan{};
+  // timing of the dominant (dense-LMI Schur) kernel
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  double time_acc_ms = 0;
+  int time_samples = 0;
+};
+
+namespace {
+
+#define CXK_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      ctx->err = std::string(#expr) + ": " + hipGetErrorString(_e);                         \
+      fprintf(stderr, "%s line %d: %s\n", __FILE__, __LINE__, ctx->err.c_str());            \
+      return CXK_FAILURE;                                                                   \
+    }                                                                                       \
+  } while (0)
+
+#define CXK_DEMAND(cond, msg)                                                    \
+  do {                                                                           \
+    if (!(cond)) {                                                               \
+      ctx->err = msg;                                                            \
+      fprintf(stderr, "%s line %d: %s\n", __FILE__, __LINE__, msg);              \
+      return CXK_FAILURE;                                                        \
+    }                                                                            \
+  } while (0)
+
+int Fail(cxk_context* ctx, const char* msg) {
+  ctx->err = msg;
+  fprintf(stderr, "conex_kkt_hip: %s\n", msg);
+  return CXK_FAILURE;
+}
+
+bool IsUnique(int N, int m, const int* x) {  // constraint_manager.h:11-24
+  std::vector<char> seen(N > 0 ? N : 1, 0);
+  for (int i = 0; i < m; i++) {
+    if (x[i] >= N || x[i] < 0) return false;
+    if (seen[x[i]]++) return false;
+  }
+  return true;
+}
+
+int AddConstraint(cxk_context* ctx, ConstraintRec&& rec, const int* vars) {
+  if (!ctx || ctx->finalized) return -1;
+  if (vars) {
+    if (!IsUnique(ctx->num_vars, rec.m, vars)) return -1;
+  } else if (rec.m != ctx->num_vars) {
+    return -1;
+  }
+  IntList cl(rec.m);
+  for (int i = 0; i < rec.m; i++) cl[i] = vars ? vars[i] : i;
+  ctx->cliques.push_back(cl);
+  ctx->dual_vars.emplace_back();
+  ctx->cons.push_back(std::move(rec));
+  return static_cast<int>(ctx->cons.size()) - 1;
+}
+
+int GridFor(size_t work, int block) {
+  size_t g = (work + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > 4096) g = 4096;
+  return static_cast<int>(g);
+}
+
+LmiGroup MakeLmi(Group& g) {
+  LmiGroup d;
+  d.n = g.n;
+  d.m = g.m;
+  d.count = static_cast<int>(g.ids.size());
+  d.A = g.A.p;
+  d.C = g.C.p;
+  d.W = g.W.p;
+  d.T1 = g.T1.p;
+  d.ids = g.dids.p;
+  return d;
+}
+VecGroup MakeVec(Group& g) {
+  VecGroup d;
+  d.len = g.type == CXK_SOC ? g.n + 1 : g.n;
+  d.m = g.m;
+  d.count = static_cast<int>(g.ids.size());
+  d.A = g.A.p;
+  d.c = g.C.p;
+  d.W = g.W.p;
+  d.T1 = g.T1.p;
+  d.T2 = g.T2.p;
+  d.ids = g.dids.p;
+  return d;
+}
+StaticGroup MakeStatic(Group& g) {
+  StaticGroup d;
+  d.m = g.m;
+  d.count = static_cast<int>(g.ids.size());
+  d.Gc = g.A.p;
+  d.ids = g.dids.p;
+  return d;
+}
+Arena MakeArena(cxk_context* ctx) {
+  Arena a;
+  a.G = ctx->G.p;
+  a.g_off = ctx->d_g_off.p;
+  a.AWc = ctx->AWc.p;
+  a.AQcc = ctx->AQcc.p;
+  a.r_off = ctx->d_r_off.p;
+  a.sc = ctx->sc.p;
+  return a;
+}
+StepArgs MakeStep(cxk_context* ctx, double* info, int affine, double cw, double ew, double ss) {
+  StepArgs s;
+  s.y = ctx->y.p;
+  s.cl_ptr = ctx->cl_ptr.p;
+  s.cl_perm = ctx->cl_perm.p;
+  s.info = info;
+  s.affine = affine;
+  s.c_weight = cw;
+  s.e_weight = ew;
+  s.step_size = ss;
+  return s;
+}
+
+size_t LmiGenericLds(int n) { return sizeof(double) * (size_t)(4 * n * n); }
+size_t LmiPrepareLds(int n, int m) {
+  return sizeof(double) * (size_t)(3 * n * n + 6 * n + 2 * (n / 2 + 2) + m + 8);
+}
+size_t LmiTakeLds(int n) { return sizeof(double) * (size_t)(5 * n * n); }
+constexpr size_t kLdsLimit = 160 * 1024 - 512;
+
+// ---------------------------------------------------------------- plan building
+int BuildPlans(cxk_context* ctx) {
+  const MatrixData& md = ctx->md;
+  const Layout& L = ctx->lay;
+  const int K = md.K, N = md.N;
+
+  // ---- assembly gather (UpdateBlocks order: elimination index descending)
+  std::vector<int> entry_of(L.slab_size, -1);
+  std::vector<int64_t> dst;
+  std::vector<std::vector<int64_t>> srcs;
+  auto entry = [&](int64_t off) -> std::vector<int64_t>& {
+    if (entry_of[off] < 0) {
+      entry_of[off] = static_cast<int>(dst.size());
+      dst.push_back(off);
+      srcs.emplace_back();
+    }
+    return srcs[entry_of[off]];
+  };
+  for (int e = K - 1; e >= 0; e--) {
+    const int i = md.clique_order[e];
+    const int m = ctx->cons[i].m;
+    const int64_t base = ctx->g_off[i];
+    const bool mine = ctx->owned[i];
+    auto coeff = [&](int a, int b) -> int64_t {  // GetCoeff supernodal_assembler.cc:59-70
+      if (a < 0 || b < 0 || !mine) return -1;
+      return a >= b ? base + (int64_t)b * m + a : base + (int64_t)a * m + b;
+    };
+    const IntList& r = md.supernodes_pos[e];
+    const IntList& s = md.separators_pos[e];
+    const int ns = (int)r.size(), nsep = (int)s.size();
+    for (int j = 0; j < ns; j++)  // SetLowerTri
+      for (int i2 = j; i2 < ns; i2++) {
+        auto& v = entry(L.diag_off[e] + (int64_t)j * ns + i2);
+        v.clear();
+        v.push_back(coeff(r[i2], r[j]));
+      }
+    if (ns > 0)
+      for (int j = 0; j < nsep; j++)  // Set
+        for (int i2 = 0; i2 < ns; i2++) {
+          auto& v = entry(L.offd_off[e] + (int64_t)j * ns + i2);
+          v.clear();
+          v.push_back(coeff(r[i2], s[j]));
+        }
+    int cnt = 0;
+    for (int j = 0; j < nsep; j++)  // Scatter
+      for (int i2 = j; i2 < nsep; i2++) entry(L.ss_index[e][cnt++]).push_back(coeff(s[i2], s[j]));
+  }
+  std::vector<int> as_ptr(dst.size() + 1, 0);
+  std::vector<int64_t> as_src;
+  for (size_t t = 0; t < dst.size(); t++) {
+    for (int64_t q : srcs[t]) as_src.push_back(q);
+    as_ptr[t + 1] = (int)as_src.size();
+  }
+  ctx->as_T = (int64_t)dst.size();
+  CXK_TRY(ctx->as_dst.upload(dst));
+  CXK_TRY(ctx->as_ptr.upload(as_ptr));
+  CXK_TRY(ctx->as_src.upload(as_src));
+
+  // ---- residual gather (constraint order)
+  {
+    std::vector<std::vector<int64_t>> per(N);
+    for (int i = 0; i < (int)ctx->cons.size(); i++) {
+      if (!ctx->owned[i]) continue;
+      for (int q = 0; q < (int)ctx->cliques[i].size(); q++)
+        per[md.permutation[ctx->cliques[i][q]]].push_back(ctx->r_off[i] + q);
+    }
+    std::vector<int> ptr(N + 1, 0);
+    std::vector<int64_t> src;
+    for (int p = 0; p < N; p++) {
+      for (int64_t q : per[p]) src.push_back(q);
+      ptr[p + 1] = (int)src.size();
+    }
+    CXK_TRY(ctx->rs_ptr.upload(ptr));
+    CXK_TRY(ctx->rs_src.upload(src));
+  }
+
+  // ---- clique variables in permuted numbering
+  {
+    std::vector<int> ptr(ctx->cons.size() + 1, 0), perm;
+    for (size_t i = 0; i < ctx->cons.size(); i++) {
+      for (int v : ctx->cliques[i]) perm.push_back(md.permutation[v]);
+      ptr[i + 1] = (int)perm.size();
+    }
+    CXK_TRY(ctx->cl_ptr.upload(ptr));
+    CXK_TRY(ctx->cl_perm.upload(perm));
+  }
+
+  // ---- factor / solve pull lists
+  std::vector<int> ns(K), nsep(K), start(K);
+  for (int e = 0; e < K; e++) {
+    ns[e] = L.supernode_size[e];
+    nsep[e] = (int)L.separators[e].size();
+    start[e] = L.supernode_start[e];
+  }
+  struct Triple {
+    int64_t ck, cj;
+    int len;
+  };
+  std::vector<int> tgt_of(L.slab_size, -1);
+  std::vector<std::vector<int>> tg_of_sn(K);
+  std::vector<int64_t> tg_dst_all;
+  std::vector<std::vector<Triple>> triples;
+  std::vector<std::vector<std::tuple<int64_t, int, int>>> fs(N);
+  std::vector<int> level(K, 0);
+  for (int i = 0; i < K; i++) {
+    if (ns[i] == 0 || nsep[i] == 0) continue;
+    const IntList& s = L.separators[i];
+    int cnt = 0;
+    for (int k = 0; k < nsep[i]; k++) {
+      const int p = L.var_to_sn[s[k]];
+      if (level[p] < level[i] + 1) level[p] = level[i] + 1;
+      for (int j = k; j < nsep[i]; j++) {
+        const int64_t off = L.ss_index[i][cnt++];
+        if (tgt_of[off] < 0) {
+          tgt_of[off] = (int)tg_dst_all.size();
+          tg_dst_all.push_back(off);
+          triples.emplace_back();
+          tg_of_sn[p].push_back(tgt_of[off]);
+        }
+        triples[tgt_of[off]].push_back(
+            {L.offd_off[i] + (int64_t)k * ns[i], L.offd_off[i] + (int64_t)j * ns[i], ns[i]});
+      }
+      fs[s[k]].emplace_back(L.offd_off[i] + (int64_t)k * ns[i], start[i], ns[i]);
+    }
+    // level must dominate every ancestor, not only the first one: handled above since all
+    // separator variables are visited.
+  }
+  // levels must be monotone along the elimination order: a supernode that receives from a
+  // child processed later in this loop has a larger index, so one pass suffices.
+  {
+    std::vector<int> tg_ptr(K + 1, 0), tr_ptr, tr_len;
+    std::vector<int64_t> tg_dst, ck, cj;
+    tr_ptr.push_back(0);
+    for (int p = 0; p < K; p++) {
+      for (int t : tg_of_sn[p]) {
+        tg_dst.push_back(tg_dst_all[t]);
+        for (const Triple& tr : triples[t]) {
+          ck.push_back(tr.ck);
+          cj.push_back(tr.cj);
+          tr_len.push_back(tr.len);
+        }
+        tr_ptr.push_back((int)ck.size());
+      }
+      tg_ptr[p + 1] = (int)tg_dst.size();
+    }
+    CXK_TRY(ctx->tg_ptr.upload(tg_ptr));
+    CXK_TRY(ctx->tg_dst.upload(tg_dst));
+    CXK_TRY(ctx->tr_ptr.upload(tr_ptr));
+    CXK_TRY(ctx->tr_colk.upload(ck));
+    CXK_TRY(ctx->tr_colj.upload(cj));
+    CXK_TRY(ctx->tr_len.upload(tr_len));
+  }
+  {
+    std::vector<int> fs_ptr(N + 1, 0), fs_start, fs_len;
+    std::vector<int64_t> fs_col;
+    for (int p = 0; p < N; p++) {
+      for (auto& t : fs[p]) {
+        fs_col.push_back(std::get<0>(t));
+        fs_start.push_back(std::get<1>(t));
+        fs_len.push_back(std::get<2>(t));
+      }
+      fs_ptr[p + 1] = (int)fs_col.size();
+    }
+    CXK_TRY(ctx->fs_ptr.upload(fs_ptr));
+    CXK_TRY(ctx->fs_col.upload(fs_col));
+    CXK_TRY(ctx->fs_start.upload(fs_start));
+    CXK_TRY(ctx->fs_len.upload(fs_len));
+  }
+  {
+    // backward accumulation order: ancestors descending, columns ascending within one ancestor
+    std::vector<int> bs_ptr(K + 1, 0), bs_c, bs_row;
+    for (int j = 0; j < K; j++) {
+      if (ns[j] > 0) {
+        const IntList& s = L.separators[j];
+        int hi = nsep[j];
+        while (hi > 0) {
+          const int anc = L.var_to_sn[s[hi - 1]];
+          int lo = hi - 1;
+          while (lo > 0 && L.var_to_sn[s[lo - 1]] == anc) lo--;
+          for (int c = lo; c < hi; c++) {
+            bs_c.push_back(c);
+            bs_row.push_back(s[c]);
+          }
+          hi = lo;
+        }
+      }
+      bs_ptr[j + 1] = (int)bs_c.size();
+    }
+    CXK_TRY(ctx->bs_ptr.upload(bs_ptr));
+    CXK_TRY(ctx->bs_c.upload(bs_c));
+    CXK_TRY(ctx->bs_row.upload(bs_row));
+  }
+  // level lists (supernodes with at least one column)
+  int nlev = 0;
+  for (int e = 0; e < K; e++)
+    if (ns[e] > 0) nlev = std::max(nlev, level[e] + 1);
+  ctx->level_ptr.assign(nlev + 1, 0);
+  ctx->level_sn.clear();
+  ctx->chol_lds = 0;
+  ctx->solve_lds = 0;
+  for (int l = 0; l < nlev; l++) {
+    for (int e = 0; e < K; e++)
+      if (ns[e] > 0 && level[e] == l) {
+        ctx->level_sn.push_back(e);
+        ctx->chol_lds = std::max(ctx->chol_lds, sizeof(double) * ((size_t)ns[e] * ns[e] +
+                                                                   (size_t)ns[e] * nsep[e] + ns[e]));
+        ctx->solve_lds = std::max(ctx->solve_lds, sizeof(double) * (size_t)ns[e]);
+      }
+    ctx->level_ptr[l + 1] = (int)ctx->level_sn.size();
+  }
+  CXK_DEMAND(ctx->chol_lds <= kLdsLimit,
+             "supernode too large for the LDS-resident block Cholesky (blocked path not built yet)");
+  CXK_TRY(ctx->d_level_sn.upload(ctx->level_sn));
+  CXK_TRY(ctx->p_ns.upload(ns));
+  CXK_TRY(ctx->p_nsep.upload(nsep));
+  CXK_TRY(ctx->p_start.upload(start));
+  CXK_TRY(ctx->p_diag.upload(L.diag_off));
+  CXK_TRY(ctx->p_offd.upload(L.offd_off));
+  FactorPlan& P = ctx->plan;
+  P.ns = ctx->p_ns.p;
+  P.nsep = ctx->p_nsep.p;
+  P.start = ctx->p_start.p;
+  P.diag_off = ctx->p_diag.p;
+  P.offd_off = ctx->p_offd.p;
+  P.tg_ptr = ctx->tg_ptr.p;
+  P.tg_dst = ctx->tg_dst.p;
+  P.tr_ptr = ctx->tr_ptr.p;
+  P.tr_colk = ctx->tr_colk.p;
+  P.tr_colj = ctx->tr_colj.p;
+  P.tr_len = ctx->tr_len.p;
+  P.fs_ptr = ctx->fs_ptr.p;
+  P.fs_col = ctx->fs_col.p;
+  P.fs_start = ctx->fs_start.p;
+  P.fs_len = ctx->fs_len.p;
+  P.bs_ptr = ctx->bs_ptr.p;
+  P.bs_c = ctx->bs_c.p;
+  P.bs_row = ctx->bs_row.p;
+  return CXK_SUCCESS;
+}
+
+int LaunchSchur(cxk_context* ctx) {
+  Arena ar = MakeArena(ctx);
+  for (Group& g : ctx->groups) {
+    const int count = (int)g.ids.size();
+    if (count == 0) continue;
+    switch (g.type) {
+      case CXK_LMI: {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ctx->timing) {
+          if (ctx->ev_used == ctx->ev_pool.size()) {
+            hipEvent_t a, b;
+            CXK_TRY(hipEventCreate(&a));
+            CXK_TRY(hipEventCreate(&b));
+            ctx->ev_pool.emplace_back(a, b);
+          }
+          e0 = ctx->ev_pool[ctx->ev_used].first;
+          e1 = ctx->ev_pool[ctx->ev_used].second;
+          ctx->ev_used++;
+          CXK_TRY(hipEventRecord(e0, ctx->stream));
+        }
+        if (g.fused) {
+          CXK_TRY(LaunchLmiSchurFused(MakeLmi(g), ar, ctx->stream));
+        } else {
+          lmi_schur_generic<<<count, 256, LmiGenericLds(g.n), ctx->stream>>>(MakeLmi(g), ar);
+        }
+        if (ctx->timing) CXK_TRY(hipEventRecord(e1, ctx->stream));
+        break;
+      }
+      case CXK_LINEAR:
+        linear_schur<<<count, 256, 0, ctx->stream>>>(MakeVec(g), ar);
+        break;
+      case CXK_SOC:
+        soc_schur<<<count, 64, sizeof(double) * (size_t)((g.n + 1) * (g.m + 2)), ctx->stream>>>(
+            MakeVec(g), ar);
+        break;
+      case CXK_STATIC:
+        static_schur<<<count, 64, 0, ctx->stream>>>(MakeStatic(g), ar);
+        break;
+    }
+  }
+  CXK_TRY(hipGetLastError());
+  return CXK_SUCCESS;
+}
+
+int LaunchGather(cxk_context* ctx) {
+  gather_slab<<<GridFor((size_t)ctx->as_T, 256), 256, 0, ctx->stream>>>(
+      ctx->as_T, ctx->as_dst.p, ctx->as_ptr.p, ctx->as_src.p, ctx->G.p, ctx->slab.p);
+  gather_residuals<<<GridFor((size_t)ctx->md.N, 256), 256, 0, ctx->stream>>>(
+      ctx->md.N, ctx->rs_ptr.p, ctx->rs_src.p, ctx->AWc.p, ctx->AQcc.p, ctx->AW.p, ctx->AQc.p,
+      (int)ctx->cons.size(), ctx->sc.p, ctx->sys_sc.p);
+  CXK_TRY(hipGetLastError());
+  return CXK_SUCCESS;
+}
+
+int LaunchFactor(cxk_context* ctx, bool with_rhs) {
+  CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));
+  const int nlev = (int)ctx->level_ptr.size() - 1;
+  for (int l = 0; l < nlev; l++) {
+    const int cnt = ctx->level_ptr[l + 1] - ctx->level_ptr[l];
+    if (cnt == 0) continue;
+    chol_level<<<cnt, 256, ctx->chol_lds, ctx->stream>>>(ctx->plan, ctx->d_level_sn.p + ctx->level_ptr[l],
+                                                        ctx->slab.p, with_rhs ? ctx->y.p : nullptr,
+                                                        ctx->d_fail.p);
+  }
+  CXK_TRY(hipGetLastError());
+  return CXK_SUCCESS;
+}
+
+int LaunchForward(cxk_context* ctx) {
+  const int nlev = (int)ctx->level_ptr.size() - 1;
+  for (int l = 0; l < nlev; l++) {
+    const int cnt = ctx->level_ptr[l + 1] - ctx->level_ptr[l];
+    if (cnt == 0) continue;
+    forward_level<<<cnt, 64, ctx->solve_lds, ctx->stream>>>(
+        ctx->plan, ctx->d_level_sn.p + ctx->level_ptr[l], ctx->slab.p, ctx->y.p);
+  }
+  CXK_TRY(hipGetLastError());
+  return CXK_SUCCESS;
+}
+
+int LaunchBackward(cxk_context* ctx) {
+  const int nlev = (int)ctx->level_ptr.size() - 1;
+  for (int l = nlev - 1; l >= 0; l--) {
+    const int cnt = ctx->level_ptr[l + 1] - ctx->level_ptr[l];
+    if (cnt == 0) continue;
+    backward_level<<<cnt, 64, ctx->solve_lds, ctx->stream>>>(
+        ctx->plan, ctx->d_level_sn.p + ctx->level_ptr[l], ctx->slab.p, ctx->y.p);
+  }
+  CXK_TRY(hipGetLastError());
+  return CXK_SUCCESS;
+}
+
+int CheckReady(cxk_context* ctx) {
+  if (!ctx) return CXK_FAILURE;
+  CXK_DEMAND(ctx->finalized, "context not finalized");
+  CXK_DEMAND(ctx->device >= 0,
+             "no HIP device bound to this context: the KKT path has no CPU fallback");
+  return CXK_SUCCESS;
+}
+
+}  // namespace
+
+// =================================================================== C-ABI
+extern "C" {
+
+int cxk_create(int num_vars, int device, void* stream, cxk_context** out) {
+  if (!out || num_vars < 0) return CXK_FAILURE;
+  cxk_context* ctx = new cxk_context();
+  ctx->num_vars = num_vars;
+  ctx->device = device;
+  ctx->stream = static_cast<hipStream_t>(stream);
+  if (device >= 0) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || device >= count) {
+      fprintf(stderr, "conex_kkt_hip: HIP device %d not available (%s)\n", device,
+              e == hipSuccess ? "out of range" : hipGetErrorString(e));
+      delete ctx;
+      return CXK_FAILURE;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+      delete ctx;
+      return CXK_FAILURE;
+    }
+  }
+  *out = ctx;
+  return CXK_SUCCESS;
+}
+
+void cxk_destroy(cxk_context* ctx) {
+  if (!ctx) return;
+  for (auto& pr : ctx->ev_pool) {
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  delete ctx;
+}
+
+const char* cxk_last_error(const cxk_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int cxk_add_lmi(cxk_context* ctx, int n, int m, const double* A, const double* C, const int* vars) {
+  if (!ctx || n < 1 || m < 0 || !A || !C) return -1;
+  ConstraintRec r;
+  r.type = CXK_LMI;
+  r.n = n;
+  r.m = m;
+  r.A.assign(A, A + (size_t)m * n * n);
+  r.C.assign(C, C + (size_t)n * n);
+  return AddConstraint(ctx, std::move(r), vars);
+}
+
+int cxk_add_linear(cxk_context* ctx, int rows, int m, const double* A, const double* c,
+                   const int* vars) {
+  if (!ctx || rows < 1 || m < 0 || !A || !c) return -1;
+  ConstraintRec r;
+  r.type = CXK_LINEAR;
+  r.n = rows;
+  r.m = m;
+  r.A.assign(A, A + (size_t)rows * m);
+  r.C.assign(c, c + rows);
+  return AddConstraint(ctx, std::move(r), vars);
+}
+
+int cxk_add_soc(cxk_context* ctx, int n, int m, const double* A, const double* c, const int* vars) {
+  if (!ctx || n < 1 || m < 0 || !A || !c) return -1;
+  ConstraintRec r;
+  r.type = CXK_SOC;
+  r.n = n;
+  r.m = m;
+  r.A.assign(A, A + (size_t)(n + 1) * m);
+  r.C.assign(c, c + n + 1);
+  return AddConstraint(ctx, std::move(r), vars);
+}
+
+int cxk_add_static(cxk_context* ctx, int m, const double* G, const int* vars) {
+  if (!ctx || m < 1 || !G) return -1;
+  ConstraintRec r;
+  r.type = CXK_STATIC;
+  r.n = 0;
+  r.m = m;
+  r.A.assign(G, G + (size_t)m * m);
+  return AddConstraint(ctx, std::move(r), vars);
+}
+
+int cxk_num_constraints(const cxk_context* ctx) { return ctx ? (int)ctx->cons.size() : 0; }
+
+int cxk_set_shard(cxk_context* ctx, int rank, int world_size) {
+  if (!ctx || ctx->finalized || world_size < 1 || rank < 0 || rank >= world_size) return CXK_FAILURE;
+  ctx->rank = rank;
+  ctx->world = world_size;
+  return CXK_SUCCESS;
+}
+
+int cxk_finalize(cxk_context* ctx) {
+  if (!ctx) return CXK_FAILURE;
+  CXK_DEMAND(!ctx->cons.empty(), "no constraints");
+  try {
+    ctx->md = Analyze(ctx->cliques, ctx->dual_vars);
+    ctx->lay = BuildLayout(ctx->md);
+  } catch (const std::exception& e) {
+    return Fail(ctx, e.what());
+  }
+  const int K = (int)ctx->cons.size();
+  // ownership: round-robin over elimination positions keeps the per-rank work balanced
+  ctx->owned.assign(K, 1);
+  if (ctx->world > 1)
+    for (int e = 0; e < K; e++) ctx->owned[ctx->md.clique_order[e]] = (e % ctx->world) == ctx->rank;
+  ctx->g_off.assign(K, 0);
+  ctx->r_off.assign(K, 0);
+  int64_t go = 0, ro = 0;
+  for (int i = 0; i < K; i++) {
+    ctx->g_off[i] = go;
+    ctx->r_off[i] = ro;
+    go += (int64_t)ctx->cons[i].m * ctx->cons[i].m;
+    ro += ctx->cons[i].m;
+  }
+  ctx->finalized = true;
+  if (ctx->device < 0) return CXK_SUCCESS;  // symbolic-only context
+
+  CXK_TRY(hipSetDevice(ctx->device));
+  // groups of identically shaped constraints (owned ones only carry data)
+  std::map<std::tuple<int, int, int>, int> gmap;
+  ctx->groups.clear();
+  for (int i = 0; i < K; i++) {
+    ConstraintRec& c = ctx->cons[i];
+    if (!ctx->owned[i]) continue;
+    auto key = std::make_tuple(c.type, c.n, c.m);
+    auto it = gmap.find(key);
+    if (it == gmap.end()) {
+      it = gmap.emplace(key, (int)ctx->groups.size()).first;
+      ctx->groups.emplace_back();
+      ctx->groups.back().type = c.type;
+      ctx->groups.back().n = c.n;
+      ctx->groups.back().m = c.m;
+    }
+    c.group = it->second;
+    c.member = (int)ctx->groups[it->second].ids.size();
+    ctx->groups[it->second].ids.push_back(i);
+  }
+  for (Group& g : ctx->groups) {
+    const size_t cnt = g.ids.size();
+    size_t a_sz = 0, c_sz = 0, w_sz = 0;
+    switch (g.type) {
+      case CXK_LMI:
+        a_sz = (size_t)g.m * g.n * g.n;
+        c_sz = w_sz = (size_t)g.n * g.n;
+        CXK_DEMAND(LmiTakeLds(g.n) <= kLdsLimit && LmiPrepareLds(g.n, g.m) <= kLdsLimit,
+                   "LMI order too large for the LDS-resident kernels (tiled path not built yet)");
+        g.fused = LmiFusedSupports(g.n, g.m);
+        break;
+      case CXK_LINEAR:
+        a_sz = (size_t)g.n * g.m;
+        c_sz = w_sz = (size_t)g.n;
+        break;
+      case CXK_SOC:
+        a_sz = (size_t)(g.n + 1) * g.m;
+        c_sz = w_sz = (size_t)(g.n + 1);
+        break;
+      case CXK_STATIC:
+        a_sz = (size_t)g.m * g.m;
+        break;
+    }
+    std::vector<double> hA(a_sz * cnt), hC(c_sz * cnt);
+    for (size_t k = 0; k < cnt; k++) {
+      const ConstraintRec& c = ctx->cons[g.ids[k]];
+      std::copy(c.A.begin(), c.A.end(), hA.begin() + k * a_sz);
+      std::copy(c.C.begin(), c.C.end(), hC.begin() + k * c_sz);
+    }
+    CXK_TRY(g.A.upload(hA));
+    CXK_TRY(g.C.upload(hC));
+    CXK_TRY(g.W.alloc(w_sz * cnt));
+    CXK_TRY(g.T1.alloc(w_sz * cnt));
+    CXK_TRY(g.T2.alloc(g.type == CXK_LINEAR ? w_sz * cnt : 0));
+    CXK_TRY(g.dids.upload(g.ids));
+  }
+  CXK_TRY(ctx->G.alloc((size_t)go));
+  CXK_TRY(ctx->AWc.alloc((size_t)ro));
+  CXK_TRY(ctx->AQcc.alloc((size_t)ro));
+  CXK_TRY(ctx->sc.alloc((size_t)2 * K));
+  CXK_TRY(ctx->d_g_off.upload(ctx->g_off));
+  CXK_TRY(ctx->d_r_off.upload(ctx->r_off));
+  CXK_TRY(ctx->slab.alloc((size_t)ctx->lay.slab_size));
+  const int N = ctx->md.N;
+  CXK_TRY(ctx->y.alloc(N));
+  CXK_TRY(ctx->b.alloc(N));
+  CXK_TRY(ctx->AW.alloc(N));
+  CXK_TRY(ctx->AQc.alloc(N));
+  CXK_TRY(ctx->sys_sc.alloc(2));
+  CXK_TRY(ctx->red_out.alloc(4));
+  CXK_TRY(ctx->d_fail.alloc(1));
+  {
+    std::vector<double> info((size_t)4 * K, 0.0);
+    for (int i = 0; i < K; i++)
+      if (ctx->cons[i].type == CXK_STATIC) {  // empty GetWeightedSlackEigenvalues: defaults stay
+        info[4 * i] = DBL_MAX;
+        info[4 * i + 1] = -DBL_MAX;
+      }
+    CXK_TRY(ctx->info.upload(info));
+    CXK_TRY(ctx->d_mask.upload(ctx->owned));
+  }
+  if (BuildPlans(ctx) != CXK_SUCCESS) return CXK_FAILURE;
+  return cxk_set_identity(ctx);
+}
+
+// ------------------------------------------------------------- symbolic getters
+int cxk_system_size(const cxk_context* ctx) { return ctx && ctx->finalized ? ctx->md.N : 0; }
+int cxk_get_order(const cxk_context* ctx, int* order) {
+  if (!ctx || !ctx->finalized) return 0;
+  std::copy(ctx->md.clique_order.begin(), ctx->md.clique_order.end(), order);
+  return ctx->md.K;
+}
+int cxk_get_permutation(const cxk_context* ctx, int* perm, int* perm_inv) {
+  if (!ctx || !ctx->finalized) return 0;
+  std::copy(ctx->md.permutation.begin(), ctx->md.permutation.end(), perm);
+  std::copy(ctx->md.permutation_inverse.begin(), ctx->md.permutation_inverse.end(), perm_inv);
+  return ctx->md.num_vars;
+}
+int cxk_get_list(const cxk_context* ctx, int which, int e, int* out) {
+  if (!ctx || !ctx->finalized || e < 0 || e >= ctx->md.K) return -1;
+  const IntList* v = nullptr;
+  switch (which) {
+    case 0: v = &ctx->md.cliques[e]; break;
+    case 1: v = &ctx->md.supernodes_orig[e]; break;
+    case 2: v = &ctx->md.separators_orig[e]; break;
+    case 3: v = &ctx->md.supernodes_pos[e]; break;
+    case 4: v = &ctx->md.separators_pos[e]; break;
+    default: return -1;
+  }
+  if (out) std::copy(v->begin(), v->end(), out);
+  return (int)v->size();
+}
+int cxk_get_supernode_sizes(const cxk_context* ctx, int* out) {
+  if (!ctx || !ctx->finalized) return 0;
+  std::copy(ctx->md.supernode_size.begin(), ctx->md.supernode_size.end(), out);
+  return ctx->md.K;
+}
+long cxk_slab_size(const cxk_context* ctx) { return ctx && ctx->finalized ? (long)ctx->lay.slab_size : 0; }
+int cxk_get_block_offsets(const cxk_context* ctx, long* diag_off, long* offd_off) {
+  if (!ctx || !ctx->finalized) return 0;
+  for (int e = 0; e < ctx->md.K; e++) {
+    diag_off[e] = (long)ctx->lay.diag_off[e];
+    offd_off[e] = (long)ctx->lay.offd_off[e];
+  }
+  return ctx->md.K;
+}
+int cxk_get_ss_index(const cxk_context* ctx, int e, long* out) {
+  if (!ctx || !ctx->finalized || e < 0 || e >= ctx->md.K) return -1;
+  const auto& v = ctx->lay.ss_index[e];
+  if (out)
+    for (size_t i = 0; i < v.size(); i++) out[i] = (long)v[i];
+  return (int)v.size();
+}
+int cxk_num_levels(const cxk_context* ctx) { return ctx ? (int)ctx->level_ptr.size() - 1 : 0; }
+
+// ------------------------------------------------------------- scaling point
+int cxk_dual_size(const cxk_context* ctx, int i) {
+  if (!ctx || i < 0 || i >= (int)ctx->cons.size()) return 0;
+  const ConstraintRec& c = ctx->cons[i];
+  switch (c.type) {
+    case CXK_LMI: return c.n * c.n;
+    case CXK_LINEAR: return c.n;
+    case CXK_SOC: return c.n + 1;
+    default: return 0;
+  }
+}
+
+int cxk_set_identity(cxk_context* ctx) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  for (Group& g : ctx->groups) {
+    const size_t cnt = g.ids.size();
+    if (cnt == 0) continue;
+    if (g.type == CXK_LMI)
+      lmi_set_identity<<<GridFor(cnt * g.n * g.n, 256), 256, 0, ctx->stream>>>(MakeLmi(g));
+    else if (g.type == CXK_LINEAR || g.type == CXK_SOC)
+      vec_set_identity<<<GridFor(cnt * (g.n + 1), 256), 256, 0, ctx->stream>>>(MakeVec(g),
+                                                                               g.type == CXK_SOC);
+  }
+  CXK_TRY(hipGetLastError());
+  return CXK_SUCCESS;
+}
+
+int cxk_get_W(cxk_context* ctx, int i, double* out) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_DEMAND(i >= 0 && i < (int)ctx->cons.size() && ctx->cons[i].group >= 0, "invalid constraint");
+  const ConstraintRec& c = ctx->cons[i];
+  const size_t sz = (size_t)cxk_dual_size(ctx, i);
+  if (sz == 0) return CXK_SUCCESS;
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(out, ctx->groups[c.group].W.p + sz * c.member, sz * sizeof(double),
+                    hipMemcpyDeviceToHost));
+  return CXK_SUCCESS;
+}
+
+int cxk_set_W(cxk_context* ctx, int i, const double* in) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_DEMAND(i >= 0 && i < (int)ctx->cons.size() && ctx->cons[i].group >= 0, "invalid constraint");
+  const ConstraintRec& c = ctx->cons[i];
+  const size_t sz = (size_t)cxk_dual_size(ctx, i);
+  if (sz == 0) return CXK_SUCCESS;
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(ctx->groups[c.group].W.p + sz * c.member, in, sz * sizeof(double),
+                    hipMemcpyHostToDevice));
+  return CXK_SUCCESS;
+}
+
+// ------------------------------------------------------------- Newton step
+int cxk_assemble_local(cxk_context* ctx) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  if (LaunchSchur(ctx)) return CXK_FAILURE;
+  return LaunchGather(ctx);
+}
+
+int cxk_finish_assemble(cxk_context* ctx) { return CheckReady(ctx); }
+
+int cxk_assemble(cxk_context* ctx) {
+  if (cxk_assemble_local(ctx)) return CXK_FAILURE;
+  return cxk_finish_assemble(ctx);
+}
+
+int cxk_factor(cxk_context* ctx, int* ok) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  if (LaunchFactor(ctx, false)) return CXK_FAILURE;
+  return cxk_sync(ctx, ok);
+}
+
+int cxk_sync(cxk_context* ctx, int* factor_ok) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  int fail = 0;
+  CXK_TRY(hipMemcpy(&fail, ctx->d_fail.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (factor_ok) *factor_ok = !fail;
+  // fold finished timing samples
+  for (size_t k = 0; k < ctx->ev_used; k++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev_pool[k].first, ctx->ev_pool[k].second) == hipSuccess) {
+      ctx->time_acc_ms += ms;
+      ctx->time_samples++;
+    }
+  }
+  ctx->ev_used = 0;
+  return CXK_SUCCESS;
+}
+
+int cxk_set_cost(cxk_context* ctx, const double* b) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  const int N = ctx->md.N;
+  std::vector<double> bp(N, 0.0);
+  for (int i = 0; i < N; i++) {
+    const int v = ctx->md.permutation_inverse[i];
+    bp[i] = v < ctx->num_vars ? b[v] : 0.0;  // multipliers carry zero cost
+  }
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(ctx->b.p, bp.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+  return CXK_SUCCESS;
+}
+
+int cxk_newton_direction(cxk_context* ctx, double k, double bs, double cs) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  const int N = ctx->md.N;
+  build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p,
+                                                      ctx->y.p);
+  if (LaunchForward(ctx)) return CXK_FAILURE;
+  return LaunchBackward(ctx);
+}
+
+int cxk_kkt_solve_async(cxk_context* ctx, double k, double bs, double cs) {
+  if (cxk_assemble_local(ctx)) return CXK_FAILURE;
+  const int N = ctx->md.N;
+  build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p,
+                                                      ctx->y.p);
+  if (LaunchFactor(ctx, true)) return CXK_FAILURE;
+  return LaunchBackward(ctx);
+}
+
+int cxk_solve_inplace(cxk_context* ctx, double* yh) {
+  if (cxk_set_y(ctx, yh)) return CXK_FAILURE;
+  if (LaunchForward(ctx)) return CXK_FAILURE;
+  if (LaunchBackward(ctx)) return CXK_FAILURE;
+  return cxk_get_y(ctx, yh);
+}
+
+int cxk_get_y(cxk_context* ctx, double* yh) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  const int N = ctx->md.N;
+  std::vector<double> yp(N);
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(yp.data(), ctx->y.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+  for (int i = 0; i < N; i++) yh[ctx->md.permutation_inverse[i]] = yp[i];
+  return CXK_SUCCESS;
+}
+
+int cxk_set_y(cxk_context* ctx, const double* yh) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  const int N = ctx->md.N;
+  std::vector<double> yp(N);
+  for (int i = 0; i < N; i++) yp[i] = yh[ctx->md.permutation_inverse[i]];
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(ctx->y.p, yp.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+  return CXK_SUCCESS;
+}
+
+int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_weight, double* info) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  StepArgs sa = MakeStep(ctx, ctx->info.p, affine, c_weight, e_weight, 1.0);
+  for (Group& g : ctx->groups) {
+    const int cnt = (int)g.ids.size();
+    if (cnt == 0) continue;
+    if (g.type == CXK_LMI)
+      lmi_prepare_generic<0><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
+    else if (g.type == CXK_LINEAR)
+      linear_prepare<0><<<cnt, 256, sizeof(double) * g.m, ctx->stream>>>(MakeVec(g), sa);
+    else if (g.type == CXK_SOC)
+      soc_prepare<0><<<cnt, 64, sizeof(double) * (size_t)(g.m + 3 * (g.n + 1)), ctx->stream>>>(
+          MakeVec(g), sa);
+  }
+  CXK_TRY(hipGetLastError());
+  if (affine) return CXK_SUCCESS;
+  reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), 0, ctx->info.p, ctx->d_mask.p,
+                                               ctx->red_out.p);
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(info, ctx->red_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost));
+  return CXK_SUCCESS;
+}
+
+int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_size) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  if (affine) return CXK_SUCCESS;  // the affine update is applied inside PrepareStep
+  StepArgs sa = MakeStep(ctx, ctx->info.p, affine, 0.0, e_weight, step_size);
+  for (Group& g : ctx->groups) {
+    const int cnt = (int)g.ids.size();
+    if (cnt == 0) continue;
+    if (g.type == CXK_LMI)
+      lmi_take_step_generic<<<cnt, 256, LmiTakeLds(g.n), ctx->stream>>>(MakeLmi(g), sa);
+    else if (g.type == CXK_LINEAR)
+      linear_take_step<<<GridFor((size_t)cnt * g.n, 256), 256, 0, ctx->stream>>>(MakeVec(g), sa);
+    else if (g.type == CXK_SOC)
+      soc_take_step<<<cnt, 64, sizeof(double) * (size_t)(4 * (g.n + 1)), ctx->stream>>>(MakeVec(g), sa);
+  }
+  CXK_TRY(hipGetLastError());
+  return CXK_SUCCESS;
+}
+
+int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* out) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  StepArgs sa = MakeStep(ctx, ctx->info.p, 0, c_weight, 0.0, 1.0);
+  for (Group& g : ctx->groups) {
+    const int cnt = (int)g.ids.size();
+    if (cnt == 0) continue;
+    if (g.type == CXK_LMI)
+      lmi_prepare_generic<1><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
+    else if (g.type == CXK_LINEAR)
+      linear_prepare<1><<<cnt, 256, sizeof(double) * g.m, ctx->stream>>>(MakeVec(g), sa);
+    else if (g.type == CXK_SOC)
+      soc_prepare<1><<<cnt, 64, sizeof(double) * (size_t)(g.m + 3 * (g.n + 1)), ctx->stream>>>(
+          MakeVec(g), sa);
+  }
+  reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), 1, ctx->info.p, ctx->d_mask.p,
+                                               ctx->red_out.p);
+  CXK_TRY(hipGetLastError());
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(out, ctx->red_out.p, 4 * sizeof(double), hipMemcpyDeviceToHost));
+  return CXK_SUCCESS;
+}
+
+// ------------------------------------------------------------- inspection
+int cxk_get_slab(cxk_context* ctx, double* out) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(out, ctx->slab.p, sizeof(double) * (size_t)ctx->lay.slab_size,
+                    hipMemcpyDeviceToHost));
+  return CXK_SUCCESS;
+}
+int cxk_set_slab(cxk_context* ctx, const double* in) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(ctx->slab.p, in, sizeof(double) * (size_t)ctx->lay.slab_size,
+                    hipMemcpyHostToDevice));
+  return CXK_SUCCESS;
+}
+int cxk_get_constraint_schur(cxk_context* ctx, int i, double* G, double* AW, double* AQc,
+                             double* scalars) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_DEMAND(i >= 0 && i < (int)ctx->cons.size(), "invalid constraint");
+  const int m = ctx->cons[i].m;
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  if (G)
+    CXK_TRY(hipMemcpy(G, ctx->G.p + ctx->g_off[i], sizeof(double) * (size_t)m * m,
+                      hipMemcpyDeviceToHost));
+  if (AW)
+    CXK_TRY(hipMemcpy(AW, ctx->AWc.p + ctx->r_off[i], sizeof(double) * m, hipMemcpyDeviceToHost));
+  if (AQc)
+    CXK_TRY(hipMemcpy(AQc, ctx->AQcc.p + ctx->r_off[i], sizeof(double) * m, hipMemcpyDeviceToHost));
+  if (scalars)
+    CXK_TRY(hipMemcpy(scalars, ctx->sc.p + 2 * i, sizeof(double) * 2, hipMemcpyDeviceToHost));
+  return CXK_SUCCESS;
+}
+int cxk_get_residuals(cxk_context* ctx, double* AW, double* AQc, double* scalars) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  const int N = ctx->md.N;
+  std::vector<double> t(N);
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  if (AW) {
+    CXK_TRY(hipMemcpy(t.data(), ctx->AW.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; i++) AW[ctx->md.permutation_inverse[i]] = t[i];
+  }
+  if (AQc) {
+    CXK_TRY(hipMemcpy(t.data(), ctx->AQc.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; i++) AQc[ctx->md.permutation_inverse[i]] = t[i];
+  }
+  if (scalars) CXK_TRY(hipMemcpy(scalars, ctx->sys_sc.p, sizeof(double) * 2, hipMemcpyDeviceToHost));
+  return CXK_SUCCESS;
+}
+
+int cxk_exchange_buffer(cxk_context* ctx, void** dev_ptr, long* count) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  *dev_ptr = ctx->slab.p;
+  *count = (long)ctx->lay.slab_size;
+  return CXK_SUCCESS;
+}
+
+int cxk_assembly_work(const cxk_context* ctx, double* bytes, double* flops) {
+  if (!ctx || !ctx->finalized) return CXK_FAILURE;
+  double B = 0, F = 0;
+  for (size_t i = 0; i < ctx->cons.size(); i++) {
+    const ConstraintRec& c = ctx->cons[i];
+    if (c.type != CXK_LMI || !ctx->owned[i]) continue;
+    const double n = c.n, m = c.m;
+    // FLOPs = 4 n^3 (m+1) + n^2 (m^2 + 3m + 4) + n m ; bytes = 8 [m n^2 + 2 n^2 + m(m+1)/2 + 2m]
+    F += 4 * n * n * n * (m + 1) + n * n * (m * m + 3 * m + 4) + n * m;
+    B += 8.0 * (m * n * n + 2 * n * n + m * (m + 1) / 2 + 2 * m);
+  }
+  if (bytes) *bytes = B;
+  if (flops) *flops = F;
+  return CXK_SUCCESS;
+}
+
+int cxk_enable_timing(cxk_context* ctx, int on) {
+  if (!ctx) return CXK_FAILURE;
+  ctx->timing = on != 0;
+  return CXK_SUCCESS;
+}
+
+int cxk_kernel_time(cxk_context* ctx, int reset, double* avg_ms) {
+  if (!ctx) return 0;
+  const int n = ctx->time_samples;
+  if (avg_ms) *avg_ms = n ? ctx->time_acc_ms / n : 0.0;
+  if (reset) {
+    ctx->time_acc_ms = 0;
+    ctx->time_samples = 0;
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,380 @@
+"""ctypes binding of the cxk_* C-ABI (include/conex_kkt_hip.h).
+
+Mirrors conex::Program / SupernodalKKTSolver method names (cone_program.h:99-233,
+kkt_solver.h:16-65) so parity tests read like the reference's own tests.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libconex.so")
+_LIB = None
+
+c_int_p = C.POINTER(C.c_int)
+c_long_p = C.POINTER(C.c_long)
+c_double_p = C.POINTER(C.c_double)
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+def _lp(a):
+    return a.ctypes.data_as(c_long_p)
+
+
+_SIGNATURES = {
+    "cxk_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "cxk_destroy": (None, [C.c_void_p]),
+    "cxk_last_error": (C.c_char_p, [C.c_void_p]),
+    "cxk_add_lmi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
+    "cxk_add_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
+    "cxk_add_soc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
+    "cxk_add_static": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_int_p]),
+    "cxk_num_constraints": (C.c_int, [C.c_void_p]),
+    "cxk_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "cxk_finalize": (C.c_int, [C.c_void_p]),
+    "cxk_system_size": (C.c_int, [C.c_void_p]),
+    "cxk_get_order": (C.c_int, [C.c_void_p, c_int_p]),
+    "cxk_get_permutation": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    "cxk_get_list": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int_p]),
+    "cxk_get_supernode_sizes": (C.c_int, [C.c_void_p, c_int_p]),
+    "cxk_slab_size": (C.c_long, [C.c_void_p]),
+    "cxk_get_block_offsets": (C.c_int, [C.c_void_p, c_long_p, c_long_p]),
+    "cxk_get_ss_index": (C.c_int, [C.c_void_p, C.c_int, c_long_p]),
+    "cxk_num_levels": (C.c_int, [C.c_void_p]),
+    "cxk_set_identity": (C.c_int, [C.c_void_p]),
+    "cxk_dual_size": (C.c_int, [C.c_void_p, C.c_int]),
+    "cxk_get_W": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+    "cxk_set_W": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+    "cxk_assemble": (C.c_int, [C.c_void_p]),
+    "cxk_factor": (C.c_int, [C.c_void_p, c_int_p]),
+    "cxk_set_cost": (C.c_int, [C.c_void_p, c_double_p]),
+    "cxk_newton_direction": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "cxk_kkt_solve_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "cxk_sync": (C.c_int, [C.c_void_p, c_int_p]),
+    "cxk_solve_inplace": (C.c_int, [C.c_void_p, c_double_p]),
+    "cxk_get_y": (C.c_int, [C.c_void_p, c_double_p]),
+    "cxk_set_y": (C.c_int, [C.c_void_p, c_double_p]),
+    "cxk_prepare_step": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, c_double_p]),
+    "cxk_take_step": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double]),
+    "cxk_weighted_slack_eigenvalues": (C.c_int, [C.c_void_p, C.c_double, c_double_p]),
+    "cxk_get_slab": (C.c_int, [C.c_void_p, c_double_p]),
+    "cxk_set_slab": (C.c_int, [C.c_void_p, c_double_p]),
+    "cxk_get_constraint_schur": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p,
+                                           c_double_p, c_double_p]),
+    "cxk_get_residuals": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
+    "cxk_exchange_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_long_p]),
+    "cxk_assemble_local": (C.c_int, [C.c_void_p]),
+    "cxk_finish_assemble": (C.c_int, [C.c_void_p]),
+    "cxk_assembly_work": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "cxk_kernel_time": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
+    "cxk_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+}
+
+
+def load_library():
+    """Load libconex.so; raises (loudly) when the HIP library has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP library first (python __graft_entry__.py or "
+            "make -C conex_amd/csrc). There is no CPU fallback for the KKT path.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if an ABI symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def _colmajor(a):
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 2:
+        return np.ascontiguousarray(a.T).ravel()
+    if a.ndim == 3:
+        return np.ascontiguousarray(np.transpose(a, (0, 2, 1))).ravel()
+    return np.ascontiguousarray(a).ravel()
+
+
+class KktError(RuntimeError):
+    pass
+
+
+class KktContext:
+    """Device-resident cone program (one HIP device, one stream)."""
+
+    def __init__(self, num_vars, device=0, stream=None):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.cxk_create(num_vars, device, C.c_void_p(stream) if stream else None,
+                               C.byref(h))
+        if rc != 0:
+            raise KktError(f"cxk_create failed for device {device} (no usable HIP device?)")
+        self.h = h
+        self.num_vars = num_vars
+        self.cons = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cxk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise KktError(f"{what}: {self.L.cxk_last_error(self.h).decode()}")
+
+    @staticmethod
+    def _vars(v):
+        if v is None:
+            return None, None
+        a = np.ascontiguousarray(v, dtype=np.int32)
+        return a, _ip(a)
+
+    # ---- construction
+    def add_lmi(self, A, Cm, vars_=None):
+        A = np.asarray(A, dtype=np.float64)
+        m, n = A.shape[0], A.shape[1]
+        a, c = _colmajor(A), _colmajor(np.asarray(Cm, dtype=np.float64))
+        keep, vp = self._vars(vars_)
+        r = self.L.cxk_add_lmi(self.h, n, m, _dp(a), _dp(c), vp)
+        if r >= 0:
+            self.cons.append(("lmi", n, m))
+        return r
+
+    def add_linear(self, A, c, vars_=None):
+        A = np.asarray(A, dtype=np.float64)
+        rows, m = A.shape
+        a = _colmajor(A)
+        cc = np.ascontiguousarray(np.asarray(c, dtype=np.float64).ravel())
+        keep, vp = self._vars(vars_)
+        r = self.L.cxk_add_linear(self.h, rows, m, _dp(a), _dp(cc), vp)
+        if r >= 0:
+            self.cons.append(("linear", rows, m))
+        return r
+
+    def add_soc(self, A, c, vars_=None):
+        A = np.asarray(A, dtype=np.float64)
+        n1, m = A.shape
+        a = _colmajor(A)
+        cc = np.ascontiguousarray(np.asarray(c, dtype=np.float64).ravel())
+        keep, vp = self._vars(vars_)
+        r = self.L.cxk_add_soc(self.h, n1 - 1, m, _dp(a), _dp(cc), vp)
+        if r >= 0:
+            self.cons.append(("soc", n1 - 1, m))
+        return r
+
+    def add_static(self, G, vars_):
+        G = np.asarray(G, dtype=np.float64)
+        m = G.shape[0]
+        g = _colmajor(G)
+        keep, vp = self._vars(vars_)
+        r = self.L.cxk_add_static(self.h, m, _dp(g), vp)
+        if r >= 0:
+            self.cons.append(("static", 0, m))
+        return r
+
+    def set_shard(self, rank, world):
+        self._check(self.L.cxk_set_shard(self.h, rank, world), "cxk_set_shard")
+
+    def initialize(self):
+        self._check(self.L.cxk_finalize(self.h), "cxk_finalize")
+        return 1
+
+    # ---- symbolic
+    @property
+    def K(self):
+        return self.L.cxk_num_constraints(self.h)
+
+    @property
+    def N(self):
+        return self.L.cxk_system_size(self.h)
+
+    def order(self):
+        o = np.zeros(self.K, dtype=np.int32)
+        self.L.cxk_get_order(self.h, _ip(o))
+        return o
+
+    def permutation(self):
+        n = max(self.num_vars, self.N) + 1
+        p = np.zeros(n, dtype=np.int32)
+        q = np.zeros(n, dtype=np.int32)
+        k = self.L.cxk_get_permutation(self.h, _ip(p), _ip(q))
+        return p[:k], q[:k]
+
+    def get_list(self, which, e):
+        n = self.L.cxk_get_list(self.h, which, e, None)
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        self.L.cxk_get_list(self.h, which, e, _ip(out))
+        return out[:n]
+
+    def supernode_sizes(self):
+        o = np.zeros(self.K, dtype=np.int32)
+        self.L.cxk_get_supernode_sizes(self.h, _ip(o))
+        return o
+
+    def slab_size(self):
+        return self.L.cxk_slab_size(self.h)
+
+    def block_offsets(self):
+        d = np.zeros(self.K, dtype=np.int64)
+        o = np.zeros(self.K, dtype=np.int64)
+        self.L.cxk_get_block_offsets(self.h, _lp(d), _lp(o))
+        return d, o
+
+    def ss_index(self, e):
+        n = self.L.cxk_get_ss_index(self.h, e, None)
+        out = np.zeros(max(n, 1), dtype=np.int64)
+        self.L.cxk_get_ss_index(self.h, e, _lp(out))
+        return out[:n]
+
+    def num_levels(self):
+        return self.L.cxk_num_levels(self.h)
+
+    # ---- numeric
+    def set_identity(self):
+        self._check(self.L.cxk_set_identity(self.h), "cxk_set_identity")
+
+    def get_W(self, i):
+        n = self.L.cxk_dual_size(self.h, i)
+        w = np.zeros(max(n, 1))
+        self._check(self.L.cxk_get_W(self.h, i, _dp(w)), "cxk_get_W")
+        return w[:n]
+
+    def set_W(self, i, w):
+        w = np.ascontiguousarray(np.asarray(w, dtype=np.float64).ravel())
+        self._check(self.L.cxk_set_W(self.h, i, _dp(w)), "cxk_set_W")
+
+    def assemble(self):
+        self._check(self.L.cxk_assemble(self.h), "cxk_assemble")
+
+    def slab(self):
+        s = np.zeros(self.slab_size())
+        self._check(self.L.cxk_get_slab(self.h, _dp(s)), "cxk_get_slab")
+        return s
+
+    def set_slab(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float64)
+        self._check(self.L.cxk_set_slab(self.h, _dp(s)), "cxk_set_slab")
+
+    def constraint_schur(self, i):
+        m = self.cons[i][2]
+        G = np.zeros(m * m)
+        AW = np.zeros(m)
+        AQc = np.zeros(m)
+        sc = np.zeros(2)
+        self._check(self.L.cxk_get_constraint_schur(self.h, i, _dp(G), _dp(AW), _dp(AQc), _dp(sc)),
+                    "cxk_get_constraint_schur")
+        return G.reshape(m, m).T.copy(), AW, AQc, sc
+
+    def residuals(self):
+        N = self.N
+        AW = np.zeros(N)
+        AQc = np.zeros(N)
+        sc = np.zeros(2)
+        self._check(self.L.cxk_get_residuals(self.h, _dp(AW), _dp(AQc), _dp(sc)),
+                    "cxk_get_residuals")
+        return AW, AQc, sc
+
+    def factor(self):
+        ok = C.c_int(0)
+        self._check(self.L.cxk_factor(self.h, C.byref(ok)), "cxk_factor")
+        return ok.value
+
+    def solve_inplace(self, y):
+        y = np.ascontiguousarray(y, dtype=np.float64).copy()
+        self._check(self.L.cxk_solve_inplace(self.h, _dp(y)), "cxk_solve_inplace")
+        return y
+
+    def set_cost(self, b):
+        b = np.ascontiguousarray(np.asarray(b, dtype=np.float64).ravel())
+        self._check(self.L.cxk_set_cost(self.h, _dp(b)), "cxk_set_cost")
+
+    def newton_direction(self, inv_sqrt_mu, b_scaling=1.0, c_scaling=1.0):
+        self._check(self.L.cxk_newton_direction(self.h, inv_sqrt_mu, b_scaling, c_scaling),
+                    "cxk_newton_direction")
+
+    def kkt_solve_async(self, inv_sqrt_mu, b_scaling=1.0, c_scaling=1.0):
+        self._check(self.L.cxk_kkt_solve_async(self.h, inv_sqrt_mu, b_scaling, c_scaling),
+                    "cxk_kkt_solve_async")
+
+    def sync(self):
+        ok = C.c_int(0)
+        self._check(self.L.cxk_sync(self.h, C.byref(ok)), "cxk_sync")
+        return ok.value
+
+    def kkt_solve(self, b, inv_sqrt_mu, b_scaling=1.0, c_scaling=1.0):
+        self.set_cost(b)
+        self.kkt_solve_async(inv_sqrt_mu, b_scaling, c_scaling)
+        ok = self.sync()
+        return ok, self.get_y()
+
+    def get_y(self):
+        y = np.zeros(self.N)
+        self._check(self.L.cxk_get_y(self.h, _dp(y)), "cxk_get_y")
+        return y
+
+    def set_y(self, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        self._check(self.L.cxk_set_y(self.h, _dp(y)), "cxk_set_y")
+
+    def prepare_step(self, y, c_weight, e_weight=1.0, affine=0):
+        if y is not None:
+            self.set_y(y)
+        info = np.zeros(2)
+        self._check(self.L.cxk_prepare_step(self.h, affine, c_weight, e_weight, _dp(info)),
+                    "cxk_prepare_step")
+        return info
+
+    def take_step(self, step_size, e_weight=1.0, affine=0):
+        self._check(self.L.cxk_take_step(self.h, affine, e_weight, step_size), "cxk_take_step")
+
+    def weighted_slack_eigenvalues(self, y, c_weight):
+        if y is not None:
+            self.set_y(y)
+        out = np.zeros(4)
+        self._check(self.L.cxk_weighted_slack_eigenvalues(self.h, c_weight, _dp(out)),
+                    "cxk_weighted_slack_eigenvalues")
+        return out
+
+    # ---- multi-GPU exchange / accounting
+    def exchange_buffer(self):
+        p = C.c_void_p()
+        n = C.c_long()
+        self._check(self.L.cxk_exchange_buffer(self.h, C.byref(p), C.byref(n)),
+                    "cxk_exchange_buffer")
+        return p.value, n.value
+
+    def assemble_local(self):
+        self._check(self.L.cxk_assemble_local(self.h), "cxk_assemble_local")
+
+    def finish_assemble(self):
+        self._check(self.L.cxk_finish_assemble(self.h), "cxk_finish_assemble")
+
+    def assembly_work(self):
+        b = C.c_double()
+        f = C.c_double()
+        self.L.cxk_assembly_work(self.h, C.byref(b), C.byref(f))
+        return b.value, f.value
+
+    def enable_timing(self, on=True):
+        self.L.cxk_enable_timing(self.h, int(on))
+
+    def kernel_time(self, reset=True):
+        ms = C.c_double()
+        n = self.L.cxk_kernel_time(self.h, int(reset), C.byref(ms))
+        return n, ms.value

@@ -1,0 +1,116 @@
+"""Seeded synthetic cone programs of the BASELINE.json shapes.
+
+Data only (numpy); used by tests/ and bench.py to feed the same inputs to the HIP path and
+to the CPU oracle.  Values are uniform in [-1, 1] to mirror Eigen's MatrixXd::Random used by
+the reference's tests (conex/test/test_util.cc:19,67-73).
+"""
+import numpy as np
+
+SEED = 20201
+
+
+def random_sym(rng, n):
+    R = rng.uniform(-1.0, 1.0, (n, n))
+    return 0.5 * (R + R.T)
+
+
+def tree_cliques(K, branching=8, clique_size=20, overlap=5):
+    """C4 structure: b-ary tree of cliques; child shares `overlap` of its parent's own variables."""
+    fresh = clique_size - overlap
+    groups = max(1, fresh // overlap)
+    cliques = [list(range(clique_size))]
+    for c in range(1, K):
+        p = (c - 1) // branching
+        start_p = 0 if p == 0 else clique_size + fresh * (p - 1)
+        g = (c - 1) % groups
+        shared = [start_p + overlap * g + t for t in range(overlap)]
+        own = [clique_size + fresh * (c - 1) + t for t in range(fresh)]
+        cliques.append(shared + own)
+    num_vars = clique_size + fresh * (K - 1)
+    return cliques, num_vars
+
+
+def chain_cliques(K, clique_size=10, overlap=2):
+    """C3 structure: clique k = {(s-o)k .. (s-o)k + s-1}."""
+    step = clique_size - overlap
+    cliques = [list(range(step * k, step * k + clique_size)) for k in range(K)]
+    return cliques, step * (K - 1) + clique_size
+
+
+def lmi_problem(K=1000, n=20, m=20, branching=8, overlap=5, seed=SEED):
+    """Chordal SDP: K dense LMIs of order n over m variables each, C = I.
+
+    Returns dict(A: (K, m, n, n), C: (K, n, n), cliques, num_vars, b).
+    b is the scatter of 1/2 tr(A_ci) (GetFeasibleObjective at W = I, cone_program.cc:535-545).
+    """
+    rng = np.random.default_rng(seed)
+    cliques, num_vars = tree_cliques(K, branching, m, overlap)
+    A = rng.uniform(-1.0, 1.0, (K, m, n, n))
+    A = 0.5 * (A + np.transpose(A, (0, 1, 3, 2)))
+    Cm = np.broadcast_to(np.eye(n), (K, n, n)).copy()
+    b = np.zeros(num_vars)
+    for c in range(K):
+        b[cliques[c]] += 0.5 * np.trace(A[c], axis1=1, axis2=2)
+    return dict(A=A, C=Cm, cliques=cliques, num_vars=num_vars, b=b, n=n, m=m)
+
+
+def scaling_points(K, n, seed=SEED + 1, scale=0.3):
+    """W_c = expm(scale * sym(R)): symmetric positive definite, W != I."""
+    rng = np.random.default_rng(seed)
+    W = np.empty((K, n, n))
+    for c in range(K):
+        S = random_sym(rng, n) * scale
+        lam, Q = np.linalg.eigh(S)
+        W[c] = (Q * np.exp(lam)) @ Q.T
+        W[c] = 0.5 * (W[c] + W[c].T)
+    return W
+
+
+def lp_problem(rows=20, num_vars=10, seed=SEED):
+    """C1: one dense linear inequality block (test_lp.cc:19-36)."""
+    rng = np.random.default_rng(seed)
+    A = rng.uniform(-1, 1, (rows, num_vars))
+    c = np.abs(rng.uniform(-1, 1, rows))
+    x0 = np.abs(rng.uniform(-1, 1, rows))
+    x0 *= 0.01 / np.linalg.norm(x0)
+    return dict(A=A, c=c, b=A.T @ x0)
+
+
+def soc_problem(K=5000, dim=10, m=10, overlap=2, seed=SEED):
+    """C3: K second-order cones in R^{dim+1}, chain overlap."""
+    rng = np.random.default_rng(seed)
+    cliques, num_vars = chain_cliques(K, m, overlap)
+    A = rng.uniform(-1, 1, (K, dim + 1, m))
+    c = np.zeros((K, dim + 1))
+    c[:, 0] = 1.0
+    b = np.zeros(num_vars)
+    for k in range(K):
+        b[cliques[k]] += A[k].T @ c[k]
+    return dict(A=A, c=c, cliques=cliques, num_vars=num_vars, b=b)
+
+
+def soc_scaling_points(K, dim, seed=SEED + 2):
+    rng = np.random.default_rng(seed)
+    W = np.zeros((K, dim + 1))
+    W[:, 1:] = rng.uniform(-0.3, 0.3, (K, dim))
+    W[:, 0] = np.linalg.norm(W[:, 1:], axis=1) + rng.uniform(0.5, 1.5, K)
+    return W
+
+
+def build(ctx_cls, prob, kind="lmi", **kw):
+    """Instantiate `ctx_cls(num_vars, **kw)` (oracle Program or KktContext) from a problem dict."""
+    if kind == "lmi":
+        p = ctx_cls(prob["num_vars"], **kw)
+        for c, cl in enumerate(prob["cliques"]):
+            assert p.add_lmi(prob["A"][c], prob["C"][c], cl) == c
+    elif kind == "soc":
+        p = ctx_cls(prob["num_vars"], **kw)
+        for c, cl in enumerate(prob["cliques"]):
+            assert p.add_soc(prob["A"][c], prob["c"][c], cl) == c
+    elif kind == "lp":
+        p = ctx_cls(prob["A"].shape[1], **kw)
+        assert p.add_linear(prob["A"], prob["c"]) == 0
+    else:
+        raise ValueError(kind)
+    p.initialize()
+    return p

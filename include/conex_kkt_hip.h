@@ -1,0 +1,146 @@
+/*
+ * conex_kkt_hip.h -- C-ABI of the MI355X-native Newton-step KKT path.
+ *
+ * This is the "inner" drop-in boundary: the device-resident replacement for
+ * what conex/cone_program.cc::Solve calls per IPM iteration.  The "outer"
+ * boundary (the reference's interfaces/conex.h, 21 CONEX_* functions) is in
+ * include/conex.h and is implemented on top of these entry points.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types cross the boundary
+ *   - all matrices column-major fp64, all indices 32-bit int (as the reference)
+ *   - every function returns 0 on success (CONEX_SUCCESS polarity,
+ *     conex/error_codes.h) unless documented otherwise; no exception escapes
+ *   - a context is bound to ONE HIP device and ONE stream and is not re-entrant
+ *     (the reference's Program is not thread-safe either: kkt_solver.h:58,62)
+ *   - host arrays are copied at call time (interfaces/conex.cc:143-159)
+ *
+ * Each entry point cites the reference interface it replaces.
+ */
+#ifndef CONEX_KKT_HIP_H
+#define CONEX_KKT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cxk_context cxk_context;
+
+enum { CXK_SUCCESS = 0, CXK_FAILURE = 1 };
+
+/* cone types; the plugin surface of conex/constraint.h:51-197 */
+enum {
+  CXK_LMI = 0,    /* DenseLMIConstraint  dense_lmi_constraint.h:24-41 */
+  CXK_LINEAR = 1, /* LinearConstraint    linear_constraint.h:14-84 */
+  CXK_SOC = 2,    /* SOCConstraint       soc_constraint.h:6-54 */
+  CXK_STATIC = 3  /* constant Schur block: QuadraticFunction quadratic_cost.cc:18-69,
+                     SupernodalAssemblerStatic supernodal_assembler.h:122-129 */
+};
+
+/* ---- lifetime --------------------------------------------------------- */
+/* Program(int number_of_variables) cone_program.h:101-104.
+ * device < 0: host-only context (symbolic analysis works, numeric calls fail loudly).
+ * stream: a hipStream_t (NULL = the device's null stream). */
+int cxk_create(int num_vars, int device, void* stream, cxk_context** out);
+void cxk_destroy(cxk_context* ctx);
+const char* cxk_last_error(const cxk_context* ctx);
+
+/* ---- constraint plugins: Program::AddConstraint(T, variables) cone_program.h:192-218,
+ *      ConstraintManager::AddConstraint constraint_manager.h:50-64 (IsUnique check).
+ *      Return the constraint id (>= 0) or -1 when rejected. vars == NULL means 0..num_vars-1. */
+int cxk_add_lmi(cxk_context* ctx, int n, int m, const double* A /* m x (n x n) */,
+                const double* C /* n x n */, const int* vars);
+int cxk_add_linear(cxk_context* ctx, int rows, int m, const double* A /* rows x m */,
+                   const double* c /* rows */, const int* vars);
+int cxk_add_soc(cxk_context* ctx, int n, int m, const double* A /* (n+1) x m */,
+                const double* c /* n+1 */, const int* vars);
+int cxk_add_static(cxk_context* ctx, int m, const double* G /* m x m */, const int* vars);
+int cxk_num_constraints(const cxk_context* ctx);
+
+/* Multi-GPU sharding (no reference counterpart -- the reference is single
+ * process).  Must precede cxk_finalize.  This context then assembles/updates only the
+ * constraints it owns (round-robin over elimination subtrees) and exposes a contiguous
+ * exchange slab that the caller sum-reduces across ranks (RCCL all-reduce). */
+int cxk_set_shard(cxk_context* ctx, int rank, int world_size);
+
+/* Initialize(): symbolic analysis (SupernodalKKTSolver ctor kkt_solver.cc:104-116),
+ * Bind (kkt_solver.h:26-33), workspace carve + SetIdentity (cone_program.cc:78-112),
+ * upload of constant data, construction of device index tables and level schedule. */
+int cxk_finalize(cxk_context* ctx);
+
+/* ---- symbolic results (MatrixData supernodal_solver.h:18-29; bit-exact vs reference) */
+int cxk_system_size(const cxk_context* ctx); /* N */
+int cxk_get_order(const cxk_context* ctx, int* order /* K */);
+int cxk_get_permutation(const cxk_context* ctx, int* perm, int* perm_inv /* num_vars */);
+/* which: 0 cliques(permuted) 1 supernodes_orig 2 separators_orig 3 supernodes_pos
+ *        4 separators_pos ; returns length (out may be NULL) */
+int cxk_get_list(const cxk_context* ctx, int which, int e, int* out);
+int cxk_get_supernode_sizes(const cxk_context* ctx, int* out /* K */);
+long cxk_slab_size(const cxk_context* ctx);
+int cxk_get_block_offsets(const cxk_context* ctx, long* diag_off, long* offd_off /* K */);
+int cxk_get_ss_index(const cxk_context* ctx, int e, long* out); /* returns count */
+int cxk_num_levels(const cxk_context* ctx);
+
+/* ---- scaling point W (workspace()->W, constraint.h:159-167) ------------ */
+int cxk_set_identity(cxk_context* ctx);                       /* SetIdentity */
+int cxk_dual_size(const cxk_context* ctx, int i);
+int cxk_get_W(cxk_context* ctx, int i, double* out);          /* get_dual_variable */
+int cxk_set_W(cxk_context* ctx, int i, const double* in);     /* warm start import */
+
+/* ---- Newton step, device resident ------------------------------------- */
+/* solver->Assemble() + AssembleSchurComplementResiduals  cone_program.cc:338-341 */
+int cxk_assemble(cxk_context* ctx);
+/* solver->Factor() kkt_solver.cc:172-199 (LLT mode). *ok = 1 success, 0 not PD. Syncs. */
+int cxk_factor(cxk_context* ctx, int* ok);
+/* y_dev = inv_sqrt_mu*(b*b_scaling + AQc*c_scaling) - 2 AW  cone_program.cc:409-411,
+ * followed by solver->SolveInPlace(&y) kkt_solver.cc:220-263.  No host sync. */
+int cxk_set_cost(cxk_context* ctx, const double* b /* num_vars, host */);
+int cxk_newton_direction(cxk_context* ctx, double inv_sqrt_mu, double b_scaling,
+                         double c_scaling);
+/* whole BASELINE metric unit: assemble + factor + rhs + solve, asynchronous on the stream;
+ * factor status is latched and returned by cxk_sync. */
+int cxk_kkt_solve_async(cxk_context* ctx, double inv_sqrt_mu, double b_scaling,
+                        double c_scaling);
+int cxk_sync(cxk_context* ctx, int* factor_ok);
+/* SolveInPlace on a host vector of length N (copy in, solve, copy out). */
+int cxk_solve_inplace(cxk_context* ctx, double* y);
+int cxk_get_y(cxk_context* ctx, double* y /* N, original variable order */);
+int cxk_set_y(cxk_context* ctx, const double* y);
+
+/* PrepareStep over all constraints (cone_program.h:69-90); info = {normsqrd, norminfd}.
+ * Uses the device-resident y.  Syncs (returns two scalars). */
+int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_weight,
+                     double* info);
+/* TakeStep (cone_program.h:92-97) */
+int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_size);
+/* GetWeightedSlackEigenvalues (cone_program.cc:31-57) on the device-resident y;
+ * out = {lambda_min, lambda_max, frobenius_norm_squared, trace} */
+int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* out);
+
+/* ---- inspection (tests, KKTMatrix() kkt_solver.cc:265-269) ------------- */
+int cxk_get_slab(cxk_context* ctx, double* out);
+int cxk_set_slab(cxk_context* ctx, const double* in);
+int cxk_get_constraint_schur(cxk_context* ctx, int i, double* G /* m*m lower */, double* AW,
+                             double* AQc, double* scalars /* 2 */);
+int cxk_get_residuals(cxk_context* ctx, double* AW /* N */, double* AQc /* N */,
+                      double* scalars /* 2 */);
+
+/* ---- multi-GPU exchange ------------------------------------ */
+/* device pointer + length (doubles) of the buffer to all-reduce(sum) between
+ * cxk_assemble_local and cxk_finish_assemble */
+int cxk_exchange_buffer(cxk_context* ctx, void** dev_ptr, long* count);
+int cxk_assemble_local(cxk_context* ctx);
+int cxk_finish_assemble(cxk_context* ctx);
+
+/* ---- timing / roofline accounting -------------------------------------- */
+/* algorithmic bytes and flops of one dense-LMI assembly launch (SURVEY 8d formulas) */
+int cxk_assembly_work(const cxk_context* ctx, double* bytes, double* flops);
+/* average device time (ms) of the dominant assembly kernel since the last reset, measured
+ * with hipEvents on the context's stream; returns number of samples */
+int cxk_kernel_time(cxk_context* ctx, int reset, double* avg_ms);
+int cxk_enable_timing(cxk_context* ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

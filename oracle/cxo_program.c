@@ -514,6 +514,9 @@ static void update_blocks(cxo_program* p, cxo_constraint* o) {
   double* D = w->slab + w->diag_off[e];
   double* B = w->slab + w->offd_off[e];
   if (o->direct_update) {
+    /* G aliases the diagonal block, which descendants scatter into later in this pass; keep a
+     * pristine copy of the constraint's own Schur block for inspection (test hook only). */
+    memcpy(o->G_own, o->G, sizeof(double) * (size_t)o->m * o->m);
     if (ns > 0 && nsep > 0) memset(B, 0, sizeof(double) * (size_t)ns * nsep);
     return;
   }
@@ -558,7 +561,7 @@ void cxo_get_slab(const cxo_program* p, double* out) {
 void cxo_get_constraint_schur(const cxo_program* p, int i, double* G, double* AW, double* AQc,
                               double* scalars) {
   const cxo_constraint* c = &p->c[i];
-  if (G) memcpy(G, c->G, sizeof(double) * (size_t)c->m * c->m);
+  if (G) memcpy(G, c->G_own, sizeof(double) * (size_t)c->m * c->m);
   if (AW) memcpy(AW, c->AW, sizeof(double) * (size_t)c->m);
   if (AQc) memcpy(AQc, c->AQc, sizeof(double) * (size_t)c->m);
   if (scalars) {

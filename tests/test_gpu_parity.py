@@ -1,0 +1,207 @@
+"""Parity of the HIP Newton-step path (through the cxk_* C-ABI) with the CPU oracle.
+
+Bars: integer/index structures bit-exact (tests/test_symbolic_parity.py); floating point --
+per-constraint Schur blocks and the assembled slab <= 1e-13 relative, the Newton direction
+<= 1e-10 relative norm (BASELINE.json north_star), scaling-point updates <= 1e-11.
+All tests need a real MI355X.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conex_amd import KktContext
+from conex_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+TOL_SCHUR = 1e-13
+TOL_DIRECTION = 1e-10
+TOL_UPDATE = 1e-11
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    d = np.linalg.norm(a - b)
+    n = np.linalg.norm(b)
+    return d / n if n > 0 else d
+
+
+def make_pair(prob, kind, W=None):
+    o = syn.build(ol.Program, prob, kind)
+    k = syn.build(KktContext, prob, kind, device=0)
+    if W is not None:
+        for i in range(o.K):
+            o.set_W(i, W[i])
+            k.set_W(i, W[i])
+    return o, k
+
+
+def check_newton_step(o, k, b, inv_sqrt_mu=0.7, bs=0.9, cs=0.8, check_update=True):
+    """assemble -> factor -> solve -> prepare -> take step, compared stage by stage."""
+    o.assemble()
+    k.assemble()
+    for i in range(0, o.K, max(1, o.K // 7)):
+        Go, AWo, AQo, sco = o.constraint_schur(i)
+        Gk, AWk, AQk, sck = k.constraint_schur(i)
+        assert rel(np.tril(Gk), np.tril(Go)) <= TOL_SCHUR
+        assert rel(AWk, AWo) <= TOL_SCHUR and rel(AQk, AQo) <= TOL_SCHUR
+        assert rel(sck, sco) <= TOL_SCHUR
+    assert rel(k.slab(), o.slab()) <= TOL_SCHUR
+    AWo, AQo, sco = o.residuals()
+    AWk, AQk, sck = k.residuals()
+    assert rel(AWk, AWo) <= TOL_SCHUR and rel(AQk, AQo) <= TOL_SCHUR and rel(sck, sco) <= 1e-12
+
+    assert o.factor() == 1
+    assert k.factor() == 1
+    assert rel(k.slab(), o.slab()) <= 1e-11
+
+    N = o.N
+    bb = np.zeros(N)
+    bb[:len(b)] = b
+    rhs = inv_sqrt_mu * (bb * bs + AQo * cs) - 2 * AWo
+    yo = o.solve_inplace(rhs)
+    k.set_cost(b)
+    k.newton_direction(inv_sqrt_mu, bs, cs)
+    yk = k.get_y()
+    assert rel(yk, yo) <= TOL_DIRECTION
+    # solve_inplace on an arbitrary host vector
+    assert rel(k.solve_inplace(rhs), yo) <= TOL_DIRECTION
+
+    if not check_update:
+        return yo
+    c_weight = inv_sqrt_mu * cs
+    eo = o.weighted_slack_eigenvalues(yo, c_weight)
+    ek = k.weighted_slack_eigenvalues(yo, c_weight)
+    assert rel(ek, eo) <= 1e-9
+    io = o.prepare_step(yo, c_weight, 1.0)
+    ik = k.prepare_step(yo, c_weight, 1.0)
+    assert rel(ik, io) <= 1e-9
+    step = min(1.0, 2.0 / (io[1] * io[1]))
+    o.take_step(step)
+    k.take_step(step)
+    for i in range(0, o.K, max(1, o.K // 11)):
+        assert rel(k.get_W(i), o.get_W(i)) <= TOL_UPDATE
+    return yo
+
+
+# --------------------------------------------------------------------- LMI
+@pytest.mark.parametrize("K,n,m,b_,ov", [(1, 4, 3, 8, 1), (9, 6, 6, 8, 2), (30, 20, 20, 8, 5),
+                                          (40, 7, 9, 3, 4), (12, 33, 5, 2, 2)])
+def test_lmi_newton_step(K, n, m, b_, ov):
+    prob = syn.lmi_problem(K=K, n=n, m=m, branching=b_, overlap=ov, seed=100 + K)
+    W = syn.scaling_points(K, n, seed=7 + K)
+    o, k = make_pair(prob, "lmi", W)
+    check_newton_step(o, k, prob["b"])
+
+
+def test_lmi_identity_start_and_iterations():
+    """Three IPM iterations from W = I through both paths stay in lock-step."""
+    prob = syn.lmi_problem(K=20, n=8, m=8, branching=3, overlap=3, seed=5)
+    o, k = make_pair(prob, "lmi")
+    for it in range(3):
+        check_newton_step(o, k, prob["b"], inv_sqrt_mu=0.5 + 0.2 * it)
+
+
+def test_lmi_cholesky_failure_is_reported():
+    prob = syn.lmi_problem(K=5, n=4, m=4, branching=2, overlap=2, seed=3)
+    k = syn.build(KktContext, prob, "lmi", device=0)
+    W = np.zeros((4, 4))  # singular scaling point => zero Schur complement
+    for i in range(k.K):
+        k.set_W(i, W)
+    k.assemble()
+    assert k.factor() == 0
+
+
+def test_lmi_affine_update():
+    prob = syn.lmi_problem(K=6, n=5, m=5, branching=2, overlap=2, seed=9)
+    W = syn.scaling_points(6, 5, seed=2)
+    o, k = make_pair(prob, "lmi", W)
+    y = np.random.default_rng(0).uniform(-0.1, 0.1, o.N)
+    o.prepare_step(y, 0.0, 0.0, affine=1)
+    k.prepare_step(y, 0.0, 0.0, affine=1)
+    for i in range(o.K):
+        assert rel(k.get_W(i), o.get_W(i)) <= 1e-13
+
+
+# --------------------------------------------------------------------- LP (C1)
+def test_c1_lp_newton_steps():
+    prob = syn.lp_problem(rows=20, num_vars=10)
+    o, k = make_pair(prob, "lp")
+    for it in range(4):
+        check_newton_step(o, k, prob["b"], inv_sqrt_mu=0.3 + 0.3 * it)
+
+
+# --------------------------------------------------------------------- SOC (C3, reduced)
+def test_c3_soc_newton_step():
+    K = 300
+    prob = syn.soc_problem(K=K, dim=10, m=10, overlap=2, seed=17)
+    W = syn.soc_scaling_points(K, 10)
+    o, k = make_pair(prob, "soc", W)
+    check_newton_step(o, k, prob["b"])
+    check_newton_step(o, k, prob["b"], inv_sqrt_mu=0.9)
+
+
+# --------------------------------------------------------------------- mixed cones
+def test_mixed_cones_with_fill_in():
+    """LMI + SOC + linear + constant block on the 4-cycle clique pattern (needs fill-in;
+    test_lp.cc:230-315 structure)."""
+    rng = np.random.default_rng(4)
+    cliques = [[0, 1], [1, 2], [0, 3], [2, 3]]
+
+    def build(cls, **kw):
+        p = cls(4, **kw)
+        A = rng0.uniform(-1, 1, (2, 3, 3))
+        A = 0.5 * (A + np.transpose(A, (0, 2, 1)))
+        p.add_lmi(A, np.eye(3), cliques[0])
+        p.add_soc(rng0.uniform(-1, 1, (4, 2)), np.array([1.0, 0, 0, 0]), cliques[1])
+        p.add_linear(rng0.uniform(-1, 1, (5, 2)), np.abs(rng0.uniform(0.5, 1, 5)), cliques[2])
+        p.add_static(np.array([[2.0, 0.3], [0.3, 1.0]]), cliques[3])
+        p.initialize()
+        return p
+
+    rng0 = np.random.default_rng(4)
+    o = build(ol.Program)
+    rng0 = np.random.default_rng(4)
+    k = build(KktContext, device=0)
+    b = rng.uniform(-1, 1, 4)
+    check_newton_step(o, k, b)
+    check_newton_step(o, k, b, inv_sqrt_mu=0.4)
+
+
+# --------------------------------------------------------------------- headline shape (C4)
+def test_c4_headline_direction_and_properties():
+    """BASELINE config 4 at full size: 1000 LMIs of order 20, N = 15005."""
+    prob = syn.lmi_problem()  # K=1000, n=20, m=20
+    W = syn.scaling_points(1000, 20)
+    k = syn.build(KktContext, prob, "lmi", device=0)
+    for i in range(k.K):
+        k.set_W(i, W[i])
+    assert k.N == 15005
+    ok, y = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    assert ok == 1
+    # size-independent property 1: linearity of the solve in the right-hand side
+    r1 = np.random.default_rng(1).uniform(-1, 1, k.N)
+    r2 = np.random.default_rng(2).uniform(-1, 1, k.N)
+    s1, s2 = k.solve_inplace(r1), k.solve_inplace(r2)
+    s12 = k.solve_inplace(2.0 * r1 - 3.0 * r2)
+    assert rel(s12, 2.0 * s1 - 3.0 * s2) <= 1e-10
+    # property 2: G y = rhs, with G applied clique by clique from the per-constraint blocks
+    k.assemble()
+    AW, AQc, _ = k.residuals()
+    rhs = 0.7 * (prob["b"] * 0.9 + AQc * 0.8) - 2 * AW
+    Gy = np.zeros(k.N)
+    for c, cl in enumerate(prob["cliques"]):
+        G, _, _, _ = k.constraint_schur(c)
+        G = np.tril(G) + np.tril(G, -1).T
+        Gy[cl] += G @ y[cl]
+    assert rel(Gy, rhs) <= 1e-9
+    # property 3: agreement with the oracle on the Newton direction (the bar: 1e-10)
+    o = syn.build(ol.Program, prob, "lmi")
+    for i in range(o.K):
+        o.set_W(i, W[i])
+    ok_o, yo = o.kkt_solve(np.concatenate([prob["b"]]), 0.7, 0.9, 0.8)
+    assert ok_o == 1
+    assert rel(y, yo) <= TOL_DIRECTION
+    # repeatability: the pull formulation has no atomics, so two runs agree bit for bit
+    _, y2 = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    assert np.array_equal(y, y2)
