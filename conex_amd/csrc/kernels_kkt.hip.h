@@ -47,10 +47,19 @@ __global__ void gather_residuals(int N, const int* __restrict__ ptr, const int64
     AW[p] = a;
     AQc[p] = q;
   }
-  if (blockIdx.x == 0 && threadIdx.x < 2) {
-    double s = 0;
-    for (int i = 0; i < K; i++) s += sc[2 * i + threadIdx.x];
-    sys_sc[threadIdx.x] = s;
+  if (blockIdx.x == 0) {  // <w,c> and <c,Qc>: fixed-order strided partial sums + block sum
+    __shared__ double red[8];
+    double s0 = 0, s1 = 0;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+      s0 += sc[2 * i];
+      s1 += sc[2 * i + 1];
+    }
+    s0 = BlockSum(s0, red);
+    s1 = BlockSum(s1, red);
+    if (threadIdx.x == 0) {
+      sys_sc[0] = s0;
+      sys_sc[1] = s1;
+    }
   }
 }
 

@@ -85,7 +85,7 @@ struct cxk_context {
   std::vector<int> level_ptr, level_sn;
   size_t chol_lds = 0, solve_lds = 0;
   // device state
-  DevBuf<double> G, AWc, AQcc, sc, slab, y, b, AW, AQc, sys_sc, info, red_out;
+  DevBuf<double> G, AWc, AQcc, sc, slab, y, b, AW, AQc, sys_sc, info2, info4, red_out;
   DevBuf<int64_t> d_g_off, d_r_off, as_dst, as_src, rs_src;
   DevBuf<int> as_ptr, rs_ptr, cl_ptr, cl_perm, d_level_sn, d_fail, d_pinv;
   DevBuf<unsigned char> d_mask;
@@ -754,13 +754,16 @@ int cxk_finalize(cxk_context* ctx) {
   CXK_TRY(ctx->red_out.alloc(4));
   CXK_TRY(ctx->d_fail.alloc(1));
   {
+    // per-constraint step outputs; constraints without a cone (constant blocks) keep the
+    // reference's defaults: StepInfo {0,0}; WeightedSlackEigenvalues {min=DBL_MAX,max=-DBL_MAX,0,0}
     std::vector<double> info((size_t)4 * K, 0.0);
     for (int i = 0; i < K; i++)
-      if (ctx->cons[i].type == CXK_STATIC) {  // empty GetWeightedSlackEigenvalues: defaults stay
+      if (ctx->cons[i].type == CXK_STATIC) {
         info[4 * i] = DBL_MAX;
         info[4 * i + 1] = -DBL_MAX;
       }
-    CXK_TRY(ctx->info.upload(info));
+    CXK_TRY(ctx->info4.upload(info));
+    CXK_TRY(ctx->info2.alloc((size_t)2 * K));
     CXK_TRY(ctx->d_mask.upload(ctx->owned));
   }
   if (BuildPlans(ctx) != CXK_SUCCESS) return CXK_FAILURE;
@@ -966,7 +969,7 @@ int cxk_set_y(cxk_context* ctx, const double* yh) {
 
 int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_weight, double* info) {
   if (CheckReady(ctx)) return CXK_FAILURE;
-  StepArgs sa = MakeStep(ctx, ctx->info.p, affine, c_weight, e_weight, 1.0);
+  StepArgs sa = MakeStep(ctx, ctx->info2.p, affine, c_weight, e_weight, 1.0);
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
     if (cnt == 0) continue;
@@ -980,7 +983,7 @@ int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_wei
   }
   CXK_TRY(hipGetLastError());
   if (affine) return CXK_SUCCESS;
-  reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), 0, ctx->info.p, ctx->d_mask.p,
+  reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), 0, ctx->info2.p, ctx->d_mask.p,
                                                ctx->red_out.p);
   CXK_TRY(hipStreamSynchronize(ctx->stream));
   CXK_TRY(hipMemcpy(info, ctx->red_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost));
@@ -990,7 +993,7 @@ int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_wei
 int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_size) {
   if (CheckReady(ctx)) return CXK_FAILURE;
   if (affine) return CXK_SUCCESS;  // the affine update is applied inside PrepareStep
-  StepArgs sa = MakeStep(ctx, ctx->info.p, affine, 0.0, e_weight, step_size);
+  StepArgs sa = MakeStep(ctx, ctx->info2.p, affine, 0.0, e_weight, step_size);
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
     if (cnt == 0) continue;
@@ -1007,7 +1010,7 @@ int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_siz
 
 int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* out) {
   if (CheckReady(ctx)) return CXK_FAILURE;
-  StepArgs sa = MakeStep(ctx, ctx->info.p, 0, c_weight, 0.0, 1.0);
+  StepArgs sa = MakeStep(ctx, ctx->info4.p, 0, c_weight, 0.0, 1.0);
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
     if (cnt == 0) continue;
@@ -1019,7 +1022,7 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
       soc_prepare<1><<<cnt, 64, sizeof(double) * (size_t)(g.m + 3 * (g.n + 1)), ctx->stream>>>(
           MakeVec(g), sa);
   }
-  reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), 1, ctx->info.p, ctx->d_mask.p,
+  reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), 1, ctx->info4.p, ctx->d_mask.p,
                                                ctx->red_out.p);
   CXK_TRY(hipGetLastError());
   CXK_TRY(hipStreamSynchronize(ctx->stream));
