@@ -34,4 +34,18 @@ __device__ __forceinline__ double BlockSum(double v, double* scratch) {
   return t;
 }
 
+// Orders LDS traffic between the lanes of ONE wavefront (program order is execution order
+// inside a wave; this only stops the compiler from reordering across it).
+__device__ __forceinline__ void WaveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// value of `v` held by lane `src` (a compile-time constant after unrolling: v_readlane_b32 x2)
+__device__ __forceinline__ double ReadLane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
 }  // namespace cxk

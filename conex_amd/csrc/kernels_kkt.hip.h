@@ -17,48 +17,68 @@
 
 namespace cxk {
 
-// slab[dst[t]] = sum_k G[src[k]], k in [ptr[t], ptr[t+1]) ; src < 0 means structural zero.
-__global__ void gather_slab(int64_t T, const int64_t* __restrict__ dst,
-                            const int* __restrict__ ptr, const int64_t* __restrict__ src,
-                            const double* __restrict__ G, double* __restrict__ slab) {
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < T;
-       t += (int64_t)gridDim.x * blockDim.x) {
-    double s = 0;
-    for (int k = ptr[t]; k < ptr[t + 1]; k++) {
-      const int64_t q = src[k];
-      if (q >= 0) s += G[q];
-    }
-    slab[dst[t]] = s;
-  }
-}
+// Assembly gather, one launch:
+//   slab[dst[t]] = sum_k G[src[k]], k in [ptr[t], ptr[t+1]) ; src < 0 means structural zero
+//   AW/AQc in permuted order (constraint order sums), the two scalars, and -- when with_rhs --
+//   y = k (b bs + AQc cs) - 2 AW  (cone_program.cc:409-411).  Also clears the factor flag.
+struct GatherArgs {
+  int64_t T;
+  const int64_t* dst;
+  const int* ptr;
+  const int64_t* src;
+  const double* G;
+  double* slab;
+  int N;
+  const int* rs_ptr;
+  const int64_t* rs_src;
+  const double* AWc;
+  const double* AQcc;
+  double* AW;
+  double* AQc;
+  int K;
+  const double* sc;
+  double* sys_sc;
+  int with_rhs;
+  double k, bs, cs;
+  const double* b;
+  double* y;
+  int* fail;
+};
 
-// Residual vectors in permuted order + the two scalars (fixed-order sums).
-__global__ void gather_residuals(int N, const int* __restrict__ ptr, const int64_t* __restrict__ src,
-                                 const double* __restrict__ AWc, const double* __restrict__ AQcc,
-                                 double* __restrict__ AW, double* __restrict__ AQc, int K,
-                                 const double* __restrict__ sc, double* __restrict__ sys_sc) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int p = tid; p < N; p += gridDim.x * blockDim.x) {
-    double a = 0, q = 0;
-    for (int k = ptr[p]; k < ptr[p + 1]; k++) {
-      a += AWc[src[k]];
-      q += AQcc[src[k]];
+__global__ void __launch_bounds__(256) assemble_gather(GatherArgs a) {
+  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = gid; t < a.T; t += stride) {
+    double s = 0;
+    for (int k = a.ptr[t]; k < a.ptr[t + 1]; k++) {
+      const int64_t q = a.src[k];
+      if (q >= 0) s += a.G[q];
     }
-    AW[p] = a;
-    AQc[p] = q;
+    a.slab[a.dst[t]] = s;
+  }
+  for (int64_t p = gid; p < a.N; p += stride) {
+    double aw = 0, aq = 0;
+    for (int k = a.rs_ptr[p]; k < a.rs_ptr[p + 1]; k++) {
+      aw += a.AWc[a.rs_src[k]];
+      aq += a.AQcc[a.rs_src[k]];
+    }
+    a.AW[p] = aw;
+    a.AQc[p] = aq;
+    if (a.with_rhs) a.y[p] = a.k * (a.b[p] * a.bs + aq * a.cs) - 2 * aw;
   }
   if (blockIdx.x == 0) {  // <w,c> and <c,Qc>: fixed-order strided partial sums + block sum
     __shared__ double red[8];
     double s0 = 0, s1 = 0;
-    for (int i = threadIdx.x; i < K; i += blockDim.x) {
-      s0 += sc[2 * i];
-      s1 += sc[2 * i + 1];
+    for (int i = threadIdx.x; i < a.K; i += blockDim.x) {
+      s0 += a.sc[2 * i];
+      s1 += a.sc[2 * i + 1];
     }
     s0 = BlockSum(s0, red);
     s1 = BlockSum(s1, red);
     if (threadIdx.x == 0) {
-      sys_sc[0] = s0;
-      sys_sc[1] = s1;
+      a.sys_sc[0] = s0;
+      a.sys_sc[1] = s1;
+      *a.fail = 0;
     }
   }
 }
@@ -78,6 +98,14 @@ __global__ void build_mu_rhs(int N, double bs, double cs, const double* __restri
     y[p] = AQc[p] * cs - b[p] * bs;
 }
 
+// In-kernel stamps (diagnostic builds only: -DCXK_DEBUG_STAMPS); values go to a buffer nothing else reads.
+#ifdef CXK_DEBUG_STAMPS
+__device__ long long g_cxk_stamp[16];
+#define CXK_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cxk_stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CXK_STAMP(i) do { } while (0)
+#endif
+
 struct FactorPlan {
   // per supernode
   const int* ns;             // [K]
@@ -85,188 +113,424 @@ struct FactorPlan {
   const int* start;          // [K] first permuted index
   const int64_t* diag_off;   // [K]
   const int64_t* offd_off;   // [K]
-  // Cholesky pull lists: targets of supernode p are [tg_ptr[p], tg_ptr[p+1])
-  const int* tg_ptr;         // [K+1]
-  const int64_t* tg_dst;     // slab offset of target entry
-  const int* tr_ptr;         // [T+1] triples of target t
-  const int64_t* tr_colk;    // slab offset of child column k
-  const int64_t* tr_colj;    // slab offset of child column j
-  const int* tr_len;         // child supernode size
-  // forward-solve pull lists per permuted row
-  const int* fs_ptr;         // [N+1]
-  const int64_t* fs_col;     // slab offset of child's off-diagonal column
-  const int* fs_start;       // start of the child's segment in the vector
-  const int* fs_len;
-  // backward: separator rows in the reference's accumulation order
+  // Every supernode publishes its Schur update  U[k,j] = off[:,k].off[:,j] (k <= j, the
+  // reference's S_S enumeration) and its forward-solve update t[c] = off[:,c].b  into private
+  // slots; ancestors pull single values in increasing child index (the reference's order).
+  const int64_t* upd_off;    // [K] offset of the s(s+1)/2 values in `upd`
+  const int* updb_off;       // [K] offset of the s values in `updb`
+  const int* tg_ptr;         // [K+1] targets of supernode p
+  const int* tg_loc;         // local offset inside [diag ns x ns | off ns x s]
+  const int* tr_ptr;         // [T+1] contributions of target t
+  const int64_t* tr_src;     // index into `upd`
+  const int* fs_ptr;         // [N+1] contributions of permuted row r
+  const int* fs_src;         // index into `updb`
+  // backward: separator columns in the reference's accumulation order
   const int* bs_ptr;         // [K+1]
   const int* bs_c;           // column index c within off block
   const int* bs_row;         // permuted index of separator variable
+  double* upd;
+  double* updb;
 };
 
-// One workgroup per supernode of the level.  Phase 1 pulls the Schur updates of all
-// finished descendants, phase 2 factors the diagonal block in LDS (right-looking, one column
-// at a time), phase 3 solves L^{-1} * off.  If `rhs` != nullptr the forward substitution of
-// the right-hand side is fused in (same dependency structure).
-__global__ void __launch_bounds__(256)
-chol_level(FactorPlan P, const int* __restrict__ level_sn, double* __restrict__ slab,
-           double* __restrict__ rhs, int* __restrict__ fail) {
-  extern __shared__ double lds[];
-  const int p = level_sn[blockIdx.x];
-  const int ns = P.ns[p], s = P.nsep[p];
-  double* D = slab + P.diag_off[p];
-  double* B = slab + P.offd_off[p];
-  double* sD = lds;            // ns x ns
-  double* sB = lds + ns * ns;  // ns x s
-  double* sb = sB + ns * s;    // ns (rhs segment)
-
-  // ---- phase 1: pull updates  S_S -= off_i[:,k] . off_i[:,j]  in increasing child index
-  for (int t = P.tg_ptr[p] + threadIdx.x; t < P.tg_ptr[p + 1]; t += blockDim.x) {
-    double acc = slab[P.tg_dst[t]];
-    for (int q = P.tr_ptr[t]; q < P.tr_ptr[t + 1]; q++) {
-      const double* ck = slab + P.tr_colk[q];
-      const double* cj = slab + P.tr_colj[q];
-      const int len = P.tr_len[q];
-      double dot = 0;
-      for (int r = 0; r < len; r++) dot = fma(ck[r], cj[r], dot);
-      acc -= dot;
+// Stage [diag | off | rhs] of supernode p into the wave's LDS region and apply the published
+// updates of its descendants in the reference's order.  Layout: sD ns*ns, sB ns*s, sb ns.
+__device__ inline void StageAndPull(const FactorPlan& P, int p, const double* __restrict__ slab,
+                                    const double* __restrict__ rhs, double* __restrict__ my,
+                                    bool with_matrix) {
+  const int lane = threadIdx.x & 63;
+  const int ns = __builtin_amdgcn_readfirstlane(P.ns[p]), s = __builtin_amdgcn_readfirstlane(P.nsep[p]);
+  const double* D = slab + P.diag_off[p];
+  const double* B = slab + P.offd_off[p];
+  double* sb = my + ns * ns + ns * s;
+  const int st = __builtin_amdgcn_readfirstlane(P.start[p]);
+  // copy [diag | off] into LDS; loads are issued in independent batches of 8 so their latencies
+  // overlap (a plain copy loop waits for each load before the next one is issued)
+  {
+    const int nd = ns * ns, total = with_matrix ? nd + ns * s : nd;
+    for (int base = 0; base < total; base += 8 * 64) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int q = base + u * 64 + lane;
+        v[u] = (q < total) ? (q < nd ? D[q] : B[q - nd]) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int q = base + u * 64 + lane;
+        if (q < total) my[q] = v[u];
+      }
     }
-    slab[P.tg_dst[t]] = acc;
+  }
+  if (rhs)
+    for (int r = lane; r < ns; r += 64) sb[r] = rhs[st + r];
+  WaveSync();
+  if (with_matrix) {
+    for (int t = P.tg_ptr[p] + lane; t < P.tg_ptr[p + 1]; t += 64) {
+      const int loc = P.tg_loc[t];
+      double acc = my[loc];
+      const int q1 = P.tr_ptr[t + 1];
+#pragma unroll 4
+      for (int q = P.tr_ptr[t]; q < q1; q++) acc -= P.upd[P.tr_src[q]];
+      my[loc] = acc;
+    }
   }
   if (rhs) {
-    const int st = P.start[p];
-    for (int r = threadIdx.x; r < ns; r += blockDim.x) {
-      double acc = rhs[st + r];
-      for (int q = P.fs_ptr[st + r]; q < P.fs_ptr[st + r + 1]; q++) {
-        const double* col = slab + P.fs_col[q];
-        const double* bi = rhs + P.fs_start[q];
-        const int len = P.fs_len[q];
-        double dot = 0;
-        for (int k = 0; k < len; k++) dot = fma(col[k], bi[k], dot);
-        acc -= dot;
-      }
+    for (int r = lane; r < ns; r += 64) {
+      double acc = sb[r];
+      const int q1 = P.fs_ptr[st + r + 1];
+#pragma unroll 4
+      for (int q = P.fs_ptr[st + r]; q < q1; q++) acc -= P.updb[P.fs_src[q]];
       sb[r] = acc;
     }
   }
-  __syncthreads();
-  for (int q = threadIdx.x; q < ns * ns; q += blockDim.x) sD[q] = D[q];
-  for (int q = threadIdx.x; q < ns * s; q += blockDim.x) sB[q] = B[q];
-  __syncthreads();
+  WaveSync();
+}
 
-  // ---- phase 2: LLT of the diagonal block (lower), column by column
-  __shared__ int s_bad;
-  if (threadIdx.x == 0) s_bad = 0;
-  __syncthreads();
+// Publish U[k,j] = off[:,k].off[:,j] and t[c] = off[:,c].b from the LDS copies sB / sb.
+__device__ inline void PublishUpdates(const FactorPlan& P, int p, const double* __restrict__ my,
+                                      bool with_matrix, bool with_rhs) {
+  const int lane = threadIdx.x & 63;
+  const int ns = __builtin_amdgcn_readfirstlane(P.ns[p]), s = __builtin_amdgcn_readfirstlane(P.nsep[p]);
+  const double* sB = my + ns * ns;
+  const double* sb = sB + ns * s;
+  if (with_matrix) {
+    double* out = P.upd + P.upd_off[p];
+    const int npairs = s * (s + 1) / 2;
+    for (int t = lane; t < npairs; t += 64) {
+      int k = 0, rem = t;
+      while (rem >= s - k) {
+        rem -= s - k;
+        k++;
+      }
+      const int j = k + rem;
+      double dot = 0;
+      for (int i = 0; i < ns; i++) dot = fma(sB[i + k * ns], sB[i + j * ns], dot);
+      out[t] = dot;
+    }
+  }
+  if (with_rhs) {
+    double* out = P.updb + P.updb_off[p];
+    for (int c = lane; c < s; c += 64) {
+      double dot = 0;
+      for (int i = 0; i < ns; i++) dot = fma(sB[i + c * ns], sb[i], dot);
+      out[c] = dot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// One wavefront factors one supernode.  Lane j owns COLUMN j of the diagonal block (col[i],
+// static register indices) and ROW j of the extra columns [off-diagonal block | rhs] (ext[c]).
+// The column loop k is a real loop (compact code: a fully unrolled body is executed once per
+// wave and is instruction-fetch bound); per step the pivot lane scales its column and
+// publishes it through a 16/32-entry LDS line, every lane applies the rank-1 update to its own
+// column, and the extra columns travel by v_readlane with a run-time lane select.
+// Right-looking: same update order per entry as the reference's column-by-column LLT + TRSM.
+// ---------------------------------------------------------------------------------------
+template <int NSMAX, int SMAX>
+__device__ inline void CholSupernodeReg(const FactorPlan& P, int p, double* __restrict__ slab,
+                                        double* __restrict__ rhs, int* __restrict__ fail,
+                                        double* __restrict__ my) {
+  const int lane = threadIdx.x & 63;
+  const int ns = __builtin_amdgcn_readfirstlane(P.ns[p]), s = __builtin_amdgcn_readfirstlane(P.nsep[p]);
+  double* sD = my;
+  double* sB = my + ns * ns;
+  double* sb = sB + ns * s;
+  CXK_STAMP(0);
+  StageAndPull(P, p, slab, rhs, my, true);
+  CXK_STAMP(1);
+  const bool active = lane < ns;
+  double col[NSMAX];   // column `lane`, rows 0..NSMAX-1 (rows < lane are never read)
+  double ext[SMAX + 1];
+#pragma unroll
+  for (int i = 0; i < NSMAX; i++) col[i] = (active && i < ns && i >= lane) ? sD[i + lane * ns] : 0.0;
+#pragma unroll
+  for (int c = 0; c < SMAX; c++) ext[c] = (active && c < s) ? sB[lane + c * ns] : 0.0;
+  ext[SMAX] = (rhs && active) ? sb[lane] : 0.0;
+  double diag = active ? sD[lane + lane * ns] : 1.0;
+  WaveSync();
+  double* piv = my;  // reuse the head of the staging area as the pivot-column line
+  CXK_STAMP(2);
+  bool bad = false;
+#pragma unroll 1
+  for (int k = 0; k < ns; k++) {
+    if (lane == k) {
+      if (!(diag > 0.0)) bad = true;
+      const double d = sqrt(diag);
+      const double rd = 1.0 / d;  // one divide per column; scalings are multiplies
+      diag = d;
+      // rows <= k of this column are never read again, so the whole register column is scaled
+      // and published without per-row selects
+#pragma unroll
+      for (int i = 0; i < NSMAX; i++) {
+        col[i] *= rd;
+        piv[i] = col[i];
+      }
+#pragma unroll
+      for (int c = 0; c <= SMAX; c++) ext[c] *= rd;
+    }
+    WaveSync();
+    // m = L[lane][k] for lanes below the pivot, 0 elsewhere (finished columns / solved rows)
+    const double m = (lane > k && lane < NSMAX) ? piv[lane] : 0.0;
+    diag = fma(-m, m, diag);
+#pragma unroll
+    for (int i = 0; i < NSMAX; i++) col[i] = fma(-piv[i], m, col[i]);
+#pragma unroll
+    for (int c = 0; c <= SMAX; c++) {
+      const double ekc = ReadLane(ext[c], k);
+      ext[c] = fma(-m, ekc, ext[c]);
+    }
+    WaveSync();
+  }
+  CXK_STAMP(3);
+  if (__any(bad)) {
+    if (lane == 0) atomicExch(fail, 1);
+    return;
+  }
+  double* D = slab + P.diag_off[p];
+  double* B = slab + P.offd_off[p];
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < NSMAX; i++)
+      if (i < ns && i > lane) D[i + (size_t)lane * ns] = col[i];
+    D[lane + (size_t)lane * ns] = diag;
+#pragma unroll
+    for (int c = 0; c < SMAX; c++)
+      if (c < s) {
+        B[lane + (size_t)c * ns] = ext[c];
+        sB[lane + c * ns] = ext[c];
+      }
+    if (rhs) {
+      rhs[P.start[p] + lane] = ext[SMAX];
+      sb[lane] = ext[SMAX];
+    }
+  }
+  WaveSync();
+  CXK_STAMP(4);
+  PublishUpdates(P, p, my, true, rhs != nullptr);
+  CXK_STAMP(5);
+}
+
+// LDS-resident fallback for supernodes that do not fit the register kernels.
+__device__ inline void CholSupernodeLds(const FactorPlan& P, int p, double* __restrict__ slab,
+                                        double* __restrict__ rhs, int* __restrict__ fail,
+                                        double* __restrict__ my) {
+  const int lane = threadIdx.x & 63;
+  const int ns = __builtin_amdgcn_readfirstlane(P.ns[p]), s = __builtin_amdgcn_readfirstlane(P.nsep[p]);
+  double* D = slab + P.diag_off[p];
+  double* B = slab + P.offd_off[p];
+  double* sD = my;
+  double* sB = my + ns * ns;
+  double* sb = sB + ns * s;
+  StageAndPull(P, p, slab, rhs, my, true);
+  const int ncols = s + (rhs ? 1 : 0);
+  bool bad = false;
   for (int k = 0; k < ns; k++) {
     const double akk = sD[k + k * ns];
     if (!(akk > 0.0)) {
-      if (threadIdx.x == 0) {
-        s_bad = 1;
-        atomicExch(fail, 1);
-      }
-      break;  // uniform: akk is the same value for every thread
+      bad = true;
+      break;
     }
     const double d = sqrt(akk);
-    __syncthreads();
-    for (int i = k + threadIdx.x; i < ns; i += blockDim.x)
-      sD[i + k * ns] = (i == k) ? d : sD[i + k * ns] / d;
-    __syncthreads();
-    const int rem = ns - k - 1;
-    // trailing update of the lower triangle: A[i][j] -= L[i][k] L[j][k], j > k, i >= j
-    for (int idx = threadIdx.x; idx < rem * rem; idx += blockDim.x) {
-      const int j = k + 1 + idx / rem, i = k + 1 + idx % rem;
-      if (i >= j) sD[i + j * ns] -= sD[i + k * ns] * sD[j + k * ns];
-    }
-    __syncthreads();
-  }
-  __syncthreads();
-  if (s_bad) return;
-
-  // ---- phase 3: off <- L^{-1} off ; rhs <- L^{-1} rhs  (forward substitution by columns)
-  const int ncols = s + (rhs ? 1 : 0);
-  for (int k = 0; k < ns; k++) {
-    const double d = sD[k + k * ns];
-    for (int c = threadIdx.x; c < ncols; c += blockDim.x) {
+    WaveSync();
+    for (int i = k + lane; i < ns; i += 64) sD[i + k * ns] = (i == k) ? d : sD[i + k * ns] / d;
+    for (int c = lane; c < ncols; c += 64) {
       double* col = (c < s) ? sB + c * ns : sb;
       col[k] /= d;
     }
-    __syncthreads();
-    const int rem = ns - k - 1;
-    for (int idx = threadIdx.x; idx < rem * ncols; idx += blockDim.x) {
-      const int c = idx / rem, i = k + 1 + idx % rem;
-      double* col = (c < s) ? sB + c * ns : sb;
-      col[i] -= sD[i + k * ns] * col[k];
+    WaveSync();
+    for (int i = k + 1 + lane; i < ns; i += 64) {
+      const double lik = sD[i + k * ns];
+      for (int j = k + 1; j <= i; j++) sD[i + j * ns] -= lik * sD[j + k * ns];
+      for (int c = 0; c < ncols; c++) {
+        double* col = (c < s) ? sB + c * ns : sb;
+        col[i] -= lik * col[k];
+      }
     }
-    __syncthreads();
+    WaveSync();
   }
-  for (int q = threadIdx.x; q < ns * ns; q += blockDim.x) {
+  if (bad) {
+    if (lane == 0) atomicExch(fail, 1);
+    return;
+  }
+  for (int q = lane; q < ns * ns; q += 64) {
     const int i = q % ns, j = q / ns;
     if (i >= j) D[q] = sD[q];
   }
-  for (int q = threadIdx.x; q < ns * s; q += blockDim.x) B[q] = sB[q];
+  for (int q = lane; q < ns * s; q += 64) B[q] = sB[q];
   if (rhs)
-    for (int r = threadIdx.x; r < ns; r += blockDim.x) rhs[P.start[p] + r] = sb[r];
+    for (int r = lane; r < ns; r += 64) rhs[P.start[p] + r] = sb[r];
+  PublishUpdates(P, p, my, true, rhs != nullptr);
 }
 
-// Forward substitution only (factor already done):  b_p <- L_p^{-1} (b_p - sum_i off_i^T b_i)
-__global__ void __launch_bounds__(64)
-forward_level(FactorPlan P, const int* __restrict__ level_sn, const double* __restrict__ slab,
-              double* __restrict__ rhs) {
-  extern __shared__ double lds[];
-  const int p = level_sn[blockIdx.x];
-  const int ns = P.ns[p];
-  const double* D = slab + P.diag_off[p];
-  double* sb = lds;
-  const int st = P.start[p];
-  for (int r = threadIdx.x; r < ns; r += blockDim.x) {
-    double acc = rhs[st + r];
-    for (int q = P.fs_ptr[st + r]; q < P.fs_ptr[st + r + 1]; q++) {
-      const double* col = slab + P.fs_col[q];
-      const double* bi = rhs + P.fs_start[q];
-      const int len = P.fs_len[q];
-      double dot = 0;
-      for (int k = 0; k < len; k++) dot = fma(col[k], bi[k], dot);
-      acc -= dot;
-    }
-    sb[r] = acc;
-  }
-  __syncthreads();
+// b_p <- L_p^{-1} (b_p - published updates); publishes t[c] = off[:,c].b_p.
+// Lane i owns b_i; L stays in LDS; the solved entry travels by v_readlane.
+__device__ inline void ForwardSupernodeWave(const FactorPlan& P, int p,
+                                            const double* __restrict__ slab,
+                                            double* __restrict__ rhs, double* __restrict__ my) {
+  const int lane = threadIdx.x & 63;
+  const int ns = __builtin_amdgcn_readfirstlane(P.ns[p]), s = __builtin_amdgcn_readfirstlane(P.nsep[p]);
+  double* sD = my;
+  double* sB = my + ns * ns;
+  double* sb = sB + ns * s;
+  const double* B = slab + P.offd_off[p];
+  StageAndPull(P, p, slab, rhs, my, false);
+  for (int q = lane; q < ns * s; q += 64) sB[q] = B[q];
+  const bool active = lane < ns;
+  double b = active ? sb[lane] : 0.0;
+  const double dinv = active ? 1.0 / sD[lane + lane * ns] : 0.0;
+#pragma unroll 1
   for (int k = 0; k < ns; k++) {
-    if (threadIdx.x == 0) sb[k] /= D[k + (size_t)k * ns];
-    __syncthreads();
-    const double bk = sb[k];
-    for (int i = k + 1 + threadIdx.x; i < ns; i += blockDim.x) sb[i] -= D[i + (size_t)k * ns] * bk;
-    __syncthreads();
+    if (lane == k) b *= dinv;
+    const double bk = ReadLane(b, k);
+    const double lik = (active && lane > k) ? sD[lane + k * ns] : 0.0;
+    b -= lik * bk;
   }
-  for (int r = threadIdx.x; r < ns; r += blockDim.x) rhs[st + r] = sb[r];
+  if (active) {
+    rhs[P.start[p] + lane] = b;
+    sb[lane] = b;
+  }
+  WaveSync();
+  PublishUpdates(P, p, my, false, true);
 }
 
-// Backward substitution:  b_j <- L_j^{-T} (b_j - sum_c off_j[:,c] y[sep_j[c]])
-__global__ void __launch_bounds__(64)
-backward_level(FactorPlan P, const int* __restrict__ level_sn, const double* __restrict__ slab,
-               double* __restrict__ rhs) {
-  extern __shared__ double lds[];
-  const int p = level_sn[blockIdx.x];
-  const int ns = P.ns[p];
+__device__ inline void ForwardSupernodeLds(const FactorPlan& P, int p,
+                                           const double* __restrict__ slab,
+                                           double* __restrict__ rhs, double* __restrict__ my) {
+  const int lane = threadIdx.x & 63;
+  const int ns = __builtin_amdgcn_readfirstlane(P.ns[p]), s = __builtin_amdgcn_readfirstlane(P.nsep[p]);
+  double* sD = my;
+  double* sB = my + ns * ns;
+  double* sb = sB + ns * s;
+  const double* B = slab + P.offd_off[p];
+  StageAndPull(P, p, slab, rhs, my, false);
+  for (int q = lane; q < ns * s; q += 64) sB[q] = B[q];
+  for (int k = 0; k < ns; k++) {
+    const double bk = sb[k] / sD[k + k * ns];
+    WaveSync();
+    if (lane == 0) sb[k] = bk;
+    for (int i = k + 1 + lane; i < ns; i += 64) sb[i] -= sD[i + k * ns] * bk;
+    WaveSync();
+  }
+  for (int r = lane; r < ns; r += 64) rhs[P.start[p] + r] = sb[r];
+  PublishUpdates(P, p, my, false, true);
+}
+
+// b_j <- L_j^{-T} (b_j - sum_c off_j[:,c] y[sep_j[c]]) for ns <= 64; lane i owns y_i.
+__device__ inline void BackwardSupernodeWave(const FactorPlan& P, int p,
+                                             const double* __restrict__ slab,
+                                             double* __restrict__ rhs, double* __restrict__ my) {
+  const int lane = threadIdx.x & 63;
+  const int ns = __builtin_amdgcn_readfirstlane(P.ns[p]);
   const double* D = slab + P.diag_off[p];
   const double* B = slab + P.offd_off[p];
-  double* sb = lds;
-  const int st = P.start[p];
-  for (int r = threadIdx.x; r < ns; r += blockDim.x) {
+  double* sD = my;
+  const bool active = lane < ns;
+  const int st = __builtin_amdgcn_readfirstlane(P.start[p]);
+  for (int q = lane; q < ns * ns; q += 64) sD[q] = D[q];
+  double acc = active ? rhs[st + lane] : 0.0;
+  const int q0 = P.bs_ptr[p], q1 = P.bs_ptr[p + 1];
+#pragma unroll 4
+  for (int q = q0; q < q1; q++) {
+    const double yv = rhs[P.bs_row[q]];
+    if (active) acc -= B[lane + (size_t)P.bs_c[q] * ns] * yv;
+  }
+  WaveSync();
+  const double dinv = active ? 1.0 / sD[lane + lane * ns] : 0.0;
+#pragma unroll 1
+  for (int k = ns - 1; k >= 0; k--) {
+    if (lane == k) acc *= dinv;
+    const double yk = ReadLane(acc, k);
+    const double lki = (lane < k) ? sD[k + lane * ns] : 0.0;  // L[k][lane]
+    acc -= lki * yk;
+  }
+  if (active) rhs[st + lane] = acc;
+}
+
+__device__ inline void BackwardSupernodeLds(const FactorPlan& P, int p,
+                                            const double* __restrict__ slab,
+                                            double* __restrict__ rhs, double* __restrict__ my) {
+  const int lane = threadIdx.x & 63;
+  const int ns = __builtin_amdgcn_readfirstlane(P.ns[p]);
+  const double* D = slab + P.diag_off[p];
+  const double* B = slab + P.offd_off[p];
+  double* sD = my;
+  double* sb = my + ns * ns;
+  const int st = __builtin_amdgcn_readfirstlane(P.start[p]);
+  for (int q = lane; q < ns * ns; q += 64) sD[q] = D[q];
+  for (int r = lane; r < ns; r += 64) {
     double acc = rhs[st + r];
     for (int q = P.bs_ptr[p]; q < P.bs_ptr[p + 1]; q++)
       acc -= B[r + (size_t)P.bs_c[q] * ns] * rhs[P.bs_row[q]];
     sb[r] = acc;
   }
-  __syncthreads();
+  WaveSync();
   for (int k = ns - 1; k >= 0; k--) {
-    // y_k = (b_k - sum_{i>k} L[i][k] y_i) / L[k][k]
-    double part = 0;
-    for (int i = k + 1 + threadIdx.x; i < ns; i += blockDim.x) part += D[i + (size_t)k * ns] * sb[i];
-    part = WaveSum(part);
-    if (threadIdx.x == 0) sb[k] = (sb[k] - part) / D[k + (size_t)k * ns];
-    __syncthreads();
+    const double yk = sb[k] / sD[k + k * ns];
+    WaveSync();
+    if (lane == 0) sb[k] = yk;
+    for (int i = lane; i < k; i += 64) sb[i] -= sD[k + i * ns] * yk;
+    WaveSync();
   }
-  for (int r = threadIdx.x; r < ns; r += blockDim.x) rhs[st + r] = sb[r];
+  for (int r = lane; r < ns; r += 64) rhs[st + r] = sb[r];
+}
+
+// mode 0: factor (+ forward if rhs), mode 1: forward only, mode 2: backward.
+// Levels [lb, le) ascending for modes 0/1; mode 2 walks the range downwards.  A launch that
+// covers several levels (or continues into the backward sweep) must be ONE workgroup: levels
+// are then separated by a workgroup barrier instead of a kernel boundary.
+__global__ void __launch_bounds__(512)
+tree_sweep(FactorPlan P, const int* __restrict__ level_ptr, const int* __restrict__ level_sn, int lb,
+           int le, int mode, int then_backward, double* __restrict__ slab, double* __restrict__ rhs,
+           int* __restrict__ fail, int lds_per_wave) {
+  extern __shared__ double lds[];
+  // wave-uniform values are forced into SGPRs: otherwise every loop bound / lane select below
+  // is treated as divergent (waterfall loops around v_readlane, vector address arithmetic)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  double* my = lds + (size_t)wave * lds_per_wave;
+  const bool multi = (le - lb > 1) || then_backward;
+  if (mode != 2) {
+    for (int l = lb; l < le; l++) {
+      const int base = level_ptr[l], cnt = level_ptr[l + 1] - base;
+      for (int idx = blockIdx.x * nw + wave; idx < cnt; idx += gridDim.x * nw) {
+        const int p = __builtin_amdgcn_readfirstlane(level_sn[base + idx]);
+        const int ns = __builtin_amdgcn_readfirstlane(P.ns[p]);
+        const int s = __builtin_amdgcn_readfirstlane(P.nsep[p]);
+        if (mode == 0) {
+          if (ns <= 16 && s <= 8)
+            CholSupernodeReg<16, 8>(P, p, slab, rhs, fail, my);
+          else if (ns <= 24 && s == 0)
+            CholSupernodeReg<24, 0>(P, p, slab, rhs, fail, my);
+          else if (ns <= 24 && s <= 8)
+            CholSupernodeReg<24, 8>(P, p, slab, rhs, fail, my);
+          else if (ns <= 32 && s <= 16)
+            CholSupernodeReg<32, 16>(P, p, slab, rhs, fail, my);
+          else
+            CholSupernodeLds(P, p, slab, rhs, fail, my);
+        } else {
+          if (ns <= 64)
+            ForwardSupernodeWave(P, p, slab, rhs, my);
+          else
+            ForwardSupernodeLds(P, p, slab, rhs, my);
+        }
+      }
+      if (multi) __syncthreads();
+    }
+  }
+  if (mode == 2 || then_backward) {
+    for (int l = le - 1; l >= lb; l--) {
+      const int base = level_ptr[l], cnt = level_ptr[l + 1] - base;
+      for (int idx = blockIdx.x * nw + wave; idx < cnt; idx += gridDim.x * nw) {
+        const int p = __builtin_amdgcn_readfirstlane(level_sn[base + idx]);
+        const int ns = __builtin_amdgcn_readfirstlane(P.ns[p]);
+        if (ns <= 64)
+          BackwardSupernodeWave(P, p, slab, rhs, my);
+        else
+          BackwardSupernodeLds(P, p, slab, rhs, my);
+      }
+      if (multi) __syncthreads();
+    }
+  }
 }
 
 // permuted <-> original order copies

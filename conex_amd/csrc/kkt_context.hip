@@ -83,15 +83,16 @@ struct cxk_context {
   std::vector<unsigned char> owned;
   // levels
   std::vector<int> level_ptr, level_sn;
-  size_t chol_lds = 0, solve_lds = 0;
+  size_t chol_lds = 0, solve_lds = 0;  // bytes of LDS staging one supernode needs
+  int top_level = 0;                   // levels [top_level, nlev) run inside one workgroup
   // device state
   DevBuf<double> G, AWc, AQcc, sc, slab, y, b, AW, AQc, sys_sc, info2, info4, red_out;
   DevBuf<int64_t> d_g_off, d_r_off, as_dst, as_src, rs_src;
-  DevBuf<int> as_ptr, rs_ptr, cl_ptr, cl_perm, d_level_sn, d_fail, d_pinv;
+  DevBuf<int> as_ptr, rs_ptr, cl_ptr, cl_perm, d_level_sn, d_level_ptr, d_fail, d_pinv, tg_loc;
   DevBuf<unsigned char> d_mask;
-  DevBuf<int> p_ns, p_nsep, p_start, tg_ptr, tr_ptr, tr_len, fs_ptr, fs_start, fs_len, bs_ptr, bs_c,
-      bs_row;
-  DevBuf<int64_t> p_diag, p_offd, tg_dst, tr_colk, tr_colj, fs_col;
+  DevBuf<int> p_ns, p_nsep, p_start, tg_ptr, tr_ptr, fs_ptr, fs_src, bs_ptr, bs_c, bs_row, updb_off;
+  DevBuf<int64_t> p_diag, p_offd, tr_src, upd_off;
+  DevBuf<double> upd, updb;
   int64_t as_T = 0;
   FactorPlan plan{};
   // timing of the dominant (dense-LMI Schur) kernel
@@ -317,15 +318,24 @@ int BuildPlans(cxk_context* ctx) {
     nsep[e] = (int)L.separators[e].size();
     start[e] = L.supernode_start[e];
   }
-  struct Triple {
-    int64_t ck, cj;
-    int len;
-  };
+  // published-update slots: s(s+1)/2 Schur values and s forward values per supernode
+  std::vector<int64_t> upd_off(K, 0);
+  std::vector<int> updb_off(K, 0);
+  int64_t upd_total = 0;
+  int updb_total = 0;
+  for (int i = 0; i < K; i++) {
+    upd_off[i] = upd_total;
+    updb_off[i] = updb_total;
+    if (ns[i] > 0) {
+      upd_total += (int64_t)nsep[i] * (nsep[i] + 1) / 2;
+      updb_total += nsep[i];
+    }
+  }
   std::vector<int> tgt_of(L.slab_size, -1);
   std::vector<std::vector<int>> tg_of_sn(K);
   std::vector<int64_t> tg_dst_all;
-  std::vector<std::vector<Triple>> triples;
-  std::vector<std::vector<std::tuple<int64_t, int, int>>> fs(N);
+  std::vector<std::vector<int64_t>> contrib;
+  std::vector<std::vector<int>> fs(N);
   std::vector<int> level(K, 0);
   for (int i = 0; i < K; i++) {
     if (ns[i] == 0 || nsep[i] == 0) continue;
@@ -335,62 +345,53 @@ int BuildPlans(cxk_context* ctx) {
       const int p = L.var_to_sn[s[k]];
       if (level[p] < level[i] + 1) level[p] = level[i] + 1;
       for (int j = k; j < nsep[i]; j++) {
-        const int64_t off = L.ss_index[i][cnt++];
+        const int64_t off = L.ss_index[i][cnt];
         if (tgt_of[off] < 0) {
           tgt_of[off] = (int)tg_dst_all.size();
           tg_dst_all.push_back(off);
-          triples.emplace_back();
+          contrib.emplace_back();
           tg_of_sn[p].push_back(tgt_of[off]);
         }
-        triples[tgt_of[off]].push_back(
-            {L.offd_off[i] + (int64_t)k * ns[i], L.offd_off[i] + (int64_t)j * ns[i], ns[i]});
+        contrib[tgt_of[off]].push_back(upd_off[i] + cnt);
+        cnt++;
       }
-      fs[s[k]].emplace_back(L.offd_off[i] + (int64_t)k * ns[i], start[i], ns[i]);
+      fs[s[k]].push_back(updb_off[i] + k);
     }
-    // level must dominate every ancestor, not only the first one: handled above since all
-    // separator variables are visited.
   }
-  // levels must be monotone along the elimination order: a supernode that receives from a
-  // child processed later in this loop has a larger index, so one pass suffices.
   {
-    std::vector<int> tg_ptr(K + 1, 0), tr_ptr, tr_len;
-    std::vector<int64_t> tg_dst, ck, cj;
+    std::vector<int> tg_ptr(K + 1, 0), tr_ptr, tg_loc;
+    std::vector<int64_t> tr_src;
     tr_ptr.push_back(0);
     for (int p = 0; p < K; p++) {
       for (int t : tg_of_sn[p]) {
-        tg_dst.push_back(tg_dst_all[t]);
-        for (const Triple& tr : triples[t]) {
-          ck.push_back(tr.ck);
-          cj.push_back(tr.cj);
-          tr_len.push_back(tr.len);
-        }
-        tr_ptr.push_back((int)ck.size());
+        const int64_t off = tg_dst_all[t];
+        const int64_t dsz = (int64_t)ns[p] * ns[p];
+        tg_loc.push_back(off >= L.diag_off[p] && off < L.diag_off[p] + dsz
+                             ? (int)(off - L.diag_off[p])
+                             : (int)(dsz + off - L.offd_off[p]));
+        for (int64_t q : contrib[t]) tr_src.push_back(q);
+        tr_ptr.push_back((int)tr_src.size());
       }
-      tg_ptr[p + 1] = (int)tg_dst.size();
+      tg_ptr[p + 1] = (int)tg_loc.size();
     }
     CXK_TRY(ctx->tg_ptr.upload(tg_ptr));
-    CXK_TRY(ctx->tg_dst.upload(tg_dst));
+    CXK_TRY(ctx->tg_loc.upload(tg_loc));
     CXK_TRY(ctx->tr_ptr.upload(tr_ptr));
-    CXK_TRY(ctx->tr_colk.upload(ck));
-    CXK_TRY(ctx->tr_colj.upload(cj));
-    CXK_TRY(ctx->tr_len.upload(tr_len));
+    CXK_TRY(ctx->tr_src.upload(tr_src));
   }
   {
-    std::vector<int> fs_ptr(N + 1, 0), fs_start, fs_len;
-    std::vector<int64_t> fs_col;
+    std::vector<int> fs_ptr(N + 1, 0), fs_src;
     for (int p = 0; p < N; p++) {
-      for (auto& t : fs[p]) {
-        fs_col.push_back(std::get<0>(t));
-        fs_start.push_back(std::get<1>(t));
-        fs_len.push_back(std::get<2>(t));
-      }
-      fs_ptr[p + 1] = (int)fs_col.size();
+      for (int q : fs[p]) fs_src.push_back(q);
+      fs_ptr[p + 1] = (int)fs_src.size();
     }
     CXK_TRY(ctx->fs_ptr.upload(fs_ptr));
-    CXK_TRY(ctx->fs_col.upload(fs_col));
-    CXK_TRY(ctx->fs_start.upload(fs_start));
-    CXK_TRY(ctx->fs_len.upload(fs_len));
+    CXK_TRY(ctx->fs_src.upload(fs_src));
   }
+  CXK_TRY(ctx->upd_off.upload(upd_off));
+  CXK_TRY(ctx->updb_off.upload(updb_off));
+  CXK_TRY(ctx->upd.alloc((size_t)upd_total));
+  CXK_TRY(ctx->updb.alloc((size_t)updb_total));
   {
     // backward accumulation order: ancestors descending, columns ascending within one ancestor
     std::vector<int> bs_ptr(K + 1, 0), bs_c, bs_row;
@@ -436,6 +437,14 @@ int BuildPlans(cxk_context* ctx) {
   CXK_DEMAND(ctx->chol_lds <= kLdsLimit,
              "supernode too large for the LDS-resident block Cholesky (blocked path not built yet)");
   CXK_TRY(ctx->d_level_sn.upload(ctx->level_sn));
+  CXK_TRY(ctx->d_level_ptr.upload(ctx->level_ptr));
+  // narrow top of the tree: trailing levels that together hold few supernodes are swept by one
+  // workgroup (levels separated by a workgroup barrier instead of a kernel boundary)
+  {
+    int top = nlev;
+    while (top > 0 && ctx->level_ptr[top] - ctx->level_ptr[top - 1] <= 8) top--;
+    ctx->top_level = top;
+  }
   CXK_TRY(ctx->p_ns.upload(ns));
   CXK_TRY(ctx->p_nsep.upload(nsep));
   CXK_TRY(ctx->p_start.upload(start));
@@ -447,16 +456,16 @@ int BuildPlans(cxk_context* ctx) {
   P.start = ctx->p_start.p;
   P.diag_off = ctx->p_diag.p;
   P.offd_off = ctx->p_offd.p;
+  P.upd_off = ctx->upd_off.p;
+  P.updb_off = ctx->updb_off.p;
   P.tg_ptr = ctx->tg_ptr.p;
-  P.tg_dst = ctx->tg_dst.p;
+  P.tg_loc = ctx->tg_loc.p;
   P.tr_ptr = ctx->tr_ptr.p;
-  P.tr_colk = ctx->tr_colk.p;
-  P.tr_colj = ctx->tr_colj.p;
-  P.tr_len = ctx->tr_len.p;
+  P.tr_src = ctx->tr_src.p;
   P.fs_ptr = ctx->fs_ptr.p;
-  P.fs_col = ctx->fs_col.p;
-  P.fs_start = ctx->fs_start.p;
-  P.fs_len = ctx->fs_len.p;
+  P.fs_src = ctx->fs_src.p;
+  P.upd = ctx->upd.p;
+  P.updb = ctx->updb.p;
   P.bs_ptr = ctx->bs_ptr.p;
   P.bs_c = ctx->bs_c.p;
   P.bs_row = ctx->bs_row.p;
@@ -507,51 +516,71 @@ int LaunchSchur(cxk_context* ctx) {
   return CXK_SUCCESS;
 }
 
-int LaunchGather(cxk_context* ctx) {
-  gather_slab<<<GridFor((size_t)ctx->as_T, 256), 256, 0, ctx->stream>>>(
-      ctx->as_T, ctx->as_dst.p, ctx->as_ptr.p, ctx->as_src.p, ctx->G.p, ctx->slab.p);
-  gather_residuals<<<GridFor((size_t)ctx->md.N, 256), 256, 0, ctx->stream>>>(
-      ctx->md.N, ctx->rs_ptr.p, ctx->rs_src.p, ctx->AWc.p, ctx->AQcc.p, ctx->AW.p, ctx->AQc.p,
-      (int)ctx->cons.size(), ctx->sc.p, ctx->sys_sc.p);
+int LaunchGather(cxk_context* ctx, bool with_rhs, double k, double bs, double cs) {
+  GatherArgs a;
+  a.T = ctx->as_T;
+  a.dst = ctx->as_dst.p;
+  a.ptr = ctx->as_ptr.p;
+  a.src = ctx->as_src.p;
+  a.G = ctx->G.p;
+  a.slab = ctx->slab.p;
+  a.N = ctx->md.N;
+  a.rs_ptr = ctx->rs_ptr.p;
+  a.rs_src = ctx->rs_src.p;
+  a.AWc = ctx->AWc.p;
+  a.AQcc = ctx->AQcc.p;
+  a.AW = ctx->AW.p;
+  a.AQc = ctx->AQc.p;
+  a.K = (int)ctx->cons.size();
+  a.sc = ctx->sc.p;
+  a.sys_sc = ctx->sys_sc.p;
+  a.with_rhs = with_rhs;
+  a.k = k;
+  a.bs = bs;
+  a.cs = cs;
+  a.b = ctx->b.p;
+  a.y = ctx->y.p;
+  a.fail = ctx->d_fail.p;
+  assemble_gather<<<GridFor((size_t)std::max<int64_t>(ctx->as_T, ctx->md.N), 256), 256, 0,
+                    ctx->stream>>>(a);
   CXK_TRY(hipGetLastError());
   return CXK_SUCCESS;
 }
 
-int LaunchFactor(cxk_context* ctx, bool with_rhs) {
-  CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));
-  const int nlev = (int)ctx->level_ptr.size() - 1;
-  for (int l = 0; l < nlev; l++) {
-    const int cnt = ctx->level_ptr[l + 1] - ctx->level_ptr[l];
-    if (cnt == 0) continue;
-    chol_level<<<cnt, 256, ctx->chol_lds, ctx->stream>>>(ctx->plan, ctx->d_level_sn.p + ctx->level_ptr[l],
-                                                        ctx->slab.p, with_rhs ? ctx->y.p : nullptr,
-                                                        ctx->d_fail.p);
+// One sweep launch over levels [lb, le).  mode 0 factor(+forward), 1 forward, 2 backward.
+int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, bool with_rhs) {
+  const int per_wave = (int)(ctx->chol_lds / sizeof(double));
+  const int wmax = std::max(1, std::min<int>(8, (int)(kLdsLimit / std::max<size_t>(ctx->chol_lds, 8))));
+  int maxcnt = 0;
+  for (int l = lb; l < le; l++) maxcnt = std::max(maxcnt, ctx->level_ptr[l + 1] - ctx->level_ptr[l]);
+  if (maxcnt == 0) return CXK_SUCCESS;
+  int waves, grid;
+  if (le - lb > 1 || then_backward) {
+    waves = std::min(wmax, maxcnt);
+    grid = 1;
+  } else {
+    waves = std::max(1, std::min(wmax, (maxcnt + 255) / 256));
+    grid = (maxcnt + waves - 1) / waves;
   }
+  tree_sweep<<<grid, waves * 64, (size_t)waves * ctx->chol_lds, ctx->stream>>>(
+      ctx->plan, ctx->d_level_ptr.p, ctx->d_level_sn.p, lb, le, mode, then_backward ? 1 : 0,
+      ctx->slab.p, (with_rhs || mode != 0) ? ctx->y.p : nullptr, ctx->d_fail.p, per_wave);
   CXK_TRY(hipGetLastError());
   return CXK_SUCCESS;
 }
 
-int LaunchForward(cxk_context* ctx) {
+// Bottom-up pass (mode 0 factor or mode 1 forward), optionally continuing straight into the
+// top-down backward pass.  The narrow top of the tree is one launch.
+int LaunchTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
   const int nlev = (int)ctx->level_ptr.size() - 1;
-  for (int l = 0; l < nlev; l++) {
-    const int cnt = ctx->level_ptr[l + 1] - ctx->level_ptr[l];
-    if (cnt == 0) continue;
-    forward_level<<<cnt, 64, ctx->solve_lds, ctx->stream>>>(
-        ctx->plan, ctx->d_level_sn.p + ctx->level_ptr[l], ctx->slab.p, ctx->y.p);
-  }
-  CXK_TRY(hipGetLastError());
-  return CXK_SUCCESS;
-}
-
-int LaunchBackward(cxk_context* ctx) {
-  const int nlev = (int)ctx->level_ptr.size() - 1;
-  for (int l = nlev - 1; l >= 0; l--) {
-    const int cnt = ctx->level_ptr[l + 1] - ctx->level_ptr[l];
-    if (cnt == 0) continue;
-    backward_level<<<cnt, 64, ctx->solve_lds, ctx->stream>>>(
-        ctx->plan, ctx->d_level_sn.p + ctx->level_ptr[l], ctx->slab.p, ctx->y.p);
-  }
-  CXK_TRY(hipGetLastError());
+  const int top = ctx->top_level;
+  for (int l = 0; l < top; l++)
+    if (LaunchSweep(ctx, l, l + 1, mode, false, with_rhs)) return CXK_FAILURE;
+  if (top < nlev)
+    if (LaunchSweep(ctx, top, nlev, mode, backward, with_rhs)) return CXK_FAILURE;
+  if (backward)
+    for (int l = top - 1; l >= 0; l--)
+      if (LaunchSweep(ctx, l, l + 1, 2, false, true)) return CXK_FAILURE;
   return CXK_SUCCESS;
 }
 
@@ -875,7 +904,7 @@ int cxk_set_W(cxk_context* ctx, int i, const double* in) {
 int cxk_assemble_local(cxk_context* ctx) {
   if (CheckReady(ctx)) return CXK_FAILURE;
   if (LaunchSchur(ctx)) return CXK_FAILURE;
-  return LaunchGather(ctx);
+  return LaunchGather(ctx, false, 0, 0, 0);
 }
 
 int cxk_finish_assemble(cxk_context* ctx) { return CheckReady(ctx); }
@@ -887,7 +916,8 @@ int cxk_assemble(cxk_context* ctx) {
 
 int cxk_factor(cxk_context* ctx, int* ok) {
   if (CheckReady(ctx)) return CXK_FAILURE;
-  if (LaunchFactor(ctx, false)) return CXK_FAILURE;
+  CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));
+  if (LaunchTree(ctx, 0, false, false)) return CXK_FAILURE;
   return cxk_sync(ctx, ok);
 }
 
@@ -927,23 +957,19 @@ int cxk_newton_direction(cxk_context* ctx, double k, double bs, double cs) {
   const int N = ctx->md.N;
   build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p,
                                                       ctx->y.p);
-  if (LaunchForward(ctx)) return CXK_FAILURE;
-  return LaunchBackward(ctx);
+  return LaunchTree(ctx, 1, true, true);
 }
 
 int cxk_kkt_solve_async(cxk_context* ctx, double k, double bs, double cs) {
-  if (cxk_assemble_local(ctx)) return CXK_FAILURE;
-  const int N = ctx->md.N;
-  build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p,
-                                                      ctx->y.p);
-  if (LaunchFactor(ctx, true)) return CXK_FAILURE;
-  return LaunchBackward(ctx);
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  if (LaunchSchur(ctx)) return CXK_FAILURE;
+  if (LaunchGather(ctx, true, k, bs, cs)) return CXK_FAILURE;
+  return LaunchTree(ctx, 0, true, true);
 }
 
 int cxk_solve_inplace(cxk_context* ctx, double* yh) {
   if (cxk_set_y(ctx, yh)) return CXK_FAILURE;
-  if (LaunchForward(ctx)) return CXK_FAILURE;
-  if (LaunchBackward(ctx)) return CXK_FAILURE;
+  if (LaunchTree(ctx, 1, true, true)) return CXK_FAILURE;
   return cxk_get_y(ctx, yh);
 }
 
@@ -1101,6 +1127,12 @@ int cxk_assembly_work(const cxk_context* ctx, double* bytes, double* flops) {
   if (flops) *flops = F;
   return CXK_SUCCESS;
 }
+
+#ifdef CXK_DEBUG_STAMPS
+int cxk_debug_stamps(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cxk_stamp), 16 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int cxk_enable_timing(cxk_context* ctx, int on) {
   if (!ctx) return CXK_FAILURE;
