@@ -91,6 +91,42 @@ __global__ void build_rhs(int N, double k, double bs, double cs, const double* _
     y[p] = k * (b[p] * bs + AQc[p] * cs) - 2 * AW[p];
 }
 
+// y = cb b + cq AQc + cw AW : every right-hand side of the IPM loop (cone_program.cc:181, 409-411, 504)
+__global__ void build_rhs_comb(int N, double cb, double cq, double cw, const double* __restrict__ b,
+                               const double* __restrict__ AQc, const double* __restrict__ AW,
+                               double* __restrict__ y) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x)
+    y[p] = cb * b[p] + cq * AQc[p] + cw * AW[p];
+}
+
+// The scalars the host loop needs per iteration (cone_program.cc:343-357, 439-446):
+// out = { b.y, AQc.y, |b|^2, |AQc|^2, <w,c>, <c,Qc> } ; one workgroup, fixed summation order.
+__global__ void __launch_bounds__(1024)
+step_scalars(int N, const double* __restrict__ b, const double* __restrict__ AQc,
+             const double* __restrict__ y, const double* __restrict__ sys_sc,
+             double* __restrict__ out) {
+  __shared__ double red[16];
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int p = threadIdx.x; p < N; p += blockDim.x) {
+    s0 = fma(b[p], y[p], s0);
+    s1 = fma(AQc[p], y[p], s1);
+    s2 = fma(b[p], b[p], s2);
+    s3 = fma(AQc[p], AQc[p], s3);
+  }
+  s0 = BlockSum(s0, red);
+  s1 = BlockSum(s1, red);
+  s2 = BlockSum(s2, red);
+  s3 = BlockSum(s3, red);
+  if (threadIdx.x == 0) {
+    out[0] = s0;
+    out[1] = s1;
+    out[2] = s2;
+    out[3] = s3;
+    out[4] = sys_sc[0];
+    out[5] = sys_sc[1];
+  }
+}
+
 // y = AQc cs - b bs  (ComputeMuFromDivergence cone_program.cc:181)
 __global__ void build_mu_rhs(int N, double bs, double cs, const double* __restrict__ b,
                              const double* __restrict__ AQc, double* __restrict__ y) {

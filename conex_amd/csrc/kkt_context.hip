@@ -86,7 +86,7 @@ struct cxk_context {
   size_t chol_lds = 0, solve_lds = 0;  // bytes of LDS staging one supernode needs
   int top_level = 0;                   // levels [top_level, nlev) run inside one workgroup
   // device state
-  DevBuf<double> G, AWc, AQcc, sc, slab, y, b, AW, AQc, sys_sc, info2, info4, red_out;
+  DevBuf<double> G, AWc, AQcc, sc, slab, y, b, AW, AQc, sys_sc, info2, info4, red_out, scal_out;
   DevBuf<int64_t> d_g_off, d_r_off, as_dst, as_src, rs_src;
   DevBuf<int> as_ptr, rs_ptr, cl_ptr, cl_perm, d_level_sn, d_level_ptr, d_fail, d_pinv, tg_loc;
   DevBuf<unsigned char> d_mask;
@@ -781,6 +781,7 @@ int cxk_finalize(cxk_context* ctx) {
   CXK_TRY(ctx->AQc.alloc(N));
   CXK_TRY(ctx->sys_sc.alloc(2));
   CXK_TRY(ctx->red_out.alloc(4));
+  CXK_TRY(ctx->scal_out.alloc(8));
   CXK_TRY(ctx->d_fail.alloc(1));
   {
     // per-constraint step outputs; constraints without a cone (constant blocks) keep the
@@ -958,6 +959,24 @@ int cxk_newton_direction(cxk_context* ctx, double k, double bs, double cs) {
   build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p,
                                                       ctx->y.p);
   return LaunchTree(ctx, 1, true, true);
+}
+
+int cxk_solve_rhs(cxk_context* ctx, double cb, double cq, double cw) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  const int N = ctx->md.N;
+  build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, cb, cq, cw, ctx->b.p, ctx->AQc.p,
+                                                           ctx->AW.p, ctx->y.p);
+  return LaunchTree(ctx, 1, true, true);
+}
+
+int cxk_step_scalars(cxk_context* ctx, double* out6) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  step_scalars<<<1, 1024, 0, ctx->stream>>>(ctx->md.N, ctx->b.p, ctx->AQc.p, ctx->y.p,
+                                            ctx->sys_sc.p, ctx->scal_out.p);
+  CXK_TRY(hipGetLastError());
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(out6, ctx->scal_out.p, 6 * sizeof(double), hipMemcpyDeviceToHost));
+  return CXK_SUCCESS;
 }
 
 int cxk_kkt_solve_async(cxk_context* ctx, double k, double bs, double cs) {

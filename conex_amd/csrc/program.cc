@@ -1,0 +1,904 @@
+// CONEX_* outer C-ABI (include/conex.h) and the IPM driver on top of the device-resident
+// Newton-step path (cxk_*, include/conex_kkt_hip.h).
+//
+// Host side only: constraint builders, argument checks, the interior-point control loop and the
+// scalar mu rules.  Restates
+//   interfaces/conex.cc:20-407        argument checks, copies, status codes
+//   conex/cone_program.cc:78-112      Initialize
+//   conex/cone_program.cc:166-224     MinimizeNormInf, ComputeMuFromDivergence, ApplyLimits
+//   conex/cone_program.cc:235-552     Solve
+//   conex/divergence.cc:17-110        DivergenceUpperBoundInverse and helpers
+//   conex/linear_constraint.cc:14-46  PreprocessLinearInequality
+//   conex/hermitian_psd.cc:249-313, linear_constraint.cc:207-228, soc_constraint.cc:305-335
+//                                     UpdateLinearOperator / UpdateAffineTerm checks
+// Every fp64 vector/matrix operation of the loop is a cxk_* call; per iteration only the
+// scalars of cxk_step_scalars / cxk_prepare_step / cxk_weighted_slack_eigenvalues cross PCIe.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/conex.h"
+#include "../../include/conex_kkt_hip.h"
+
+namespace {
+
+#define CONEX_DEMAND(x, msg)                                         \
+  if (!(x)) {                                                        \
+    fprintf(stderr, "%s line %d: %s\n", __FILE__, __LINE__, msg);    \
+    return 1;                                                        \
+  }
+
+int g_verbose = -1;
+bool Verbose() {
+  if (g_verbose < 0) {
+    const char* e = getenv("CONEX_VERBOSE");
+    g_verbose = (e && *e && *e != '0') ? 1 : 0;
+  }
+  return g_verbose == 1;
+}
+
+enum ConeKind { kLmi, kLinear, kSoc, kQuadCost };
+
+struct Cone {
+  ConeKind kind = kLmi;
+  int order = 0;        // LMI n ; linear rows ; SOC n (vectors in R^{n+1})
+  int hyper = 1;        // LMI only: 1, 2, 4, 8
+  std::vector<int> vars;                   // clique (variable ids) fixed at creation time
+  // LMI: mats[v] = hyper planes of n*n (col-major); affine likewise. Linear/SOC: dense A (rows x cols)
+  std::vector<std::vector<double>> mats;
+  std::vector<double> affine;
+  int cols = 0;         // linear / SOC: number of columns currently allocated in `A`
+  std::vector<double> A;
+  std::vector<double> c;
+};
+
+struct Program {
+  unsigned magic = 0xC0DEC0DEu;
+  int num_vars = 0;
+  std::vector<Cone> cones;
+  bool contains_quadratic_costs = false;
+  std::vector<double> linear_cost;
+  // solver state
+  cxk_context* ctx = nullptr;
+  bool initialized = false;
+  bool dirty = true;
+  int device = 0;
+  double b_scaling = 1, c_scaling = 1;
+  std::vector<double> sqrt_inv_mu;
+  int num_iter = 0;
+  bool stats_ready = false;
+  int solved = 0, primal_infeasible = 0, dual_infeasible = 0;
+  std::string why;
+  ~Program() {
+    if (ctx) cxk_destroy(ctx);
+  }
+};
+
+// SAFER_CAST_TO_Program interfaces/conex.cc:20-33
+#define CAST_PROGRAM(x, prog)                                       \
+  CONEX_DEMAND(x, "Program pointer is null.");                      \
+  Program* prog = static_cast<Program*>(x);                         \
+  CONEX_DEMAND(prog->magic == 0xC0DEC0DEu, "Program corrupted or invalid pointer.");
+
+std::vector<int> AllVars(const Program& p) {
+  std::vector<int> v(p.num_vars);
+  for (int i = 0; i < p.num_vars; i++) v[i] = i;
+  return v;
+}
+
+int AddCone(Program* p, Cone&& c) {
+  p->cones.push_back(std::move(c));
+  p->dirty = true;
+  return static_cast<int>(p->cones.size()) - 1;
+}
+
+// ---------------------------------------------------------------- divergence.cc
+struct Wse {
+  double frob = 0, trace = 0, lmin = 0, lmax = 0, rank = 0;
+};
+
+double SolveRational(double a, double b, double c, double d, double k) {
+  const double ur = b * b - 4 * a * c + 8 * a * k + 2 * b * d * k + std::pow(d * k, 2);
+  return -(b + d * k - std::sqrt(ur)) / (2 * a);
+}
+bool InLimits(double x, double lo, double hi) { return x >= lo && x <= hi; }
+double InverseLambdaMaxBranch(double bound, const Wse& p) {
+  const double x = SolveRational(p.frob, -2 * p.trace, p.rank, p.lmax, bound);
+  const double lower = 2.0 / (p.lmax + p.lmin);
+  return x >= lower ? x : -1;
+}
+double InverseLambdaMinBranch(double bound, const Wse& p) {
+  const double upper = 2.0 / (p.lmax + p.lmin);
+  const double a = p.frob / p.lmin, b = 2 * p.trace / p.lmin, n = p.rank / p.lmin, c = bound;
+  const double ur = b * b + 2 * b * c + c * c - 4 * a * n;
+  const double f = (b + c + std::sqrt(ur)) / (2 * a), s = (b + c - std::sqrt(ur)) / (2 * a);
+  double k = -1;
+  if (!(ur < 0)) {
+    if (InLimits(f, 0, upper)) k = f;
+    if (InLimits(s, 0, upper) && s > k) k = s;
+  }
+  return k;
+}
+bool BoundIsFinite(double k, const Wse& p) {
+  double ni = std::fabs(k * p.lmax - 1);
+  if (ni < std::fabs(k * p.lmin - 1)) ni = std::fabs(k * p.lmin - 1);
+  return ni < 1;
+}
+double DivergenceUpperBoundInverse(double bound, const Wse& p) {
+  double k = -1;
+  const double k1 = InverseLambdaMinBranch(bound, p);
+  const double k2 = InverseLambdaMaxBranch(bound, p);
+  if (BoundIsFinite(k1, p)) k = k1;
+  if (k2 > k && BoundIsFinite(k2, p)) k = k2;
+  return k;
+}
+
+int RankOf(const Cone& c) {
+  switch (c.kind) {
+    case kLmi: return c.order;
+    case kLinear: return c.order;
+    case kSoc: return 2;
+    default: return 0;
+  }
+}
+
+// Upload the builder state into a fresh device context (Initialize, cone_program.cc:78-112).
+int BuildContext(Program* p) {
+  if (p->ctx) {
+    cxk_destroy(p->ctx);
+    p->ctx = nullptr;
+  }
+  if (cxk_create(p->num_vars, p->device, nullptr, &p->ctx) != CXK_SUCCESS) {
+    fprintf(stderr, "conex: no HIP device available; this library has no CPU fallback.\n");
+    return 1;
+  }
+  for (const Cone& c : p->cones) {
+    int id = -1;
+    const int m = static_cast<int>(c.vars.size());
+    switch (c.kind) {
+      case kLmi: {
+        CONEX_DEMAND(c.hyper == 1,
+                     "complex / quaternion / octonion LMIs are not on the device yet (see DESIGN.md)");
+        const size_t nn = (size_t)c.order * c.order;
+        std::vector<double> A((size_t)m * nn, 0.0), C(nn, 0.0);
+        for (int v = 0; v < m && v < (int)c.mats.size(); v++)
+          if (!c.mats[v].empty()) std::copy(c.mats[v].begin(), c.mats[v].begin() + nn, A.begin() + v * nn);
+        if (!c.affine.empty()) std::copy(c.affine.begin(), c.affine.begin() + nn, C.begin());
+        id = cxk_add_lmi(p->ctx, c.order, m, A.data(), C.data(), c.vars.data());
+        break;
+      }
+      case kLinear: {
+        std::vector<double> A((size_t)c.order * m, 0.0);
+        for (int j = 0; j < m && j < c.cols; j++)
+          std::copy(c.A.begin() + (size_t)j * c.order, c.A.begin() + (size_t)(j + 1) * c.order,
+                    A.begin() + (size_t)j * c.order);
+        id = cxk_add_linear(p->ctx, c.order, m, A.data(), c.c.data(), c.vars.data());
+        break;
+      }
+      case kSoc: {
+        const int len = c.order + 1;
+        std::vector<double> A((size_t)len * m, 0.0), cc(len, 0.0);
+        for (int j = 0; j < m && j < c.cols; j++)
+          std::copy(c.A.begin() + (size_t)j * len, c.A.begin() + (size_t)(j + 1) * len,
+                    A.begin() + (size_t)j * len);
+        std::copy(c.c.begin(), c.c.end(), cc.begin());
+        id = cxk_add_soc(p->ctx, c.order, m, A.data(), cc.data(), c.vars.data());
+        break;
+      }
+      case kQuadCost:
+        id = cxk_add_static(p->ctx, m, c.A.data(), c.vars.data());
+        break;
+    }
+    CONEX_DEMAND(id >= 0, "constraint rejected while building the device program");
+  }
+  CONEX_DEMAND(cxk_finalize(p->ctx) == CXK_SUCCESS, cxk_last_error(p->ctx));
+  p->dirty = false;
+  return 0;
+}
+
+void ApplyLimits(double* x, double lb, double ub) {
+  if (*x > ub) *x = ub;
+  if (*x < lb) *x = lb;
+}
+
+#define REPORT(name, val) \
+  if (Verbose()) printf(#name ": %.2e, ", (double)(val));
+#define PRINTSTATUS(x) \
+  if (Verbose()) printf("Status: %s\n\n", x);
+
+struct Config {  // conex::SolverConfiguration
+  int prepare_dual_variables, initialization_mode;
+  double inv_sqrt_mu_max, minimum_mu, maximum_mu, divergence_upper_bound;
+  int enable_line_search;
+  double dinf_upper_bound;
+  int final_centering_steps;
+  double final_centering_tolerance;
+  int initial_centering_steps_warmstart, initial_centering_steps_coldstart;
+  double warmstart_abort_threshold;
+  int max_iterations;
+  double infeasibility_threshold, kkt_error_tolerance;
+  int kkt_solver, enable_rescaling, iterative_refinement_iterations;
+};
+
+Config FromApi(const CONEX_SolverConfiguration* c) {  // interfaces/conex.cc:65-90
+  Config o;
+  o.prepare_dual_variables = c->prepare_dual_variables;
+  o.initialization_mode = c->initialization_mode;
+  o.inv_sqrt_mu_max = c->inv_sqrt_mu_max;
+  o.minimum_mu = c->minimum_mu;
+  o.maximum_mu = c->maximum_mu;
+  o.divergence_upper_bound = c->divergence_upper_bound;
+  o.enable_line_search = c->enable_line_search;
+  o.dinf_upper_bound = c->dinf_upper_bound;
+  o.final_centering_steps = c->final_centering_steps;
+  o.final_centering_tolerance = c->final_centering_tolerance;
+  o.initial_centering_steps_warmstart = c->initial_centering_steps_warmstart;
+  o.initial_centering_steps_coldstart = c->initial_centering_steps_coldstart;
+  o.warmstart_abort_threshold = c->warmstart_abort_threshold;
+  o.max_iterations = c->max_iterations;
+  o.iterative_refinement_iterations = c->iterative_refinement_iterations;
+  o.infeasibility_threshold = c->infeasibility_threshold;
+  o.kkt_error_tolerance = c->kkt_error_tolerance;
+  o.enable_rescaling = c->enable_rescaling;
+  o.kkt_solver = c->kkt_solver;
+  return o;
+}
+
+// ComputeMuFromDivergence cone_program.cc:173-214
+int MuFromDivergence(Program* p, const Config& cfg, int rankK, double* out) {
+  cxk_context* ctx = p->ctx;
+  const double bs = p->b_scaling, cs = p->c_scaling;
+  if (cxk_solve_rhs(ctx, -bs, cs, 0.0)) return 1;  // y = AQc*cs - b*bs ; SolveInPlace
+  double e4[4];
+  if (cxk_weighted_slack_eigenvalues(ctx, cs, e4)) return 1;
+  Wse mp;
+  mp.lmin = e4[0];
+  mp.lmax = e4[1];
+  mp.frob = e4[2];
+  mp.trace = e4[3];
+  mp.rank = rankK;
+  const double bound = cfg.divergence_upper_bound * rankK;
+  double inv = DivergenceUpperBoundInverse(bound, mp);
+  if (inv == -1) {  // MinimizeNormInf :166-172
+    inv = -1;
+    if (mp.lmin > 0) inv = 2.0 / (mp.lmin + mp.lmax);
+  }
+  if (inv < 0 && mp.trace > 1e-12) {
+    const double kstar = mp.trace / mp.frob;
+    double nb = 1.5 * (mp.frob * kstar * kstar - 2 * mp.trace * kstar + rankK);
+    if (nb > rankK * .7) nb = rankK * .7;
+    const double a = mp.frob, b = -2 * mp.trace, c = rankK - nb;
+    if (b * b - 4 * a * c < 0)
+      inv = mp.trace / mp.frob;
+    else
+      inv = (-b + std::sqrt(b * b - 4 * a * c)) / (2 * a);
+  }
+  *out = inv;
+  return 0;
+}
+
+// conex::Solve cone_program.cc:235-533. Returns the solved flag (1 = solved).
+int SolveProgram(Program* p, const Config& cfg, double* yout) {
+  if (p->contains_quadratic_costs && !(cfg.enable_line_search && !cfg.enable_rescaling)) {
+    fprintf(stderr, "%s line %d: %s\n", __FILE__, __LINE__,
+            "Must enable line search and disable rescaling for problems with quadratic costs.");
+    return 1;  // the reference's CONEX_DEMAND returns 1 here too
+  }
+  const int m = p->num_vars;
+  p->solved = 0;
+  p->primal_infeasible = 0;
+  p->dual_infeasible = 0;
+  bool max_iters_reached = true;
+  if (p->cones.empty()) {  // empty program :265-270
+    for (int i = 0; i < m; i++) yout[i] = -p->linear_cost[i] * std::numeric_limits<double>::infinity();
+    return 0;
+  }
+  if (cfg.enable_line_search) {
+    // The line-search mu rule (cone_program.cc:118-160) is not on the device yet; the reference
+    // falls back to the divergence rule whenever a cone reports failure, which is what happens
+    // here for every call.  Programs with quadratic costs rely on it and are rejected below.
+    if (p->contains_quadratic_costs) {
+      fprintf(stderr, "%s line %d: Solver terminating with error: line-search failed.\n", __FILE__,
+              __LINE__);
+      return 1;
+    }
+  }
+  if (cfg.kkt_solver != 0 || cfg.iterative_refinement_iterations != 0) {
+    fprintf(stderr,
+            "conex: kkt_solver/iterative_refinement options need the dense KKT matrix and are not "
+            "available on the device path; using LLT without refinement.\n");
+  }
+  // Initialize :78-112
+  if (!p->initialized || p->dirty || cfg.initialization_mode == 0) {
+    if (p->dirty || !p->ctx) {
+      if (BuildContext(p)) return 0;
+    }
+    if (cfg.initialization_mode == 0) {
+      p->b_scaling = 1;
+      p->c_scaling = 1;
+      if (cxk_set_identity(p->ctx)) return 0;
+    }
+    p->initialized = true;
+  }
+  cxk_context* ctx = p->ctx;
+  p->sqrt_inv_mu.assign(std::max(cfg.max_iterations, 1), 0.0);
+  p->num_iter = 0;
+  p->stats_ready = true;
+  if (Verbose()) printf("\n");
+
+  const int N = cxk_system_size(ctx);
+  std::vector<double> bin(m);
+  for (int i = 0; i < m; i++) bin[i] = -p->linear_cost[i];
+  if (cxk_set_cost(ctx, bin.data())) return 0;
+
+  double inv_sqrt_mu_max = cfg.inv_sqrt_mu_max;
+  double cx = 1, by = -1, kkt_error = 0;
+  double inv_sqrt_mu = 0, e_weight = 1, c_weight = 0, step_size = 1;
+  int rankK = 0;
+  for (const Cone& c : p->cones) rankK += RankOf(c);
+  int centering_steps = 0;
+  bool warmstart_aborted = false;
+  int initial_centering_steps = cfg.initial_centering_steps_coldstart;
+  int initial_centering = 1;
+  double& c_scaling = p->c_scaling;
+  double& b_scaling = p->b_scaling;
+  if (cfg.initialization_mode) {
+    PRINTSTATUS("Warmstarting...");
+    initial_centering_steps = cfg.initial_centering_steps_warmstart;
+  }
+
+  for (int i = 0; i < cfg.max_iterations; i++) {
+    if (i >= initial_centering_steps) initial_centering = 0;
+    if (Verbose()) printf(i < 10 ? "i:  %d, " : "i: %d, ", i);
+    const bool final_centering = (inv_sqrt_mu >= inv_sqrt_mu_max) ||
+                                 (kkt_error > cfg.kkt_error_tolerance) ||
+                                 i >= (cfg.max_iterations - cfg.final_centering_steps);
+    const bool update_mu = (i == 0) || !(initial_centering || final_centering) || warmstart_aborted;
+    warmstart_aborted = false;
+    if (final_centering) {
+      if (centering_steps >= cfg.final_centering_steps) {
+        max_iters_reached = (i >= cfg.max_iterations - 1);
+        break;
+      }
+    }
+    if (cxk_assemble(ctx)) return 0;
+    if (i < 1 && cfg.enable_rescaling) {
+      if (cfg.initialization_mode == 0) {
+        double sc[6];
+        if (cxk_step_scalars(ctx, sc)) return 0;
+        b_scaling = 1.0 / (1 + std::sqrt(sc[2]));
+        c_scaling = 1.0 / (1 + std::sqrt(sc[3]));
+      }
+      double mu_target = 1.0 / (inv_sqrt_mu_max * inv_sqrt_mu_max);
+      mu_target *= (b_scaling * c_scaling);
+      inv_sqrt_mu_max = 1.0 / std::sqrt(mu_target);
+    }
+    int ok = 0;
+    if (cxk_factor(ctx, &ok)) return 0;
+    if (!ok) {
+      if (i == 0 && cfg.initialization_mode == 1) {
+        PRINTSTATUS("Aborting warmstart...");
+        cxk_set_identity(ctx);
+        warmstart_aborted = true;
+        continue;
+      }
+      p->solved = 0;
+      PRINTSTATUS("Factorization failed.");
+      return 0;
+    }
+    if (update_mu) {
+      double temp = -1;
+      if (MuFromDivergence(p, cfg, rankK, &temp)) return 0;
+      if (temp > 0)
+        inv_sqrt_mu = temp;
+      else
+        inv_sqrt_mu *= .5;
+    } else {
+      if (initial_centering == 0) centering_steps++;
+    }
+    ApplyLimits(&inv_sqrt_mu, std::sqrt(1.0 / (1e-15 + cfg.maximum_mu)), inv_sqrt_mu_max);
+
+    if (cxk_newton_direction(ctx, inv_sqrt_mu, b_scaling, c_scaling)) return 0;
+    e_weight = 1;
+    c_weight = inv_sqrt_mu * c_scaling;
+    double info[2];
+    if (cxk_prepare_step(ctx, 0, c_weight, e_weight, info)) return 0;
+    step_size = 2.0 / (info[1] * info[1]);
+    if (step_size > 1) step_size = 1;
+    double sc[6];
+    if (cxk_step_scalars(ctx, sc)) return 0;
+    if (i == 0 && cfg.initialization_mode == 1 && info[1] >= cfg.warmstart_abort_threshold) {
+      PRINTSTATUS("Aborting warmstart...");
+      cxk_set_identity(ctx);
+      warmstart_aborted = true;
+    } else {
+      if (cxk_take_step(ctx, 0, e_weight, step_size)) return 0;
+    }
+    const double d_2 = std::sqrt(std::fabs(info[0]));
+    const double d_inf = std::fabs(info[1]);
+    by = sc[0] * 1.0 / (inv_sqrt_mu * c_scaling);
+    cx = 2 * sc[4] + sc[1] - inv_sqrt_mu * sc[5] * c_scaling;
+    cx /= (inv_sqrt_mu * b_scaling);
+    double mu = 1.0 / inv_sqrt_mu;
+    mu *= mu;
+    const double s_dot_x = mu * (rankK - d_2 * d_2) / (b_scaling * c_scaling);
+    mu = mu / (c_scaling * b_scaling);
+    REPORT(mu, mu);
+    REPORT(d_2, d_2);
+    REPORT(d_inf, d_inf);
+    if (!p->contains_quadratic_costs) {
+      REPORT(by, by);
+      REPORT(cx, cx);
+      kkt_error = std::fabs(cx - by - s_dot_x) / s_dot_x;
+      REPORT(kkt_error, kkt_error);
+    }
+    p->num_iter = i + 1;
+    p->sqrt_inv_mu[i] = inv_sqrt_mu;
+    if (Verbose()) printf("\n");
+    if (final_centering || inv_sqrt_mu >= inv_sqrt_mu_max) {
+      if (d_inf <= cfg.final_centering_tolerance) {
+        max_iters_reached = false;
+        break;
+      }
+    }
+  }
+  std::vector<double> y(N, 0.0);
+  if (cxk_get_y(ctx, y.data())) return 0;
+  for (int i = 0; i < m; i++) yout[i] = y[i];
+
+  double mu = 1.0 / inv_sqrt_mu;
+  mu *= mu;
+  if (mu > cfg.infeasibility_threshold) {
+    PRINTSTATUS("Infeasible Or Unbounded!!.");
+    p->solved = 0;
+    p->primal_infeasible = cx * inv_sqrt_mu <= -.5;
+    p->dual_infeasible = by * inv_sqrt_mu >= .5;
+  } else {
+    p->solved = 1;
+  }
+  if (cfg.prepare_dual_variables) {  // :500-516
+    int ok = 0;
+    if (cxk_assemble(ctx) || cxk_factor(ctx, &ok)) return 0;
+    if (cxk_solve_rhs(ctx, inv_sqrt_mu * b_scaling, 0.0, -1.0)) return 0;
+    double info[2];
+    if (cxk_prepare_step(ctx, 1, 0.0, 0.0, info)) return 0;
+  }
+  if (p->solved) {
+    for (int i = 0; i < m; i++) yout[i] /= inv_sqrt_mu;
+    for (int i = 0; i < m; i++) yout[i] /= c_scaling;
+  }
+  if (p->solved) {
+    if (max_iters_reached) {
+      p->solved = 0;
+      PRINTSTATUS("Terminating at maximum iteration limit.");
+    } else {
+      PRINTSTATUS("Solved.");
+    }
+  }
+  return p->solved;
+}
+
+}  // namespace
+
+// =========================================================================== C-ABI
+extern "C" {
+
+void* CONEX_CreateConeProgram() { return new Program(); }
+
+void CONEX_DeleteConeProgram(void* prog) { delete static_cast<Program*>(prog); }
+
+CONEX_STATUS CONEX_SetNumberOfVariables(void* x, int number_of_variables) {
+  CONEX_DEMAND(number_of_variables >= 1, "Number of variables must be > 0.");
+  CAST_PROGRAM(x, p);
+  CONEX_DEMAND(p->num_vars == 0, "Number of variables already set.");
+  p->num_vars = number_of_variables;
+  p->linear_cost.assign(number_of_variables, 0.0);
+  p->dirty = true;
+  return CONEX_SUCCESS;
+}
+
+int CONEX_AddDenseLMIConstraint(void* x, const double* A, int Ar, int Ac, int m, const double* c,
+                                int cr, int cc) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || Ar != Ac || Ar != cr || cc != cr || !A || !c) return -1;
+  if (p->num_vars == 0) {  // Program(0) + dense constraint: the reference sizes by the clique
+    p->num_vars = m;
+    p->linear_cost.assign(m, 0.0);
+  }
+  Cone k;
+  k.kind = kLmi;
+  k.order = cc;
+  k.hyper = 1;
+  k.vars = AllVars(*p);
+  const size_t nn = (size_t)Ar * Ac;
+  for (int i = 0; i < m; i++) k.mats.emplace_back(A + i * nn, A + (i + 1) * nn);
+  k.affine.assign(c, c + nn);
+  return AddCone(p, std::move(k));
+}
+
+int CONEX_AddSparseLMIConstraint(void* x, const double* A, int Ar, int Ac, int num_vars,
+                                 const double* c, int cr, int cc, const long* vars, int vars_rows) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || Ar != Ac || Ar != cr || cc != cr || vars_rows != num_vars || !A || !c || !vars) return -1;
+  Cone k;
+  k.kind = kLmi;
+  k.order = cc;
+  k.hyper = 1;
+  std::vector<char> seen(std::max(p->num_vars, 1), 0);
+  for (int i = 0; i < num_vars; i++) {  // IsUnique constraint_manager.h:11-24
+    const long v = vars[i];
+    if (v < 0 || v >= p->num_vars || seen[v]++) return -1;
+    k.vars.push_back(static_cast<int>(v));
+  }
+  const size_t nn = (size_t)Ar * Ac;
+  for (int i = 0; i < num_vars; i++) k.mats.emplace_back(A + i * nn, A + (i + 1) * nn);
+  k.affine.assign(c, c + nn);
+  return AddCone(p, std::move(k));
+}
+
+int CONEX_AddDenseLinearConstraint(void* x, const double* A, int Ar, int Ac, const double* c,
+                                   int cr) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || Ar != cr || !A || !c) return -1;
+  if (p->num_vars == 0) {
+    p->num_vars = Ac;
+    p->linear_cost.assign(Ac, 0.0);
+  }
+  Cone k;
+  k.kind = kLinear;
+  k.order = Ar;
+  k.cols = Ac;
+  k.vars = AllVars(*p);
+  k.A.assign(A, A + (size_t)Ar * Ac);
+  k.c.assign(c, c + Ar);
+  return AddCone(p, std::move(k));
+}
+
+int CONEX_AddLinearInequalities(void* x, const double* A, int Ar, int Ac, const double* lb,
+                                int num_lb, const double* ub, int num_ub) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || Ar != num_lb || Ar != num_ub) return -1;
+  // PreprocessLinearInequality linear_constraint.cc:14-46
+  std::vector<std::vector<double>> rows;
+  std::vector<double> rhs;
+  for (int i = 0; i < Ar; i++) {
+    double n2 = 0;
+    for (int j = 0; j < Ac; j++) n2 += A[i + (size_t)j * Ar] * A[i + (size_t)j * Ar];
+    if (lb[i] == ub[i]) {
+      fprintf(stderr, "%s line %d: %s\n", __FILE__, __LINE__,
+              "equality rows (lb == ub) need the LDLT path, which is not on the device yet.");
+      return -1;
+    }
+    if (ub[i] < 1e8) {
+      const double scale = 1.0 / std::sqrt(n2 + ub[i] * ub[i]);
+      std::vector<double> r(Ac);
+      for (int j = 0; j < Ac; j++) r[j] = scale * A[i + (size_t)j * Ar];
+      rows.push_back(r);
+      rhs.push_back(scale * ub[i]);
+    }
+    if (lb[i] > -1e8) {
+      const double scale = 1.0 / std::sqrt(n2 + lb[i] * lb[i]);
+      std::vector<double> r(Ac);
+      for (int j = 0; j < Ac; j++) r[j] = -scale * A[i + (size_t)j * Ar];
+      rows.push_back(r);
+      rhs.push_back(-scale * lb[i]);
+    }
+  }
+  if (!rows.empty()) {
+    if (p->num_vars == 0) {
+      p->num_vars = Ac;
+      p->linear_cost.assign(Ac, 0.0);
+    }
+    Cone k;
+    k.kind = kLinear;
+    k.order = static_cast<int>(rows.size());
+    k.cols = Ac;
+    k.vars = AllVars(*p);
+    k.A.assign((size_t)k.order * Ac, 0.0);
+    for (int i = 0; i < k.order; i++)
+      for (int j = 0; j < Ac; j++) k.A[i + (size_t)j * k.order] = rows[i][j];
+    k.c = rhs;
+    AddCone(p, std::move(k));
+  }
+  return -1;  // interfaces/conex.cc:213-214
+}
+
+CONEX_STATUS CONEX_AddQuadraticCost(void* x, const double* A, int Ar, int Ac) {
+  CAST_PROGRAM(x, p);
+  CONEX_DEMAND(A && Ar == Ac, "Quadratic cost matrix must be square.");
+  // NonZeroSubMat interfaces/conex.cc:44-64
+  std::vector<int> vars;
+  for (int i = 0; i < Ar; i++)
+    if (A[i + (size_t)i * Ar] > 0) vars.push_back(i);
+  const int m = static_cast<int>(vars.size());
+  Cone k;
+  k.kind = kQuadCost;
+  k.vars = vars;
+  k.A.assign((size_t)m * m, 0.0);
+  for (int r = 0; r < m; r++)
+    for (int c = 0; c < m; c++) {
+      const double v = (A[vars[r] + (size_t)vars[c] * Ar] + A[vars[c] + (size_t)vars[r] * Ar]) / 2.0;
+      k.A[r + (size_t)c * m] = v;
+      k.A[c + (size_t)r * m] = v;
+    }
+  p->contains_quadratic_costs = true;
+  AddCone(p, std::move(k));
+  return CONEX_SUCCESS;  // AddQuadraticCost returns "failure = false"
+}
+
+CONEX_STATUS CONEX_NewQuadraticCost(void* x, int* constraint_id) {
+  CONEX_DEMAND(constraint_id, "Received output null pointer.");
+  CAST_PROGRAM(x, p);
+  Cone k;
+  k.kind = kQuadCost;
+  k.vars = AllVars(*p);
+  k.A.assign((size_t)p->num_vars * p->num_vars, 0.0);
+  p->contains_quadratic_costs = true;
+  *constraint_id = AddCone(p, std::move(k));
+  return CONEX_SUCCESS;
+}
+
+CONEX_STATUS CONEX_NewLinearMatrixInequality(void* x, int order, int hyper_complex_dim,
+                                             int* constraint_id) {
+  CONEX_DEMAND(order >= 1, "Invalid LMI dimensions.");
+  CONEX_DEMAND(constraint_id, "Received output null pointer.");
+  CONEX_DEMAND(hyper_complex_dim == 1 || hyper_complex_dim == 2 || hyper_complex_dim == 4 ||
+                   hyper_complex_dim == 8,
+               "Hypercomplex dimension must be 1, 2, 4, or 8.");
+  CAST_PROGRAM(x, p);
+  if (hyper_complex_dim == 8)
+    CONEX_DEMAND(order <= 3, "Order of octonion algebra cannot be greater than 3.");
+  Cone k;
+  k.kind = kLmi;
+  k.order = order;
+  k.hyper = hyper_complex_dim;
+  k.vars = AllVars(*p);
+  *constraint_id = AddCone(p, std::move(k));
+  return CONEX_SUCCESS;
+}
+
+CONEX_STATUS CONEX_NewLinearInequality(void* x, int num_rows, int* constraint_id) {
+  CONEX_DEMAND(constraint_id, "Received output null pointer.");
+  CAST_PROGRAM(x, p);
+  CONEX_DEMAND(num_rows >= 1, "Number of rows must be positive.");
+  Cone k;
+  k.kind = kLinear;
+  k.order = num_rows;
+  k.cols = p->num_vars;
+  k.vars = AllVars(*p);
+  k.A.assign((size_t)num_rows * p->num_vars, 0.0);
+  k.c.assign(num_rows, 0.0);
+  *constraint_id = AddCone(p, std::move(k));
+  return CONEX_SUCCESS;
+}
+
+CONEX_STATUS CONEX_NewLorentzConeConstraint(void* x, int order, int* constraint_id) {
+  CONEX_DEMAND(order >= 1, "Received invalid n. Second order cone must have order (n + 1) >= 2.");
+  CONEX_DEMAND(constraint_id, "Received output null pointer.");
+  CAST_PROGRAM(x, p);
+  Cone k;
+  k.kind = kSoc;
+  k.order = order;
+  k.cols = 0;
+  k.vars = AllVars(*p);
+  k.c.assign(order + 1, 0.0);
+  *constraint_id = AddCone(p, std::move(k));
+  return CONEX_SUCCESS;
+}
+
+CONEX_STATUS CONEX_UpdateLinearOperator(void* x, int constraint, double value, int variable,
+                                        int row, int col, int hyper_complex_dim) {
+  CAST_PROGRAM(x, p);
+  CONEX_DEMAND(constraint >= 0 && constraint < (int)p->cones.size(), "Invalid Constraint.");
+  Cone& k = p->cones[constraint];
+  const int dim = hyper_complex_dim;
+  switch (k.kind) {
+    case kLmi: {  // hermitian_psd.cc:249-275
+      CONEX_DEMAND(dim >= 0 && dim < k.hyper, "Complex dimension out of bounds.");
+      CONEX_DEMAND(row >= 0 && col >= 0 && row < k.order && col < k.order,
+                   "Matrix dimension out of bounds.");
+      CONEX_DEMAND(!(value != 0 && row == col && dim > 0),
+                   "Imaginary components must be skew-symmetric.");
+      CONEX_DEMAND(variable >= 0, "Indices cannot be negative.");
+      if (k.hyper == 8 && dim >= 3) return 0;  // reference returns false (= success) here
+      const size_t nn = (size_t)k.order * k.order;
+      if ((int)k.mats.size() <= variable) k.mats.resize(variable + 1);
+      if (k.mats[variable].empty()) k.mats[variable].assign(nn * k.hyper, 0.0);
+      double* M = k.mats[variable].data() + nn * dim;
+      M[row + (size_t)col * k.order] = value;
+      M[col + (size_t)row * k.order] = dim == 0 ? value : -value;
+      break;
+    }
+    case kLinear: {  // linear_constraint.cc:207-217
+      CONEX_DEMAND(dim == 0, "Complex linear constraints not supported.");
+      CONEX_DEMAND(col == 0, "Linear constraint is not matrix valued.");
+      CONEX_DEMAND(row < k.order, "Row index out of bounds.");
+      CONEX_DEMAND(variable >= 0 && row >= 0, "Indices cannot be negative.");
+      CONEX_DEMAND(variable < k.cols, "Variable index out of bounds.");
+      k.A[row + (size_t)variable * k.order] = value;
+      break;
+    }
+    case kSoc: {  // soc_constraint.cc:314-324
+      CONEX_DEMAND(dim == 0, "Complex second-order cone not supported.");
+      CONEX_DEMAND(col == 0, "Second-order constraint is not matrix valued.");
+      CONEX_DEMAND(row <= k.order, "Row index out of bounds.");
+      CONEX_DEMAND(variable >= 0 && row >= 0, "Indices cannot be negative.");
+      const int len = k.order + 1;
+      if (variable >= k.cols) {  // ConservativeResizeHelper
+        k.A.resize((size_t)len * (variable + 1), 0.0);
+        k.cols = variable + 1;
+      }
+      k.A[row + (size_t)variable * len] = value;
+      break;
+    }
+    case kQuadCost:
+      CONEX_DEMAND(false, "Constraint does not support updates of linear operator.");
+  }
+  p->dirty = true;
+  return CONEX_SUCCESS;
+}
+
+CONEX_STATUS CONEX_UpdateAffineTerm(void* x, int constraint, double value, int row, int col,
+                                    int hyper_complex_dim) {
+  CAST_PROGRAM(x, p);
+  CONEX_DEMAND(constraint >= 0 && constraint < (int)p->cones.size(), "Invalid Constraint.");
+  Cone& k = p->cones[constraint];
+  const int dim = hyper_complex_dim;
+  switch (k.kind) {
+    case kLmi: {  // hermitian_psd.cc:286-313
+      CONEX_DEMAND(dim >= 0 && dim < k.hyper, "Complex dimension out of bounds.");
+      CONEX_DEMAND(row >= 0 && col >= 0 && row < k.order && col < k.order,
+                   "Matrix dimension out of bounds.");
+      CONEX_DEMAND(!(value != 0 && row == col && dim > 0),
+                   "Imaginary components must be skew-symmetric.");
+      if (k.hyper == 8 && dim >= 3) return 0;
+      const size_t nn = (size_t)k.order * k.order;
+      if (k.affine.empty()) k.affine.assign(nn * k.hyper, 0.0);
+      double* M = k.affine.data() + nn * dim;
+      M[row + (size_t)col * k.order] = value;
+      M[col + (size_t)row * k.order] = dim == 0 ? value : -value;
+      break;
+    }
+    case kLinear:  // linear_constraint.cc:219-228
+      CONEX_DEMAND(dim == 0, "Complex linear cone not supported.");
+      CONEX_DEMAND(col == 0, "Linear constraint is not matrix valued.");
+      CONEX_DEMAND(row < k.order, "Row index out of bounds.");
+      CONEX_DEMAND(row >= 0, "Indices cannot be negative.");
+      k.c[row] = value;
+      break;
+    case kSoc:  // soc_constraint.cc:326-335
+      CONEX_DEMAND(dim == 0, "Complex second-order cone not supported.");
+      CONEX_DEMAND(col == 0, "Second-order constraint is not matrix valued.");
+      CONEX_DEMAND(row <= k.order, "Row index out of bounds.");
+      CONEX_DEMAND(row >= 0, "Indices cannot be negative.");
+      k.c[row] = value;
+      break;
+    case kQuadCost:  // quadratic_cost.cc:33-39 (dim must be 0: "hyper complex dimension")
+      CONEX_DEMAND(dim == 0, "Quadratic cost must be real valued matrix.");
+      {
+        const int m = static_cast<int>(k.vars.size());
+        CONEX_DEMAND(row >= 0 && col >= 0 && row < m && col < m, "Index out of bounds");
+        k.A[row + (size_t)col * m] = value;
+      }
+      break;
+  }
+  p->dirty = true;
+  return CONEX_SUCCESS;
+}
+
+CONEX_STATUS CONEX_UpdateQuadraticCostMatrix(void* x, int constraint, double value, int row,
+                                             int col) {
+  return CONEX_UpdateAffineTerm(x, constraint, value, row, col, 0);
+}
+
+void CONEX_SetDefaultOptions(CONEX_SolverConfiguration* c) {  // cone_program.h:17-38
+  if (c == NULL) {
+    fprintf(stderr, "Received null pointer.");
+    return;
+  }
+  c->prepare_dual_variables = 0;
+  c->initialization_mode = 0;
+  c->inv_sqrt_mu_max = 1000;
+  c->minimum_mu = 1e-15;
+  c->maximum_mu = 1e4;
+  c->divergence_upper_bound = 1;
+  c->enable_line_search = 0;
+  c->dinf_upper_bound = 1;
+  c->final_centering_steps = 5;
+  c->final_centering_tolerance = .01;
+  c->initial_centering_steps_warmstart = 0;
+  c->initial_centering_steps_coldstart = 0;
+  c->warmstart_abort_threshold = 2;
+  c->max_iterations = 25;
+  c->iterative_refinement_iterations = 0;
+  c->infeasibility_threshold = 1e5;
+  c->kkt_error_tolerance = 1e10;
+  c->enable_rescaling = 1;
+  c->kkt_solver = 0;
+}
+
+int CONEX_Solve(void* x, const CONEX_SolverConfiguration* config, double* y, int yr) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || !config || !y || yr < p->num_vars) return 0;
+  return SolveProgram(p, FromApi(config), y);
+}
+
+int CONEX_Maximize(void* x, const double* b, int br, const CONEX_SolverConfiguration* config,
+                   double* y, int yr) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || !config || !y || !b) return 0;
+  if (br != p->num_vars) {  // Program::AddLinearCost CONEX_DEMAND
+    fprintf(stderr, "%s line %d: %s\n", __FILE__, __LINE__,
+            "Cost vector dimension does not equal number of variables");
+  }
+  // Solve(b, prog, ...): ClearLinearCosts(); AddLinearCost(-b)
+  p->linear_cost.assign(p->num_vars, 0.0);
+  if (br == p->num_vars)
+    for (int i = 0; i < br; i++) p->linear_cost[i] = -b[i];
+  if (yr < p->num_vars) return 0;
+  return SolveProgram(p, FromApi(config), y);
+}
+
+int CONEX_GetDualVariableSize(void* x, int i) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || i < 0 || i >= (int)p->cones.size()) {
+    fprintf(stderr, "%s line %d: Invalid Constraint\n", __FILE__, __LINE__);
+    return 1;
+  }
+  const Cone& k = p->cones[i];
+  switch (k.kind) {
+    case kLmi: return k.order * k.order;
+    case kLinear: return k.order;
+    case kSoc: return k.order + 1;
+    default: return 0;
+  }
+}
+
+void CONEX_GetDualVariable(void* x, int i, double* out, int xr, int xc) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || !p->ctx || !out) return;
+  const int n = CONEX_GetDualVariableSize(x, i);
+  if (n != xr * xc || n == 0) return;
+  if (cxk_get_W(p->ctx, i, out)) return;
+  // Program::GetDualVariable cone_program.h:120-134
+  if (!p->primal_infeasible && p->num_iter > 0) {
+    const double s = p->sqrt_inv_mu[p->num_iter - 1] * p->b_scaling;
+    for (int q = 0; q < n; q++) out[q] /= s;
+  }
+}
+
+void CONEX_GetIterationStats(void* x, CONEX_IterationStats* stats, int iter_num_circular) {
+  if ((x == NULL) || (stats == NULL)) {
+    fprintf(stderr, "Received null pointer.");
+    return;
+  }
+  Program* p = static_cast<Program*>(x);
+  if (!p->stats_ready) {
+    fprintf(stderr, "No statistics available.");
+    return;
+  }
+  int iter_num = iter_num_circular;
+  if (iter_num_circular < 0) iter_num = p->num_iter + iter_num_circular;
+  if ((p->num_iter <= iter_num) || (iter_num < 0)) {
+    fprintf(stderr, "Specified iteration is out of bounds.");
+    return;
+  }
+  stats->mu = 1.0 / (p->sqrt_inv_mu[iter_num] * p->sqrt_inv_mu[iter_num]);
+  stats->iteration_number = iter_num;
+}
+
+/* not part of conex.h: lets a host pick the HIP device ordinal before the first solve */
+int CONEX_HIP_SetDevice(void* x, int device) {
+  Program* p = static_cast<Program*>(x);
+  if (!p) return CONEX_FAILURE;
+  p->device = device;
+  p->dirty = true;
+  return CONEX_SUCCESS;
+}
+
+}  // extern "C"

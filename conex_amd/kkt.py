@@ -56,6 +56,8 @@ _SIGNATURES = {
     "cxk_factor": (C.c_int, [C.c_void_p, c_int_p]),
     "cxk_set_cost": (C.c_int, [C.c_void_p, c_double_p]),
     "cxk_newton_direction": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "cxk_solve_rhs": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "cxk_step_scalars": (C.c_int, [C.c_void_p, c_double_p]),
     "cxk_kkt_solve_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
     "cxk_sync": (C.c_int, [C.c_void_p, c_int_p]),
     "cxk_solve_inplace": (C.c_int, [C.c_void_p, c_double_p]),
@@ -307,6 +309,14 @@ class KktContext:
     def newton_direction(self, inv_sqrt_mu, b_scaling=1.0, c_scaling=1.0):
         self._check(self.L.cxk_newton_direction(self.h, inv_sqrt_mu, b_scaling, c_scaling),
                     "cxk_newton_direction")
+
+    def solve_rhs(self, cb, cq, cw):
+        self._check(self.L.cxk_solve_rhs(self.h, cb, cq, cw), "cxk_solve_rhs")
+
+    def step_scalars(self):
+        out = np.zeros(6)
+        self._check(self.L.cxk_step_scalars(self.h, _dp(out)), "cxk_step_scalars")
+        return out
 
     def kkt_solve_async(self, inv_sqrt_mu, b_scaling=1.0, c_scaling=1.0):
         self._check(self.L.cxk_kkt_solve_async(self.h, inv_sqrt_mu, b_scaling, c_scaling),

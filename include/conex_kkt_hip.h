@@ -97,6 +97,13 @@ int cxk_factor(cxk_context* ctx, int* ok);
 int cxk_set_cost(cxk_context* ctx, const double* b /* num_vars, host */);
 int cxk_newton_direction(cxk_context* ctx, double inv_sqrt_mu, double b_scaling,
                          double c_scaling);
+/* y_dev = cb*b + cq*AQc + cw*AW, then SolveInPlace: covers the Newton right-hand side
+ * (k*bs, k*cs, -2), the mu-rule solve of ComputeMuFromDivergence cone_program.cc:181
+ * (-bs, cs, 0) and the dual-recovery solve cone_program.cc:504 (k*bs, 0, -1).  No host sync. */
+int cxk_solve_rhs(cxk_context* ctx, double cb, double cq, double cw);
+/* the scalars of one IPM iteration (cone_program.cc:343-357, 439-446), computed on device:
+ * out = { b.y, AQc.y, |b|^2, |AQc|^2, <w,c>, <c,Qc> }.  Syncs. */
+int cxk_step_scalars(cxk_context* ctx, double* out6);
 /* whole BASELINE metric unit: assemble + factor + rhs + solve, asynchronous on the stream;
  * factor status is latched and returned by cxk_sync. */
 int cxk_kkt_solve_async(cxk_context* ctx, double inv_sqrt_mu, double b_scaling,
