@@ -569,6 +569,91 @@ tree_sweep(FactorPlan P, const int* __restrict__ level_ptr, const int* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Multi-GPU exchange.  Buffer layout, all doubles:
+//   [ T slab entries (n_xs) | AW_T (n_xv) | AQc_T (n_xv) | fwd_T (n_xv) | <w,c> | <c,Qc> | fail | pad ]
+// pack:   fold this rank's subtree updates into its PARTIAL top blocks (pre-reduce pulls), then
+//         copy the partial top, the partial residuals of top variables and the forward-solve
+//         contributions of this rank's subtrees into the buffer.
+// unpack: after the caller's sum all-reduce the buffer holds the complete assembled-and-updated
+//         top; write it back, rebuild the right-hand side of top variables and latch `fail`.
+// ---------------------------------------------------------------------------------------
+struct ExchangeArgs {
+  int64_t n_xs;
+  int n_xv;
+  const int64_t* xs_off;
+  const int* xv_idx;
+  int64_t pt_T;
+  const int64_t* pt_dst;
+  const int* pt_ptr;
+  const int64_t* pt_src;
+  const int* pf_ptr;
+  const int* pf_src;
+  const double* upd;
+  const double* updb;
+  double* slab;
+  double* AW;
+  double* AQc;
+  const double* b;
+  double* y;
+  double* sys_sc;
+  int* fail;
+  double* x;
+  double cb, cq, cw;
+};
+
+__global__ void __launch_bounds__(256) exchange_pack(ExchangeArgs a) {
+  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // slab entries: partial assembled value minus the updates of this rank's subtrees (exchange_fold)
+  for (int64_t i = gid; i < a.n_xs; i += stride) a.x[i] = a.slab[a.xs_off[i]];
+  for (int64_t j = gid; j < a.n_xv; j += stride) {
+    const int p = a.xv_idx[j];
+    a.x[a.n_xs + j] = a.AW[p];
+    a.x[a.n_xs + a.n_xv + j] = a.AQc[p];
+    double f = 0;
+    for (int q = a.pf_ptr[j]; q < a.pf_ptr[j + 1]; q++) f += a.updb[a.pf_src[q]];
+    a.x[a.n_xs + 2 * (int64_t)a.n_xv + j] = f;
+  }
+  if (gid == 0) {
+    const int64_t o = a.n_xs + 3 * (int64_t)a.n_xv;
+    a.x[o] = a.sys_sc[0];
+    a.x[o + 1] = a.sys_sc[1];
+    a.x[o + 2] = (double)(*a.fail);
+    a.x[o + 3] = 0;
+  }
+}
+
+// runs BEFORE exchange_pack: subtracts the Schur updates of this rank's subtrees from its partial
+// top blocks, in place in the slab (one thread per top entry)
+__global__ void __launch_bounds__(256) exchange_fold(ExchangeArgs a) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < a.pt_T;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0;
+    for (int q = a.pt_ptr[t]; q < a.pt_ptr[t + 1]; q++) s += a.upd[a.pt_src[q]];
+    a.slab[a.pt_dst[t]] -= s;
+  }
+}
+
+__global__ void __launch_bounds__(256) exchange_unpack(ExchangeArgs a) {
+  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = gid; i < a.n_xs; i += stride) a.slab[a.xs_off[i]] = a.x[i];
+  for (int64_t j = gid; j < a.n_xv; j += stride) {
+    const int p = a.xv_idx[j];
+    const double aw = a.x[a.n_xs + j], aq = a.x[a.n_xs + a.n_xv + j];
+    a.AW[p] = aw;
+    a.AQc[p] = aq;
+    a.y[p] = a.cb * a.b[p] + a.cq * aq + a.cw * aw - a.x[a.n_xs + 2 * (int64_t)a.n_xv + j];
+  }
+  if (gid == 0) {
+    const int64_t o = a.n_xs + 3 * (int64_t)a.n_xv;
+    a.sys_sc[0] = a.x[o];
+    a.sys_sc[1] = a.x[o + 1];
+    if (a.x[o + 2] > 0.0) *a.fail = 1;
+  }
+}
+
 // permuted <-> original order copies
 __global__ void permute_gather(int N, const int* __restrict__ idx, const double* __restrict__ in,
                                double* __restrict__ out) {

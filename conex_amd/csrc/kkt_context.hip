@@ -80,7 +80,15 @@ struct cxk_context {
   Layout lay;
   std::vector<Group> groups;
   std::vector<int64_t> g_off, r_off;
-  std::vector<unsigned char> owned;
+  std::vector<unsigned char> owned;      // constraint i assembled/updated by this rank
+  // elimination-tree structure + partition
+  std::vector<int> t_ns, t_nsep, t_start, t_level, t_parent;
+  std::vector<unsigned char> sn_top;     // supernode belongs to the replicated top T
+  std::vector<unsigned char> sn_mine;    // supernode factored by this rank (own subtree or T)
+  std::vector<unsigned char> var_valid;  // permuted variable whose y this rank holds
+  int nlev = 0, cut_level = 0;           // levels >= cut_level form T (world > 1)
+  int64_t n_xs = 0;                      // exchange: T slab entries
+  int n_xv = 0;                          // exchange: T variables
   // levels
   std::vector<int> level_ptr, level_sn;
   size_t chol_lds = 0, solve_lds = 0;  // bytes of LDS staging one supernode needs
@@ -92,7 +100,9 @@ struct cxk_context {
   DevBuf<unsigned char> d_mask;
   DevBuf<int> p_ns, p_nsep, p_start, tg_ptr, tr_ptr, fs_ptr, fs_src, bs_ptr, bs_c, bs_row, updb_off;
   DevBuf<int64_t> p_diag, p_offd, tr_src, upd_off;
-  DevBuf<double> upd, updb;
+  DevBuf<double> upd, updb, xbuf;
+  DevBuf<int64_t> xs_off, pt_dst, pt_src;
+  DevBuf<int> xv_idx, pt_ptr, pf_ptr, pf_src;
   int64_t as_T = 0;
   FactorPlan plan{};
   // timing of the dominant (dense-LMI Schur) kernel
@@ -224,13 +234,155 @@ size_t LmiPrepareLds(int n, int m) {
 size_t LmiTakeLds(int n) { return sizeof(double) * (size_t)(5 * n * n); }
 constexpr size_t kLdsLimit = 160 * 1024 - 512;
 
+// ---------------------------------------------------------------- tree structure + partition
+// Dependency levels of the supernodal elimination tree and (world > 1) the split into a
+// replicated top T (all levels >= cut_level) and per-rank subtrees.
+void ComputeTreeStructure(cxk_context* ctx) {
+  const Layout& L = ctx->lay;
+  const int K = ctx->md.K;
+  ctx->t_ns.assign(K, 0);
+  ctx->t_nsep.assign(K, 0);
+  ctx->t_start.assign(K, 0);
+  ctx->t_level.assign(K, 0);
+  ctx->t_parent.assign(K, -1);
+  for (int e = 0; e < K; e++) {
+    ctx->t_ns[e] = L.supernode_size[e];
+    ctx->t_nsep[e] = (int)L.separators[e].size();
+    ctx->t_start[e] = L.supernode_start[e];
+    if (ctx->t_nsep[e] > 0) ctx->t_parent[e] = L.var_to_sn[L.separators[e][0]];
+  }
+  // a supernode sits one level above every supernode that updates it (children have smaller
+  // elimination index, so one ascending pass suffices)
+  for (int i = 0; i < K; i++) {
+    if (ctx->t_ns[i] == 0) continue;
+    for (int v : L.separators[i]) {
+      const int p = L.var_to_sn[v];
+      if (ctx->t_level[p] < ctx->t_level[i] + 1) ctx->t_level[p] = ctx->t_level[i] + 1;
+    }
+  }
+  ctx->nlev = 0;
+  for (int e = 0; e < K; e++)
+    if (ctx->t_ns[e] > 0) ctx->nlev = std::max(ctx->nlev, ctx->t_level[e] + 1);
+}
+
+double ConstraintWork(const ConstraintRec& c) {
+  const double n = c.n, m = c.m;
+  switch (c.type) {
+    case CXK_LMI: return 4 * n * n * n * (m + 1) + n * n * m * m;
+    case CXK_LINEAR: return n * m * m;
+    case CXK_SOC: return (n + 1) * m * m;
+    default: return m * m;
+  }
+}
+
+void PartitionTree(cxk_context* ctx) {
+  const int K = ctx->md.K, G = ctx->world;
+  ctx->sn_top.assign(K, 0);
+  ctx->sn_mine.assign(K, 1);
+  ctx->owned.assign(K, 1);
+  ctx->cut_level = ctx->nlev;
+  ctx->var_valid.assign(ctx->md.N, 1);
+  ctx->n_xs = 0;
+  ctx->n_xv = 0;
+  if (G <= 1) return;
+  // Choose the cut: the highest level (smallest replicated top, smallest exchange) whose
+  // longest-processing-time assignment of subtrees is balanced within 15 % of the ideal;
+  // if no level achieves that, the best-balanced one.
+  std::vector<int> root_of(K, -1), owner_of_root(K, 0);
+  double total = 0;
+  for (int e = 0; e < K; e++) total += ConstraintWork(ctx->cons[ctx->md.clique_order[e]]);
+  auto try_cut = [&](int cut, std::vector<int>* roots_out, std::vector<int>* root_of_out,
+                     std::vector<int>* owner_out) -> double {
+    std::vector<int> ro(K, -1);
+    std::vector<double> weight(K, 0.0);
+    auto is_top = [&](int e) { return ctx->t_ns[e] > 0 && ctx->t_level[e] >= cut; };
+    for (int e = K - 1; e >= 0; e--) {  // parents have larger elimination index
+      if (is_top(e)) continue;
+      const int par = ctx->t_parent[e];
+      ro[e] = (par < 0 || is_top(par)) ? e : ro[par];
+    }
+    double top_work = 0;
+    for (int e = 0; e < K; e++) {
+      const double w = ConstraintWork(ctx->cons[ctx->md.clique_order[e]]);
+      if (is_top(e))
+        top_work += w;
+      else
+        weight[ro[e]] += w;
+    }
+    std::vector<int> roots;
+    for (int e = 0; e < K; e++)
+      if (!is_top(e) && ro[e] == e) roots.push_back(e);
+    std::stable_sort(roots.begin(), roots.end(), [&](int a, int b) { return weight[a] > weight[b]; });
+    std::vector<double> load(G, top_work / G);
+    std::vector<int> owner(K, 0);
+    for (int r : roots) {  // longest processing time first, ties to the lowest rank
+      int best = 0;
+      for (int g = 1; g < G; g++)
+        if (load[g] < load[best]) best = g;
+      owner[r] = best;
+      load[best] += weight[r];
+    }
+    if (roots_out) *roots_out = roots;
+    if (root_of_out) *root_of_out = ro;
+    if (owner_out) *owner_out = owner;
+    return *std::max_element(load.begin(), load.end());
+  };
+  int cut = ctx->nlev;
+  if (ctx->nlev > 1) {
+    int best_cut = std::max(ctx->nlev - 1, 1);
+    double best_load = -1;
+    for (int c = std::max(ctx->nlev - 1, 1); c >= 1; c--) {
+      const double mx = try_cut(c, nullptr, nullptr, nullptr);
+      if (best_load < 0 || mx < best_load * 0.999) {
+        best_load = mx;
+        best_cut = c;
+      }
+      if (mx <= 1.15 * total / G) {
+        best_cut = c;
+        break;
+      }
+    }
+    cut = best_cut;
+  }
+  ctx->cut_level = cut;
+  std::vector<int> roots;
+  try_cut(cut, &roots, &root_of, &owner_of_root);
+  for (int e = 0; e < K; e++) ctx->sn_top[e] = ctx->t_ns[e] > 0 && ctx->t_level[e] >= cut;
+  int rr = 0;
+  for (int e = 0; e < K; e++) {
+    const int i = ctx->md.clique_order[e];
+    if (ctx->sn_top[e]) {
+      ctx->sn_mine[e] = 1;                             // T is factored by every rank
+      ctx->owned[i] = (rr++ % G) == ctx->rank;          // its constraints are dealt round-robin
+    } else {
+      const bool mine = owner_of_root[root_of[e]] == ctx->rank;
+      ctx->sn_mine[e] = mine;
+      ctx->owned[i] = mine;
+    }
+  }
+  for (int p = 0; p < ctx->md.N; p++) ctx->var_valid[p] = ctx->sn_mine[ctx->lay.var_to_sn[p]];
+  for (int e = 0; e < K; e++)
+    if (ctx->sn_top[e]) {
+      const int64_t n = ctx->t_ns[e];
+      ctx->n_xs += n * (n + 1) / 2 + n * ctx->t_nsep[e];
+      ctx->n_xv += (int)n;
+    }
+}
+
 // ---------------------------------------------------------------- plan building
 int BuildPlans(cxk_context* ctx) {
   const MatrixData& md = ctx->md;
   const Layout& L = ctx->lay;
   const int K = md.K, N = md.N;
+  const std::vector<int>& ns = ctx->t_ns;
+  const std::vector<int>& nsep = ctx->t_nsep;
+  const std::vector<int>& start = ctx->t_start;
+  const bool sharded = ctx->world > 1;
+  auto block_wanted = [&](int e) { return !sharded || ctx->sn_mine[e]; };
 
-  // ---- assembly gather (UpdateBlocks order: elimination index descending)
+  // ---- assembly gather (UpdateBlocks order: elimination index descending).  In sharded mode
+  // only the blocks this rank factors are written; sources of constraints owned elsewhere are
+  // dropped, which leaves PARTIAL sums in the top blocks (completed by the exchange).
   std::vector<int> entry_of(L.slab_size, -1);
   std::vector<int64_t> dst;
   std::vector<std::vector<int64_t>> srcs;
@@ -253,23 +405,29 @@ int BuildPlans(cxk_context* ctx) {
     };
     const IntList& r = md.supernodes_pos[e];
     const IntList& s = md.separators_pos[e];
-    const int ns = (int)r.size(), nsep = (int)s.size();
-    for (int j = 0; j < ns; j++)  // SetLowerTri
-      for (int i2 = j; i2 < ns; i2++) {
-        auto& v = entry(L.diag_off[e] + (int64_t)j * ns + i2);
-        v.clear();
-        v.push_back(coeff(r[i2], r[j]));
-      }
-    if (ns > 0)
-      for (int j = 0; j < nsep; j++)  // Set
-        for (int i2 = 0; i2 < ns; i2++) {
-          auto& v = entry(L.offd_off[e] + (int64_t)j * ns + i2);
+    const int nse = (int)r.size(), nsp = (int)s.size();
+    if (block_wanted(e)) {
+      for (int j = 0; j < nse; j++)  // SetLowerTri
+        for (int i2 = j; i2 < nse; i2++) {
+          auto& v = entry(L.diag_off[e] + (int64_t)j * nse + i2);
           v.clear();
-          v.push_back(coeff(r[i2], s[j]));
+          v.push_back(coeff(r[i2], r[j]));
         }
+      if (nse > 0)
+        for (int j = 0; j < nsp; j++)  // Set
+          for (int i2 = 0; i2 < nse; i2++) {
+            auto& v = entry(L.offd_off[e] + (int64_t)j * nse + i2);
+            v.clear();
+            v.push_back(coeff(r[i2], s[j]));
+          }
+    }
     int cnt = 0;
-    for (int j = 0; j < nsep; j++)  // Scatter
-      for (int i2 = j; i2 < nsep; i2++) entry(L.ss_index[e][cnt++]).push_back(coeff(s[i2], s[j]));
+    for (int j = 0; j < nsp; j++)  // Scatter
+      for (int i2 = j; i2 < nsp; i2++) {
+        const int64_t off = L.ss_index[e][cnt++];
+        const int owner_sn = L.var_to_sn[L.separators[e][j]];
+        if (block_wanted(owner_sn)) entry(off).push_back(coeff(s[i2], s[j]));
+      }
   }
   std::vector<int> as_ptr(dst.size() + 1, 0);
   std::vector<int64_t> as_src;
@@ -282,7 +440,7 @@ int BuildPlans(cxk_context* ctx) {
   CXK_TRY(ctx->as_ptr.upload(as_ptr));
   CXK_TRY(ctx->as_src.upload(as_src));
 
-  // ---- residual gather (constraint order)
+  // ---- residual gather (constraint order); variables of foreign subtrees are skipped
   {
     std::vector<std::vector<int64_t>> per(N);
     for (int i = 0; i < (int)ctx->cons.size(); i++) {
@@ -311,14 +469,7 @@ int BuildPlans(cxk_context* ctx) {
     CXK_TRY(ctx->cl_perm.upload(perm));
   }
 
-  // ---- factor / solve pull lists
-  std::vector<int> ns(K), nsep(K), start(K);
-  for (int e = 0; e < K; e++) {
-    ns[e] = L.supernode_size[e];
-    nsep[e] = (int)L.separators[e].size();
-    start[e] = L.supernode_start[e];
-  }
-  // published-update slots: s(s+1)/2 Schur values and s forward values per supernode
+  // ---- published-update slots: s(s+1)/2 Schur values and s forward values per supernode
   std::vector<int64_t> upd_off(K, 0);
   std::vector<int> updb_off(K, 0);
   int64_t upd_total = 0;
@@ -331,46 +482,58 @@ int BuildPlans(cxk_context* ctx) {
       updb_total += nsep[i];
     }
   }
+  // pull lists.  A target inside a subtree only has children of the same subtree.  A target in
+  // the top T pulls its T children during the T sweep; the updates of THIS rank's subtrees are
+  // folded in before the exchange (pre-reduce lists pt_* / pf_*).
   std::vector<int> tgt_of(L.slab_size, -1);
   std::vector<std::vector<int>> tg_of_sn(K);
   std::vector<int64_t> tg_dst_all;
-  std::vector<std::vector<int64_t>> contrib;
-  std::vector<std::vector<int>> fs(N);
-  std::vector<int> level(K, 0);
+  std::vector<std::vector<int64_t>> contrib, pre_contrib;
+  std::vector<std::vector<int>> fs(N), pre_fs(N);
   for (int i = 0; i < K; i++) {
     if (ns[i] == 0 || nsep[i] == 0) continue;
+    if (sharded && !ctx->sn_mine[i]) continue;  // foreign subtree: its updates arrive by exchange
     const IntList& s = L.separators[i];
     int cnt = 0;
     for (int k = 0; k < nsep[i]; k++) {
       const int p = L.var_to_sn[s[k]];
-      if (level[p] < level[i] + 1) level[p] = level[i] + 1;
+      const bool pre = sharded && ctx->sn_top[p] && !ctx->sn_top[i];
       for (int j = k; j < nsep[i]; j++) {
         const int64_t off = L.ss_index[i][cnt];
         if (tgt_of[off] < 0) {
           tgt_of[off] = (int)tg_dst_all.size();
           tg_dst_all.push_back(off);
           contrib.emplace_back();
+          pre_contrib.emplace_back();
           tg_of_sn[p].push_back(tgt_of[off]);
         }
-        contrib[tgt_of[off]].push_back(upd_off[i] + cnt);
+        (pre ? pre_contrib : contrib)[tgt_of[off]].push_back(upd_off[i] + cnt);
         cnt++;
       }
-      fs[s[k]].push_back(updb_off[i] + k);
+      (pre ? pre_fs : fs)[s[k]].push_back(updb_off[i] + k);
     }
   }
   {
-    std::vector<int> tg_ptr(K + 1, 0), tr_ptr, tg_loc;
-    std::vector<int64_t> tr_src;
+    std::vector<int> tg_ptr(K + 1, 0), tr_ptr, tg_loc, pt_ptr;
+    std::vector<int64_t> tr_src, pt_dst, pt_src;
     tr_ptr.push_back(0);
+    pt_ptr.push_back(0);
     for (int p = 0; p < K; p++) {
       for (int t : tg_of_sn[p]) {
         const int64_t off = tg_dst_all[t];
         const int64_t dsz = (int64_t)ns[p] * ns[p];
-        tg_loc.push_back(off >= L.diag_off[p] && off < L.diag_off[p] + dsz
-                             ? (int)(off - L.diag_off[p])
-                             : (int)(dsz + off - L.offd_off[p]));
-        for (int64_t q : contrib[t]) tr_src.push_back(q);
-        tr_ptr.push_back((int)tr_src.size());
+        if (!contrib[t].empty()) {
+          tg_loc.push_back(off >= L.diag_off[p] && off < L.diag_off[p] + dsz
+                               ? (int)(off - L.diag_off[p])
+                               : (int)(dsz + off - L.offd_off[p]));
+          for (int64_t q : contrib[t]) tr_src.push_back(q);
+          tr_ptr.push_back((int)tr_src.size());
+        }
+        if (!pre_contrib[t].empty()) {
+          pt_dst.push_back(off);
+          for (int64_t q : pre_contrib[t]) pt_src.push_back(q);
+          pt_ptr.push_back((int)pt_src.size());
+        }
       }
       tg_ptr[p + 1] = (int)tg_loc.size();
     }
@@ -378,6 +541,9 @@ int BuildPlans(cxk_context* ctx) {
     CXK_TRY(ctx->tg_loc.upload(tg_loc));
     CXK_TRY(ctx->tr_ptr.upload(tr_ptr));
     CXK_TRY(ctx->tr_src.upload(tr_src));
+    CXK_TRY(ctx->pt_dst.upload(pt_dst));
+    CXK_TRY(ctx->pt_ptr.upload(pt_ptr));
+    CXK_TRY(ctx->pt_src.upload(pt_src));
   }
   {
     std::vector<int> fs_ptr(N + 1, 0), fs_src;
@@ -392,6 +558,33 @@ int BuildPlans(cxk_context* ctx) {
   CXK_TRY(ctx->updb_off.upload(updb_off));
   CXK_TRY(ctx->upd.alloc((size_t)upd_total));
   CXK_TRY(ctx->updb.alloc((size_t)updb_total));
+
+  // ---- exchange layout: [T slab entries | AW_T | AQc_T | fwd_T | <w,c> <c,Qc> fail]
+  if (sharded) {
+    std::vector<int64_t> xs;
+    std::vector<int> xv, pf_ptr, pf_src;
+    pf_ptr.push_back(0);
+    for (int e = 0; e < K; e++) {
+      if (!ctx->sn_top[e]) continue;
+      for (int j = 0; j < ns[e]; j++)
+        for (int i2 = j; i2 < ns[e]; i2++) xs.push_back(L.diag_off[e] + (int64_t)j * ns[e] + i2);
+      for (int64_t q = 0; q < (int64_t)ns[e] * nsep[e]; q++) xs.push_back(L.offd_off[e] + q);
+      for (int r = 0; r < ns[e]; r++) {
+        const int p = start[e] + r;
+        xv.push_back(p);
+        for (int q : pre_fs[p]) pf_src.push_back(q);
+        pf_ptr.push_back((int)pf_src.size());
+      }
+    }
+    CXK_DEMAND(ctx->n_xs == (int64_t)xs.size() && ctx->n_xv == (int)xv.size(),
+               "internal error: exchange layout mismatch");
+    CXK_TRY(ctx->xs_off.upload(xs));
+    CXK_TRY(ctx->xv_idx.upload(xv));
+    CXK_TRY(ctx->pf_ptr.upload(pf_ptr));
+    CXK_TRY(ctx->pf_src.upload(pf_src));
+    CXK_TRY(ctx->xbuf.alloc((size_t)ctx->n_xs + 3 * (size_t)ctx->n_xv + 4));
+  }
+
   {
     // backward accumulation order: ancestors descending, columns ascending within one ancestor
     std::vector<int> bs_ptr(K + 1, 0), bs_c, bs_row;
@@ -416,21 +609,17 @@ int BuildPlans(cxk_context* ctx) {
     CXK_TRY(ctx->bs_c.upload(bs_c));
     CXK_TRY(ctx->bs_row.upload(bs_row));
   }
-  // level lists (supernodes with at least one column)
-  int nlev = 0;
-  for (int e = 0; e < K; e++)
-    if (ns[e] > 0) nlev = std::max(nlev, level[e] + 1);
+  // level lists: supernodes with at least one column that this rank factors
+  const int nlev = ctx->nlev;
   ctx->level_ptr.assign(nlev + 1, 0);
   ctx->level_sn.clear();
-  ctx->chol_lds = 0;
-  ctx->solve_lds = 0;
+  ctx->chol_lds = 8;
   for (int l = 0; l < nlev; l++) {
     for (int e = 0; e < K; e++)
-      if (ns[e] > 0 && level[e] == l) {
+      if (ns[e] > 0 && ctx->t_level[e] == l && block_wanted(e)) {
         ctx->level_sn.push_back(e);
         ctx->chol_lds = std::max(ctx->chol_lds, sizeof(double) * ((size_t)ns[e] * ns[e] +
                                                                    (size_t)ns[e] * nsep[e] + ns[e]));
-        ctx->solve_lds = std::max(ctx->solve_lds, sizeof(double) * (size_t)ns[e]);
       }
     ctx->level_ptr[l + 1] = (int)ctx->level_sn.size();
   }
@@ -438,11 +627,12 @@ int BuildPlans(cxk_context* ctx) {
              "supernode too large for the LDS-resident block Cholesky (blocked path not built yet)");
   CXK_TRY(ctx->d_level_sn.upload(ctx->level_sn));
   CXK_TRY(ctx->d_level_ptr.upload(ctx->level_ptr));
-  // narrow top of the tree: trailing levels that together hold few supernodes are swept by one
-  // workgroup (levels separated by a workgroup barrier instead of a kernel boundary)
+  // narrow top of the tree: trailing levels that hold few supernodes are swept by one workgroup
+  // (levels separated by a workgroup barrier instead of a kernel boundary); never below the cut
   {
     int top = nlev;
     while (top > 0 && ctx->level_ptr[top] - ctx->level_ptr[top - 1] <= 8) top--;
+    if (sharded) top = std::max(top, ctx->cut_level);
     ctx->top_level = top;
   }
   CXK_TRY(ctx->p_ns.upload(ns));
@@ -470,6 +660,34 @@ int BuildPlans(cxk_context* ctx) {
   P.bs_c = ctx->bs_c.p;
   P.bs_row = ctx->bs_row.p;
   return CXK_SUCCESS;
+}
+
+ExchangeArgs MakeExchange(cxk_context* ctx, double k, double bs, double cs) {
+  ExchangeArgs a;
+  a.n_xs = ctx->n_xs;
+  a.n_xv = ctx->n_xv;
+  a.xs_off = ctx->xs_off.p;
+  a.xv_idx = ctx->xv_idx.p;
+  a.pt_T = (int64_t)(ctx->pt_ptr.n > 0 ? ctx->pt_ptr.n - 1 : 0);
+  a.pt_dst = ctx->pt_dst.p;
+  a.pt_ptr = ctx->pt_ptr.p;
+  a.pt_src = ctx->pt_src.p;
+  a.pf_ptr = ctx->pf_ptr.p;
+  a.pf_src = ctx->pf_src.p;
+  a.upd = ctx->upd.p;
+  a.updb = ctx->updb.p;
+  a.slab = ctx->slab.p;
+  a.AW = ctx->AW.p;
+  a.AQc = ctx->AQc.p;
+  a.b = ctx->b.p;
+  a.y = ctx->y.p;
+  a.sys_sc = ctx->sys_sc.p;
+  a.fail = ctx->d_fail.p;
+  a.x = ctx->xbuf.p;
+  a.cb = k * bs;
+  a.cq = k * cs;
+  a.cw = -2.0;
+  return a;
 }
 
 int LaunchSchur(cxk_context* ctx) {
@@ -695,10 +913,8 @@ int cxk_finalize(cxk_context* ctx) {
     return Fail(ctx, e.what());
   }
   const int K = (int)ctx->cons.size();
-  // ownership: round-robin over elimination positions keeps the per-rank work balanced
-  ctx->owned.assign(K, 1);
-  if (ctx->world > 1)
-    for (int e = 0; e < K; e++) ctx->owned[ctx->md.clique_order[e]] = (e % ctx->world) == ctx->rank;
+  ComputeTreeStructure(ctx);
+  PartitionTree(ctx);  // world == 1: everything is owned
   ctx->g_off.assign(K, 0);
   ctx->r_off.assign(K, 0);
   int64_t go = 0, ro = 0;
@@ -1126,8 +1342,82 @@ int cxk_get_residuals(cxk_context* ctx, double* AW, double* AQc, double* scalars
 
 int cxk_exchange_buffer(cxk_context* ctx, void** dev_ptr, long* count) {
   if (CheckReady(ctx)) return CXK_FAILURE;
-  *dev_ptr = ctx->slab.p;
-  *count = (long)ctx->lay.slab_size;
+  CXK_DEMAND(ctx->world > 1, "exchange buffer exists only for sharded contexts");
+  *dev_ptr = ctx->xbuf.p;
+  *count = (long)(ctx->n_xs + 3 * (int64_t)ctx->n_xv + 4);
+  return CXK_SUCCESS;
+}
+
+// host copies of the exchange buffer (tests; a real run all-reduces the device buffer in place)
+int cxk_exchange_download(cxk_context* ctx, double* out) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_DEMAND(ctx->world > 1, "exchange buffer exists only for sharded contexts");
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(out, ctx->xbuf.p, sizeof(double) * (size_t)(ctx->n_xs + 3 * (int64_t)ctx->n_xv + 4),
+                    hipMemcpyDeviceToHost));
+  return CXK_SUCCESS;
+}
+int cxk_exchange_upload(cxk_context* ctx, const double* in) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_DEMAND(ctx->world > 1, "exchange buffer exists only for sharded contexts");
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(ctx->xbuf.p, in, sizeof(double) * (size_t)(ctx->n_xs + 3 * (int64_t)ctx->n_xv + 4),
+                    hipMemcpyHostToDevice));
+  return CXK_SUCCESS;
+}
+
+// Sharded KKT solve, part 1 (no communication): assemble own constraints, factor + forward own
+// subtrees, fold their updates into the partial top blocks and pack the exchange buffer.
+int cxk_kkt_local_async(cxk_context* ctx, double k, double bs, double cs) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_DEMAND(ctx->world > 1, "cxk_kkt_local_async needs cxk_set_shard(world > 1)");
+  if (LaunchSchur(ctx)) return CXK_FAILURE;
+  if (LaunchGather(ctx, true, k, bs, cs)) return CXK_FAILURE;
+  for (int l = 0; l < ctx->cut_level; l++)
+    if (LaunchSweep(ctx, l, l + 1, 0, false, true)) return CXK_FAILURE;
+  ExchangeArgs a = MakeExchange(ctx, k, bs, cs);
+  const size_t work = (size_t)std::max<int64_t>(ctx->n_xs, ctx->n_xv);
+  if (a.pt_T > 0) exchange_fold<<<GridFor((size_t)a.pt_T, 256), 256, 0, ctx->stream>>>(a);
+  exchange_pack<<<GridFor(work, 256), 256, 0, ctx->stream>>>(a);
+  CXK_TRY(hipGetLastError());
+  return CXK_SUCCESS;
+}
+
+// Part 2, after the caller has sum-reduced the exchange buffer across ranks: unpack the
+// completed top, factor/solve it (replicated), back-substitute the own subtrees.
+int cxk_kkt_finish_async(cxk_context* ctx, double k, double bs, double cs) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_DEMAND(ctx->world > 1, "cxk_kkt_finish_async needs cxk_set_shard(world > 1)");
+  ExchangeArgs a = MakeExchange(ctx, k, bs, cs);
+  const size_t work = (size_t)std::max<int64_t>(ctx->n_xs, ctx->n_xv);
+  exchange_unpack<<<GridFor(work, 256), 256, 0, ctx->stream>>>(a);
+  CXK_TRY(hipGetLastError());
+  const int nlev = ctx->nlev, top = ctx->top_level;
+  for (int l = ctx->cut_level; l < top; l++)
+    if (LaunchSweep(ctx, l, l + 1, 0, false, true)) return CXK_FAILURE;
+  if (top < nlev)
+    if (LaunchSweep(ctx, top, nlev, 0, true, true)) return CXK_FAILURE;
+  for (int l = top - 1; l >= 0; l--)
+    if (LaunchSweep(ctx, l, l + 1, 2, false, true)) return CXK_FAILURE;
+  return CXK_SUCCESS;
+}
+
+int cxk_owns_constraint(const cxk_context* ctx, int i) {
+  if (!ctx || !ctx->finalized || i < 0 || i >= (int)ctx->cons.size()) return 0;
+  return ctx->owned[i];
+}
+
+int cxk_get_valid_variables(const cxk_context* ctx, unsigned char* mask /* N, original order */) {
+  if (!ctx || !ctx->finalized) return CXK_FAILURE;
+  for (int p = 0; p < ctx->md.N; p++) mask[ctx->md.permutation_inverse[p]] = ctx->var_valid[p];
+  return CXK_SUCCESS;
+}
+
+int cxk_shard_info(const cxk_context* ctx, int* cut_level, int* num_levels, long* exchange_count) {
+  if (!ctx || !ctx->finalized) return CXK_FAILURE;
+  if (cut_level) *cut_level = ctx->cut_level;
+  if (num_levels) *num_levels = ctx->nlev;
+  if (exchange_count) *exchange_count = ctx->world > 1 ? (long)(ctx->n_xs + 3 * (int64_t)ctx->n_xv + 4) : 0;
   return CXK_SUCCESS;
 }
 

@@ -72,6 +72,13 @@ _SIGNATURES = {
                                            c_double_p, c_double_p]),
     "cxk_get_residuals": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "cxk_exchange_buffer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_long_p]),
+    "cxk_exchange_download": (C.c_int, [C.c_void_p, c_double_p]),
+    "cxk_exchange_upload": (C.c_int, [C.c_void_p, c_double_p]),
+    "cxk_kkt_local_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "cxk_kkt_finish_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "cxk_owns_constraint": (C.c_int, [C.c_void_p, C.c_int]),
+    "cxk_get_valid_variables": (C.c_int, [C.c_void_p, C.POINTER(C.c_ubyte)]),
+    "cxk_shard_info": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_long_p]),
     "cxk_assemble_local": (C.c_int, [C.c_void_p]),
     "cxk_finish_assemble": (C.c_int, [C.c_void_p]),
     "cxk_assembly_work": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
@@ -368,6 +375,48 @@ class KktContext:
         self._check(self.L.cxk_exchange_buffer(self.h, C.byref(p), C.byref(n)),
                     "cxk_exchange_buffer")
         return p.value, n.value
+
+    def kkt_local_async(self, inv_sqrt_mu, b_scaling=1.0, c_scaling=1.0):
+        self._check(self.L.cxk_kkt_local_async(self.h, inv_sqrt_mu, b_scaling, c_scaling),
+                    "cxk_kkt_local_async")
+
+    def kkt_finish_async(self, inv_sqrt_mu, b_scaling=1.0, c_scaling=1.0):
+        self._check(self.L.cxk_kkt_finish_async(self.h, inv_sqrt_mu, b_scaling, c_scaling),
+                    "cxk_kkt_finish_async")
+
+    def owns(self, i):
+        return bool(self.L.cxk_owns_constraint(self.h, i))
+
+    def valid_variables(self):
+        m = np.zeros(self.N, dtype=np.uint8)
+        self._check(self.L.cxk_get_valid_variables(self.h, m.ctypes.data_as(C.POINTER(C.c_ubyte))),
+                    "cxk_get_valid_variables")
+        return m.astype(bool)
+
+    def shard_info(self):
+        cut, nlev, cnt = C.c_int(), C.c_int(), C.c_long()
+        self._check(self.L.cxk_shard_info(self.h, C.byref(cut), C.byref(nlev), C.byref(cnt)),
+                    "cxk_shard_info")
+        return cut.value, nlev.value, cnt.value
+
+    def exchange_download(self):
+        _, count = self.exchange_buffer()
+        out = np.zeros(count)
+        self._check(self.L.cxk_exchange_download(self.h, _dp(out)), "cxk_exchange_download")
+        return out
+
+    def exchange_upload(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        self._check(self.L.cxk_exchange_upload(self.h, _dp(x)), "cxk_exchange_upload")
+
+    def exchange_tensor(self, torch):
+        """Zero-copy torch view of the device exchange buffer (for torch.distributed.all_reduce)."""
+        ptr, count = self.exchange_buffer()
+
+        class _Arr:
+            __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False),
+                                        "version": 2}
+        return torch.as_tensor(_Arr(), device="cuda")
 
     def assemble_local(self):
         self._check(self.L.cxk_assemble_local(self.h), "cxk_assemble_local")

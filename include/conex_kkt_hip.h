@@ -132,10 +132,27 @@ int cxk_get_constraint_schur(cxk_context* ctx, int i, double* G /* m*m lower */,
 int cxk_get_residuals(cxk_context* ctx, double* AW /* N */, double* AQc /* N */,
                       double* scalars /* 2 */);
 
-/* ---- multi-GPU exchange ------------------------------------ */
-/* device pointer + length (doubles) of the buffer to all-reduce(sum) between
- * cxk_assemble_local and cxk_finish_assemble */
-int cxk_exchange_buffer(cxk_context* ctx, void** dev_ptr, long* count);
+/* ---- multi-GPU (the reference is single process, so no counterpart) ----------
+ * After cxk_set_shard(rank, world) + cxk_finalize every rank holds the same symbolic analysis
+ * and the same deterministic partition: the elimination tree is cut at a level; everything
+ * above the cut (the "top") is replicated, the subtrees below are dealt to ranks (longest
+ * processing time first), each constraint lives with the subtree that eliminates it.
+ * One KKT solve is then
+ *     cxk_kkt_local_async   assemble own constraints, factor + forward-solve own subtrees,
+ *                           fold their updates into the partial top, pack the exchange buffer
+ *     all-reduce(sum) of the exchange buffer across ranks (RCCL; a few KB: latency bound)
+ *     cxk_kkt_finish_async  unpack, factor/solve the top (replicated), back-substitute own
+ *                           subtrees
+ * after which a rank holds y for its own and for the top variables (cxk_get_valid_variables). */
+int cxk_exchange_buffer(cxk_context* ctx, void** dev_ptr, long* count /* doubles */);
+int cxk_exchange_download(cxk_context* ctx, double* out);   /* host copy, tests */
+int cxk_exchange_upload(cxk_context* ctx, const double* in);
+int cxk_kkt_local_async(cxk_context* ctx, double inv_sqrt_mu, double b_scaling, double c_scaling);
+int cxk_kkt_finish_async(cxk_context* ctx, double inv_sqrt_mu, double b_scaling, double c_scaling);
+int cxk_owns_constraint(const cxk_context* ctx, int i);
+int cxk_get_valid_variables(const cxk_context* ctx, unsigned char* mask /* N, original order */);
+int cxk_shard_info(const cxk_context* ctx, int* cut_level, int* num_levels, long* exchange_count);
+/* single-GPU building blocks kept for symmetry with the reference call sequence */
 int cxk_assemble_local(cxk_context* ctx);
 int cxk_finish_assemble(cxk_context* ctx);
 
