@@ -25,6 +25,20 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 correction + WRITE_SIZE, profiles/rNN/pmc_summary.json); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return float(json.load(f)["lmi_schur_fused"]["hbm_traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(prob, W, budget_s=12.0):
     """The oracle (plain-C port of the reference path, 1 thread) on the same workload."""
     import oracle_lib as ol
@@ -149,7 +163,9 @@ def main():
             gbs = abytes / (kern_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "lmi_schur", "achieved": gbs,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                               "traffic": None, "kernel_ms": kern_ms,
+                               "traffic": pmc_traffic() if args.K == 1000 else None,
+                               "traffic_source": "rocprofv3 PMC passes committed under profiles/",
+                               "kernel_ms": kern_ms,
                                "algorithmic_bytes": abytes, "algorithmic_gflop": aflops / 1e9,
                                "achieved_tflops": aflops / (kern_ms * 1e-3) / 1e12}
         if not args.no_cpu and world == 1:
