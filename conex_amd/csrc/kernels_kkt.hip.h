@@ -136,13 +136,51 @@ __global__ void build_mu_rhs(int N, double bs, double cs, const double* __restri
 
 // In-kernel stamps (diagnostic builds only: -DCXK_DEBUG_STAMPS); values go to a buffer nothing else reads.
 #ifdef CXK_DEBUG_STAMPS
-__device__ long long g_cxk_stamp[16];
-#define CXK_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cxk_stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ long long g_cxk_stamp[32];
+__device__ int g_cxk_sel;
+#define CXK_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_cxk_sel == 1) g_cxk_stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CXK_STAMPB(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_cxk_sel == 2) g_cxk_stamp[16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CXK_STAMP_SELECT(lb, mode) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cxk_sel = ((lb) == 0) ? ((mode) == 0 ? 1 : ((mode) == 2 ? 2 : 0)) : 0; } while (0)
 #else
 #define CXK_STAMP(i) do { } while (0)
+#define CXK_STAMPB(i) do { } while (0)
+#define CXK_STAMP_SELECT(lb, mode) do { } while (0)
 #endif
 
+// Everything a wavefront needs to start on one supernode: one 64-byte record per position of
+// the level lists (level order), fetched with a single coalesced load.
+struct SnRec {
+  int p, ns, nsep, start;
+  int tg_beg, tg_end;  // pull targets (tg_loc / tr_ptr range)
+  int bs_beg, bs_end;  // backward separator list (bs_c / bs_row range)
+  int64_t diag_off, offd_off, upd_off;
+  int updb_off, has_fs;  // has_fs: some row of this supernode pulls forward-solve updates
+};
+static_assert(sizeof(SnRec) == 64, "SnRec is read as 16 lanes x 4 bytes");
+
+__device__ __forceinline__ SnRec LoadRec(const SnRec* __restrict__ rec, int pos) {
+  const int lane = threadIdx.x & 63;
+  const int w = reinterpret_cast<const int*>(rec + pos)[lane & 15];
+  auto f = [&](int i) { return __builtin_amdgcn_readlane(w, i); };
+  SnRec R;
+  R.p = f(0);
+  R.ns = f(1);
+  R.nsep = f(2);
+  R.start = f(3);
+  R.tg_beg = f(4);
+  R.tg_end = f(5);
+  R.bs_beg = f(6);
+  R.bs_end = f(7);
+  R.diag_off = ((int64_t)f(9) << 32) | (uint32_t)f(8);
+  R.offd_off = ((int64_t)f(11) << 32) | (uint32_t)f(10);
+  R.upd_off = ((int64_t)f(13) << 32) | (uint32_t)f(12);
+  R.updb_off = f(14);
+  R.has_fs = f(15);
+  return R;
+}
+
 struct FactorPlan {
+  const SnRec* rec;          // [level positions]
   // per supernode
   const int* ns;             // [K]
   const int* nsep;           // [K]
@@ -255,96 +293,230 @@ __device__ inline void PublishUpdates(const FactorPlan& P, int p, const double* 
 }
 
 // ---------------------------------------------------------------------------------------
-// One wavefront factors one supernode.  Lane j owns COLUMN j of the diagonal block (col[i],
-// static register indices) and ROW j of the extra columns [off-diagonal block | rhs] (ext[c]).
-// The column loop k is a real loop (compact code: a fully unrolled body is executed once per
-// wave and is instruction-fetch bound); per step the pivot lane scales its column and
-// publishes it through a 16/32-entry LDS line, every lane applies the rank-1 update to its own
-// column, and the extra columns travel by v_readlane with a run-time lane select.
-// Right-looking: same update order per entry as the reference's column-by-column LLT + TRSM.
+// One wavefront factors one supernode, ROW PER LANE, everything in registers with static
+// indices and no LDS traffic in the elimination loop:
+//   lane r < ns            row r of the diagonal block          a[j] = L[r][j]
+//   lane NSMAX + c, c < s  row of separator variable c          a[j] = off[j][c]
+//   a[NSMAX + c]           the (initially zero) separator x separator trailing block: after the
+//                          ns elimination steps it holds  -U[.,c] = -off[:, .] . off[:, c]
+//   a[RB]                  right-hand side column: rows < ns end as the forward-solved b, the
+//                          separator rows end as  -t[c] = -off[:,c] . b
+// i.e. the Schur update and the forward-solve update this supernode publishes for its ancestors
+// fall out of the same right-looking elimination (same fma chains as separate dot products).
+// Step j: d = a[j] of lane j (v_readlane, static lane), L_jj = sqrt(d) and 1/L_jj from one
+// v_rsq_f64 refined by two Goldschmidt iterations, column j scaled, then for every later column
+// c:  a[c] -= L[c][j] * a[j]  with L[c][j] read from lane c.  Entries above the diagonal pick up
+// garbage and are never read.  Padding pivots (ns <= j < NSMAX) are identity steps.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void SqrtAndInverse(double d, double& root, double& inv) {
+  const double r0 = __builtin_amdgcn_rsq(d);
+  double g = d * r0, h = 0.5 * r0;
+  double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  const double res = fma(-g, g, d);  // final correction: root is within 1 ulp of sqrt(d)
+  root = fma(res, h, g);
+  inv = h + h;
+}
+
+// a[c] += w[lane (c - BASE) of the own 16-lane DPP row] * v   for c in [C0, C1).
+template <int LEN, int C0, int C1, int BASE>
+struct DppColumns {
+  static __device__ __forceinline__ void run(double (&a)[LEN], double w, double v) {
+    if constexpr (C0 < C1) {
+      asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+          : "+v"(a[C0])
+          : "v"(w), "v"(v), "n"(C0 - BASE));
+      DppColumns<LEN, C0 + 1, C1, BASE>::run(a, w, v);
+    }
+  }
+};
+
+// The compiler cannot see that the asm above is a DPP instruction, so the hazard "VALU writes a
+// VGPR, a DPP instruction reads it within 2 wait states" is covered by hand: operands pass
+// through this fence (s_nop 1) after their last write and before any DPP use.
+__device__ __forceinline__ void DppOperandFence(double& x, double& y, double& z) {
+  asm("s_nop 1" : "+v"(x), "+v"(y), "+v"(z));
+}
+
+// DPP rows 0 and 2 of v copied over rows 1 and 3 (v_permlane16_swap, gfx950).
+__device__ __forceinline__ double EvenRowsToOddRows(double v) {
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const u2 a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const u2 b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(b.x, a.x);
+}
+
+// Elimination steps J .. NSMAX-1 of FactorSupernodeRows (compile-time recursion: every register
+// index, lane select and DPP control is an immediate).
+template <int NSMAX, int SMAX, int J>
+struct ElimSteps {
+  static constexpr int LEN = NSMAX + SMAX + 1, RB = NSMAX + SMAX;
+  static __device__ __forceinline__ void run(double (&a)[LEN], int lane, bool& bad) {
+    if constexpr (J < NSMAX) {
+      const double d = ReadLane(a[J], J);
+      bad |= !(d > 0.0);
+      double root, inv;
+      SqrtAndInverse(d, root, inv);
+      a[J] = (lane == J) ? root : a[J] * inv;
+      if constexpr (NSMAX == 16 && SMAX <= 16) {
+        // supernode rows fill DPP row 0, separator rows start DPP row 1.  L[c][J] (c < 16) is
+        // lane c of row 0: with row 0 mirrored into row 1 a row_newbcast DPP operand delivers it
+        // to both rows; L[sep c][J] is lane c of row 1, only row 1 needs the trailing block.
+        double x = EvenRowsToOddRows(a[J]);
+        double naj = -a[J];
+        DppOperandFence(x, naj, a[J]);
+        DppColumns<LEN, J + 1, NSMAX, 0>::run(a, x, naj);
+        DppColumns<LEN, NSMAX, NSMAX + SMAX, NSMAX>::run(a, a[J], naj);
+      } else {
+#pragma unroll
+        for (int c = J + 1; c < NSMAX + SMAX; c++) a[c] = fma(-ReadLane(a[J], c), a[J], a[c]);
+      }
+      const double yj = ReadLane(a[RB], J) * inv;
+      if (lane > J)
+        a[RB] = fma(-yj, a[J], a[RB]);
+      else if (lane == J)
+        a[RB] = yj;
+      ElimSteps<NSMAX, SMAX, J + 1>::run(a, lane, bad);
+    }
+  }
+};
+
 template <int NSMAX, int SMAX>
-__device__ inline void CholSupernodeReg(const FactorPlan& P, int p, double* __restrict__ slab,
-                                        double* __restrict__ rhs, int* __restrict__ fail,
-                                        double* __restrict__ my) {
+__device__ inline void FactorSupernodeRows(const FactorPlan& P, const SnRec& R,
+                                           double* __restrict__ slab, double* __restrict__ rhs,
+                                           int* __restrict__ fail, double* __restrict__ my) {
+  static_assert(NSMAX + SMAX <= 64, "one lane per panel row");
+  constexpr int RB = NSMAX + SMAX;
   const int lane = threadIdx.x & 63;
-  const int ns = __builtin_amdgcn_readfirstlane(P.ns[p]), s = __builtin_amdgcn_readfirstlane(P.nsep[p]);
-  double* sD = my;
-  double* sB = my + ns * ns;
-  double* sb = sB + ns * s;
+  const int ns = R.ns, s = R.nsep;
+  const bool is_row = lane < ns;
+  const int sc = lane - NSMAX;
+  const bool is_sep = sc >= 0 && sc < s;
+  // panel element (lane, j) lives at base[o0 + j * st]:  D[r + j*ns]  or  B[j + c*ns]
+  double* base = slab + R.diag_off;
+  const unsigned rel = (unsigned)(R.offd_off - R.diag_off);
+  const unsigned o0 = is_row ? (unsigned)lane : (is_sep ? rel + (unsigned)(sc * ns) : 0u);
+  const unsigned st = is_row ? (unsigned)ns : 1u;
+  const int lim = is_row ? lane + 1 : (is_sep ? ns : 0);  // valid j < lim
   CXK_STAMP(0);
-  StageAndPull(P, p, slab, rhs, my, true);
+  double a[NSMAX + SMAX + 1];
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? base[o0 + j * st] : 0.0;
+#pragma unroll
+  for (int c = 0; c < SMAX; c++) a[NSMAX + c] = 0.0;
+  a[RB] = (rhs && is_row) ? rhs[R.start + lane] : 0.0;
   CXK_STAMP(1);
-  const bool active = lane < ns;
-  double col[NSMAX];   // column `lane`, rows 0..NSMAX-1 (rows < lane are never read)
-  double ext[SMAX + 1];
+  if (R.tg_end > R.tg_beg || (rhs && R.has_fs)) {
+    // descendants published updates: apply them in the reference's order through an LDS copy
+    // laid out like the slab ([diag ns x ns | off ns x s | rhs ns])
+    double* sb = my + ns * ns + ns * s;
+    const unsigned l0 = is_row ? (unsigned)lane : (unsigned)(ns * ns + (is_sep ? sc : 0) * ns);
 #pragma unroll
-  for (int i = 0; i < NSMAX; i++) col[i] = (active && i < ns && i >= lane) ? sD[i + lane * ns] : 0.0;
+    for (int j = 0; j < NSMAX; j++)
+      if ((is_row || is_sep) && j < ns) my[l0 + j * st] = a[j];
+    if (is_row) sb[lane] = a[RB];
+    WaveSync();
+    for (int t = R.tg_beg + lane; t < R.tg_end; t += 64) {
+      const int loc = P.tg_loc[t];
+      double acc = my[loc];
+      const int q1 = P.tr_ptr[t + 1];
+#pragma unroll 4
+      for (int q = P.tr_ptr[t]; q < q1; q++) acc -= P.upd[P.tr_src[q]];
+      my[loc] = acc;
+    }
+    if (rhs && is_row) {
+      double acc = sb[lane];
+      const int q1 = P.fs_ptr[R.start + lane + 1];
+#pragma unroll 4
+      for (int q = P.fs_ptr[R.start + lane]; q < q1; q++) acc -= P.updb[P.fs_src[q]];
+      sb[lane] = acc;
+    }
+    WaveSync();
 #pragma unroll
-  for (int c = 0; c < SMAX; c++) ext[c] = (active && c < s) ? sB[lane + c * ns] : 0.0;
-  ext[SMAX] = (rhs && active) ? sb[lane] : 0.0;
-  double diag = active ? sD[lane + lane * ns] : 1.0;
-  WaveSync();
-  double* piv = my;  // reuse the head of the staging area as the pivot-column line
+    for (int j = 0; j < NSMAX; j++)
+      if (j < lim) a[j] = my[l0 + j * st];
+    if (is_row) a[RB] = sb[lane];
+  }
+  // padding pivots: unit diagonal
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++)
+    if (j >= ns && lane == j) a[j] = 1.0;
   CXK_STAMP(2);
   bool bad = false;
-#pragma unroll 1
-  for (int k = 0; k < ns; k++) {
-    if (lane == k) {
-      if (!(diag > 0.0)) bad = true;
-      const double d = sqrt(diag);
-      const double rd = 1.0 / d;  // one divide per column; scalings are multiplies
-      diag = d;
-      // rows <= k of this column are never read again, so the whole register column is scaled
-      // and published without per-row selects
-#pragma unroll
-      for (int i = 0; i < NSMAX; i++) {
-        col[i] *= rd;
-        piv[i] = col[i];
-      }
-#pragma unroll
-      for (int c = 0; c <= SMAX; c++) ext[c] *= rd;
-    }
-    WaveSync();
-    // m = L[lane][k] for lanes below the pivot, 0 elsewhere (finished columns / solved rows)
-    const double m = (lane > k && lane < NSMAX) ? piv[lane] : 0.0;
-    diag = fma(-m, m, diag);
-#pragma unroll
-    for (int i = 0; i < NSMAX; i++) col[i] = fma(-piv[i], m, col[i]);
-#pragma unroll
-    for (int c = 0; c <= SMAX; c++) {
-      const double ekc = ReadLane(ext[c], k);
-      ext[c] = fma(-m, ekc, ext[c]);
-    }
-    WaveSync();
-  }
+  ElimSteps<NSMAX, SMAX, 0>::run(a, lane, bad);
   CXK_STAMP(3);
-  if (__any(bad)) {
+  if (bad) {
     if (lane == 0) atomicExch(fail, 1);
     return;
   }
-  double* D = slab + P.diag_off[p];
-  double* B = slab + P.offd_off[p];
-  if (active) {
 #pragma unroll
-    for (int i = 0; i < NSMAX; i++)
-      if (i < ns && i > lane) D[i + (size_t)lane * ns] = col[i];
-    D[lane + (size_t)lane * ns] = diag;
+  for (int j = 0; j < NSMAX; j++)
+    if (j < lim) base[o0 + j * st] = a[j];
+  if (rhs && is_row) rhs[R.start + lane] = a[RB];
+  CXK_STAMP(4);
+  if (is_sep) {
+    // U[k][c], k <= c, in the reference's S_S enumeration: t = k*s - k(k-1)/2 + (c - k)
+    double* out = P.upd + R.upd_off + (sc * s - sc * (sc - 1) / 2 - sc);
 #pragma unroll
     for (int c = 0; c < SMAX; c++)
-      if (c < s) {
-        B[lane + (size_t)c * ns] = ext[c];
-        sB[lane + c * ns] = ext[c];
-      }
-    if (rhs) {
-      rhs[P.start[p] + lane] = ext[SMAX];
-      sb[lane] = ext[SMAX];
+      if (c >= sc && c < s) out[c] = -a[NSMAX + c];
+    if (rhs) P.updb[R.updb_off + sc] = -a[RB];
+  }
+  CXK_STAMP(5);
+}
+
+// b_j <- L_j^{-T} (b_j - sum_c off_j[:,c] y[sep_j[c]]): lane i owns y_i and column i of L
+// (col[k] = L[k][i], k > i) in registers; the solved entry travels by v_readlane.
+template <int NSMAX, int SMAX>
+__device__ inline void BackwardSupernodeRows(const FactorPlan& P, const SnRec& R,
+                                             const double* __restrict__ slab,
+                                             double* __restrict__ rhs) {
+  const int lane = threadIdx.x & 63;
+  const int ns = R.ns;
+  const bool active = lane < ns;
+  const double* D = slab + R.diag_off + (size_t)(active ? lane : 0) * ns;  // column `lane`
+  const double* B = slab + R.offd_off + (active ? lane : 0);
+  CXK_STAMPB(1);
+  double col[NSMAX];
+#pragma unroll
+  for (int k = 0; k < NSMAX; k++) col[k] = (active && k > lane && k < ns) ? D[k] : 0.0;
+  const double dg = active ? D[lane] : 1.0;
+  double acc = active ? rhs[R.start + lane] : 0.0;
+  const int cnt = R.bs_end - R.bs_beg;
+  if (cnt <= SMAX) {
+    double bv[SMAX > 0 ? SMAX : 1], yv[SMAX > 0 ? SMAX : 1];
+#pragma unroll
+    for (int q = 0; q < SMAX; q++) {
+      const bool on = q < cnt;
+      const int cc = on ? P.bs_c[R.bs_beg + q] : 0;
+      const int row = on ? P.bs_row[R.bs_beg + q] : 0;
+      yv[q] = on ? rhs[row] : 0.0;
+      bv[q] = (on && active) ? B[(size_t)cc * ns] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < SMAX; q++) acc -= bv[q] * yv[q];
+  } else {
+#pragma unroll 4
+    for (int q = R.bs_beg; q < R.bs_end; q++) {
+      const double yq = rhs[P.bs_row[q]];
+      if (active) acc -= B[(size_t)P.bs_c[q] * ns] * yq;
     }
   }
-  WaveSync();
-  CXK_STAMP(4);
-  PublishUpdates(P, p, my, true, rhs != nullptr);
-  CXK_STAMP(5);
+  CXK_STAMPB(2);
+  const double dinv = 1.0 / dg;
+  CXK_STAMPB(3);
+#pragma unroll
+  for (int k = NSMAX - 1; k >= 0; k--) {
+    if (lane == k) acc *= dinv;
+    acc = fma(-col[k], ReadLane(acc, k), acc);  // col[k] is zero for lanes >= k
+  }
+  CXK_STAMPB(4);
+  if (active) rhs[R.start + lane] = acc;
 }
 
 // LDS-resident fallback for supernodes that do not fit the register kernels.
@@ -514,40 +686,44 @@ __device__ inline void BackwardSupernodeLds(const FactorPlan& P, int p,
 // mode 0: factor (+ forward if rhs), mode 1: forward only, mode 2: backward.
 // Levels [lb, le) ascending for modes 0/1; mode 2 walks the range downwards.  A launch that
 // covers several levels (or continues into the backward sweep) must be ONE workgroup: levels
-// are then separated by a workgroup barrier instead of a kernel boundary.
+// are then separated by a workgroup barrier instead of a kernel boundary.  (base0, cnt0) is the
+// position range of level lb, passed by value so a one-level launch starts without a lookup.
 __global__ void __launch_bounds__(512)
-tree_sweep(FactorPlan P, const int* __restrict__ level_ptr, const int* __restrict__ level_sn, int lb,
-           int le, int mode, int then_backward, double* __restrict__ slab, double* __restrict__ rhs,
+tree_sweep(FactorPlan P, const int* __restrict__ level_ptr, int base0, int cnt0, int lb, int le,
+           int mode, int then_backward, double* __restrict__ slab, double* __restrict__ rhs,
            int* __restrict__ fail, int lds_per_wave) {
   extern __shared__ double lds[];
   // wave-uniform values are forced into SGPRs: otherwise every loop bound / lane select below
   // is treated as divergent (waterfall loops around v_readlane, vector address arithmetic)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   double* my = lds + (size_t)wave * lds_per_wave;
+  CXK_STAMP_SELECT(lb, mode);
+  CXK_STAMP(6);
+  CXK_STAMPB(0);
   const bool multi = (le - lb > 1) || then_backward;
   if (mode != 2) {
     for (int l = lb; l < le; l++) {
-      const int base = level_ptr[l], cnt = level_ptr[l + 1] - base;
+      const int base = (l == lb) ? base0 : level_ptr[l];
+      const int cnt = (l == lb) ? cnt0 : level_ptr[l + 1] - base;
       for (int idx = blockIdx.x * nw + wave; idx < cnt; idx += gridDim.x * nw) {
-        const int p = __builtin_amdgcn_readfirstlane(level_sn[base + idx]);
-        const int ns = __builtin_amdgcn_readfirstlane(P.ns[p]);
-        const int s = __builtin_amdgcn_readfirstlane(P.nsep[p]);
+        const SnRec R = LoadRec(P.rec, base + idx);
+        const int ns = R.ns, s = R.nsep;
         if (mode == 0) {
           if (ns <= 16 && s <= 8)
-            CholSupernodeReg<16, 8>(P, p, slab, rhs, fail, my);
+            FactorSupernodeRows<16, 8>(P, R, slab, rhs, fail, my);
           else if (ns <= 24 && s == 0)
-            CholSupernodeReg<24, 0>(P, p, slab, rhs, fail, my);
+            FactorSupernodeRows<24, 0>(P, R, slab, rhs, fail, my);
           else if (ns <= 24 && s <= 8)
-            CholSupernodeReg<24, 8>(P, p, slab, rhs, fail, my);
+            FactorSupernodeRows<24, 8>(P, R, slab, rhs, fail, my);
           else if (ns <= 32 && s <= 16)
-            CholSupernodeReg<32, 16>(P, p, slab, rhs, fail, my);
+            FactorSupernodeRows<32, 16>(P, R, slab, rhs, fail, my);
           else
-            CholSupernodeLds(P, p, slab, rhs, fail, my);
+            CholSupernodeLds(P, R.p, slab, rhs, fail, my);
         } else {
           if (ns <= 64)
-            ForwardSupernodeWave(P, p, slab, rhs, my);
+            ForwardSupernodeWave(P, R.p, slab, rhs, my);
           else
-            ForwardSupernodeLds(P, p, slab, rhs, my);
+            ForwardSupernodeLds(P, R.p, slab, rhs, my);
         }
       }
       if (multi) __syncthreads();
@@ -555,18 +731,27 @@ tree_sweep(FactorPlan P, const int* __restrict__ level_ptr, const int* __restric
   }
   if (mode == 2 || then_backward) {
     for (int l = le - 1; l >= lb; l--) {
-      const int base = level_ptr[l], cnt = level_ptr[l + 1] - base;
+      const int base = (l == lb) ? base0 : level_ptr[l];
+      const int cnt = (l == lb) ? cnt0 : level_ptr[l + 1] - base;
       for (int idx = blockIdx.x * nw + wave; idx < cnt; idx += gridDim.x * nw) {
-        const int p = __builtin_amdgcn_readfirstlane(level_sn[base + idx]);
-        const int ns = __builtin_amdgcn_readfirstlane(P.ns[p]);
-        if (ns <= 64)
-          BackwardSupernodeWave(P, p, slab, rhs, my);
+        const SnRec R = LoadRec(P.rec, base + idx);
+        const int ns = R.ns, s = R.nsep;
+        if (ns <= 16 && s <= 8)
+          BackwardSupernodeRows<16, 8>(P, R, slab, rhs);
+        else if (ns <= 24 && s <= 8)
+          BackwardSupernodeRows<24, 8>(P, R, slab, rhs);
+        else if (ns <= 32 && s <= 16)
+          BackwardSupernodeRows<32, 16>(P, R, slab, rhs);
+        else if (ns <= 64)
+          BackwardSupernodeWave(P, R.p, slab, rhs, my);
         else
-          BackwardSupernodeLds(P, p, slab, rhs, my);
+          BackwardSupernodeLds(P, R.p, slab, rhs, my);
       }
       if (multi) __syncthreads();
     }
   }
+  CXK_STAMP(7);
+  CXK_STAMPB(5);
 }
 
 // ---------------------------------------------------------------------------------------

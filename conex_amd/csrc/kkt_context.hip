@@ -100,6 +100,7 @@ struct cxk_context {
   DevBuf<unsigned char> d_mask;
   DevBuf<int> p_ns, p_nsep, p_start, tg_ptr, tr_ptr, fs_ptr, fs_src, bs_ptr, bs_c, bs_row, updb_off;
   DevBuf<int64_t> p_diag, p_offd, tr_src, upd_off;
+  DevBuf<SnRec> p_rec;
   DevBuf<double> upd, updb, xbuf;
   DevBuf<int64_t> xs_off, pt_dst, pt_src;
   DevBuf<int> xv_idx, pt_ptr, pf_ptr, pf_src;
@@ -470,6 +471,7 @@ int BuildPlans(cxk_context* ctx) {
   }
 
   // ---- published-update slots: s(s+1)/2 Schur values and s forward values per supernode
+  std::vector<int> h_tg_ptr, h_fs_ptr, h_bs_ptr;  // host copies for the per-supernode records
   std::vector<int64_t> upd_off(K, 0);
   std::vector<int> updb_off(K, 0);
   int64_t upd_total = 0;
@@ -538,6 +540,7 @@ int BuildPlans(cxk_context* ctx) {
       tg_ptr[p + 1] = (int)tg_loc.size();
     }
     CXK_TRY(ctx->tg_ptr.upload(tg_ptr));
+    h_tg_ptr = tg_ptr;
     CXK_TRY(ctx->tg_loc.upload(tg_loc));
     CXK_TRY(ctx->tr_ptr.upload(tr_ptr));
     CXK_TRY(ctx->tr_src.upload(tr_src));
@@ -552,6 +555,7 @@ int BuildPlans(cxk_context* ctx) {
       fs_ptr[p + 1] = (int)fs_src.size();
     }
     CXK_TRY(ctx->fs_ptr.upload(fs_ptr));
+    h_fs_ptr = fs_ptr;
     CXK_TRY(ctx->fs_src.upload(fs_src));
   }
   CXK_TRY(ctx->upd_off.upload(upd_off));
@@ -606,6 +610,7 @@ int BuildPlans(cxk_context* ctx) {
       bs_ptr[j + 1] = (int)bs_c.size();
     }
     CXK_TRY(ctx->bs_ptr.upload(bs_ptr));
+    h_bs_ptr = bs_ptr;
     CXK_TRY(ctx->bs_c.upload(bs_c));
     CXK_TRY(ctx->bs_row.upload(bs_row));
   }
@@ -627,6 +632,27 @@ int BuildPlans(cxk_context* ctx) {
              "supernode too large for the LDS-resident block Cholesky (blocked path not built yet)");
   CXK_TRY(ctx->d_level_sn.upload(ctx->level_sn));
   CXK_TRY(ctx->d_level_ptr.upload(ctx->level_ptr));
+  {
+    std::vector<SnRec> recs(ctx->level_sn.size());
+    for (size_t pos = 0; pos < recs.size(); pos++) {
+      const int e = ctx->level_sn[pos];
+      SnRec& r = recs[pos];
+      r.p = e;
+      r.ns = ns[e];
+      r.nsep = nsep[e];
+      r.start = start[e];
+      r.tg_beg = h_tg_ptr[e];
+      r.tg_end = h_tg_ptr[e + 1];
+      r.bs_beg = h_bs_ptr[e];
+      r.bs_end = h_bs_ptr[e + 1];
+      r.diag_off = L.diag_off[e];
+      r.offd_off = L.offd_off[e];
+      r.upd_off = upd_off[e];
+      r.updb_off = updb_off[e];
+      r.has_fs = h_fs_ptr[start[e] + ns[e]] > h_fs_ptr[start[e]] ? 1 : 0;
+    }
+    CXK_TRY(ctx->p_rec.upload(recs));
+  }
   // narrow top of the tree: trailing levels that hold few supernodes are swept by one workgroup
   // (levels separated by a workgroup barrier instead of a kernel boundary); never below the cut
   {
@@ -641,6 +667,7 @@ int BuildPlans(cxk_context* ctx) {
   CXK_TRY(ctx->p_diag.upload(L.diag_off));
   CXK_TRY(ctx->p_offd.upload(L.offd_off));
   FactorPlan& P = ctx->plan;
+  P.rec = ctx->p_rec.p;
   P.ns = ctx->p_ns.p;
   P.nsep = ctx->p_nsep.p;
   P.start = ctx->p_start.p;
@@ -781,7 +808,8 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
     grid = (maxcnt + waves - 1) / waves;
   }
   tree_sweep<<<grid, waves * 64, (size_t)waves * ctx->chol_lds, ctx->stream>>>(
-      ctx->plan, ctx->d_level_ptr.p, ctx->d_level_sn.p, lb, le, mode, then_backward ? 1 : 0,
+      ctx->plan, ctx->d_level_ptr.p, ctx->level_ptr[lb], ctx->level_ptr[lb + 1] - ctx->level_ptr[lb], lb,
+      le, mode, then_backward ? 1 : 0,
       ctx->slab.p, (with_rhs || mode != 0) ? ctx->y.p : nullptr, ctx->d_fail.p, per_wave);
   CXK_TRY(hipGetLastError());
   return CXK_SUCCESS;
@@ -1442,7 +1470,7 @@ int cxk_debug_fused_stamps(long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamp), 64 * sizeof(long long)) == hipSuccess ? 0 : 1;
 }
 int cxk_debug_stamps(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cxk_stamp), 16 * sizeof(long long)) == hipSuccess ? 0 : 1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cxk_stamp), 32 * sizeof(long long)) == hipSuccess ? 0 : 1;
 }
 #endif
 
