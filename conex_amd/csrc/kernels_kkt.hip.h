@@ -147,21 +147,28 @@ __device__ int g_cxk_sel;
 #define CXK_STAMP_SELECT(lb, mode) do { } while (0)
 #endif
 
-// Everything a wavefront needs to start on one supernode: one 64-byte record per position of
+// Everything a wavefront needs to start on one supernode: one 128-byte record per position of
 // the level lists (level order), fetched with a single coalesced load.
 struct SnRec {
   int p, ns, nsep, start;
   int tg_beg, tg_end;  // pull targets (tg_loc / tr_ptr range)
   int bs_beg, bs_end;  // backward separator list (bs_c / bs_row range)
   int64_t diag_off, offd_off, upd_off;
-  int updb_off, has_fs;  // has_fs: some row of this supernode pulls forward-solve updates
+  int updb_off;
+  int m;               // slots per pull target:   upd[ubase + t_local * m + i]
+  int64_t ubase;
+  int fbase, mf;       // forward-solve slots:     updb[fbase + row * mf + i]
+  int nsep_inline;     // > 0: sep[q] = row | column << 26 replaces the bs_* lists
+  int pad_[3];
+  int sep[8];
 };
-static_assert(sizeof(SnRec) == 64, "SnRec is read as 16 lanes x 4 bytes");
+static_assert(sizeof(SnRec) == 128, "SnRec is read as 32 lanes x 4 bytes");
 
 __device__ __forceinline__ SnRec LoadRec(const SnRec* __restrict__ rec, int pos) {
   const int lane = threadIdx.x & 63;
-  const int w = reinterpret_cast<const int*>(rec + pos)[lane & 15];
+  const int w = reinterpret_cast<const int*>(rec + pos)[lane & 31];
   auto f = [&](int i) { return __builtin_amdgcn_readlane(w, i); };
+  auto f64 = [&](int i) { return ((int64_t)f(i + 1) << 32) | (uint32_t)f(i); };
   SnRec R;
   R.p = f(0);
   R.ns = f(1);
@@ -171,11 +178,17 @@ __device__ __forceinline__ SnRec LoadRec(const SnRec* __restrict__ rec, int pos)
   R.tg_end = f(5);
   R.bs_beg = f(6);
   R.bs_end = f(7);
-  R.diag_off = ((int64_t)f(9) << 32) | (uint32_t)f(8);
-  R.offd_off = ((int64_t)f(11) << 32) | (uint32_t)f(10);
-  R.upd_off = ((int64_t)f(13) << 32) | (uint32_t)f(12);
+  R.diag_off = f64(8);
+  R.offd_off = f64(10);
+  R.upd_off = f64(12);
   R.updb_off = f(14);
-  R.has_fs = f(15);
+  R.m = f(15);
+  R.ubase = f64(16);
+  R.fbase = f(18);
+  R.mf = f(19);
+  R.nsep_inline = f(20);
+#pragma unroll
+  for (int q = 0; q < 8; q++) R.sep[q] = f(24 + q);
   return R;
 }
 
@@ -202,8 +215,10 @@ struct FactorPlan {
   const int* bs_ptr;         // [K+1]
   const int* bs_c;           // column index c within off block
   const int* bs_row;         // permuted index of separator variable
-  double* upd;
+  double* upd;               // slot-ordered (see BuildPlans)
   double* updb;
+  const int* pub_dst;        // [child-side numbering upd_off[p] + t] -> slot in upd
+  const int* pubb_dst;       // [updb_off[p] + c] -> slot in updb
 };
 
 // Stage [diag | off | rhs] of supernode p into the wave's LDS region and apply the published
@@ -268,7 +283,7 @@ __device__ inline void PublishUpdates(const FactorPlan& P, int p, const double* 
   const double* sB = my + ns * ns;
   const double* sb = sB + ns * s;
   if (with_matrix) {
-    double* out = P.upd + P.upd_off[p];
+    const int* dst = P.pub_dst + P.upd_off[p];
     const int npairs = s * (s + 1) / 2;
     for (int t = lane; t < npairs; t += 64) {
       int k = 0, rem = t;
@@ -279,15 +294,15 @@ __device__ inline void PublishUpdates(const FactorPlan& P, int p, const double* 
       const int j = k + rem;
       double dot = 0;
       for (int i = 0; i < ns; i++) dot = fma(sB[i + k * ns], sB[i + j * ns], dot);
-      out[t] = dot;
+      P.upd[dst[t]] = dot;
     }
   }
   if (with_rhs) {
-    double* out = P.updb + P.updb_off[p];
+    const int* dst = P.pubb_dst + P.updb_off[p];
     for (int c = lane; c < s; c += 64) {
       double dot = 0;
       for (int i = 0; i < ns; i++) dot = fma(sB[i + c * ns], sb[i], dot);
-      out[c] = dot;
+      P.updb[dst[c]] = dot;
     }
   }
 }
@@ -404,43 +419,107 @@ __device__ inline void FactorSupernodeRows(const FactorPlan& P, const SnRec& R,
   const unsigned st = is_row ? (unsigned)ns : 1u;
   const int lim = is_row ? lane + 1 : (is_sep ? ns : 0);  // valid j < lim
   CXK_STAMP(0);
+  // ---- one round trip: panel, right-hand side, publish destinations and every value this
+  // supernode pulls (dense slots: addresses depend on the record only)
+  constexpr int TU = 2, MMAX = 8, MFMAX = 8;
+  const int ntg = R.tg_end - R.tg_beg;
+  const bool fast_pull = ntg <= 64 * TU && R.m <= MMAX && R.mf <= MFMAX;
   double a[NSMAX + SMAX + 1];
 #pragma unroll
   for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? base[o0 + j * st] : 0.0;
 #pragma unroll
   for (int c = 0; c < SMAX; c++) a[NSMAX + c] = 0.0;
   a[RB] = (rhs && is_row) ? rhs[R.start + lane] : 0.0;
+  // The remaining loads are guarded by wave-uniform branches and use clamped (always valid)
+  // addresses instead of per-lane predicates: a leaf skips them at the cost of a scalar branch.
+  int pdst[SMAX > 0 ? SMAX : 1], pdstb = 0;
+#pragma unroll
+  for (int c = 0; c < SMAX; c++) pdst[c] = 0;
+  if (s > 0) {
+    const int k = is_sep ? sc : 0;
+    const int* dst = P.pub_dst + R.upd_off + (k * s - k * (k - 1) / 2 - k);
+#pragma unroll
+    for (int c = 0; c < SMAX; c++) {
+      const int cc = c < k ? k : (c < s ? c : s - 1);
+      pdst[c] = dst[cc];
+    }
+    if (rhs) pdstb = P.pubb_dst[R.updb_off + k];
+  }
+  double pv[TU][MMAX], pb[MFMAX];
+  int ploc[TU];
+#pragma unroll
+  for (int u = 0; u < TU; u++) {
+    ploc[u] = -1;
+#pragma unroll
+    for (int i = 0; i < MMAX; i++) pv[u][i] = 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < MFMAX; i++) pb[i] = 0.0;
+  if (fast_pull && ntg > 0) {
+#pragma unroll
+    for (int u = 0; u < TU; u++)
+      if (64 * u < ntg) {
+        const int t = lane + 64 * u;
+        const int ts = t < ntg ? t : 0;
+        const int loc = P.tg_loc[R.tg_beg + ts];
+        ploc[u] = t < ntg ? loc : -1;
+        const double* src = P.upd + R.ubase + (int64_t)ts * R.m;
+#pragma unroll
+        for (int i = 0; i < MMAX; i++)
+          if (i < R.m) pv[u][i] = src[i];
+      }
+  }
+  if (fast_pull && rhs && R.mf > 0) {
+    const double* src = P.updb + R.fbase + (is_row ? lane : 0) * R.mf;
+#pragma unroll
+    for (int i = 0; i < MFMAX; i++)
+      if (i < R.mf) {
+        const double v = src[i];
+        pb[i] = is_row ? v : 0.0;
+      }
+  }
   CXK_STAMP(1);
-  if (R.tg_end > R.tg_beg || (rhs && R.has_fs)) {
-    // descendants published updates: apply them in the reference's order through an LDS copy
-    // laid out like the slab ([diag ns x ns | off ns x s | rhs ns])
-    double* sb = my + ns * ns + ns * s;
+  if (ntg > 0) {
+    // descendants published Schur updates: apply them in the reference's order through an LDS
+    // copy laid out like the slab ([diag ns x ns | off ns x s]); tg_loc indexes that copy
     const unsigned l0 = is_row ? (unsigned)lane : (unsigned)(ns * ns + (is_sep ? sc : 0) * ns);
 #pragma unroll
     for (int j = 0; j < NSMAX; j++)
       if ((is_row || is_sep) && j < ns) my[l0 + j * st] = a[j];
-    if (is_row) sb[lane] = a[RB];
     WaveSync();
-    for (int t = R.tg_beg + lane; t < R.tg_end; t += 64) {
-      const int loc = P.tg_loc[t];
-      double acc = my[loc];
-      const int q1 = P.tr_ptr[t + 1];
+    if (fast_pull) {
+#pragma unroll
+      for (int u = 0; u < TU; u++)
+        if (ploc[u] >= 0) {
+          double acc = my[ploc[u]];
+#pragma unroll
+          for (int i = 0; i < MMAX; i++) acc -= pv[u][i];  // unused slots hold 0.0: exact no-ops
+          my[ploc[u]] = acc;
+        }
+    } else {
+      for (int t = R.tg_beg + lane; t < R.tg_end; t += 64) {
+        const int loc = P.tg_loc[t];
+        double acc = my[loc];
+        const int q1 = P.tr_ptr[t + 1];
 #pragma unroll 4
-      for (int q = P.tr_ptr[t]; q < q1; q++) acc -= P.upd[P.tr_src[q]];
-      my[loc] = acc;
-    }
-    if (rhs && is_row) {
-      double acc = sb[lane];
-      const int q1 = P.fs_ptr[R.start + lane + 1];
-#pragma unroll 4
-      for (int q = P.fs_ptr[R.start + lane]; q < q1; q++) acc -= P.updb[P.fs_src[q]];
-      sb[lane] = acc;
+        for (int q = P.tr_ptr[t]; q < q1; q++) acc -= P.upd[P.tr_src[q]];
+        my[loc] = acc;
+      }
     }
     WaveSync();
 #pragma unroll
     for (int j = 0; j < NSMAX; j++)
       if (j < lim) a[j] = my[l0 + j * st];
-    if (is_row) a[RB] = sb[lane];
+  }
+  if (fast_pull) {
+#pragma unroll
+    for (int i = 0; i < MFMAX; i++) a[RB] -= pb[i];
+  } else if (rhs && is_row) {
+    double acc = a[RB];
+    const int q1 = P.fs_ptr[R.start + lane + 1];
+#pragma unroll 4
+    for (int q = P.fs_ptr[R.start + lane]; q < q1; q++) acc -= P.updb[P.fs_src[q]];
+    a[RB] = acc;
   }
   // padding pivots: unit diagonal
 #pragma unroll
@@ -460,12 +539,12 @@ __device__ inline void FactorSupernodeRows(const FactorPlan& P, const SnRec& R,
   if (rhs && is_row) rhs[R.start + lane] = a[RB];
   CXK_STAMP(4);
   if (is_sep) {
-    // U[k][c], k <= c, in the reference's S_S enumeration: t = k*s - k(k-1)/2 + (c - k)
-    double* out = P.upd + R.upd_off + (sc * s - sc * (sc - 1) / 2 - sc);
+    // U[k][c], k <= c (child-side numbering t = k*s - k(k-1)/2 + (c - k), the reference's S_S
+    // enumeration), written straight into the consumer's slot
 #pragma unroll
     for (int c = 0; c < SMAX; c++)
-      if (c >= sc && c < s) out[c] = -a[NSMAX + c];
-    if (rhs) P.updb[R.updb_off + sc] = -a[RB];
+      if (c >= sc && c < s) P.upd[pdst[c]] = -a[NSMAX + c];
+    if (rhs) P.updb[pdstb] = -a[RB];
   }
   CXK_STAMP(5);
 }
@@ -488,18 +567,19 @@ __device__ inline void BackwardSupernodeRows(const FactorPlan& P, const SnRec& R
   const double dg = active ? D[lane] : 1.0;
   double acc = active ? rhs[R.start + lane] : 0.0;
   const int cnt = R.bs_end - R.bs_beg;
-  if (cnt <= SMAX) {
-    double bv[SMAX > 0 ? SMAX : 1], yv[SMAX > 0 ? SMAX : 1];
+  if (R.nsep_inline == cnt) {
+    // separator rows / columns come with the record: y[sep] and off[:, c] load in the same trip
+    constexpr int QN = SMAX < 8 ? SMAX : 8;
+    double bv[QN > 0 ? QN : 1], yv[QN > 0 ? QN : 1];
 #pragma unroll
-    for (int q = 0; q < SMAX; q++) {
+    for (int q = 0; q < QN; q++) {
       const bool on = q < cnt;
-      const int cc = on ? P.bs_c[R.bs_beg + q] : 0;
-      const int row = on ? P.bs_row[R.bs_beg + q] : 0;
-      yv[q] = on ? rhs[row] : 0.0;
-      bv[q] = (on && active) ? B[(size_t)cc * ns] : 0.0;
+      const unsigned w = (unsigned)R.sep[q];
+      yv[q] = on ? rhs[w & 0x3ffffffu] : 0.0;
+      bv[q] = (on && active) ? B[(size_t)(w >> 26) * ns] : 0.0;
     }
 #pragma unroll
-    for (int q = 0; q < SMAX; q++) acc -= bv[q] * yv[q];
+    for (int q = 0; q < QN; q++) acc -= bv[q] * yv[q];
   } else {
 #pragma unroll 4
     for (int q = R.bs_beg; q < R.bs_end; q++) {
@@ -683,32 +763,38 @@ __device__ inline void BackwardSupernodeLds(const FactorPlan& P, int p,
   for (int r = lane; r < ns; r += 64) rhs[st + r] = sb[r];
 }
 
-// mode 0: factor (+ forward if rhs), mode 1: forward only, mode 2: backward.
-// Levels [lb, le) ascending for modes 0/1; mode 2 walks the range downwards.  A launch that
-// covers several levels (or continues into the backward sweep) must be ONE workgroup: levels
-// are then separated by a workgroup barrier instead of a kernel boundary.  (base0, cnt0) is the
-// position range of level lb, passed by value so a one-level launch starts without a lookup.
+// MODE 0: factor (+ forward if rhs), MODE 1: forward only, MODE 2: backward.
+// TOP = false: one level per launch, positions [base0, base0 + cnt0) of the level lists, one
+// wavefront per supernode.  TOP = true: levels [lb, le) ascending (MODE 0/1; MODE 2 walks the
+// range downwards), optionally continuing into the backward sweep, in ONE workgroup: levels are
+// then separated by a workgroup barrier instead of a kernel boundary.
+// The kernel is specialised per (MODE, TOP) so that each instance keeps only the plan fields it
+// uses in SGPRs.
+template <int MODE, bool TOP>
 __global__ void __launch_bounds__(512)
 tree_sweep(FactorPlan P, const int* __restrict__ level_ptr, int base0, int cnt0, int lb, int le,
-           int mode, int then_backward, double* __restrict__ slab, double* __restrict__ rhs,
+           int then_backward, double* __restrict__ slab, double* __restrict__ rhs,
            int* __restrict__ fail, int lds_per_wave) {
   extern __shared__ double lds[];
   // wave-uniform values are forced into SGPRs: otherwise every loop bound / lane select below
   // is treated as divergent (waterfall loops around v_readlane, vector address arithmetic)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   double* my = lds + (size_t)wave * lds_per_wave;
-  CXK_STAMP_SELECT(lb, mode);
+  CXK_STAMP_SELECT(lb, MODE);
   CXK_STAMP(6);
   CXK_STAMPB(0);
-  const bool multi = (le - lb > 1) || then_backward;
-  if (mode != 2) {
+  if constexpr (!TOP) {
+    le = lb + 1;
+    then_backward = 0;
+  }
+  if constexpr (MODE != 2) {
     for (int l = lb; l < le; l++) {
-      const int base = (l == lb) ? base0 : level_ptr[l];
-      const int cnt = (l == lb) ? cnt0 : level_ptr[l + 1] - base;
+      const int base = (!TOP || l == lb) ? base0 : level_ptr[l];
+      const int cnt = (!TOP || l == lb) ? cnt0 : level_ptr[l + 1] - base;
       for (int idx = blockIdx.x * nw + wave; idx < cnt; idx += gridDim.x * nw) {
         const SnRec R = LoadRec(P.rec, base + idx);
         const int ns = R.ns, s = R.nsep;
-        if (mode == 0) {
+        if constexpr (MODE == 0) {
           if (ns <= 16 && s <= 8)
             FactorSupernodeRows<16, 8>(P, R, slab, rhs, fail, my);
           else if (ns <= 24 && s == 0)
@@ -726,13 +812,13 @@ tree_sweep(FactorPlan P, const int* __restrict__ level_ptr, int base0, int cnt0,
             ForwardSupernodeLds(P, R.p, slab, rhs, my);
         }
       }
-      if (multi) __syncthreads();
+      if constexpr (TOP) __syncthreads();
     }
   }
-  if (mode == 2 || then_backward) {
+  if (MODE == 2 || (TOP && then_backward)) {
     for (int l = le - 1; l >= lb; l--) {
-      const int base = (l == lb) ? base0 : level_ptr[l];
-      const int cnt = (l == lb) ? cnt0 : level_ptr[l + 1] - base;
+      const int base = (!TOP || l == lb) ? base0 : level_ptr[l];
+      const int cnt = (!TOP || l == lb) ? cnt0 : level_ptr[l + 1] - base;
       for (int idx = blockIdx.x * nw + wave; idx < cnt; idx += gridDim.x * nw) {
         const SnRec R = LoadRec(P.rec, base + idx);
         const int ns = R.ns, s = R.nsep;
@@ -747,7 +833,7 @@ tree_sweep(FactorPlan P, const int* __restrict__ level_ptr, int base0, int cnt0,
         else
           BackwardSupernodeLds(P, R.p, slab, rhs, my);
       }
-      if (multi) __syncthreads();
+      if constexpr (TOP) __syncthreads();
     }
   }
   CXK_STAMP(7);

@@ -101,6 +101,7 @@ struct cxk_context {
   DevBuf<int> p_ns, p_nsep, p_start, tg_ptr, tr_ptr, fs_ptr, fs_src, bs_ptr, bs_c, bs_row, updb_off;
   DevBuf<int64_t> p_diag, p_offd, tr_src, upd_off;
   DevBuf<SnRec> p_rec;
+  DevBuf<int> pub_dst, pubb_dst;
   DevBuf<double> upd, updb, xbuf;
   DevBuf<int64_t> xs_off, pt_dst, pt_src;
   DevBuf<int> xv_idx, pt_ptr, pf_ptr, pf_src;
@@ -471,7 +472,7 @@ int BuildPlans(cxk_context* ctx) {
   }
 
   // ---- published-update slots: s(s+1)/2 Schur values and s forward values per supernode
-  std::vector<int> h_tg_ptr, h_fs_ptr, h_bs_ptr;  // host copies for the per-supernode records
+  std::vector<int> h_tg_ptr, h_fs_ptr, h_bs_ptr, h_bs_c, h_bs_row;  // host copies for the per-supernode records
   std::vector<int64_t> upd_off(K, 0);
   std::vector<int> updb_off(K, 0);
   int64_t upd_total = 0;
@@ -515,12 +516,29 @@ int BuildPlans(cxk_context* ctx) {
       (pre ? pre_fs : fs)[s[k]].push_back(updb_off[i] + k);
     }
   }
+  // Slots.  A published value is written straight to the place its (single) consumer reads it
+  // from: the contributions of target t of supernode p occupy  upd[ubase_p + t_local * m_p + i],
+  // i = position in the reference's accumulation order, m_p = longest list of p (unused slots
+  // stay 0.0: subtracting them is exact).  The consumer can therefore issue every load as soon
+  // as it knows its record -- no index lists on the critical path.  Publishers look their slot up
+  // in pub_dst (indexed by the child-side numbering upd_off[i] + t).  Pre-reduce contributions
+  // (subtree -> top, sharded runs) get plain list slots after the dense region.
+  std::vector<int64_t> h_ubase(K, 0);
+  std::vector<int> h_m(K, 0), h_fbase(K, 0), h_mf(K, 0);
+  std::vector<int> pub_dst((size_t)upd_total, -1), pubb_dst((size_t)updb_total, -1);
+  int64_t slots = 0;
+  int slotsb = 0;
   {
     std::vector<int> tg_ptr(K + 1, 0), tr_ptr, tg_loc, pt_ptr;
     std::vector<int64_t> tr_src, pt_dst, pt_src;
     tr_ptr.push_back(0);
     pt_ptr.push_back(0);
     for (int p = 0; p < K; p++) {
+      size_t m = 0;
+      for (int t : tg_of_sn[p]) m = std::max(m, contrib[t].size());
+      h_ubase[p] = slots;
+      h_m[p] = (int)m;
+      int tl = 0;
       for (int t : tg_of_sn[p]) {
         const int64_t off = tg_dst_all[t];
         const int64_t dsz = (int64_t)ns[p] * ns[p];
@@ -528,17 +546,29 @@ int BuildPlans(cxk_context* ctx) {
           tg_loc.push_back(off >= L.diag_off[p] && off < L.diag_off[p] + dsz
                                ? (int)(off - L.diag_off[p])
                                : (int)(dsz + off - L.offd_off[p]));
-          for (int64_t q : contrib[t]) tr_src.push_back(q);
+          for (size_t i = 0; i < contrib[t].size(); i++) {
+            const int64_t slot = slots + (int64_t)tl * (int64_t)m + (int64_t)i;
+            pub_dst[contrib[t][i]] = (int)slot;
+            tr_src.push_back(slot);
+          }
           tr_ptr.push_back((int)tr_src.size());
-        }
-        if (!pre_contrib[t].empty()) {
-          pt_dst.push_back(off);
-          for (int64_t q : pre_contrib[t]) pt_src.push_back(q);
-          pt_ptr.push_back((int)pt_src.size());
+          tl++;
         }
       }
+      slots += (int64_t)tl * (int64_t)m;
       tg_ptr[p + 1] = (int)tg_loc.size();
     }
+    for (int p = 0; p < K; p++)
+      for (int t : tg_of_sn[p])
+        if (!pre_contrib[t].empty()) {
+          pt_dst.push_back(tg_dst_all[t]);
+          for (int64_t q : pre_contrib[t]) {
+            pub_dst[q] = (int)slots;
+            pt_src.push_back(slots++);
+          }
+          pt_ptr.push_back((int)pt_src.size());
+        }
+    CXK_DEMAND(slots < (int64_t)INT32_MAX, "published-update slots exceed 32-bit indexing");
     CXK_TRY(ctx->tg_ptr.upload(tg_ptr));
     h_tg_ptr = tg_ptr;
     CXK_TRY(ctx->tg_loc.upload(tg_loc));
@@ -548,20 +578,45 @@ int BuildPlans(cxk_context* ctx) {
     CXK_TRY(ctx->pt_ptr.upload(pt_ptr));
     CXK_TRY(ctx->pt_src.upload(pt_src));
   }
+  std::vector<std::vector<int>> pre_fs_slots(N);
   {
     std::vector<int> fs_ptr(N + 1, 0), fs_src;
+    for (int e = 0; e < K; e++) {
+      size_t m = 0;
+      for (int r = 0; r < ns[e]; r++) m = std::max(m, fs[start[e] + r].size());
+      h_fbase[e] = slotsb;
+      h_mf[e] = (int)m;
+      slotsb += ns[e] * (int)m;
+    }
+    for (int e = 0; e < K; e++)
+      for (int r = 0; r < ns[e]; r++) {
+        const int p = start[e] + r;
+        for (size_t i = 0; i < fs[p].size(); i++) pubb_dst[fs[p][i]] = h_fbase[e] + r * h_mf[e] + (int)i;
+      }
     for (int p = 0; p < N; p++) {
-      for (int q : fs[p]) fs_src.push_back(q);
+      for (int q : fs[p]) fs_src.push_back(pubb_dst[q]);
       fs_ptr[p + 1] = (int)fs_src.size();
     }
+    for (int p = 0; p < N; p++)
+      for (int q : pre_fs[p]) {
+        pubb_dst[q] = slotsb;
+        pre_fs_slots[p].push_back(slotsb++);
+      }
     CXK_TRY(ctx->fs_ptr.upload(fs_ptr));
     h_fs_ptr = fs_ptr;
     CXK_TRY(ctx->fs_src.upload(fs_src));
   }
+  // values nobody on this rank consumes land in one dump slot at the end
+  for (int& d : pub_dst)
+    if (d < 0) d = (int)slots;
+  for (int& d : pubb_dst)
+    if (d < 0) d = slotsb;
   CXK_TRY(ctx->upd_off.upload(upd_off));
   CXK_TRY(ctx->updb_off.upload(updb_off));
-  CXK_TRY(ctx->upd.alloc((size_t)upd_total));
-  CXK_TRY(ctx->updb.alloc((size_t)updb_total));
+  CXK_TRY(ctx->pub_dst.upload(pub_dst));
+  CXK_TRY(ctx->pubb_dst.upload(pubb_dst));
+  CXK_TRY(ctx->upd.alloc((size_t)slots + 1));
+  CXK_TRY(ctx->updb.alloc((size_t)slotsb + 1));
 
   // ---- exchange layout: [T slab entries | AW_T | AQc_T | fwd_T | <w,c> <c,Qc> fail]
   if (sharded) {
@@ -576,7 +631,7 @@ int BuildPlans(cxk_context* ctx) {
       for (int r = 0; r < ns[e]; r++) {
         const int p = start[e] + r;
         xv.push_back(p);
-        for (int q : pre_fs[p]) pf_src.push_back(q);
+        for (int q : pre_fs_slots[p]) pf_src.push_back(q);
         pf_ptr.push_back((int)pf_src.size());
       }
     }
@@ -611,6 +666,8 @@ int BuildPlans(cxk_context* ctx) {
     }
     CXK_TRY(ctx->bs_ptr.upload(bs_ptr));
     h_bs_ptr = bs_ptr;
+    h_bs_c = bs_c;
+    h_bs_row = bs_row;
     CXK_TRY(ctx->bs_c.upload(bs_c));
     CXK_TRY(ctx->bs_row.upload(bs_row));
   }
@@ -649,7 +706,16 @@ int BuildPlans(cxk_context* ctx) {
       r.offd_off = L.offd_off[e];
       r.upd_off = upd_off[e];
       r.updb_off = updb_off[e];
-      r.has_fs = h_fs_ptr[start[e] + ns[e]] > h_fs_ptr[start[e]] ? 1 : 0;
+      r.ubase = h_ubase[e];
+      r.m = h_m[e];
+      r.fbase = h_fbase[e];
+      r.mf = h_mf[e];
+      r.nsep_inline = 0;
+      const int cnt = r.bs_end - r.bs_beg;
+      if (cnt <= 8 && N < (1 << 26)) {
+        r.nsep_inline = cnt;
+        for (int q = 0; q < cnt; q++) r.sep[q] = h_bs_row[r.bs_beg + q] | (h_bs_c[r.bs_beg + q] << 26);
+      }
     }
     CXK_TRY(ctx->p_rec.upload(recs));
   }
@@ -682,6 +748,8 @@ int BuildPlans(cxk_context* ctx) {
   P.fs_ptr = ctx->fs_ptr.p;
   P.fs_src = ctx->fs_src.p;
   P.upd = ctx->upd.p;
+  P.pub_dst = ctx->pub_dst.p;
+  P.pubb_dst = ctx->pubb_dst.p;
   P.updb = ctx->updb.p;
   P.bs_ptr = ctx->bs_ptr.p;
   P.bs_c = ctx->bs_c.p;
@@ -807,10 +875,21 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
     waves = std::max(1, std::min(wmax, (maxcnt + 255) / 256));
     grid = (maxcnt + waves - 1) / waves;
   }
-  tree_sweep<<<grid, waves * 64, (size_t)waves * ctx->chol_lds, ctx->stream>>>(
-      ctx->plan, ctx->d_level_ptr.p, ctx->level_ptr[lb], ctx->level_ptr[lb + 1] - ctx->level_ptr[lb], lb,
-      le, mode, then_backward ? 1 : 0,
-      ctx->slab.p, (with_rhs || mode != 0) ? ctx->y.p : nullptr, ctx->d_fail.p, per_wave);
+  const bool is_top = le - lb > 1 || then_backward;
+  const size_t lds = (size_t)waves * ctx->chol_lds;
+  double* rhs = (with_rhs || mode != 0) ? ctx->y.p : nullptr;
+#define CXK_SWEEP(MODE, TOP)                                                                   \
+  tree_sweep<MODE, TOP><<<grid, waves * 64, lds, ctx->stream>>>(                               \
+      ctx->plan, ctx->d_level_ptr.p, ctx->level_ptr[lb], ctx->level_ptr[lb + 1] - ctx->level_ptr[lb], \
+      lb, le, then_backward ? 1 : 0, ctx->slab.p, rhs, ctx->d_fail.p, per_wave)
+  if (mode == 0) {
+    if (is_top) CXK_SWEEP(0, true); else CXK_SWEEP(0, false);
+  } else if (mode == 1) {
+    if (is_top) CXK_SWEEP(1, true); else CXK_SWEEP(1, false);
+  } else {
+    if (is_top) CXK_SWEEP(2, true); else CXK_SWEEP(2, false);
+  }
+#undef CXK_SWEEP
   CXK_TRY(hipGetLastError());
   return CXK_SUCCESS;
 }
