@@ -109,6 +109,7 @@ struct cxk_context {
   FactorPlan plan{};
   // timing of the dominant (dense-LMI Schur) kernel
   bool timing = false;
+  int timing_period = 1, timing_tick = 0;  // hipEvents bracket every timing_period-th launch
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   double time_acc_ms = 0;
@@ -793,7 +794,8 @@ int LaunchSchur(cxk_context* ctx) {
     switch (g.type) {
       case CXK_LMI: {
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (ctx->timing) {
+        const bool sample = ctx->timing && (ctx->timing_tick++ % ctx->timing_period) == 0;
+        if (sample) {
           if (ctx->ev_used == ctx->ev_pool.size()) {
             hipEvent_t a, b;
             CXK_TRY(hipEventCreate(&a));
@@ -810,7 +812,7 @@ int LaunchSchur(cxk_context* ctx) {
         } else {
           lmi_schur_generic<<<count, 256, LmiGenericLds(g.n), ctx->stream>>>(MakeLmi(g), ar);
         }
-        if (ctx->timing) CXK_TRY(hipEventRecord(e1, ctx->stream));
+        if (sample) CXK_TRY(hipEventRecord(e1, ctx->stream));
         break;
       }
       case CXK_LINEAR:
@@ -1556,6 +1558,8 @@ int cxk_debug_stamps(long long* out) {
 int cxk_enable_timing(cxk_context* ctx, int on) {
   if (!ctx) return CXK_FAILURE;
   ctx->timing = on != 0;
+  ctx->timing_period = on > 1 ? on : 1;
+  ctx->timing_tick = 0;
   return CXK_SUCCESS;
 }
 

@@ -162,6 +162,9 @@ int cxk_assembly_work(const cxk_context* ctx, double* bytes, double* flops);
 /* average device time (ms) of the dominant assembly kernel since the last reset, measured
  * with hipEvents on the context's stream; returns number of samples */
 int cxk_kernel_time(cxk_context* ctx, int reset, double* avg_ms);
+/* on = 0: off; on = 1: bracket every launch of that kernel with a hipEvent pair; on = P > 1:
+ * every P-th launch (an event pair costs a few us of stream time, sampling keeps the timed
+ * region representative) */
 int cxk_enable_timing(cxk_context* ctx, int on);
 
 #ifdef __cplusplus
