@@ -17,6 +17,7 @@
 
 #include "../../include/conex_kkt_hip.h"
 #include "kernels_cone.hip.h"
+#include "kernels_gemm.hip.h"
 #include "kernels_kkt.hip.h"
 #include "kernels_lmi.hip.h"
 #include "kernels_lmi_fused.hip.h"
@@ -1527,6 +1528,63 @@ int cxk_shard_info(const cxk_context* ctx, int* cut_level, int* num_levels, long
   if (cut_level) *cut_level = ctx->cut_level;
   if (num_levels) *num_levels = ctx->nlev;
   if (exchange_count) *exchange_count = ctx->world > 1 ? (long)(ctx->n_xs + 3 * (int64_t)ctx->n_xv + 4) : 0;
+  return CXK_SUCCESS;
+}
+
+int cxk_gemm_f64(int device, int ta, int tb, int M, int N, int K, int batch, const double* A,
+                 const double* B, double* C, double alpha, double beta, int lower_only, int splits,
+                 int reps, double* avg_ms) {
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || !A || !B || !C) return CXK_FAILURE;
+  cxk_context scratch_ctx;  // carries the error string for CXK_TRY
+  cxk_context* ctx = &scratch_ctx;
+  CXK_TRY(hipSetDevice(device));
+  const size_t na = (size_t)M * K, nb = (size_t)K * N, nc = (size_t)M * N;
+  DevBuf<double> dA, dB, dC, dP;
+  CXK_TRY(dA.alloc(na * batch));
+  CXK_TRY(dB.alloc(nb * batch));
+  CXK_TRY(dC.alloc(nc * batch));
+  if (splits > 1) CXK_TRY(dP.alloc(nc * batch * splits));
+  CXK_TRY(hipMemcpy(dA.p, A, sizeof(double) * na * batch, hipMemcpyHostToDevice));
+  CXK_TRY(hipMemcpy(dB.p, B, sizeof(double) * nb * batch, hipMemcpyHostToDevice));
+  GemmArgs g{};
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.A = dA.p;
+  g.lda = ta ? K : M;
+  g.sA1 = (int64_t)na;
+  g.B = dB.p;
+  g.ldb = tb ? N : K;
+  g.sB1 = (int64_t)nb;
+  g.C = dC.p;
+  g.ldc = M;
+  g.sC1 = (int64_t)nc * (splits > 1 ? 1 : 1);
+  g.inner = 1;
+  g.alpha = alpha;
+  g.beta = beta;
+  g.lower_only = lower_only;
+  g.splits = splits > 1 ? splits : 1;
+  g.sCs = (int64_t)nc * batch;  // partial s of batch b at part + s*sCs + b*sC1
+  hipEvent_t e0, e1;
+  CXK_TRY(hipEventCreate(&e0));
+  CXK_TRY(hipEventCreate(&e1));
+  float total = 0;
+  const int n = reps > 0 ? reps : 1;
+  for (int r = 0; r < n; r++) {
+    // beta != 0 accumulates into C: restore the input every repetition (untimed)
+    CXK_TRY(hipMemcpy(dC.p, C, sizeof(double) * nc * batch, hipMemcpyHostToDevice));
+    CXK_TRY(hipEventRecord(e0, nullptr));
+    CXK_TRY(LaunchGemmSplitK(g, ta != 0, tb != 0, batch, dP.p, nullptr));
+    CXK_TRY(hipEventRecord(e1, nullptr));
+    CXK_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    CXK_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0 || n == 1) total += ms;
+  }
+  if (avg_ms) *avg_ms = total / (n > 1 ? n - 1 : 1);
+  CXK_TRY(hipMemcpy(C, dC.p, sizeof(double) * nc * batch, hipMemcpyDeviceToHost));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return CXK_SUCCESS;
 }
 

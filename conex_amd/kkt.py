@@ -437,3 +437,31 @@ class KktContext:
         ms = C.c_double()
         n = self.L.cxk_kernel_time(self.h, int(reset), C.byref(ms))
         return n, ms.value
+
+
+def gemm_f64(A, B, C=None, ta=False, tb=False, alpha=1.0, beta=0.0, lower_only=False, splits=1,
+             reps=1, device=0):
+    """Batched C = alpha op(A) op(B) + beta C through cxk_gemm_f64 (fp64 MFMA kernel).
+
+    A: (batch, M, K) logical operand op(A); B: (batch, K, N); returns (C, avg_ms).  The packed
+    column-major buffers the C-ABI expects are built here (ta / tb choose the stored layout)."""
+    import ctypes as C_
+    L = load_library()
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    batch, M, K = A.shape
+    N = B.shape[2]
+    # stored A: M x K column-major (ta False) or K x M column-major (ta True)
+    Ap = np.ascontiguousarray(A if ta else A.transpose(0, 2, 1))     # col-major(MxK) == C-order(KxM)
+    Bp = np.ascontiguousarray(B.transpose(0, 2, 1) if not tb else B)  # stored K x N col-major, or N x K
+    Cp = np.zeros((batch, N, M)) if C is None else np.ascontiguousarray(
+        np.asarray(C, dtype=np.float64).transpose(0, 2, 1))
+    ms = C_.c_double(0.0)
+    L.cxk_gemm_f64.restype = C_.c_int
+    L.cxk_gemm_f64.argtypes = [C_.c_int] * 7 + [C_.c_void_p] * 3 + [C_.c_double] * 2 + [C_.c_int] * 3 + [
+        C_.POINTER(C_.c_double)]
+    rc = L.cxk_gemm_f64(device, int(ta), int(tb), M, N, K, batch, Ap.ctypes.data, Bp.ctypes.data,
+                        Cp.ctypes.data, alpha, beta, int(lower_only), splits, reps, C_.byref(ms))
+    if rc != 0:
+        raise RuntimeError("cxk_gemm_f64 failed")
+    return Cp.transpose(0, 2, 1).copy(), ms.value

@@ -156,6 +156,18 @@ int cxk_shard_info(const cxk_context* ctx, int* cut_level, int* num_levels, long
 int cxk_assemble_local(cxk_context* ctx);
 int cxk_finish_assemble(cxk_context* ctx);
 
+/* ---- isolated batched fp64 GEMM on the matrix pipe ----------------------------------------
+ * C[b] = alpha op(A[b]) op(B[b]) + beta C[b], packed column-major host buffers (A is M x K, or
+ * K x M when ta; B is K x N, or N x K when tb).  This is the kernel behind the large-order LMI
+ * assembly (Eigen GEMM call sites dense_lmi_constraint.cc:72-103, psd_constraint.cc:13-28,45-84)
+ * and the blocked supernode updates (block_triangular_operations.cc:184-219: LLT trailing update
+ * and off^T off); exported so tests can check it and bench tools can time it against the fp64
+ * MFMA roofline at the supernode sizes SURVEY 8(d) names.  lower_only: SYRK-shaped output
+ * (m >= n).  splits > 1: split-K with an ordered reduction.  avg_ms: device time per launch. */
+int cxk_gemm_f64(int device, int ta, int tb, int M, int N, int K, int batch, const double* A,
+                 const double* B, double* C, double alpha, double beta, int lower_only, int splits,
+                 int reps, double* avg_ms);
+
 /* ---- timing / roofline accounting -------------------------------------- */
 /* algorithmic bytes and flops of one dense-LMI assembly launch (SURVEY 8d formulas) */
 int cxk_assembly_work(const cxk_context* ctx, double* bytes, double* flops);
