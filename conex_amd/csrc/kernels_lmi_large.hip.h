@@ -1,0 +1,477 @@
+// Dense-LMI kernels for orders whose working set does not fit LDS (n > 60): every n x n product
+// runs on the fp64 matrix pipe through the batched GEMM of kernels_gemm.hip.h, with the matrices
+// resident in HBM; the remaining steps are streaming or one-workgroup-per-constraint kernels.
+//
+// Reference semantics (same as kernels_lmi.hip.h, which holds the LDS-resident forms):
+//   ConstructSchurComplementSystem(DenseLMIConstraint*)  dense_lmi_constraint.cc:72-103
+//   PrepareStep / GetWeightedSlackEigenvalues            psd_constraint.cc:45-84, 97-128
+//   TakeStep / GeodesicUpdate (Pade[3/3] + PartialPivLU) psd_constraint.cc:13-28, 86-90
+//   AffineUpdate                                         psd_constraint.cc:33-43
+//   AsymmetricLanczos                                    approximate_eigenvalues.cc:178-239
+//
+// Assembly:  P_i = A_i W and its transpose (one batched NN GEMM with a transposed second
+// output), then  G(i,j) = tr(P_i P_j) = sum_k P_i[k] * P_j^T[k]  as ONE (m+1) x n^2 x (m+1)
+// GEMM per constraint (TN, split-K with an ordered reduction) -- the second product W (A_i W) of
+// the reference is never formed.  Row m of that product is AQc, its corner <c,Qc>.
+#pragma once
+#include "kernels_gemm.hip.h"
+#include "kernels_lmi.hip.h"
+
+namespace cxk {
+
+struct LmiLargeWs {
+  double* P;     // count x (m+1) x n^2   P_i = A_i W   (index m: C W)
+  double* PT;    // count x (m+1) x n^2   transposes
+  double* Gf;    // count x (m+1)^2       contraction result (lower triangle)
+  double* part;  // splits x count x (m+1)^2 split-K partials
+  double* tmp;   // count x 8 x n^2       step temporaries (aliases P: never live together)
+  int splits;
+};
+
+// ---- assembly ---------------------------------------------------------------------------
+// G, AQc, <c,Qc> from Gf; AW(i) = tr(P_i), <w,c> = tr(P_C).  One workgroup per constraint.
+__global__ void __launch_bounds__(256) lmi_large_finalize(LmiGroup g, Arena ar, LmiLargeWs ws) {
+  const int n = g.n, m = g.m, nn = n * n, m1 = m + 1;
+  const int mem = blockIdx.x, id = g.ids[mem];
+  const double* Gf = ws.Gf + (size_t)mem * m1 * m1;
+  const double* P = ws.P + (size_t)mem * m1 * nn;
+  double* G = ar.G + ar.g_off[id];
+  double* AW = ar.AWc + ar.r_off[id];
+  double* AQc = ar.AQcc + ar.r_off[id];
+  for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
+    const int i = e % m, j = e / m;
+    if (i >= j) G[i + (size_t)j * m] = Gf[i + (size_t)j * m1];
+  }
+  for (int i = threadIdx.x; i < m; i += blockDim.x) AQc[i] = Gf[m + (size_t)i * m1];
+  if (threadIdx.x == 0) ar.sc[2 * id + 1] = Gf[m + (size_t)m * m1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int i = wave; i <= m; i += nw) {
+    const double* Pi = P + (size_t)i * nn;
+    double t = 0;
+    for (int r = lane; r < n; r += 64) t += Pi[r + (size_t)r * n];
+    t = WaveSum(t);
+    if (lane == 0) {
+      if (i < m)
+        AW[i] = t;
+      else
+        ar.sc[2 * id] = t;
+    }
+  }
+}
+
+// ---- step kernels -------------------------------------------------------------------------
+// S = sum_i y_i A_i - k C   (dense_lmi_constraint.cc:8-27); grid (blocks over n^2, count)
+__global__ void __launch_bounds__(256) lmi_large_slack(LmiGroup g, StepArgs sa, double* __restrict__ S) {
+  const int n = g.n, m = g.m, nn = n * n;
+  const int mem = blockIdx.y, id = g.ids[mem];
+  extern __shared__ double sy[];
+  for (int q = threadIdx.x; q < m; q += blockDim.x) sy[q] = sa.y[sa.cl_perm[sa.cl_ptr[id] + q]];
+  __syncthreads();
+  const double* A = g.A + (size_t)mem * m * nn;
+  const double* Cm = g.C + (size_t)mem * nn;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x) {
+    double s = 0;
+    for (int i = 0; i < m; i++) s += sy[i] * A[(size_t)i * nn + q];
+    s -= sa.c_weight * Cm[q];
+    S[(size_t)mem * nn + q] = s;
+  }
+}
+
+// out = a * X + d * I  (per constraint; stride n^2)
+__global__ void __launch_bounds__(256) lmi_large_axpd(int n, const double* __restrict__ X, double a, double d,
+                                                      double* __restrict__ out) {
+  const int nn = n * n;
+  const size_t base = (size_t)blockIdx.y * nn;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x)
+    out[base + q] = a * X[base + q] + ((q % n == q / n) ? d : 0.0);
+}
+
+// X = (WS + e I) * alpha, exactly as psd_constraint.cc:86-90 orders it (add, then scale if != 1)
+__global__ void __launch_bounds__(256) lmi_large_step_arg(int n, const double* __restrict__ WS, double e, double alpha,
+                                                          double* __restrict__ X) {
+  const int nn = n * n;
+  const size_t base = (size_t)blockIdx.y * nn;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x) {
+    double x = WS[base + q];
+    if (q % n == q / n) x += e;
+    if (alpha != 1.0) x *= alpha;
+    X[base + q] = x;
+  }
+}
+
+// aug = [ V - U | V + U ],  V = 12 X2 + 120 I   (exponential_map_pade.cc:23-32); aug is n x 2n
+__global__ void __launch_bounds__(256) lmi_large_pade_system(int n, const double* __restrict__ X2,
+                                                             const double* __restrict__ U, double* __restrict__ aug) {
+  const int nn = n * n;
+  const size_t base = (size_t)blockIdx.y * nn;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x) {
+    const double v = X2[base + q] * 12.0 + ((q % n == q / n) ? 120.0 : 0.0);
+    const double u = U[base + q];
+    aug[2 * base + q] = -u + v;
+    aug[2 * base + nn + q] = u + v;
+  }
+}
+
+// Partial-pivot LU of the n x n left half of aug carrying the n right-hand sides, then back
+// substitution; the solution E overwrites the right half.  One workgroup per constraint, matrix in
+// HBM / L2 (Eigen PartialPivLU semantics: first largest |entry| of the column is the pivot).
+__global__ void __launch_bounds__(1024) lmi_large_lu_solve(int n, double* __restrict__ aug_all) {
+  double* aug = aug_all + (size_t)blockIdx.x * 2 * n * n;
+  __shared__ double s_val[16];
+  __shared__ int s_idx[16];
+  __shared__ int s_piv;
+  const int n2 = 2 * n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  for (int k = 0; k < n; k++) {
+    // pivot search: first index of the maximum |aug[i][k]|, i >= k
+    double best = -1.0;
+    int bi = k;
+    for (int i = k + tid; i < n; i += blockDim.x) {
+      const double v = fabs(aug[i + (size_t)k * n]);
+      if (v > best) {
+        best = v;
+        bi = i;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(best, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > best || (ov == best && oi < bi)) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      s_val[wave] = best;
+      s_idx[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double b = s_val[0];
+      int p = s_idx[0];
+      for (int w = 1; w < nw; w++)
+        if (s_val[w] > b || (s_val[w] == b && s_idx[w] < p)) {
+          b = s_val[w];
+          p = s_idx[w];
+        }
+      s_piv = p;
+    }
+    __syncthreads();
+    const int piv = s_piv;
+    if (piv != k) {
+      for (int c = tid; c < n2; c += blockDim.x) {
+        const double t = aug[k + (size_t)c * n];
+        aug[k + (size_t)c * n] = aug[piv + (size_t)c * n];
+        aug[piv + (size_t)c * n] = t;
+      }
+      __syncthreads();
+    }
+    const double d = aug[k + (size_t)k * n];
+    for (int i = k + 1 + tid; i < n; i += blockDim.x) aug[i + (size_t)k * n] /= d;
+    __syncthreads();
+    const int rows = n - k - 1, cols = n2 - k - 1;
+    for (int idx = tid; idx < rows * cols; idx += blockDim.x) {
+      const int i = k + 1 + idx % rows, c = k + 1 + idx / rows;
+      aug[i + (size_t)c * n] -= aug[i + (size_t)k * n] * aug[k + (size_t)c * n];
+    }
+    __syncthreads();
+  }
+  // back substitution on all right-hand sides, one pivot row per step
+  double* rhs = aug + (size_t)n * n;
+  for (int j = n - 1; j >= 0; j--) {
+    const double d = aug[j + (size_t)j * n];
+    for (int c = tid; c < n; c += blockDim.x) rhs[j + (size_t)c * n] /= d;
+    __syncthreads();
+    for (int idx = tid; idx < j * n; idx += blockDim.x) {
+      const int i = idx % j, c = idx / j;
+      rhs[i + (size_t)c * n] -= aug[i + (size_t)j * n] * rhs[j + (size_t)c * n];
+    }
+    __syncthreads();
+  }
+}
+
+// W = (T + T^T) / 2
+__global__ void __launch_bounds__(256) lmi_large_symmetrize(int n, const double* __restrict__ T, double* __restrict__ W) {
+  const int nn = n * n;
+  const size_t base = (size_t)blockIdx.y * nn;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x) {
+    const int a = q % n, b = q / n;
+    W[base + q] = (T[base + q] + T[base + b + (size_t)a * n]) * 0.5;
+  }
+}
+
+// AffineUpdate tail: W = W (1 + e) + T   (psd_constraint.cc:33-43)
+__global__ void __launch_bounds__(256) lmi_large_affine(int n, double e, const double* __restrict__ T, double* __restrict__ W) {
+  const int nn = n * n;
+  const size_t base = (size_t)blockIdx.y * nn;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x) {
+    const double w = (e == 0) ? W[base + q] : W[base + q] * (1 + e);
+    W[base + q] = w + T[base + q];
+  }
+}
+
+// Block-wide two-sided Lanczos on WS (HBM) with V = [W r, r]; all vectors in LDS.
+// y0 = M x (thread per row, coalesced), y1 = M^T x (wave per column).
+__device__ inline void BlockGemvBoth(int n, const double* __restrict__ M, const double* x0, const double* x1,
+                                     double* y0, double* y1) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  for (int i = tid; i < n; i += blockDim.x) {
+    double s = 0;
+    for (int k = 0; k < n; k++) s = fma(M[i + (size_t)k * n], x0[k], s);
+    y0[i] = s;
+  }
+  for (int i = wave; i < n; i += nw) {
+    double s = 0;
+    for (int k = lane; k < n; k += 64) s = fma(M[k + (size_t)i * n], x1[k], s);
+    s = WaveSum(s);
+    if (lane == 0) y1[i] = s;
+  }
+}
+
+// mode 0: PrepareStep tail; mode 1: GetWeightedSlackEigenvalues tail.  WS and S in HBM.
+template <int MODE>
+__global__ void __launch_bounds__(512) lmi_large_spectrum(LmiGroup g, StepArgs sa, const double* __restrict__ WS_all,
+                                                          const double* __restrict__ S_all) {
+  extern __shared__ double lds[];
+  const int n = g.n, nn = n * n;
+  const int mem = blockIdx.x, id = g.ids[mem];
+  const double* WS = WS_all + (size_t)mem * nn;
+  const double* S = S_all + (size_t)mem * nn;
+  const double* W = g.W + (size_t)mem * nn;
+  double* V0 = lds;
+  double* V1 = V0 + n;
+  double* U0 = V1 + n;
+  double* U1 = U0 + n;
+  double* P0 = U1 + n;
+  double* P1 = P0 + n;
+  double* rr = P1 + n;
+  const int num_iter = n / 2;
+  double* alpha = rr + n;
+  double* beta = alpha + num_iter + 1;
+  double* red = beta + num_iter + 1;  // 16
+  __shared__ int s_index;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int idx = 0;
+    for (int i = 1; i < n; i++)
+      if (WS[i + (size_t)i * n] > WS[idx + (size_t)idx * n]) idx = i;
+    s_index = idx;
+  }
+  __syncthreads();
+  // PrepareStep aliases minus_s and WS (psd_constraint.cc:60-69): its start vector is a column of
+  // WS; GetWeightedSlackEigenvalues starts from the column of minus_s.
+  const double* r = (MODE == 0 ? WS : S) + (size_t)s_index * n;
+  for (int i = tid; i < n; i += blockDim.x) {
+    rr[i] = r[i];
+    V1[i] = r[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += blockDim.x) {
+    double s = 0;
+    for (int k = 0; k < n; k++) s = fma(W[i + (size_t)k * n], rr[k], s);
+    V0[i] = s;
+  }
+  __syncthreads();
+  double ip = 0;
+  for (int i = tid; i < n; i += blockDim.x) ip = fma(V0[i], V1[i], ip);
+  const double nrm = sqrt(BlockSum(ip, red));
+  __syncthreads();
+  for (int i = tid; i < n; i += blockDim.x) {
+    V0[i] /= nrm;
+    V1[i] /= nrm;
+    P0[i] = V0[i];
+    P1[i] = V1[i];
+  }
+  __syncthreads();
+  int cnt = 0;
+  double beta_prev = 0;
+  for (int j = 0; j < num_iter; j++) {
+    if (j > 0) {
+      double b2 = 0;
+      for (int i = tid; i < n; i += blockDim.x) b2 = fma(U0[i], U1[i], b2);
+      b2 = BlockSum(b2, red);
+      __syncthreads();
+      if (b2 < 1e-6) break;
+      beta_prev = sqrt(b2);
+      if (tid == 0) beta[j - 1] = beta_prev;
+      for (int i = tid; i < n; i += blockDim.x) {
+        P0[i] = V0[i];
+        P1[i] = V1[i];
+        V0[i] = U0[i] / beta_prev;
+        V1[i] = U1[i] / beta_prev;
+      }
+      cnt++;
+      __syncthreads();
+    }
+    BlockGemvBoth(n, WS, V0, V1, U0, U1);
+    __syncthreads();
+    double a = 0;
+    for (int i = tid; i < n; i += blockDim.x) a = fma(V0[i], U1[i], a);
+    a = BlockSum(a, red);
+    __syncthreads();
+    if (tid == 0) alpha[j] = a;
+    for (int i = tid; i < n; i += blockDim.x) {
+      double u0 = U0[i] - a * V0[i], u1 = U1[i] - a * V1[i];
+      if (j > 0) {
+        u0 -= beta_prev * P0[i];
+        u1 -= beta_prev * P1[i];
+      }
+      U0[i] = u0;
+      U1[i] = u1;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) TridiagMinMax(cnt + 1, alpha, beta, &red[8], &red[9]);
+  // tr(WS WS) and tr(WS)
+  double t2 = 0, t1 = 0;
+  for (int q = tid; q < nn; q += blockDim.x) {
+    const int a = q % n, b = q / n;
+    t2 = fma(WS[q], WS[b + (size_t)a * n], t2);
+    if (a == b) t1 += WS[q];
+  }
+  t2 = BlockSum(t2, red);
+  __syncthreads();
+  t1 = BlockSum(t1, red);
+  __syncthreads();
+  if (tid == 0) {
+    const double mn = red[8], mx = red[9];
+    if (MODE == 0) {
+      const double l1 = fabs(sa.e_weight + mn), l2 = fabs(sa.e_weight + mx);
+      sa.info[2 * id] = t2 + 2 * t1 + n;
+      sa.info[2 * id + 1] = l1 < l2 ? l2 : l1;
+    } else {
+      sa.info[4 * id] = -mx;
+      sa.info[4 * id + 1] = -mn;
+      sa.info[4 * id + 2] = t2;
+      sa.info[4 * id + 3] = -t1;
+    }
+  }
+}
+
+inline size_t LmiLargeSpectrumLds(int n) { return sizeof(double) * (size_t)(7 * n + 2 * (n / 2 + 1) + 16); }
+
+// ---- host-side drivers --------------------------------------------------------------------
+inline GemmArgs SquareGemm(int n, const double* A, int64_t sA, const double* B, int64_t sB, double* C,
+                           int64_t sC) {
+  GemmArgs a{};
+  a.M = a.N = a.K = n;
+  a.A = A;
+  a.lda = n;
+  a.sA1 = sA;
+  a.B = B;
+  a.ldb = n;
+  a.sB1 = sB;
+  a.C = C;
+  a.ldc = n;
+  a.sC1 = sC;
+  a.inner = 1;
+  a.alpha = 1.0;
+  a.beta = 0.0;
+  a.splits = 1;
+  return a;
+}
+
+inline hipError_t LmiLargeSchur(const LmiGroup& g, const Arena& ar, const LmiLargeWs& ws, hipStream_t st) {
+  const int n = g.n, m = g.m, m1 = m + 1;
+  const int64_t nn = (int64_t)n * n;
+  hipError_t e;
+  {  // P[c,i] = A[c,i] W[c], PT = transpose;  batch (c, i)
+    GemmArgs a = SquareGemm(n, g.A, m * nn, g.W, nn, ws.P, m1 * nn);
+    a.sA2 = nn;
+    a.sB2 = 0;
+    a.sC2 = nn;
+    a.Ct = ws.PT;
+    a.ldct = n;
+    a.sT1 = m1 * nn;
+    a.sT2 = nn;
+    a.inner = m;
+    if (m > 0 && (e = LaunchGemm(a, false, false, g.count * m, st)) != hipSuccess) return e;
+  }
+  {  // P[c,m] = C[c] W[c]
+    GemmArgs a = SquareGemm(n, g.C, nn, g.W, nn, ws.P + m * nn, m1 * nn);
+    a.Ct = ws.PT + m * nn;
+    a.ldct = n;
+    a.sT1 = m1 * nn;
+    if ((e = LaunchGemm(a, false, false, g.count, st)) != hipSuccess) return e;
+  }
+  {  // Gf[c] = X^T Y, X = P[c] (n^2 x m1), Y = PT[c]
+    GemmArgs a{};
+    a.M = a.N = m1;
+    a.K = (int)nn;
+    a.A = ws.P;
+    a.lda = nn;
+    a.sA1 = m1 * nn;
+    a.B = ws.PT;
+    a.ldb = nn;
+    a.sB1 = m1 * nn;
+    a.C = ws.Gf;
+    a.ldc = m1;
+    a.sC1 = (int64_t)m1 * m1;
+    a.inner = 1;
+    a.alpha = 1.0;
+    a.beta = 0.0;
+    a.lower_only = 1;
+    a.splits = ws.splits;
+    a.sCs = (int64_t)g.count * m1 * m1;
+    if ((e = LaunchGemmSplitK(a, true, false, g.count, ws.part, st)) != hipSuccess) return e;
+  }
+  lmi_large_finalize<<<g.count, 256, 0, st>>>(g, ar, ws);
+  return hipGetLastError();
+}
+
+inline dim3 ElemGrid(int n, int count) {
+  const int blocks = (n * n + 255) / 256;
+  return dim3(blocks < 256 ? blocks : 256, count);
+}
+
+// mode 0: PrepareStep (stores WS in g.T1; affine branch updates W), mode 1: eigenvalue query
+inline hipError_t LmiLargePrepare(const LmiGroup& g, const StepArgs& sa, const LmiLargeWs& ws, int mode,
+                                  hipStream_t st) {
+  const int n = g.n;
+  const int64_t nn = (int64_t)n * n;
+  double* S = ws.tmp;                        // count x nn
+  double* WS = (mode == 0) ? g.T1 : ws.tmp + (size_t)g.count * nn;
+  double* T = ws.tmp + 2 * (size_t)g.count * nn;
+  hipError_t e;
+  lmi_large_slack<<<ElemGrid(n, g.count), 256, sizeof(double) * g.m, st>>>(g, sa, S);
+  GemmArgs a = SquareGemm(n, g.W, nn, S, nn, WS, nn);
+  if ((e = LaunchGemm(a, false, false, g.count, st)) != hipSuccess) return e;
+  if (mode == 0 && sa.affine) {
+    GemmArgs b = SquareGemm(n, WS, nn, g.W, nn, T, nn);
+    if ((e = LaunchGemm(b, false, false, g.count, st)) != hipSuccess) return e;
+    lmi_large_affine<<<ElemGrid(n, g.count), 256, 0, st>>>(n, sa.e_weight, T, g.W);
+    return hipGetLastError();
+  }
+  if (mode == 0)
+    lmi_large_spectrum<0><<<g.count, 512, LmiLargeSpectrumLds(n), st>>>(g, sa, WS, S);
+  else
+    lmi_large_spectrum<1><<<g.count, 512, LmiLargeSpectrumLds(n), st>>>(g, sa, WS, S);
+  return hipGetLastError();
+}
+
+// W <- sym( pade33( (WS + e I) alpha ) W )
+inline hipError_t LmiLargeTakeStep(const LmiGroup& g, const StepArgs& sa, const LmiLargeWs& ws, hipStream_t st) {
+  const int n = g.n, count = g.count;
+  const int64_t nn = (int64_t)n * n;
+  double* X = ws.tmp;
+  double* X2 = X + (size_t)count * nn;
+  double* T4 = X2 + (size_t)count * nn;
+  double* U = T4 + (size_t)count * nn;
+  double* aug = U + (size_t)count * nn;  // count x 2 nn
+  double* EW = aug + 2 * (size_t)count * nn;
+  hipError_t e;
+  const dim3 eg = ElemGrid(n, count);
+  lmi_large_step_arg<<<eg, 256, 0, st>>>(n, g.T1, sa.e_weight, sa.step_size, X);
+  GemmArgs a = SquareGemm(n, X, nn, X, nn, X2, nn);
+  if ((e = LaunchGemm(a, false, false, count, st)) != hipSuccess) return e;
+  lmi_large_axpd<<<eg, 256, 0, st>>>(n, X2, 1.0, 60.0, T4);
+  GemmArgs b = SquareGemm(n, X, nn, T4, nn, U, nn);
+  if ((e = LaunchGemm(b, false, false, count, st)) != hipSuccess) return e;
+  lmi_large_pade_system<<<eg, 256, 0, st>>>(n, X2, U, aug);
+  lmi_large_lu_solve<<<count, 1024, 0, st>>>(n, aug);
+  GemmArgs c = SquareGemm(n, aug + nn, 2 * nn, g.W, nn, EW, nn);
+  if ((e = LaunchGemm(c, false, false, count, st)) != hipSuccess) return e;
+  lmi_large_symmetrize<<<eg, 256, 0, st>>>(n, EW, g.W);
+  return hipGetLastError();
+}
+
+}  // namespace cxk

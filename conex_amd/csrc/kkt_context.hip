@@ -21,6 +21,7 @@
 #include "kernels_kkt.hip.h"
 #include "kernels_lmi.hip.h"
 #include "kernels_lmi_fused.hip.h"
+#include "kernels_lmi_large.hip.h"
 #include "symbolic.h"
 
 using namespace cxk;
@@ -64,6 +65,10 @@ struct Group {
   DevBuf<double> A, C, W, T1, T2;
   DevBuf<int> dids;
   bool fused = false;
+  // orders beyond the LDS-resident kernels: HBM-resident matrices + MFMA GEMM pipeline
+  bool large = false;
+  DevBuf<double> ws_main, ws_gf, ws_part;
+  int splits = 1;
 };
 
 }  // namespace
@@ -229,6 +234,18 @@ StepArgs MakeStep(cxk_context* ctx, double* info, int affine, double cw, double 
   s.e_weight = ew;
   s.step_size = ss;
   return s;
+}
+
+LmiLargeWs MakeLargeWs(Group& g) {
+  LmiLargeWs w;
+  const size_t cnt = g.ids.size(), nn = (size_t)g.n * g.n, m1 = (size_t)g.m + 1;
+  w.P = g.ws_main.p;
+  w.PT = g.ws_main.p + cnt * m1 * nn;
+  w.tmp = g.ws_main.p;
+  w.Gf = g.ws_gf.p;
+  w.part = g.ws_part.p;
+  w.splits = g.splits;
+  return w;
 }
 
 size_t LmiGenericLds(int n) { return sizeof(double) * (size_t)(4 * n * n); }
@@ -808,7 +825,9 @@ int LaunchSchur(cxk_context* ctx) {
           ctx->ev_used++;
           CXK_TRY(hipEventRecord(e0, ctx->stream));
         }
-        if (g.fused) {
+        if (g.large) {
+          CXK_TRY(LmiLargeSchur(MakeLmi(g), ar, MakeLargeWs(g), ctx->stream));
+        } else if (g.fused) {
           CXK_TRY(LaunchLmiSchurFused(MakeLmi(g), ar, ctx->stream));
         } else {
           lmi_schur_generic<<<count, 256, LmiGenericLds(g.n), ctx->stream>>>(MakeLmi(g), ar);
@@ -1064,9 +1083,8 @@ int cxk_finalize(cxk_context* ctx) {
       case CXK_LMI:
         a_sz = (size_t)g.m * g.n * g.n;
         c_sz = w_sz = (size_t)g.n * g.n;
-        CXK_DEMAND(LmiTakeLds(g.n) <= kLdsLimit && LmiPrepareLds(g.n, g.m) <= kLdsLimit,
-                   "LMI order too large for the LDS-resident kernels (tiled path not built yet)");
-        g.fused = LmiFusedSupports(g.n, g.m);
+        g.large = !(LmiTakeLds(g.n) <= kLdsLimit && LmiPrepareLds(g.n, g.m) <= kLdsLimit);
+        g.fused = !g.large && LmiFusedSupports(g.n, g.m);
         break;
       case CXK_LINEAR:
         a_sz = (size_t)g.n * g.m;
@@ -1092,6 +1110,16 @@ int cxk_finalize(cxk_context* ctx) {
     CXK_TRY(g.T1.alloc(w_sz * cnt));
     CXK_TRY(g.T2.alloc(g.type == CXK_LINEAR ? w_sz * cnt : 0));
     CXK_TRY(g.dids.upload(g.ids));
+    if (g.large) {
+      const size_t nn = (size_t)g.n * g.n, m1 = (size_t)g.m + 1;
+      // split-K of the contraction: enough workgroups to fill the chip, at most one K step each
+      const int ksteps = (int)((nn + kGemmBK - 1) / kGemmBK);
+      const int tiles = (int)(((m1 + 63) / 64) * ((m1 + 63) / 64));
+      g.splits = std::max(1, std::min(ksteps, (int)((1024 + cnt * tiles - 1) / (cnt * tiles))));
+      CXK_TRY(g.ws_main.alloc(cnt * std::max(2 * m1 * nn, 8 * nn)));
+      CXK_TRY(g.ws_gf.alloc(cnt * m1 * m1));
+      CXK_TRY(g.ws_part.alloc(g.splits > 1 ? (size_t)g.splits * cnt * m1 * m1 : 0));
+    }
   }
   CXK_TRY(ctx->G.alloc((size_t)go));
   CXK_TRY(ctx->AWc.alloc((size_t)ro));
@@ -1344,7 +1372,9 @@ int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_wei
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
     if (cnt == 0) continue;
-    if (g.type == CXK_LMI)
+    if (g.type == CXK_LMI && g.large)
+      CXK_TRY(LmiLargePrepare(MakeLmi(g), sa, MakeLargeWs(g), 0, ctx->stream));
+    else if (g.type == CXK_LMI)
       lmi_prepare_generic<0><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
     else if (g.type == CXK_LINEAR)
       linear_prepare<0><<<cnt, 256, sizeof(double) * g.m, ctx->stream>>>(MakeVec(g), sa);
@@ -1368,7 +1398,9 @@ int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_siz
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
     if (cnt == 0) continue;
-    if (g.type == CXK_LMI)
+    if (g.type == CXK_LMI && g.large)
+      CXK_TRY(LmiLargeTakeStep(MakeLmi(g), sa, MakeLargeWs(g), ctx->stream));
+    else if (g.type == CXK_LMI)
       lmi_take_step_generic<<<cnt, 256, LmiTakeLds(g.n), ctx->stream>>>(MakeLmi(g), sa);
     else if (g.type == CXK_LINEAR)
       linear_take_step<<<GridFor((size_t)cnt * g.n, 256), 256, 0, ctx->stream>>>(MakeVec(g), sa);
@@ -1385,7 +1417,9 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
     if (cnt == 0) continue;
-    if (g.type == CXK_LMI)
+    if (g.type == CXK_LMI && g.large)
+      CXK_TRY(LmiLargePrepare(MakeLmi(g), sa, MakeLargeWs(g), 1, ctx->stream));
+    else if (g.type == CXK_LMI)
       lmi_prepare_generic<1><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
     else if (g.type == CXK_LINEAR)
       linear_prepare<1><<<cnt, 256, sizeof(double) * g.m, ctx->stream>>>(MakeVec(g), sa);

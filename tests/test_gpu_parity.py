@@ -51,7 +51,7 @@ def make_pair(prob, kind, W=None):
     return o, k
 
 
-def check_newton_step(o, k, b, inv_sqrt_mu=0.7, bs=0.9, cs=0.8, check_update=True):
+def check_newton_step(o, k, b, inv_sqrt_mu=0.7, bs=0.9, cs=0.8, check_update=True, lanczos_tol=None):
     """assemble -> factor -> solve -> prepare -> take step, compared stage by stage."""
     o.assemble()
     k.assemble()
@@ -87,10 +87,20 @@ def check_newton_step(o, k, b, inv_sqrt_mu=0.7, bs=0.9, cs=0.8, check_update=Tru
     c_weight = inv_sqrt_mu * cs
     eo = o.weighted_slack_eigenvalues(yo, c_weight)
     ek = k.weighted_slack_eigenvalues(yo, c_weight)
-    assert rel(ek, eo) <= 1e-9
     io = o.prepare_step(yo, c_weight, 1.0)
     ik = k.prepare_step(yo, c_weight, 1.0)
-    assert rel(ik, io) <= 1e-9
+    if lanczos_tol is None:
+        assert rel(ek, eo) <= 1e-9
+        assert rel(ik, io) <= 1e-9
+    else:
+        # Dozens of unreorthogonalised Lanczos steps amplify summation-order differences in the
+        # extreme Ritz values (they are estimates in the reference too): compare them relative to
+        # the spectral width; traces / norms stay tight.
+        width = abs(eo[1] - eo[0])
+        assert np.max(np.abs(ek[:2] - eo[:2])) <= lanczos_tol * width
+        assert rel(ek[2:], eo[2:]) <= 1e-11
+        assert abs(ik[0] - io[0]) <= 1e-11 * abs(io[0])
+        assert abs(ik[1] - io[1]) <= lanczos_tol * max(width, abs(io[1]))
     step = min(1.0, 2.0 / (io[1] * io[1]))
     o.take_step(step)
     k.take_step(step)
@@ -107,6 +117,29 @@ def test_lmi_newton_step(K, n, m, b_, ov):
     W = syn.scaling_points(K, n, seed=7 + K)
     o, k = make_pair(prob, "lmi", W)
     check_newton_step(o, k, prob["b"])
+
+
+@pytest.mark.parametrize("K,n,m,b_,ov", [(1, 70, 6, 2, 1), (3, 96, 9, 2, 3), (1, 200, 50, 2, 1)])
+def test_lmi_large_order_newton_step(K, n, m, b_, ov):
+    """Orders beyond the LDS-resident kernels: HBM-resident matrices, every product on the fp64
+    MFMA GEMM (kernels_lmi_large.hip.h).  (1, 200, 50) is BASELINE config 2."""
+    prob = syn.lmi_problem(K=K, n=n, m=m, branching=b_, overlap=ov, seed=300 + n)
+    W = syn.scaling_points(K, n, seed=11 + n)
+    o, k = make_pair(prob, "lmi", W)
+    # 100 unreorthogonalised Lanczos steps at n = 200: the small-end Ritz value is converged to
+    # ~1e-3 of the spectral width only (in the reference as well); the large end agrees to 1e-15
+    check_newton_step(o, k, prob["b"], lanczos_tol=1e-5 if n < 200 else 2e-3)
+
+
+def test_lmi_large_order_affine_update():
+    prob = syn.lmi_problem(K=2, n=80, m=4, branching=2, overlap=2, seed=19)
+    W = syn.scaling_points(2, 80, seed=4)
+    o, k = make_pair(prob, "lmi", W)
+    y = np.random.default_rng(0).uniform(-0.05, 0.05, o.N)
+    o.prepare_step(y, 0.0, 0.0, affine=1)
+    k.prepare_step(y, 0.0, 0.0, affine=1)
+    for i in range(o.K):
+        assert rel(k.get_W(i), o.get_W(i)) <= 1e-13
 
 
 def test_lmi_identity_start_and_iterations():
