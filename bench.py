@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6  # dense fp64 matrix peak
 
 
 def pmc_traffic():
@@ -55,7 +56,7 @@ def cpu_baseline(prob, W, budget_s=12.0):
         if el >= budget_s or n >= 200:
             break
     return {"value": n / el, "unit": "KKT-solves/s", "cores": 1, "kind": "port",
-            "sample": f"{n} full KKT-solves of the same 1000x(20x20) workload, 1 thread, "
+            "sample": f"{n} full KKT-solves of the same workload ({o.K} LMI blocks), 1 thread, "
                       f"{el:.1f} s"}, y
 
 
@@ -65,6 +66,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--K", type=int, default=1000)
+    ap.add_argument("--workload", choices=["c4", "c2"], default="c4",
+                    help="c4 (default, the metric's config): 1000 LMIs n=20; c2: one LMI n=200 m=50 "
+                         "(BASELINE config 2, MFMA-bound assembly; extra measurement, single GPU)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--event-period", type=int, default=8,
                     help="hipEvent-bracket every P-th launch of the dominant kernel in the timed region")
@@ -86,8 +90,15 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl")
 
-    prob = syn.lmi_problem(K=args.K, n=20, m=20, branching=8, overlap=5)
-    W = syn.scaling_points(args.K, 20)
+    if args.workload == "c2":
+        if world > 1:
+            raise SystemExit("config 2 is one constraint: it does not shard (replicas only)")
+        args.K, n_order, m_vars = 1, 200, 50
+        prob = syn.lmi_problem(K=1, n=200, m=50, branching=2, overlap=1)
+    else:
+        n_order, m_vars = 20, 20
+        prob = syn.lmi_problem(K=args.K, n=20, m=20, branching=8, overlap=5)
+    W = syn.scaling_points(args.K, n_order)
     stream = torch.cuda.current_stream().cuda_stream
     ctx = KktContext(prob["num_vars"], device=local_rank, stream=stream)
     for c, cl in enumerate(prob["cliques"]):
@@ -141,7 +152,9 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Newton KKT-solves/sec (assemble+factor+solve), 1000x(20x20) PSD blocks, fp64",
+            "metric": ("Newton KKT-solves/sec (assemble+factor+solve), 1000x(20x20) PSD blocks, fp64"
+                       if args.workload == "c4" else
+                       "Newton KKT-solves/sec (assemble+factor+solve), one 200x200 PSD block m=50, fp64"),
             "value": args.steps / elapsed,
             "unit": "KKT-solves/s",
             "n_gpus": world,
@@ -153,9 +166,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 4: chordal SDP, 1000 dense LMIs n=20 m=20, "
-                                   "8-ary clique tree overlap 5, N=15005",
-                       "K": args.K, "n": 20, "m": 20, "N": ctx.N,
+            "config": {"workload": ("BASELINE config 4: chordal SDP, 1000 dense LMIs n=20 m=20, "
+                                    "8-ary clique tree overlap 5, N=15005") if args.workload == "c4"
+                       else "BASELINE config 2: one dense LMI n=200, m=50 (profile_sdp.cc shape)",
+                       "K": args.K, "n": n_order, "m": m_vars, "N": ctx.N,
                        "parallelism": (f"elimination-subtree sharding x{world}, one RCCL all-reduce "
                                        f"of {exch.numel() * 8} B per solve") if world > 1
                        else "single GPU",
@@ -163,7 +177,18 @@ def main():
         }
         if nsamp > 0 and kern_ms > 0:
             gbs = abytes / (kern_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "lmi_schur", "achieved": gbs,
+            if args.workload == "c2":
+                tf = aflops / (kern_ms * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "kernel": "lmi assembly (gemm_f64_mfma x3 + finalize)",
+                                   "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": tf / FP64_MFMA_PEAK_TF, "traffic": None,
+                                   "kernel_ms": kern_ms, "kernel_samples": nsamp,
+                                   "algorithmic_bytes": abytes, "algorithmic_gflop": aflops / 1e9,
+                                   "note": "algorithmic flops = the reference's 4n^3(m+1)+n^2(m^2+3m+4) "
+                                           "(SURVEY 8d); the kernel executes about half of them "
+                                           "(W A_i W is never formed)"}
+            else:
+              out["roofline"] = {"bound": "hbm", "kernel": "lmi_schur", "achieved": gbs,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                "traffic": pmc_traffic() if args.K == 1000 else None,
                                "traffic_source": "rocprofv3 PMC passes committed under profiles/",

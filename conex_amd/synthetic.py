@@ -97,12 +97,72 @@ def soc_scaling_points(K, dim, seed=SEED + 2):
     return W
 
 
+def random_hermitian(rng, d, n):
+    """d real planes of a Hermitian matrix over R / C / H: plane 0 symmetric, the others skew
+    (the reference builds them as T::Random + ConjugateTranspose, hermitian_psd_test.cc:36-40)."""
+    R = rng.uniform(-1.0, 1.0, (d, n, n))
+    H = np.empty_like(R)
+    H[0] = R[0] + R[0].T
+    for p in range(1, d):
+        H[p] = R[p] - R[p].T
+    return H
+
+
+def hermitian_problem(K=6, n=5, d=2, m=6, branching=2, overlap=2, seed=SEED):
+    """K Hermitian PSD constraints of order n over R (d=1), C (d=2) or H (d=4), clique tree as in
+    lmi_problem, C = identity, b = scatter of 1/2 Re tr(A_ci)."""
+    rng = np.random.default_rng(seed)
+    cliques, num_vars = tree_cliques(K, branching, m, overlap)
+    A = np.empty((K, m, d, n, n))
+    for c in range(K):
+        for i in range(m):
+            A[c, i] = random_hermitian(rng, d, n)
+    Cm = np.zeros((K, d, n, n))
+    Cm[:, 0] = np.eye(n)
+    b = np.zeros(num_vars)
+    for c in range(K):
+        b[cliques[c]] += 0.5 * np.trace(A[c, :, 0], axis1=1, axis2=2)
+    return dict(A=A, C=Cm, cliques=cliques, num_vars=num_vars, b=b, n=n, m=m, d=d)
+
+
+def hermitian_scaling_points(K, n, d, seed=SEED + 3, scale=0.2):
+    """Hermitian positive definite W = (I + s H)^2 as d real planes."""
+    rng = np.random.default_rng(seed)
+    W = np.zeros((K, d, n, n))
+    for c in range(K):
+        H = random_hermitian(rng, d, n) * (scale / 2)
+        H[0] += np.eye(n)
+        W[c] = hc_multiply(H, H)
+        W[c, 0] = 0.5 * (W[c, 0] + W[c, 0].T)
+        for p in range(1, d):
+            W[c, p] = 0.5 * (W[c, p] - W[c, p].T)
+    return W
+
+
+# sign table of the reference's hyper-complex product (jordan_matrix_algebra.cc:103-124, 4x4
+# corner): plane (i ^ j) receives  sign[i][j] * X_i Y_j
+HC_SIGN = np.array([[1, 1, 1, 1], [1, -1, -1, 1], [1, 1, -1, -1], [1, -1, 1, -1]])
+
+
+def hc_multiply(X, Y):
+    d = X.shape[0]
+    Z = np.zeros((d, X.shape[1], Y.shape[2]))
+    for i in range(d):
+        for j in range(d):
+            Z[i ^ j] += HC_SIGN[i, j] * (X[i] @ Y[j])
+    return Z
+
+
 def build(ctx_cls, prob, kind="lmi", **kw):
     """Instantiate `ctx_cls(num_vars, **kw)` (oracle Program or KktContext) from a problem dict."""
     if kind == "lmi":
         p = ctx_cls(prob["num_vars"], **kw)
         for c, cl in enumerate(prob["cliques"]):
             assert p.add_lmi(prob["A"][c], prob["C"][c], cl) == c
+    elif kind == "herm":
+        p = ctx_cls(prob["num_vars"], **kw)
+        for c, cl in enumerate(prob["cliques"]):
+            assert p.add_hermitian(prob["A"][c], prob["C"][c], cl) == c
     elif kind == "soc":
         p = ctx_cls(prob["num_vars"], **kw)
         for c, cl in enumerate(prob["cliques"]):

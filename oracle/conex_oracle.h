@@ -14,7 +14,8 @@ enum {
   CXO_LMI = 0,       /* DenseLMIConstraint   dense_lmi_constraint.{h,cc}, psd_constraint.{h,cc} */
   CXO_LINEAR = 1,    /* LinearConstraint     linear_constraint.{h,cc} */
   CXO_SOC = 2,       /* SOCConstraint        soc_constraint.{h,cc} */
-  CXO_STATIC = 3     /* SupernodalAssemblerStatic supernodal_assembler.h:122-129 (fixed G) */
+  CXO_STATIC = 3,    /* SupernodalAssemblerStatic supernodal_assembler.h:122-129 (fixed G) */
+  CXO_HERMITIAN = 4  /* HermitianPsdConstraint<Real|Complex|Quaternions> hermitian_psd.{h,cc} */
 };
 
 /* cone_program.h:17-38 */
@@ -55,6 +56,16 @@ int cxo_add_linear(cxo_program* p, int r, int m, const double* A, const double* 
                    const int* vars);
 /* A: (n+1) x m col-major, c: n+1 */
 int cxo_add_soc(cxo_program* p, int n, int m, const double* A, const double* c, const int* vars);
+/* Hermitian PSD cone over R (d=1), C (d=2) or H (d=4): A = m x d planes of n x n (column-major),
+ * C = d planes.  W / dual variable: d planes.  hermitian_psd.h:41-116 */
+int cxo_add_hermitian(cxo_program* p, int n, int d, int m, const double* A, const double* C,
+                      const int* vars);
+/* stand-alone hooks for the hyper-complex algebra (KATs against numpy complex / quaternion) */
+void cxo_hc_multiply(int d, int r, int k, int c, const double* X, const double* Y, double* Z);
+void cxo_hc_exponential_map(int d, int n, const double* x, double* y);
+int cxo_hc_approximate_eigenvalues(int d, int n, const double* WS, const double* W, const double* r,
+                                   int num_iter, double* eigs);
+double cxo_hc_random(unsigned long id, unsigned long call, unsigned long idx);
 /* fixed m x m Schur block (SupernodalAssemblerStatic) */
 int cxo_add_static(cxo_program* p, int m, const double* G, const int* vars);
 int cxo_num_constraints(const cxo_program* p);

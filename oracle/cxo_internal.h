@@ -132,6 +132,17 @@ int cxo_symmetric_lanczos(int n, const double* A, const double* r0, int num_iter
 /* eigenvalues of symmetric tridiagonal (diag d[n], offdiag e[n-1]) ascending */
 int cxo_tridiagonal_eigenvalues(int n, const double* d, const double* e, double* out);
 
+/* cxo_hermitian.c -- hyper-complex (d real planes) matrix algebra, jordan_matrix_algebra.cc */
+#include <stdint.h>
+double cxo_hc_random(uint64_t id, uint64_t call, uint64_t idx);
+void cxo_hc_multiply(int d, int r, int k, int c, const double* X, const double* Y, double* Z);
+void cxo_hc_conj_transpose(int d, int r, int c, const double* X, double* Z);
+double cxo_hc_trace_inner_product(int d, int n, const double* X, const double* Y);
+void cxo_hc_quadratic_representation(int d, int n, const double* x, const double* y, double* out);
+int cxo_hc_approximate_eigenvalues(int d, int n, const double* WS, const double* W, const double* r,
+                                   int num_iter, double* eigs);
+void cxo_hc_exponential_map(int d, int n, const double* x, double* y);
+
 #ifdef __cplusplus
 }
 #endif

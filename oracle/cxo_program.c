@@ -38,6 +38,7 @@ typedef struct {
   double* temp2;
   double* wa;     /* linear weighted_constraints n*m ; SOC scratch */
   double d0;      /* SOC */
+  int hd;         /* Hermitian: number of real planes d (1 real, 2 complex, 4 quaternion) */
   /* Schur workspace (newton_step.h:55-109) */
   double* G_own;  /* m*m */
   double* G;      /* == G_own or slab diag block when direct_update */
@@ -73,6 +74,7 @@ struct cxo_program {
   int solved;
   int primal_infeasible;
   int dual_infeasible;
+  unsigned long lanczos_calls; /* index of the next PrepareStep / eigenvalue query (start vectors) */
 };
 
 /* ------------------------------------------------------------------ helpers */
@@ -224,6 +226,25 @@ int cxo_add_lmi(cxo_program* p, int n, int m, const double* A, const double* C, 
   return p->K - 1;
 }
 
+/* HermitianPsdConstraint<T>(n, a, c) hermitian_psd.h:46-51; A: m x d planes of n x n, C: d planes */
+int cxo_add_hermitian(cxo_program* p, int n, int d, int m, const double* A, const double* C,
+                      const int* vars) {
+  if (!vars && m != p->num_vars) return -1;
+  if (d != 1 && d != 2 && d != 4) return -1; /* octonions: different (heuristic) reference path */
+  cxo_constraint* c = new_constraint(p, m, vars);
+  if (!c) return -1;
+  size_t sz = (size_t)n * n * d;
+  c->type = CXO_HERMITIAN;
+  c->n = n;
+  c->hd = d;
+  c->A = dupd(A, (size_t)m * sz);
+  c->C = dupd(C, sz);
+  c->W = (double*)calloc(sz, sizeof(double));
+  c->temp1 = (double*)calloc(sz, sizeof(double)); /* WS */
+  c->temp2 = (double*)calloc(sz, sizeof(double)); /* minus_s */
+  return p->K - 1;
+}
+
 int cxo_add_linear(cxo_program* p, int r, int m, const double* A, const double* cc,
                    const int* vars) {
   if (!vars && m != p->num_vars) return -1;
@@ -272,6 +293,10 @@ static void set_identity_one(cxo_constraint* c) {
   switch (c->type) {
     case CXO_LMI: /* psd_constraint.cc:92-95 */
       memset(c->W, 0, sizeof(double) * (size_t)c->n * c->n);
+      for (int i = 0; i < c->n; i++) c->W[(size_t)i * c->n + i] = 1;
+      break;
+    case CXO_HERMITIAN: /* hermitian_psd.h:54-56: T::Identity(rank) */
+      memset(c->W, 0, sizeof(double) * (size_t)c->n * c->n * c->hd);
       for (int i = 0; i < c->n; i++) c->W[(size_t)i * c->n + i] = 1;
       break;
     case CXO_LINEAR: /* linear_constraint.cc:105 */
@@ -375,6 +400,7 @@ int cxo_dual_size(const cxo_program* p, int i) {
   const cxo_constraint* c = &p->c[i];
   switch (c->type) {
     case CXO_LMI: return c->n * c->n;
+    case CXO_HERMITIAN: return c->n * c->n * c->hd;
     case CXO_LINEAR: return c->n;
     case CXO_SOC: return c->n + 1;
     default: return 0;
@@ -488,9 +514,11 @@ static void schur_static(cxo_constraint* o) { /* supernodal_assembler.h:127 G = 
   o->ip_cQc = 0;
 }
 
+static void schur_hermitian(cxo_constraint* o);
 static void set_dense_data(cxo_constraint* o) {
   switch (o->type) {
     case CXO_LMI: schur_lmi(o); break;
+    case CXO_HERMITIAN: schur_hermitian(o); break;
     case CXO_LINEAR: schur_linear(o); break;
     case CXO_SOC: schur_soc(o); break;
     case CXO_STATIC: schur_static(o); break;
@@ -856,6 +884,134 @@ static void soc_weighted_eigs(cxo_constraint* o, const double* y, double c_weigh
 }
 
 /* Vars() cone_program.h:59-67 */
+/* ------------------------------------------------------------- Hermitian PSD over R / C / H */
+/* ConstructSchurComplementSystem(HermitianPsdConstraint<T>*) hermitian_psd.cc:171-230, initialize */
+static void schur_hermitian(cxo_constraint* o) {
+  int n = o->n, m = o->m, d = o->hd;
+  size_t sz = (size_t)n * n * d;
+  double* AW = (double*)malloc(sizeof(double) * sz);
+  double* WAW = (double*)malloc(sizeof(double) * sz);
+  for (int i = 0; i < m; i++) {
+    cxo_hc_multiply(d, n, n, n, o->A + (size_t)i * sz, o->W, AW);
+    cxo_hc_multiply(d, n, n, n, o->W, AW, WAW);
+    for (int j = i; j < m; j++)
+      o->G[(size_t)i * m + j] = cxo_hc_trace_inner_product(d, n, o->A + (size_t)j * sz, WAW);
+    o->AW[i] = trace_n(n, AW); /* AW.at(0).trace() */
+    o->AQc[i] = cxo_hc_trace_inner_product(d, n, o->C, WAW);
+  }
+  o->ip_wc = 0;
+  o->ip_wc += cxo_hc_trace_inner_product(d, n, o->C, o->W);
+  cxo_hc_quadratic_representation(d, n, o->W, o->C, WAW);
+  o->ip_cQc = cxo_hc_trace_inner_product(d, n, o->C, WAW);
+  free(AW);
+  free(WAW);
+}
+
+/* ComputeNegativeSlack hermitian_psd.h:110-115 */
+static void herm_negative_slack(const cxo_constraint* o, double k, const double* y, double* s) {
+  size_t sz = (size_t)o->n * o->n * o->hd;
+  for (size_t q = 0; q < sz; q++) s[q] = o->C[q] * -k;
+  for (int i = 0; i < o->m; i++) {
+    const double* Ai = o->A + (size_t)i * sz;
+    for (size_t q = 0; q < sz; q++) s[q] = s[q] + Ai[q] * y[i];
+  }
+}
+
+static void herm_start_vector(const cxo_constraint* o, int id, unsigned long call, double* r) {
+  for (int q = 0; q < o->n * o->hd; q++) r[q] = cxo_hc_random((uint64_t)id, call, (uint64_t)q);
+}
+
+/* PrepareStep hermitian_psd.cc:34-71 */
+static void herm_prepare_step(cxo_constraint* o, int id, unsigned long call, int affine,
+                              double c_weight, double e_weight, const double* y, double* normsqrd,
+                              double* norminfd) {
+  int n = o->n, d = o->hd;
+  size_t sz = (size_t)n * n * d;
+  double* WS = o->temp1;
+  double* minus_s = o->temp2;
+  herm_negative_slack(o, c_weight, y, minus_s);
+  cxo_hc_multiply(d, n, n, n, o->W, minus_s, WS);
+  if (affine) {
+    double* WSW = (double*)malloc(sizeof(double) * sz);
+    cxo_hc_multiply(d, n, n, n, WS, o->W, WSW);
+    if (e_weight != 0)
+      for (size_t q = 0; q < sz; q++) o->W[q] = o->W[q] * (1 + e_weight);
+    for (size_t q = 0; q < sz; q++) o->W[q] = o->W[q] + WSW[q];
+    free(WSW);
+    return;
+  }
+  double* r = (double*)malloc(sizeof(double) * (size_t)n * d);
+  double* eigs = (double*)malloc(sizeof(double) * (size_t)(n + 2));
+  herm_start_vector(o, id, call, r);
+  int ne = cxo_hc_approximate_eigenvalues(d, n, WS, o->W, r, n / 2 + 1, eigs);
+  double mn = eigs[0], mx = eigs[0];
+  for (int i = 1; i < ne; i++) {
+    if (eigs[i] < mn) mn = eigs[i];
+    if (eigs[i] > mx) mx = eigs[i];
+  }
+  double l1 = fabs(e_weight + mn), l2 = fabs(e_weight + mx);
+  double norminf = l1;
+  if (norminf < l2) norminf = l2;
+  double* WSWS = (double*)malloc(sizeof(double) * sz);
+  cxo_hc_multiply(d, n, n, n, WS, WS, WSWS);
+  *norminfd = norminf;
+  *normsqrd = trace_n(n, WSWS) + 2 * trace_n(n, WS) + n;
+  free(WSWS);
+  free(eigs);
+  free(r);
+}
+
+/* TakeStep hermitian_psd.cc:10-31 */
+static void herm_take_step(cxo_constraint* o, double e_weight, double step_size) {
+  int n = o->n, d = o->hd;
+  size_t nn = (size_t)n * n, sz = nn * d;
+  double* WS = o->temp1;
+  for (int i = 0; i < n; i++) WS[(size_t)i * n + i] += e_weight;
+  if (step_size != 1.0)
+    for (size_t q = 0; q < sz; q++) WS[q] = WS[q] * step_size;
+  double* E = (double*)malloc(sizeof(double) * sz);
+  double* T = (double*)malloc(sizeof(double) * sz);
+  double* Tc = (double*)malloc(sizeof(double) * sz);
+  cxo_hc_exponential_map(d, n, WS, E);
+  cxo_hc_multiply(d, n, n, n, E, o->W, T);
+  cxo_hc_conj_transpose(d, n, n, T, Tc);
+  for (size_t q = 0; q < sz; q++) o->W[q] = (T[q] + Tc[q]) * .5;
+  free(E);
+  free(T);
+  free(Tc);
+}
+
+/* GetWeightedSlackEigenvalues hermitian_psd.cc:73-91 */
+static void herm_weighted_eigs(cxo_constraint* o, int id, unsigned long call, const double* y,
+                               double c_weight, double* lmin, double* lmax, double* frob, double* tr) {
+  int n = o->n, d = o->hd;
+  size_t sz = (size_t)n * n * d;
+  double* minus_s = (double*)malloc(sizeof(double) * sz);
+  double* WS = (double*)malloc(sizeof(double) * sz);
+  double* WSWS = (double*)malloc(sizeof(double) * sz);
+  double* r = (double*)malloc(sizeof(double) * (size_t)n * d);
+  double* eigs = (double*)malloc(sizeof(double) * (size_t)(n + 2));
+  herm_negative_slack(o, c_weight, y, minus_s);
+  cxo_hc_multiply(d, n, n, n, o->W, minus_s, WS);
+  herm_start_vector(o, id, call, r);
+  int ne = cxo_hc_approximate_eigenvalues(d, n, WS, o->W, r, n / 2 + 1, eigs);
+  double mn = eigs[0], mx = eigs[0];
+  for (int i = 1; i < ne; i++) {
+    if (eigs[i] < mn) mn = eigs[i];
+    if (eigs[i] > mx) mx = eigs[i];
+  }
+  *lmax = -mn;
+  *lmin = -mx;
+  cxo_hc_multiply(d, n, n, n, WS, WS, WSWS);
+  *frob = trace_n(n, WSWS);
+  *tr = -trace_n(n, WS);
+  free(minus_s);
+  free(WS);
+  free(WSWS);
+  free(r);
+  free(eigs);
+}
+
 static void gather_vars(const cxo_program* p, int i, const double* y, double* z) {
   for (int q = 0; q < p->cliques[i].n; q++) z[q] = y[p->cliques[i].d[q]];
 }
@@ -874,6 +1030,9 @@ void cxo_prepare_step(cxo_program* p, int affine, double c_weight, double e_weig
     gather_vars(p, i, y, z);
     switch (c->type) {
       case CXO_LMI: lmi_prepare_step(c, affine, c_weight, e_weight, z, &ni_sq, &ni_inf); break;
+      case CXO_HERMITIAN:
+        herm_prepare_step(c, i, p->lanczos_calls, affine, c_weight, e_weight, z, &ni_sq, &ni_inf);
+        break;
       case CXO_LINEAR: lin_prepare_step(c, affine, c_weight, e_weight, 1.0, z, &ni_sq, &ni_inf); break;
       case CXO_SOC: soc_prepare_step(c, c_weight, z, &ni_sq, &ni_inf); break;
       default: ni_sq = 0; ni_inf = 0; break;
@@ -881,6 +1040,7 @@ void cxo_prepare_step(cxo_program* p, int affine, double c_weight, double e_weig
     if (ni_inf > norminfd) norminfd = ni_inf;
     normsqrd += ni_sq;
   }
+  p->lanczos_calls++;
   info[0] = normsqrd;
   info[1] = norminfd;
   free(z);
@@ -891,6 +1051,7 @@ void cxo_take_step(cxo_program* p, int affine, double e_weight, double step_size
     cxo_constraint* c = &p->c[i];
     switch (c->type) {
       case CXO_LMI: lmi_take_step(c, e_weight, step_size); break;
+      case CXO_HERMITIAN: herm_take_step(c, e_weight, step_size); break;
       case CXO_LINEAR: lin_take_step(c, affine, step_size); break;
       case CXO_SOC: soc_take_step(c, step_size); break;
       default: break;
@@ -912,6 +1073,9 @@ void cxo_weighted_slack_eigenvalues(cxo_program* p, const double* y, double c_we
     double t_min = DBL_MAX, t_max = -DBL_MAX, t_frob = 0, t_tr = 0;
     switch (c->type) {
       case CXO_LMI: lmi_weighted_eigs(c, z, c_weight, &t_min, &t_max, &t_frob, &t_tr); break;
+      case CXO_HERMITIAN:
+        herm_weighted_eigs(c, i, p->lanczos_calls, z, c_weight, &t_min, &t_max, &t_frob, &t_tr);
+        break;
       case CXO_LINEAR: lin_weighted_eigs(c, z, c_weight, &t_min, &t_max, &t_frob, &t_tr); break;
       case CXO_SOC: soc_weighted_eigs(c, z, c_weight, &t_min, &t_max, &t_frob, &t_tr); break;
       default: break;
@@ -921,6 +1085,7 @@ void cxo_weighted_slack_eigenvalues(cxo_program* p, const double* y, double c_we
     frob += t_frob;
     tr += t_tr;
   }
+  p->lanczos_calls++;
   out[0] = lmin;
   out[1] = lmax;
   out[2] = frob;
@@ -997,6 +1162,7 @@ int cxo_kkt_solve(cxo_program* p, const double* b, double k, double bs, double c
 static int rank_of(const cxo_constraint* c) {
   switch (c->type) {
     case CXO_LMI: return c->n;
+    case CXO_HERMITIAN: return c->n;
     case CXO_LINEAR: return c->n;
     case CXO_SOC: return 2;
     default: return 0;

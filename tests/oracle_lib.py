@@ -63,6 +63,14 @@ def lib():
         "cxo_add_linear": (C.c_int, [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
         "cxo_add_soc": (C.c_int, [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
         "cxo_add_static": (C.c_int, [vp, C.c_int, c_double_p, c_int_p]),
+        "cxo_add_hermitian": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p,
+                                        c_int_p]),
+        "cxo_hc_multiply": (None, [C.c_int, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p,
+                                   c_double_p]),
+        "cxo_hc_exponential_map": (None, [C.c_int, C.c_int, c_double_p, c_double_p]),
+        "cxo_hc_approximate_eigenvalues": (C.c_int, [C.c_int, C.c_int, c_double_p, c_double_p,
+                                                     c_double_p, C.c_int, c_double_p]),
+        "cxo_hc_random": (C.c_double, [C.c_ulong, C.c_ulong, C.c_ulong]),
         "cxo_num_constraints": (C.c_int, [vp]),
         "cxo_initialize": (C.c_int, [vp]),
         "cxo_system_size": (C.c_int, [vp]),
@@ -153,6 +161,12 @@ def colmajor(a):
     return np.ascontiguousarray(a).ravel()
 
 
+def planes_colmajor(a):
+    """(..., n, n) stacks of real planes -> flat buffer with every plane column-major."""
+    a = np.asarray(a, dtype=np.float64)
+    return np.ascontiguousarray(np.swapaxes(a, -1, -2)).ravel()
+
+
 def flatten_lists(lists):
     ptr = np.zeros(len(lists) + 1, dtype=np.int32)
     for i, l in enumerate(lists):
@@ -194,6 +208,18 @@ class Program:
         r = self.L.cxo_add_lmi(self.h, n, m, dp(a), dp(c), vp_)
         if r >= 0:
             self.cons.append(("lmi", n, m))
+        return r
+
+    def add_hermitian(self, A, Cm, vars_=None):
+        """A: (m, d, n, n) real planes (plane 0 symmetric, the others skew), Cm: (d, n, n)."""
+        A = np.asarray(A, dtype=np.float64)
+        m, d, n = A.shape[0], A.shape[1], A.shape[2]
+        a = planes_colmajor(A)
+        c = planes_colmajor(np.asarray(Cm, dtype=np.float64))
+        v, vp_ = self._vars(vars_)
+        r = self.L.cxo_add_hermitian(self.h, n, d, m, dp(a), dp(c), vp_)
+        if r >= 0:
+            self.cons.append(("herm", n, m, d))
         return r
 
     def add_linear(self, A, c, vars_=None):
@@ -286,10 +312,16 @@ class Program:
         n = self.L.cxo_dual_size(self.h, i)
         w = np.zeros(max(n, 1))
         self.L.cxo_get_W(self.h, i, dp(w))
+        if self.cons[i][0] == "herm":   # (d, n, n) logical planes
+            _, order, _, d = self.cons[i]
+            return np.transpose(w[:n].reshape(d, order, order), (0, 2, 1)).copy()
         return w[:n]
 
     def set_W(self, i, w):
-        w = f64(np.asarray(w).ravel())
+        if self.cons[i][0] == "herm":
+            w = planes_colmajor(np.asarray(w, dtype=np.float64))
+        else:
+            w = f64(np.asarray(w).ravel())
         self.L.cxo_set_W(self.h, i, dp(w))
 
     def assemble(self):
