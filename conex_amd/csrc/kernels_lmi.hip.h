@@ -26,7 +26,25 @@ struct LmiGroup {
   double* W;        // count x (n*n)
   double* T1;       // count x (n*n)   temp_1 of WorkspaceDensePSD (WS between Prepare/TakeStep)
   const int* ids;   // member -> constraint id
+  // 0: DenseLMIConstraint semantics.  d in {1,2,4}: HermitianPsdConstraint over R / C / H stored
+  // through its real representation (order n = d * hyper-complex order): outputs carry the
+  // factor 1/d (tr over the representation = d * Re tr), TakeStep uses the reference's
+  // Taylor-squaring exponential and the eigenvalue estimates its random-start Lanczos
+  // (hermitian_psd.cc:10-91, exponential_map.cc:15-43, jordan_matrix_algebra.cc:386-452).
+  int herm_d;
 };
+
+// Stateless generator shared with the oracle (oracle/cxo_hermitian.c cxo_hc_random): the
+// reference's start vector is libc rand() and unpinned.
+__device__ __forceinline__ double HcRandom(unsigned long long id, unsigned long long call,
+                                           unsigned long long idx) {
+  unsigned long long z = 0x243F6A8885A308D3ull + id * 0x9E3779B97F4A7C15ull +
+                         call * 0xD1B54A32D192ED03ull + idx * 0x8CB92BA72F3D8DD7ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
 
 struct Arena {
   double* G;              // per-constraint m x m Schur blocks (lower triangle meaningful)
@@ -63,6 +81,7 @@ __global__ void __launch_bounds__(256) lmi_schur_generic(LmiGroup g, Arena ar) {
   double* AW = ar.AWc + ar.r_off[id];
   double* AQc = ar.AQcc + ar.r_off[id];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;  // exact (power of two)
 
   for (int q = threadIdx.x; q < nn; q += blockDim.x) sW[q] = Wg[q];
   for (int i = 0; i <= m; i++) {
@@ -87,6 +106,7 @@ __global__ void __launch_bounds__(256) lmi_schur_generic(LmiGroup g, Arena ar) {
         }
         v = WaveSum(v);
         if (lane == 0) {
+          v *= osc;
           if (task <= i)
             G[i + (size_t)task * m] = v;
           else if (task == i + 1)
@@ -100,12 +120,12 @@ __global__ void __launch_bounds__(256) lmi_schur_generic(LmiGroup g, Arena ar) {
         double v = 0;
         for (int q = lane; q < nn; q += 64) v = fma(Cm[q], sW[q], v);
         v = WaveSum(v);
-        if (lane == 0) ar.sc[2 * id] = v;
+        if (lane == 0) ar.sc[2 * id] = v * osc;
       } else if (wave == 1) {
         double v = 0;
         for (int q = lane; q < nn; q += 64) v = fma(Cm[q], sX[q], v);
         v = WaveSum(v);
-        if (lane == 0) ar.sc[2 * id + 1] = v;
+        if (lane == 0) ar.sc[2 * id + 1] = v * osc;
       }
     }
   }
@@ -164,8 +184,12 @@ __device__ inline void TridiagMinMax(int n, double* d, double* e, double* mn, do
 
 // Two-sided Lanczos on WS with V = [W r, r] run by wave 0; result (min,max eigenvalue of the
 // Jacobi matrix) is left in out[0], out[1] (LDS).  vec: 6n doubles of LDS; ab: 2*num_iter+2.
+// herm = false: AsymmetricLanczos of approximate_eigenvalues.cc (absolute break 1e-6, divisions);
+// herm = true: MatrixAlgebra<d>::ApproximateEigenvalues of jordan_matrix_algebra.cc:386-452
+// (break relative to <U,U> of the first step, normalisations by reciprocal multiply).
 __device__ inline void LanczosWave0(int n, const double* sWS, const double* sW, const double* r,
-                                    int num_iter, double* vec, double* ab, double* out) {
+                                    int num_iter, double* vec, double* ab, double* out,
+                                    bool herm = false) {
   if (threadIdx.x >= 64) return;
   const int lane = threadIdx.x;
   if (n == 1) {
@@ -190,27 +214,29 @@ __device__ inline void LanczosWave0(int n, const double* sWS, const double* sW, 
   double ip = 0;
   for (int i = lane; i < n; i += 64) ip = fma(V0[i], V1[i], ip);
   const double nrm = sqrt(WaveSum(ip));
+  const double inrm = 1.0 / nrm;
   for (int i = lane; i < n; i += 64) {
-    V0[i] /= nrm;
-    V1[i] /= nrm;
+    V0[i] = herm ? V0[i] * inrm : V0[i] / nrm;
+    V1[i] = herm ? V1[i] * inrm : V1[i] / nrm;
     P0[i] = V0[i];
     P1[i] = V1[i];
   }
   int cnt = 0;
-  double beta_prev = 0;
+  double beta_prev = 0, scaling = 0;
   for (int j = 0; j < num_iter; j++) {
     if (j > 0) {
       double b2 = 0;
       for (int i = lane; i < n; i += 64) b2 = fma(U0[i], U1[i], b2);
       b2 = WaveSum(b2);
-      if (b2 < 1e-6) break;
+      if (herm ? (b2 < 1e-5 * scaling) : (b2 < 1e-6)) break;
       beta_prev = sqrt(b2);
       if (lane == 0) beta[j - 1] = beta_prev;
+      const double ib = 1.0 / beta_prev;
       for (int i = lane; i < n; i += 64) {
         P0[i] = V0[i];
         P1[i] = V1[i];
-        V0[i] = U0[i] / beta_prev;
-        V1[i] = U1[i] / beta_prev;
+        V0[i] = herm ? U0[i] * ib : U0[i] / beta_prev;
+        V1[i] = herm ? U1[i] * ib : U1[i] / beta_prev;
       }
       cnt++;
     }
@@ -224,6 +250,11 @@ __device__ inline void LanczosWave0(int n, const double* sWS, const double* sW, 
       }
       U0[i] = s0;
       U1[i] = s1;
+    }
+    if (j == 0 && herm) {
+      double sc = 0;
+      for (int i = lane; i < n; i += 64) sc = fma(U0[i], U1[i], sc);
+      scaling = WaveSum(sc);
     }
     for (int i = lane; i < n; i += 64) a = fma(V0[i], U1[i], a);
     a = WaveSum(a);
@@ -250,6 +281,7 @@ struct StepArgs {
   double c_weight;
   double e_weight;
   double step_size;
+  unsigned long long call;  // index of this PrepareStep / eigenvalue query (Hermitian start vectors)
 };
 
 // mode 0: PrepareStep ; mode 1: GetWeightedSlackEigenvalues
@@ -308,7 +340,15 @@ __global__ void __launch_bounds__(256) lmi_prepare_generic(LmiGroup g, StepArgs 
   // PrepareStep aliases minus_s and WS (both temp_1), so its start vector is WS.col(index);
   // GetWeightedSlackEigenvalues keeps them apart and starts from minus_s.col(index).
   const double* r = (MODE == 0 ? sWS : sS) + s_index * n;
-  LanczosWave0(n, sWS, sW, r, n / 2, vec, ab, red + 4);
+  int iters = n / 2;
+  if (g.herm_d) {  // T::Random(n, 1), n/2 + 1 iterations on the hyper-complex order
+    double* rnd = vec + 5 * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) rnd[i] = HcRandom(id, sa.call, i);
+    __syncthreads();
+    r = rnd;
+    iters = (n / g.herm_d) / 2 + 1;
+  }
+  LanczosWave0(n, sWS, sW, r, iters, vec, ab, red + 4, g.herm_d != 0);
   // tr(WS*WS) and tr(WS)
   double t2 = 0, t1 = 0;
   for (int q = threadIdx.x; q < nn; q += blockDim.x) {
@@ -321,9 +361,14 @@ __global__ void __launch_bounds__(256) lmi_prepare_generic(LmiGroup g, StepArgs 
   __syncthreads();
   if (threadIdx.x == 0) {
     const double mn = red[4], mx = red[5];
+    if (g.herm_d > 1) {  // traces over the real representation are d x the reference's
+      t2 /= g.herm_d;
+      t1 /= g.herm_d;
+    }
+    const int rank = g.herm_d ? n / g.herm_d : n;
     if (MODE == 0) {
       const double l1 = fabs(sa.e_weight + mn), l2 = fabs(sa.e_weight + mx);
-      sa.info[2 * id] = t2 + 2 * t1 + n;
+      sa.info[2 * id] = t2 + 2 * t1 + rank;
       sa.info[2 * id + 1] = l1 < l2 ? l2 : l1;
     } else {
       sa.info[4 * id] = -mx;      // lambda_min
@@ -354,6 +399,30 @@ __global__ void __launch_bounds__(256) lmi_take_step_generic(LmiGroup g, StepArg
     sX[q] = x;
   }
   __syncthreads();
+  if (g.herm_d) {
+    // DoExponentialMap (exponential_map.cc:15-43): E = ((I + X/4 + X^2/32)^2)^2, then
+    // W <- sym(E W).  aug: Y, aug + nn: scratch.
+    double* sY = aug;
+    double* sT = aug + nn;
+    for (int q = threadIdx.x; q < nn; q += blockDim.x) sV[q] = sX[q] * 1.0 / 4.0;
+    __syncthreads();
+    LdsGemm(n, sX, sV, sT);  // X * (X/4)
+    __syncthreads();
+    for (int q = threadIdx.x; q < nn; q += blockDim.x)
+      sY[q] = (sV[q] + ((q % n == q / n) ? 1.0 : 0.0)) + sT[q] * 0.125;
+    __syncthreads();
+    LdsGemm(n, sY, sY, sT);
+    __syncthreads();
+    LdsGemm(n, sT, sT, sY);
+    __syncthreads();
+    LdsGemm(n, sY, sW, sV);  // E * W
+    __syncthreads();
+    for (int q = threadIdx.x; q < nn; q += blockDim.x) {
+      const int a = q % n, b = q / n;
+      Wg[q] = (sV[q] + sV[b + a * n]) * 0.5;
+    }
+    return;
+  }
   LdsGemm(n, sX, sX, sV);  // A^2
   __syncthreads();
   // tmp = A^2 + 60 I (in aug[0:nn]) ; U = A * tmp (in aug[nn:2nn])

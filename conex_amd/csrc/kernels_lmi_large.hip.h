@@ -38,18 +38,19 @@ __global__ void __launch_bounds__(256) lmi_large_finalize(LmiGroup g, Arena ar, 
   double* G = ar.G + ar.g_off[id];
   double* AW = ar.AWc + ar.r_off[id];
   double* AQc = ar.AQcc + ar.r_off[id];
+  const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;  // exact (power of two)
   for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
     const int i = e % m, j = e / m;
-    if (i >= j) G[i + (size_t)j * m] = Gf[i + (size_t)j * m1];
+    if (i >= j) G[i + (size_t)j * m] = Gf[i + (size_t)j * m1] * osc;
   }
-  for (int i = threadIdx.x; i < m; i += blockDim.x) AQc[i] = Gf[m + (size_t)i * m1];
-  if (threadIdx.x == 0) ar.sc[2 * id + 1] = Gf[m + (size_t)m * m1];
+  for (int i = threadIdx.x; i < m; i += blockDim.x) AQc[i] = Gf[m + (size_t)i * m1] * osc;
+  if (threadIdx.x == 0) ar.sc[2 * id + 1] = Gf[m + (size_t)m * m1] * osc;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int i = wave; i <= m; i += nw) {
     const double* Pi = P + (size_t)i * nn;
     double t = 0;
     for (int r = lane; r < n; r += 64) t += Pi[r + (size_t)r * n];
-    t = WaveSum(t);
+    t = WaveSum(t) * osc;
     if (lane == 0) {
       if (i < m)
         AW[i] = t;
@@ -189,6 +190,22 @@ __global__ void __launch_bounds__(1024) lmi_large_lu_solve(int n, double* __rest
   }
 }
 
+// Y = (X/4 + I) + T * 0.125 with T = X (X/4): the degree-2 Taylor head of DoExponentialMap
+// (exponential_map.cc:23-37); Xq = X * 1.0 / 4.0 is produced by lmi_large_quarter.
+__global__ void __launch_bounds__(256) lmi_large_quarter(int n, const double* __restrict__ X, double* __restrict__ Xq) {
+  const int nn = n * n;
+  const size_t base = (size_t)blockIdx.y * nn;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x)
+    Xq[base + q] = X[base + q] * 1.0 / 4.0;
+}
+__global__ void __launch_bounds__(256) lmi_large_taylor_head(int n, const double* __restrict__ Xq,
+                                                             const double* __restrict__ T, double* __restrict__ Y) {
+  const int nn = n * n;
+  const size_t base = (size_t)blockIdx.y * nn;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x)
+    Y[base + q] = (Xq[base + q] + ((q % n == q / n) ? 1.0 : 0.0)) + T[base + q] * 0.125;
+}
+
 // W = (T + T^T) / 2
 __global__ void __launch_bounds__(256) lmi_large_symmetrize(int n, const double* __restrict__ T, double* __restrict__ W) {
   const int nn = n * n;
@@ -244,7 +261,8 @@ __global__ void __launch_bounds__(512) lmi_large_spectrum(LmiGroup g, StepArgs s
   double* P0 = U1 + n;
   double* P1 = P0 + n;
   double* rr = P1 + n;
-  const int num_iter = n / 2;
+  const bool herm = g.herm_d != 0;
+  const int num_iter = herm ? (n / g.herm_d) / 2 + 1 : n / 2;
   double* alpha = rr + n;
   double* beta = alpha + num_iter + 1;
   double* red = beta + num_iter + 1;  // 16
@@ -261,8 +279,9 @@ __global__ void __launch_bounds__(512) lmi_large_spectrum(LmiGroup g, StepArgs s
   // WS; GetWeightedSlackEigenvalues starts from the column of minus_s.
   const double* r = (MODE == 0 ? WS : S) + (size_t)s_index * n;
   for (int i = tid; i < n; i += blockDim.x) {
-    rr[i] = r[i];
-    V1[i] = r[i];
+    const double ri = herm ? HcRandom(id, sa.call, i) : r[i];  // T::Random(n,1) for Hermitian
+    rr[i] = ri;
+    V1[i] = ri;
   }
   __syncthreads();
   for (int i = tid; i < n; i += blockDim.x) {
@@ -274,36 +293,44 @@ __global__ void __launch_bounds__(512) lmi_large_spectrum(LmiGroup g, StepArgs s
   double ip = 0;
   for (int i = tid; i < n; i += blockDim.x) ip = fma(V0[i], V1[i], ip);
   const double nrm = sqrt(BlockSum(ip, red));
+  const double inrm = 1.0 / nrm;
   __syncthreads();
   for (int i = tid; i < n; i += blockDim.x) {
-    V0[i] /= nrm;
-    V1[i] /= nrm;
+    V0[i] = herm ? V0[i] * inrm : V0[i] / nrm;
+    V1[i] = herm ? V1[i] * inrm : V1[i] / nrm;
     P0[i] = V0[i];
     P1[i] = V1[i];
   }
   __syncthreads();
   int cnt = 0;
-  double beta_prev = 0;
+  double beta_prev = 0, scaling = 0;
   for (int j = 0; j < num_iter; j++) {
     if (j > 0) {
       double b2 = 0;
       for (int i = tid; i < n; i += blockDim.x) b2 = fma(U0[i], U1[i], b2);
       b2 = BlockSum(b2, red);
       __syncthreads();
-      if (b2 < 1e-6) break;
+      if (herm ? (b2 < 1e-5 * scaling) : (b2 < 1e-6)) break;
       beta_prev = sqrt(b2);
       if (tid == 0) beta[j - 1] = beta_prev;
+      const double ib = 1.0 / beta_prev;
       for (int i = tid; i < n; i += blockDim.x) {
         P0[i] = V0[i];
         P1[i] = V1[i];
-        V0[i] = U0[i] / beta_prev;
-        V1[i] = U1[i] / beta_prev;
+        V0[i] = herm ? U0[i] * ib : U0[i] / beta_prev;
+        V1[i] = herm ? U1[i] * ib : U1[i] / beta_prev;
       }
       cnt++;
       __syncthreads();
     }
     BlockGemvBoth(n, WS, V0, V1, U0, U1);
     __syncthreads();
+    if (j == 0 && herm) {
+      double sc = 0;
+      for (int i = tid; i < n; i += blockDim.x) sc = fma(U0[i], U1[i], sc);
+      scaling = BlockSum(sc, red);
+      __syncthreads();
+    }
     double a = 0;
     for (int i = tid; i < n; i += blockDim.x) a = fma(V0[i], U1[i], a);
     a = BlockSum(a, red);
@@ -334,9 +361,14 @@ __global__ void __launch_bounds__(512) lmi_large_spectrum(LmiGroup g, StepArgs s
   __syncthreads();
   if (tid == 0) {
     const double mn = red[8], mx = red[9];
+    if (g.herm_d > 1) {
+      t2 /= g.herm_d;
+      t1 /= g.herm_d;
+    }
+    const int rank = herm ? n / g.herm_d : n;
     if (MODE == 0) {
       const double l1 = fabs(sa.e_weight + mn), l2 = fabs(sa.e_weight + mx);
-      sa.info[2 * id] = t2 + 2 * t1 + n;
+      sa.info[2 * id] = t2 + 2 * t1 + rank;
       sa.info[2 * id + 1] = l1 < l2 ? l2 : l1;
     } else {
       sa.info[4 * id] = -mx;
@@ -347,7 +379,7 @@ __global__ void __launch_bounds__(512) lmi_large_spectrum(LmiGroup g, StepArgs s
   }
 }
 
-inline size_t LmiLargeSpectrumLds(int n) { return sizeof(double) * (size_t)(7 * n + 2 * (n / 2 + 1) + 16); }
+inline size_t LmiLargeSpectrumLds(int n) { return sizeof(double) * (size_t)(7 * n + 2 * (n / 2 + 2) + 16); }
 
 // ---- host-side drivers --------------------------------------------------------------------
 inline GemmArgs SquareGemm(int n, const double* A, int64_t sA, const double* B, int64_t sB, double* C,
@@ -461,6 +493,24 @@ inline hipError_t LmiLargeTakeStep(const LmiGroup& g, const StepArgs& sa, const 
   hipError_t e;
   const dim3 eg = ElemGrid(n, count);
   lmi_large_step_arg<<<eg, 256, 0, st>>>(n, g.T1, sa.e_weight, sa.step_size, X);
+  if (g.herm_d) {
+    // E = ((I + X/4 + X^2/32)^2)^2 (exponential_map.cc:15-43), W <- sym(E W)
+    double* Xq = X2;
+    double* T = T4;
+    double* Y = U;
+    lmi_large_quarter<<<eg, 256, 0, st>>>(n, X, Xq);
+    GemmArgs t0 = SquareGemm(n, X, nn, Xq, nn, T, nn);
+    if ((e = LaunchGemm(t0, false, false, count, st)) != hipSuccess) return e;
+    lmi_large_taylor_head<<<eg, 256, 0, st>>>(n, Xq, T, Y);
+    GemmArgs t1 = SquareGemm(n, Y, nn, Y, nn, T, nn);
+    if ((e = LaunchGemm(t1, false, false, count, st)) != hipSuccess) return e;
+    GemmArgs t2 = SquareGemm(n, T, nn, T, nn, Y, nn);
+    if ((e = LaunchGemm(t2, false, false, count, st)) != hipSuccess) return e;
+    GemmArgs t3 = SquareGemm(n, Y, nn, g.W, nn, EW, nn);
+    if ((e = LaunchGemm(t3, false, false, count, st)) != hipSuccess) return e;
+    lmi_large_symmetrize<<<eg, 256, 0, st>>>(n, EW, g.W);
+    return hipGetLastError();
+  }
   GemmArgs a = SquareGemm(n, X, nn, X, nn, X2, nn);
   if ((e = LaunchGemm(a, false, false, count, st)) != hipSuccess) return e;
   lmi_large_axpd<<<eg, 256, 0, st>>>(n, X2, 1.0, 60.0, T4);

@@ -30,6 +30,7 @@ namespace {
 
 struct ConstraintRec {
   int type = 0, n = 0, m = 0;
+  int herm_d = 0;  // Hermitian PSD over R/C/H: number of real planes d; n is then d * order
   std::vector<double> A, C;
   int group = -1, member = -1;
 };
@@ -64,6 +65,7 @@ struct Group {
   std::vector<int> ids;
   DevBuf<double> A, C, W, T1, T2;
   DevBuf<int> dids;
+  int herm_d = 0;
   bool fused = false;
   // orders beyond the LDS-resident kernels: HBM-resident matrices + MFMA GEMM pipeline
   bool large = false;
@@ -113,6 +115,8 @@ struct cxk_context {
   DevBuf<int> xv_idx, pt_ptr, pf_ptr, pf_src;
   int64_t as_T = 0;
   FactorPlan plan{};
+  // index of the next PrepareStep / eigenvalue query (keys the Hermitian start vectors)
+  unsigned long long lanczos_calls = 0;
   // timing of the dominant (dense-LMI Schur) kernel
   bool timing = false;
   int timing_period = 1, timing_tick = 0;  // hipEvents bracket every timing_period-th launch
@@ -190,6 +194,7 @@ LmiGroup MakeLmi(Group& g) {
   d.W = g.W.p;
   d.T1 = g.T1.p;
   d.ids = g.dids.p;
+  d.herm_d = g.herm_d;
   return d;
 }
 VecGroup MakeVec(Group& g) {
@@ -233,6 +238,7 @@ StepArgs MakeStep(cxk_context* ctx, double* info, int affine, double cw, double 
   s.c_weight = cw;
   s.e_weight = ew;
   s.step_size = ss;
+  s.call = ctx->lanczos_calls;
   return s;
 }
 
@@ -990,6 +996,50 @@ int cxk_add_lmi(cxk_context* ctx, int n, int m, const double* A, const double* C
   return AddConstraint(ctx, std::move(r), vars);
 }
 
+namespace {
+// jordan_matrix_algebra.cc:103-124 (4 x 4 corner): plane i ^ j of X Y receives sign[i][j] X_i Y_j.
+// Real representation L(X): block (k, j) = sign[k ^ j][j] X_{k ^ j}; L(XY) = L(X) L(Y),
+// L(X^*) = L(X)^T, tr L(X) = d Re tr X.
+const int kHcSign[4][4] = {{1, 1, 1, 1}, {1, -1, -1, 1}, {1, 1, -1, -1}, {1, -1, 1, -1}};
+void EmbedPlanes(int d, int n, const double* planes, double* out /* (d n)^2 col-major */) {
+  const size_t nn = (size_t)n * n, N = (size_t)d * n;
+  for (int k = 0; k < d; k++)
+    for (int j = 0; j < d; j++) {
+      const double* X = planes + (size_t)(k ^ j) * nn;
+      const double sg = kHcSign[k ^ j][j];
+      for (int c = 0; c < n; c++)
+        for (int r = 0; r < n; r++) out[((size_t)j * n + c) * N + (size_t)k * n + r] = sg * X[(size_t)c * n + r];
+    }
+}
+void ExtractPlanes(int d, int n, const double* emb, double* planes) {
+  const size_t nn = (size_t)n * n, N = (size_t)d * n;
+  for (int k = 0; k < d; k++)  // block (k, 0) = sign[k][0] X_k = X_k
+    for (int c = 0; c < n; c++)
+      for (int r = 0; r < n; r++) planes[(size_t)k * nn + (size_t)c * n + r] = emb[(size_t)c * N + (size_t)k * n + r];
+}
+}  // namespace
+
+int cxk_add_hermitian(cxk_context* ctx, int n, int d, int m, const double* A, const double* C,
+                      const int* vars) {
+  if (!ctx || n < 1 || m < 0 || !A || !C) return -1;
+  if (d != 1 && d != 2 && d != 4) {
+    fprintf(stderr, "cxk_add_hermitian: hyper-complex dimension %d not supported (octonions take a "
+                    "separate heuristic path in the reference, hermitian_psd.cc:108-168)\n", d);
+    return -1;
+  }
+  ConstraintRec r;
+  r.type = CXK_LMI;
+  r.herm_d = d;
+  r.n = d * n;
+  r.m = m;
+  const size_t nn = (size_t)n * n, NN = (size_t)r.n * r.n;
+  r.A.resize((size_t)m * NN);
+  r.C.resize(NN);
+  for (int i = 0; i < m; i++) EmbedPlanes(d, n, A + (size_t)i * d * nn, r.A.data() + (size_t)i * NN);
+  EmbedPlanes(d, n, C, r.C.data());
+  return AddConstraint(ctx, std::move(r), vars);
+}
+
 int cxk_add_linear(cxk_context* ctx, int rows, int m, const double* A, const double* c,
                    const int* vars) {
   if (!ctx || rows < 1 || m < 0 || !A || !c) return -1;
@@ -1058,12 +1108,12 @@ int cxk_finalize(cxk_context* ctx) {
 
   CXK_TRY(hipSetDevice(ctx->device));
   // groups of identically shaped constraints (owned ones only carry data)
-  std::map<std::tuple<int, int, int>, int> gmap;
+  std::map<std::tuple<int, int, int, int>, int> gmap;
   ctx->groups.clear();
   for (int i = 0; i < K; i++) {
     ConstraintRec& c = ctx->cons[i];
     if (!ctx->owned[i]) continue;
-    auto key = std::make_tuple(c.type, c.n, c.m);
+    auto key = std::make_tuple(c.type, c.n, c.m, c.herm_d);
     auto it = gmap.find(key);
     if (it == gmap.end()) {
       it = gmap.emplace(key, (int)ctx->groups.size()).first;
@@ -1071,6 +1121,7 @@ int cxk_finalize(cxk_context* ctx) {
       ctx->groups.back().type = c.type;
       ctx->groups.back().n = c.n;
       ctx->groups.back().m = c.m;
+      ctx->groups.back().herm_d = c.herm_d;
     }
     c.group = it->second;
     c.member = (int)ctx->groups[it->second].ids.size();
@@ -1084,7 +1135,7 @@ int cxk_finalize(cxk_context* ctx) {
         a_sz = (size_t)g.m * g.n * g.n;
         c_sz = w_sz = (size_t)g.n * g.n;
         g.large = !(LmiTakeLds(g.n) <= kLdsLimit && LmiPrepareLds(g.n, g.m) <= kLdsLimit);
-        g.fused = !g.large && LmiFusedSupports(g.n, g.m);
+        g.fused = !g.large && !g.herm_d && LmiFusedSupports(g.n, g.m);
         break;
       case CXK_LINEAR:
         a_sz = (size_t)g.n * g.m;
@@ -1209,7 +1260,7 @@ int cxk_dual_size(const cxk_context* ctx, int i) {
   if (!ctx || i < 0 || i >= (int)ctx->cons.size()) return 0;
   const ConstraintRec& c = ctx->cons[i];
   switch (c.type) {
-    case CXK_LMI: return c.n * c.n;
+    case CXK_LMI: return c.herm_d ? (c.n / c.herm_d) * (c.n / c.herm_d) * c.herm_d : c.n * c.n;
     case CXK_LINEAR: return c.n;
     case CXK_SOC: return c.n + 1;
     default: return 0;
@@ -1238,6 +1289,14 @@ int cxk_get_W(cxk_context* ctx, int i, double* out) {
   const size_t sz = (size_t)cxk_dual_size(ctx, i);
   if (sz == 0) return CXK_SUCCESS;
   CXK_TRY(hipStreamSynchronize(ctx->stream));
+  if (c.herm_d) {  // device holds the real representation; the interface speaks planes
+    const size_t NN = (size_t)c.n * c.n;
+    std::vector<double> emb(NN);
+    CXK_TRY(hipMemcpy(emb.data(), ctx->groups[c.group].W.p + NN * c.member, NN * sizeof(double),
+                      hipMemcpyDeviceToHost));
+    ExtractPlanes(c.herm_d, c.n / c.herm_d, emb.data(), out);
+    return CXK_SUCCESS;
+  }
   CXK_TRY(hipMemcpy(out, ctx->groups[c.group].W.p + sz * c.member, sz * sizeof(double),
                     hipMemcpyDeviceToHost));
   return CXK_SUCCESS;
@@ -1250,6 +1309,14 @@ int cxk_set_W(cxk_context* ctx, int i, const double* in) {
   const size_t sz = (size_t)cxk_dual_size(ctx, i);
   if (sz == 0) return CXK_SUCCESS;
   CXK_TRY(hipStreamSynchronize(ctx->stream));
+  if (c.herm_d) {
+    const size_t NN = (size_t)c.n * c.n;
+    std::vector<double> emb(NN);
+    EmbedPlanes(c.herm_d, c.n / c.herm_d, in, emb.data());
+    CXK_TRY(hipMemcpy(ctx->groups[c.group].W.p + NN * c.member, emb.data(), NN * sizeof(double),
+                      hipMemcpyHostToDevice));
+    return CXK_SUCCESS;
+  }
   CXK_TRY(hipMemcpy(ctx->groups[c.group].W.p + sz * c.member, in, sz * sizeof(double),
                     hipMemcpyHostToDevice));
   return CXK_SUCCESS;
@@ -1369,6 +1436,7 @@ int cxk_set_y(cxk_context* ctx, const double* yh) {
 int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_weight, double* info) {
   if (CheckReady(ctx)) return CXK_FAILURE;
   StepArgs sa = MakeStep(ctx, ctx->info2.p, affine, c_weight, e_weight, 1.0);
+  ctx->lanczos_calls++;
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
     if (cnt == 0) continue;
@@ -1414,6 +1482,7 @@ int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_siz
 int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* out) {
   if (CheckReady(ctx)) return CXK_FAILURE;
   StepArgs sa = MakeStep(ctx, ctx->info4.p, 0, c_weight, 0.0, 1.0);
+  ctx->lanczos_calls++;
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
     if (cnt == 0) continue;

@@ -35,6 +35,8 @@ _SIGNATURES = {
     "cxk_add_lmi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
     "cxk_add_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
     "cxk_add_soc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
+    "cxk_add_hermitian": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p,
+                                    c_int_p]),
     "cxk_add_static": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_int_p]),
     "cxk_num_constraints": (C.c_int, [C.c_void_p]),
     "cxk_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
@@ -176,6 +178,18 @@ class KktContext:
             self.cons.append(("linear", rows, m))
         return r
 
+    def add_hermitian(self, A, Cm, vars_=None):
+        """Hermitian PSD over R/C/H: A (m, d, n, n) real planes, Cm (d, n, n); d in {1, 2, 4}."""
+        A = np.asarray(A, dtype=np.float64)
+        m, d, n = A.shape[0], A.shape[1], A.shape[2]
+        a = np.ascontiguousarray(np.swapaxes(A, -1, -2)).ravel()
+        c = np.ascontiguousarray(np.swapaxes(np.asarray(Cm, dtype=np.float64), -1, -2)).ravel()
+        keep, vp = self._vars(vars_)
+        r = self.L.cxk_add_hermitian(self.h, n, d, m, _dp(a), _dp(c), vp)
+        if r >= 0:
+            self.cons.append(("herm", n, m, d))
+        return r
+
     def add_soc(self, A, c, vars_=None):
         A = np.asarray(A, dtype=np.float64)
         n1, m = A.shape
@@ -262,10 +276,16 @@ class KktContext:
         n = self.L.cxk_dual_size(self.h, i)
         w = np.zeros(max(n, 1))
         self._check(self.L.cxk_get_W(self.h, i, _dp(w)), "cxk_get_W")
+        if self.cons[i][0] == "herm":   # (d, n, n) logical planes
+            _, order, _, d = self.cons[i]
+            return np.transpose(w[:n].reshape(d, order, order), (0, 2, 1)).copy()
         return w[:n]
 
     def set_W(self, i, w):
-        w = np.ascontiguousarray(np.asarray(w, dtype=np.float64).ravel())
+        if self.cons[i][0] == "herm":
+            w = np.ascontiguousarray(np.swapaxes(np.asarray(w, dtype=np.float64), -1, -2)).ravel()
+        else:
+            w = np.ascontiguousarray(np.asarray(w, dtype=np.float64).ravel())
         self._check(self.L.cxk_set_W(self.h, i, _dp(w)), "cxk_set_W")
 
     def assemble(self):

@@ -50,6 +50,15 @@ const char* cxk_last_error(const cxk_context* ctx);
  *      Return the constraint id (>= 0) or -1 when rejected. vars == NULL means 0..num_vars-1. */
 int cxk_add_lmi(cxk_context* ctx, int n, int m, const double* A /* m x (n x n) */,
                 const double* C /* n x n */, const int* vars);
+/* HermitianPsdConstraint<Real|Complex|Quaternions>(n, a, c) (hermitian_psd.h:41-52; what
+ * CONEX_NewLinearMatrixInequality creates, interfaces/conex.cc:286-318).  d = 1, 2 or 4 real
+ * planes; A = m x d planes of n x n (column-major, plane 0 symmetric, the others skew),
+ * C = d planes.  W / dual variables are exchanged as d planes (cxk_dual_size = d n^2).  On the
+ * device the cone is held through its real representation of order d n and runs on the LMI
+ * kernels with the reference's Hermitian step rules (Taylor-squaring exponential, random-start
+ * Lanczos, hermitian_psd.cc:10-91).  d = 8 (octonions) is rejected. */
+int cxk_add_hermitian(cxk_context* ctx, int n, int d, int m, const double* A, const double* C,
+                      const int* vars);
 int cxk_add_linear(cxk_context* ctx, int rows, int m, const double* A /* rows x m */,
                    const double* c /* rows */, const int* vars);
 int cxk_add_soc(cxk_context* ctx, int n, int m, const double* A /* (n+1) x m */,

@@ -171,6 +171,45 @@ def test_lmi_affine_update():
         assert rel(k.get_W(i), o.get_W(i)) <= 1e-13
 
 
+# --------------------------------------------------------------------- Hermitian PSD over R/C/H
+@pytest.mark.parametrize("d", [1, 2, 4])
+@pytest.mark.parametrize("K,n,m,b_,ov", [(1, 3, 2, 2, 1), (7, 6, 5, 2, 2), (3, 12, 8, 2, 3)])
+def test_hermitian_newton_step(d, K, n, m, b_, ov):
+    """B2 / C7: HermitianPsdConstraint<Real|Complex|Quaternions> (hermitian_psd.cc) against the
+    plane-by-plane oracle.  The device runs the real representation of order d n on the LMI
+    kernels with the Hermitian step rules; W comes back as d planes."""
+    prob = syn.hermitian_problem(K=K, n=n, d=d, m=m, branching=b_, overlap=ov, seed=500 + 7 * n + d)
+    W = syn.hermitian_scaling_points(K, n, d, seed=31 + n)
+    o, k = make_pair(prob, "herm", W)
+    check_newton_step(o, k, prob["b"])
+
+
+def test_hermitian_large_order_and_iterations():
+    """Quaternion order 20 -> real representation of order 80 (HBM-resident GEMM path), three
+    Newton iterations from W = I in lock-step with the oracle."""
+    prob = syn.hermitian_problem(K=2, n=20, d=4, m=6, branching=2, overlap=2, seed=77)
+    o, k = make_pair(prob, "herm")
+    for it in range(3):
+        check_newton_step(o, k, prob["b"], inv_sqrt_mu=0.4 + 0.2 * it, lanczos_tol=1e-6)
+
+
+def test_hermitian_affine_update_and_identity():
+    prob = syn.hermitian_problem(K=3, n=5, d=2, m=4, branching=2, overlap=2, seed=12)
+    o, k = make_pair(prob, "herm")
+    W0 = k.get_W(0)
+    assert W0.shape == (2, 5, 5) and np.array_equal(W0[0], np.eye(5)) and not W0[1].any()
+    W = syn.hermitian_scaling_points(3, 5, 2, seed=9)
+    for i in range(3):
+        o.set_W(i, W[i])
+        k.set_W(i, W[i])
+        assert np.array_equal(k.get_W(i), W[i])
+    y = np.random.default_rng(0).uniform(-0.1, 0.1, o.N)
+    o.prepare_step(y, 0.0, 0.3, affine=1)
+    k.prepare_step(y, 0.0, 0.3, affine=1)
+    for i in range(o.K):
+        assert rel(k.get_W(i), o.get_W(i)) <= 1e-13
+
+
 # --------------------------------------------------------------------- LP (C1)
 def test_c1_lp_newton_steps():
     prob = syn.lp_problem(rows=20, num_vars=10)
