@@ -48,6 +48,9 @@ struct Cone {
   ConeKind kind = kLmi;
   int order = 0;        // LMI n ; linear rows ; SOC n (vectors in R^{n+1})
   int hyper = 1;        // LMI only: 1, 2, 4, 8
+  // true: HermitianPsdConstraint<T> (CONEX_NewLinearMatrixInequality, conex.cc:286-318);
+  // false: DenseLMIConstraint (CONEX_Add{Dense,Sparse}LMIConstraint, conex.cc:137-188)
+  bool hermitian = false;
   std::vector<int> vars;                   // clique (variable ids) fixed at creation time
   // LMI: mats[v] = hyper planes of n*n (col-major); affine likewise. Linear/SOC: dense A (rows x cols)
   std::vector<std::vector<double>> mats;
@@ -162,8 +165,16 @@ int BuildContext(Program* p) {
     const int m = static_cast<int>(c.vars.size());
     switch (c.kind) {
       case kLmi: {
-        CONEX_DEMAND(c.hyper == 1,
-                     "complex / quaternion / octonion LMIs are not on the device yet (see DESIGN.md)");
+        if (c.hermitian) {
+          CONEX_DEMAND(c.hyper != 8, "octonion LMIs are not on the device (see DESIGN.md)");
+          const size_t sz = (size_t)c.order * c.order * c.hyper;
+          std::vector<double> A((size_t)m * sz, 0.0), C(sz, 0.0);
+          for (int v = 0; v < m && v < (int)c.mats.size(); v++)
+            if (!c.mats[v].empty()) std::copy(c.mats[v].begin(), c.mats[v].begin() + sz, A.begin() + v * sz);
+          if (!c.affine.empty()) std::copy(c.affine.begin(), c.affine.begin() + sz, C.begin());
+          id = cxk_add_hermitian(p->ctx, c.order, c.hyper, m, A.data(), C.data(), c.vars.data());
+          break;
+        }
         const size_t nn = (size_t)c.order * c.order;
         std::vector<double> A((size_t)m * nn, 0.0), C(nn, 0.0);
         for (int v = 0; v < m && v < (int)c.mats.size(); v++)
@@ -657,6 +668,7 @@ CONEX_STATUS CONEX_NewLinearMatrixInequality(void* x, int order, int hyper_compl
   k.kind = kLmi;
   k.order = order;
   k.hyper = hyper_complex_dim;
+  k.hermitian = true;
   k.vars = AllVars(*p);
   *constraint_id = AddCone(p, std::move(k));
   return CONEX_SUCCESS;
@@ -864,7 +876,14 @@ void CONEX_GetDualVariable(void* x, int i, double* out, int xr, int xc) {
   if (!p || !p->ctx || !out) return;
   const int n = CONEX_GetDualVariableSize(x, i);
   if (n != xr * xc || n == 0) return;
-  if (cxk_get_W(p->ctx, i, out)) return;
+  if (p->cones[i].kind == kLmi && p->cones[i].hermitian) {
+    // the reference exposes the real plane of W only (hermitian_psd.cc:24-29)
+    std::vector<double> planes((size_t)n * p->cones[i].hyper);
+    if (cxk_get_W(p->ctx, i, planes.data())) return;
+    std::copy(planes.begin(), planes.begin() + n, out);
+  } else if (cxk_get_W(p->ctx, i, out)) {
+    return;
+  }
   // Program::GetDualVariable cone_program.h:120-134
   if (!p->primal_infeasible && p->num_iter > 0) {
     const double s = p->sqrt_inv_mu[p->num_iter - 1] * p->b_scaling;

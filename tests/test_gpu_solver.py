@@ -47,13 +47,103 @@ def test_config0_lp_through_conex_h():
     Cm = np.zeros((n, n))
     Cm[0, 0] = .3
     o = ol.Program(n)
-    o.add_lmi(A, Cm)
+    # CONEX_NewLinearMatrixInequality(.., hyper = 1) is a HermitianPsdConstraint<Real>
+    # (interfaces/conex.cc:299-302), not a DenseLMIConstraint
+    o.add_hermitian(A[:, None], Cm[None])
     oko, yo = o.solve(np.ones(n))
     assert ok == oko
     assert np.allclose(y, yo, rtol=1e-7, atol=1e-9)
     st = ca.IterationStats()
     L.CONEX_GetIterationStats(p, C.byref(st), -1)
     assert st.iteration_number == o.num_iterations() - 1
+    L.CONEX_DeleteConeProgram(p)
+
+
+def _new_hermitian(L, p, order, d, A, Cm):
+    """Build a Hermitian LMI entry by entry (CONEX_NewLinearMatrixInequality + Update*), the way
+    interfaces/test/test_app.cc and the MATLAB/Python front ends do."""
+    cid = C.c_int()
+    assert L.CONEX_NewLinearMatrixInequality(p, order, d, C.byref(cid)) == 0
+    for v in range(A.shape[0]):
+        for dim in range(d):
+            for r in range(order):
+                for c in range(r if dim == 0 else r + 1, order):
+                    assert L.CONEX_UpdateLinearOperator(p, cid.value, float(A[v, dim, r, c]), v, r, c,
+                                                        dim) == 0
+    for dim in range(d):
+        for r in range(order):
+            for c in range(r if dim == 0 else r + 1, order):
+                if Cm[dim, r, c] != 0:
+                    assert L.CONEX_UpdateAffineTerm(p, cid.value, float(Cm[dim, r, c]), r, c, dim) == 0
+    return cid.value
+
+
+def test_real_hermitian_equals_dense_lmi_through_conex_h():
+    """hermitian_psd_test.cc:25-66, 109-116: the same LMI as HermitianPsdConstraint<Real> and as
+    DenseLMIConstraint gives the same y and X (the two classes use different exponential-map and
+    Lanczos rules, so only the converged point agrees)."""
+    from conex_amd import synthetic as syn
+    L = ca.api()
+    for inst in range(2):
+        hp = syn.hermitian_problem(K=1, n=8, d=1, m=4, seed=140 + inst)
+        cfg = ca.default_config()
+        cfg.inv_sqrt_mu_max = float(np.sqrt(1.0 / 1e-4))
+        cfg.final_centering_tolerance = 1e-8
+        cfg.prepare_dual_variables = 1
+        p1 = L.CONEX_CreateConeProgram()
+        assert L.CONEX_SetNumberOfVariables(p1, 4) == 0
+        _new_hermitian(L, p1, 8, 1, hp["A"][0], hp["C"][0])
+        ok1, y1 = _maximize(L, p1, hp["b"], cfg)
+        p2 = L.CONEX_CreateConeProgram()
+        a = ca.colmajor(hp["A"][0][:, 0])
+        c = ca.colmajor(hp["C"][0][0])
+        assert L.CONEX_AddDenseLMIConstraint(p2, ca.dp(a), 8, 8, 4, ca.dp(c), 8, 8) == 0
+        ok2, y2 = _maximize(L, p2, hp["b"], cfg)
+        assert ok1 == 1 and ok2 == 1
+        assert np.linalg.norm(y1 - y2) <= 1e-8
+        X1, X2 = np.zeros(64), np.zeros(64)
+        L.CONEX_GetDualVariable(p1, 0, ca.dp(X1), 8, 8)
+        L.CONEX_GetDualVariable(p2, 0, ca.dp(X2), 8, 8)
+        assert np.linalg.norm(X1 - X2) <= 1e-7
+        L.CONEX_DeleteConeProgram(p1)
+        L.CONEX_DeleteConeProgram(p2)
+
+
+@pytest.mark.parametrize("d,order,m", [(2, 3, 2), (2, 13, 5), (4, 3, 2), (4, 9, 5)])
+def test_complex_and_quaternion_lmi_solve_matches_oracle(d, order, m):
+    """hermitian_psd_test.cc:69-107 (TestCases<Complex|Quaternions>::SolveRandomInstances) through
+    conex.h, against the oracle's restatement of the same solve."""
+    from conex_amd import synthetic as syn
+    L = ca.api()
+    prob = syn.hermitian_problem(K=1, n=order, d=d, m=m, seed=170 + order + d)
+    cfg = ca.default_config()
+    cfg.inv_sqrt_mu_max = 1000
+    cfg.final_centering_steps = 4
+    cfg.max_iterations = 100
+    p = L.CONEX_CreateConeProgram()
+    assert L.CONEX_SetNumberOfVariables(p, m) == 0
+    _new_hermitian(L, p, order, d, prob["A"][0], prob["C"][0])
+    ok, y = _maximize(L, p, prob["b"], cfg)
+    o = ol.Program(m)
+    o.add_hermitian(prob["A"][0], prob["C"][0])
+    oko, yo = o.solve(prob["b"], _sync_cfg(cfg))
+    assert ok == 1 and oko == 1
+    assert np.allclose(y, yo, rtol=1e-7, atol=1e-9)
+    st = ca.IterationStats()
+    L.CONEX_GetIterationStats(p, C.byref(st), -1)
+    assert st.iteration_number == o.num_iterations() - 1
+    L.CONEX_DeleteConeProgram(p)
+
+
+def test_octonion_lmi_is_rejected_loudly():
+    L = ca.api()
+    p = L.CONEX_CreateConeProgram()
+    assert L.CONEX_SetNumberOfVariables(p, 1) == 0
+    cid = C.c_int()
+    assert L.CONEX_NewLinearMatrixInequality(p, 3, 8, C.byref(cid)) == 0   # accepted by the builder
+    assert L.CONEX_UpdateLinearOperator(p, cid.value, 1.0, 0, 0, 0, 0) == 0
+    ok, _ = _maximize(L, p, np.ones(1))
+    assert ok == 0                                                          # ... refused at solve time
     L.CONEX_DeleteConeProgram(p)
 
 
