@@ -171,19 +171,25 @@ __global__ void __launch_bounds__(256) gemm_f64_mfma(GemmArgs g) {
   }
 }
 
-// C = alpha * sum_s partial[s] + beta * C over the split partials, fixed order.
+// C = alpha * sum_s partial[s] + beta * C over the split partials.  One wavefront per output
+// element: lane l adds partials l, l+64, ... in order, then a fixed butterfly -- the summation
+// order depends only on `splits`, so results are reproducible run to run.
 __global__ void __launch_bounds__(256) gemm_reduce_splits(GemmArgs g, const double* __restrict__ part) {
   const int b1 = blockIdx.z / g.inner, b2 = blockIdx.z % g.inner;
   const double* P = part + b1 * g.sC1 + b2 * g.sC2;
   double* C = g.C + b1 * g.sC1 + b2 * g.sC2;
   const int64_t total = (int64_t)g.M * g.N;
-  for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t e = (int64_t)blockIdx.x * 4 + wave; e < total; e += (int64_t)gridDim.x * 4) {
     const int m = (int)(e % g.M), n = (int)(e / g.M);
     if (g.lower_only && m < n) continue;
     double acc = 0.0;
-    for (int s = 0; s < g.splits; s++) acc += P[s * g.sCs + m + (int64_t)n * g.ldc];
-    double* dst = C + m + (int64_t)n * g.ldc;
-    *dst = (g.beta == 0.0) ? g.alpha * acc : g.alpha * acc + g.beta * *dst;
+    for (int s = lane; s < g.splits; s += 64) acc += P[s * g.sCs + m + (int64_t)n * g.ldc];
+    acc = WaveSum(acc);
+    if (lane == 0) {
+      double* dst = C + m + (int64_t)n * g.ldc;
+      *dst = (g.beta == 0.0) ? g.alpha * acc : g.alpha * acc + g.beta * *dst;
+    }
   }
 }
 
@@ -215,7 +221,7 @@ inline hipError_t LaunchGemmSplitK(GemmArgs g, bool ta, bool tb, int batch, doub
   hipError_t e = LaunchGemm(p, ta, tb, batch, stream);
   if (e != hipSuccess) return e;
   const int64_t total = (int64_t)g.M * g.N;
-  dim3 grid((unsigned)std::min<int64_t>((total + 255) / 256, 1024), 1, batch);
+  dim3 grid((unsigned)std::min<int64_t>((total + 3) / 4, 4096), 1, batch);
   gemm_reduce_splits<<<grid, 256, 0, stream>>>(g, part);
   return hipGetLastError();
 }

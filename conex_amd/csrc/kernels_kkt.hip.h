@@ -841,6 +841,139 @@ tree_sweep(FactorPlan P, const int* __restrict__ level_ptr, int base0, int cnt0,
 }
 
 // ---------------------------------------------------------------------------------------
+// Mid-size supernodes (ns > 32 or s > 16, panel still LDS resident): ONE WORKGROUP per
+// supernode.  Same arithmetic as the register kernels -- right-looking elimination with
+// reciprocal scaling and fma updates, published updates as fma chains over the solved panel --
+// executed block-wide on an LDS copy [diag ns x ns | off ns x s | rhs ns], two barriers per column.
+// MODE as in tree_sweep.  grid = supernodes of the level (positions base0 ..).
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256)
+tree_sweep_block(FactorPlan P, int base0, double* __restrict__ slab, double* __restrict__ rhs,
+                 int* __restrict__ fail) {
+  extern __shared__ double lds[];
+  __shared__ int s_bad;
+  const SnRec R = LoadRec(P.rec, base0 + blockIdx.x);
+  const int ns = R.ns, s = R.nsep, tid = threadIdx.x, nt = blockDim.x;
+  double* D = slab + R.diag_off;
+  double* B = slab + R.offd_off;
+  double* sD = lds;
+  double* sB = sD + ns * ns;
+  double* sb = sB + ns * s;
+  if (tid == 0) s_bad = 0;
+  if (MODE == 2) {
+    // b <- L^{-T} (b - sum_c off[:,c] y[sep c]); separator terms in the reference's order
+    for (int q = tid; q < ns * ns; q += nt) sD[q] = D[q];
+    for (int i = tid; i < ns; i += nt) {
+      double acc = rhs[R.start + i];
+      for (int q = R.bs_beg; q < R.bs_end; q++) acc -= B[i + (size_t)P.bs_c[q] * ns] * rhs[P.bs_row[q]];
+      sb[i] = acc;
+    }
+    __syncthreads();
+    for (int k = ns - 1; k >= 0; k--) {
+      if (tid == 0) sb[k] = sb[k] * (1.0 / sD[k + k * ns]);
+      __syncthreads();
+      const double yk = sb[k];
+      for (int i = tid; i < k; i += nt) sb[i] = fma(-sD[k + i * ns], yk, sb[i]);
+      __syncthreads();
+    }
+    for (int i = tid; i < ns; i += nt) rhs[R.start + i] = sb[i];
+    return;
+  }
+  const bool with_matrix = MODE == 0;
+  const bool with_rhs = rhs != nullptr;
+  {
+    const int nd = ns * ns, total = nd + ns * s;
+    for (int q = tid; q < total; q += nt) lds[q] = q < nd ? D[q] : B[q - nd];
+    if (with_rhs)
+      for (int i = tid; i < ns; i += nt) sb[i] = rhs[R.start + i];
+  }
+  __syncthreads();
+  if (with_matrix)
+    for (int t = R.tg_beg + tid; t < R.tg_end; t += nt) {
+      const int loc = P.tg_loc[t];
+      double acc = lds[loc];
+      const int q1 = P.tr_ptr[t + 1];
+      for (int q = P.tr_ptr[t]; q < q1; q++) acc -= P.upd[P.tr_src[q]];
+      lds[loc] = acc;
+    }
+  if (with_rhs)
+    for (int i = tid; i < ns; i += nt) {
+      double acc = sb[i];
+      const int q1 = P.fs_ptr[R.start + i + 1];
+      for (int q = P.fs_ptr[R.start + i]; q < q1; q++) acc -= P.updb[P.fs_src[q]];
+      sb[i] = acc;
+    }
+  __syncthreads();
+  // extra columns carried along: off block (factor sweep only; solved already otherwise), rhs
+  const int ext = s + (with_rhs ? 1 : 0), c0 = with_matrix ? 0 : s;
+  for (int k = 0; k < ns; k++) {
+    double inv;
+    if (with_matrix) {
+      const double d = sD[k + k * ns];
+      double root;
+      SqrtAndInverse(d, root, inv);
+      if (!(d > 0.0) && tid == 0) s_bad = 1;
+      __syncthreads();  // everybody has read the pivot
+      for (int i = k + tid; i < ns; i += nt) sD[i + k * ns] = (i == k) ? root : sD[i + k * ns] * inv;
+    } else {
+      inv = 1.0 / sD[k + k * ns];
+    }
+    for (int c = c0 + tid; c < ext; c += nt) {
+      double* col = c < s ? sB + c * ns : sb;
+      col[k] = col[k] * inv;
+    }
+    __syncthreads();
+    const int rows = ns - k - 1;
+    const int dcols = with_matrix ? rows : 0;
+    for (int idx = tid; idx < rows * (dcols + ext - c0); idx += nt) {
+      const int i = k + 1 + idx % rows, cc = idx / rows;
+      const double lik = sD[i + k * ns];
+      if (cc < dcols) {
+        const int j = k + 1 + cc;
+        if (j <= i) sD[i + j * ns] = fma(-lik, sD[j + k * ns], sD[i + j * ns]);
+      } else {
+        const int c = c0 + cc - dcols;
+        double* col = c < s ? sB + c * ns : sb;
+        col[i] = fma(-lik, col[k], col[i]);
+      }
+    }
+    __syncthreads();
+  }
+  if (with_matrix && s_bad) {
+    if (tid == 0) atomicExch(fail, 1);
+    return;
+  }
+  if (with_matrix) {
+    for (int q = tid; q < ns * ns; q += nt)
+      if (q % ns >= q / ns) D[q] = sD[q];
+    for (int q = tid; q < ns * s; q += nt) B[q] = sB[q];
+    const int* dst = P.pub_dst + R.upd_off;
+    const int npairs = s * (s + 1) / 2;
+    for (int t = tid; t < npairs; t += nt) {
+      int k = 0, rem = t;
+      while (rem >= s - k) {
+        rem -= s - k;
+        k++;
+      }
+      const int j = k + rem;
+      double dot = 0;
+      for (int i = 0; i < ns; i++) dot = fma(sB[i + k * ns], sB[i + j * ns], dot);
+      P.upd[dst[t]] = dot;
+    }
+  }
+  if (with_rhs) {
+    for (int i = tid; i < ns; i += nt) rhs[R.start + i] = sb[i];
+    const int* dst = P.pubb_dst + R.updb_off;
+    for (int c = tid; c < s; c += nt) {
+      double dot = 0;
+      for (int i = 0; i < ns; i++) dot = fma(sB[i + c * ns], sb[i], dot);
+      P.updb[dst[c]] = dot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Multi-GPU exchange.  Buffer layout, all doubles:
 //   [ T slab entries (n_xs) | AW_T (n_xv) | AQc_T (n_xv) | fwd_T (n_xv) | <w,c> | <c,Qc> | fail | pad ]
 // pack:   fold this rank's subtree updates into its PARTIAL top blocks (pre-reduce pulls), then

@@ -29,14 +29,12 @@ struct LmiLargeWs {
 };
 
 // ---- assembly ---------------------------------------------------------------------------
-// G, AQc, <c,Qc> from Gf; AW(i) = tr(P_i), <w,c> = tr(P_C).  One workgroup per constraint.
+// G, AQc, <c,Qc> from Gf.  One workgroup per constraint.
 __global__ void __launch_bounds__(256) lmi_large_finalize(LmiGroup g, Arena ar, LmiLargeWs ws) {
-  const int n = g.n, m = g.m, nn = n * n, m1 = m + 1;
+  const int m = g.m, m1 = m + 1;
   const int mem = blockIdx.x, id = g.ids[mem];
   const double* Gf = ws.Gf + (size_t)mem * m1 * m1;
-  const double* P = ws.P + (size_t)mem * m1 * nn;
   double* G = ar.G + ar.g_off[id];
-  double* AW = ar.AWc + ar.r_off[id];
   double* AQc = ar.AQcc + ar.r_off[id];
   const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;  // exact (power of two)
   for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
@@ -45,18 +43,22 @@ __global__ void __launch_bounds__(256) lmi_large_finalize(LmiGroup g, Arena ar, 
   }
   for (int i = threadIdx.x; i < m; i += blockDim.x) AQc[i] = Gf[m + (size_t)i * m1] * osc;
   if (threadIdx.x == 0) ar.sc[2 * id + 1] = Gf[m + (size_t)m * m1] * osc;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int i = wave; i <= m; i += nw) {
-    const double* Pi = P + (size_t)i * nn;
-    double t = 0;
-    for (int r = lane; r < n; r += 64) t += Pi[r + (size_t)r * n];
-    t = WaveSum(t) * osc;
-    if (lane == 0) {
-      if (i < m)
-        AW[i] = t;
-      else
-        ar.sc[2 * id] = t;
-    }
+}
+
+// AW(i) = tr(P_i), <w,c> = tr(P_C): one wavefront per (matrix, constraint)
+__global__ void __launch_bounds__(64) lmi_large_traces(LmiGroup g, Arena ar, LmiLargeWs ws) {
+  const int n = g.n, m = g.m, nn = n * n, m1 = m + 1;
+  const int i = blockIdx.x, mem = blockIdx.y, id = g.ids[mem];
+  const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;
+  const double* Pi = ws.P + ((size_t)mem * m1 + i) * nn;
+  double t = 0;
+  for (int r = threadIdx.x; r < n; r += 64) t += Pi[r + (size_t)r * n];
+  t = WaveSum(t) * osc;
+  if (threadIdx.x == 0) {
+    if (i < m)
+      ar.AWc[ar.r_off[id] + i] = t;
+    else
+      ar.sc[2 * id] = t;
   }
 }
 
@@ -447,6 +449,7 @@ inline hipError_t LmiLargeSchur(const LmiGroup& g, const Arena& ar, const LmiLar
     if ((e = LaunchGemmSplitK(a, true, false, g.count, ws.part, st)) != hipSuccess) return e;
   }
   lmi_large_finalize<<<g.count, 256, 0, st>>>(g, ar, ws);
+  lmi_large_traces<<<dim3(m1, g.count), 64, 0, st>>>(g, ar, ws);
   return hipGetLastError();
 }
 

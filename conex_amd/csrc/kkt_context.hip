@@ -101,6 +101,7 @@ struct cxk_context {
   std::vector<int> level_ptr, level_sn;
   size_t chol_lds = 0, solve_lds = 0;  // bytes of LDS staging one supernode needs
   int top_level = 0;                   // levels [top_level, nlev) run inside one workgroup
+  std::vector<unsigned char> level_big;  // level holds a supernode beyond the wave-per-supernode kernels
   // device state
   DevBuf<double> G, AWc, AQcc, sc, slab, y, b, AW, AQc, sys_sc, info2, info4, red_out, scal_out;
   DevBuf<int64_t> d_g_off, d_r_off, as_dst, as_src, rs_src;
@@ -701,10 +702,12 @@ int BuildPlans(cxk_context* ctx) {
   ctx->level_ptr.assign(nlev + 1, 0);
   ctx->level_sn.clear();
   ctx->chol_lds = 8;
+  ctx->level_big.assign(nlev, 0);
   for (int l = 0; l < nlev; l++) {
     for (int e = 0; e < K; e++)
       if (ns[e] > 0 && ctx->t_level[e] == l && block_wanted(e)) {
         ctx->level_sn.push_back(e);
+        if (ns[e] > 32 || nsep[e] > 16) ctx->level_big[l] = 1;
         ctx->chol_lds = std::max(ctx->chol_lds, sizeof(double) * ((size_t)ns[e] * ns[e] +
                                                                    (size_t)ns[e] * nsep[e] + ns[e]));
       }
@@ -748,7 +751,7 @@ int BuildPlans(cxk_context* ctx) {
   // (levels separated by a workgroup barrier instead of a kernel boundary); never below the cut
   {
     int top = nlev;
-    while (top > 0 && ctx->level_ptr[top] - ctx->level_ptr[top - 1] <= 8) top--;
+    while (top > 0 && ctx->level_ptr[top] - ctx->level_ptr[top - 1] <= 8 && !ctx->level_big[top - 1]) top--;
     if (sharded) top = std::max(top, ctx->cut_level);
     ctx->top_level = top;
   }
@@ -780,6 +783,35 @@ int BuildPlans(cxk_context* ctx) {
   P.bs_c = ctx->bs_c.p;
   P.bs_row = ctx->bs_row.p;
   return CXK_SUCCESS;
+}
+
+// Kernels that may be launched with more than the default 64 KB of dynamic LDS.
+hipError_t RaiseLdsLimits() {
+  static hipError_t status = [] {
+    const int lim = (int)kLdsLimit;
+    const void* ks[] = {
+        reinterpret_cast<const void*>(&lmi_schur_generic),
+        reinterpret_cast<const void*>(&lmi_prepare_generic<0>),
+        reinterpret_cast<const void*>(&lmi_prepare_generic<1>),
+        reinterpret_cast<const void*>(&lmi_take_step_generic),
+        reinterpret_cast<const void*>(&tree_sweep<0, false>),
+        reinterpret_cast<const void*>(&tree_sweep<0, true>),
+        reinterpret_cast<const void*>(&tree_sweep<1, false>),
+        reinterpret_cast<const void*>(&tree_sweep<1, true>),
+        reinterpret_cast<const void*>(&tree_sweep<2, false>),
+        reinterpret_cast<const void*>(&tree_sweep<2, true>),
+        reinterpret_cast<const void*>(&tree_sweep_block<0>),
+        reinterpret_cast<const void*>(&tree_sweep_block<1>),
+        reinterpret_cast<const void*>(&tree_sweep_block<2>),
+        reinterpret_cast<const void*>(&soc_schur),
+    };
+    for (const void* k : ks) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }();
+  return status;
 }
 
 ExchangeArgs MakeExchange(cxk_context* ctx, double k, double bs, double cs) {
@@ -904,6 +936,18 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
     grid = (maxcnt + waves - 1) / waves;
   }
   const bool is_top = le - lb > 1 || then_backward;
+  if (!is_top && ctx->level_big[lb]) {  // one workgroup per supernode
+    double* r = (with_rhs || mode != 0) ? ctx->y.p : nullptr;
+    const int base = ctx->level_ptr[lb];
+    if (mode == 0)
+      tree_sweep_block<0><<<maxcnt, 256, ctx->chol_lds, ctx->stream>>>(ctx->plan, base, ctx->slab.p, r, ctx->d_fail.p);
+    else if (mode == 1)
+      tree_sweep_block<1><<<maxcnt, 256, ctx->chol_lds, ctx->stream>>>(ctx->plan, base, ctx->slab.p, r, ctx->d_fail.p);
+    else
+      tree_sweep_block<2><<<maxcnt, 256, ctx->chol_lds, ctx->stream>>>(ctx->plan, base, ctx->slab.p, r, ctx->d_fail.p);
+    CXK_TRY(hipGetLastError());
+    return CXK_SUCCESS;
+  }
   const size_t lds = (size_t)waves * ctx->chol_lds;
   double* rhs = (with_rhs || mode != 0) ? ctx->y.p : nullptr;
 #define CXK_SWEEP(MODE, TOP)                                                                   \
@@ -1107,6 +1151,7 @@ int cxk_finalize(cxk_context* ctx) {
   if (ctx->device < 0) return CXK_SUCCESS;  // symbolic-only context
 
   CXK_TRY(hipSetDevice(ctx->device));
+  CXK_TRY(RaiseLdsLimits());
   // groups of identically shaped constraints (owned ones only carry data)
   std::map<std::tuple<int, int, int, int>, int> gmap;
   ctx->groups.clear();
@@ -1166,7 +1211,7 @@ int cxk_finalize(cxk_context* ctx) {
       // split-K of the contraction: enough workgroups to fill the chip, at most one K step each
       const int ksteps = (int)((nn + kGemmBK - 1) / kGemmBK);
       const int tiles = (int)(((m1 + 63) / 64) * ((m1 + 63) / 64));
-      g.splits = std::max(1, std::min(ksteps, (int)((1024 + cnt * tiles - 1) / (cnt * tiles))));
+      g.splits = std::max(1, std::min(std::max(1, ksteps / 8), (int)((512 + cnt * tiles - 1) / (cnt * tiles))));
       CXK_TRY(g.ws_main.alloc(cnt * std::max(2 * m1 * nn, 8 * nn)));
       CXK_TRY(g.ws_gf.alloc(cnt * m1 * m1));
       CXK_TRY(g.ws_part.alloc(g.splits > 1 ? (size_t)g.splits * cnt * m1 * m1 : 0));

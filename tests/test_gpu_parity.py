@@ -142,6 +142,17 @@ def test_lmi_large_order_affine_update():
         assert rel(k.get_W(i), o.get_W(i)) <= 1e-13
 
 
+@pytest.mark.parametrize("K,n,m,b_,ov", [(1, 52, 40, 2, 1), (5, 10, 60, 2, 20), (3, 45, 100, 2, 30)])
+def test_mid_size_supernodes_and_lds_resident_orders(K, n, m, b_, ov):
+    """Supernodes beyond the wave-per-supernode kernels (ns > 32 or separators > 16) take the
+    workgroup-per-supernode kernel; n = 45..52 exercises the LDS-resident LMI kernels above 64 KB
+    of dynamic LDS."""
+    prob = syn.lmi_problem(K=K, n=n, m=m, branching=b_, overlap=ov, seed=400 + m)
+    W = syn.scaling_points(K, n, seed=13 + n)
+    o, k = make_pair(prob, "lmi", W)
+    check_newton_step(o, k, prob["b"], lanczos_tol=1e-7)
+
+
 def test_lmi_identity_start_and_iterations():
     """Three IPM iterations from W = I through both paths stay in lock-step."""
     prob = syn.lmi_problem(K=20, n=8, m=8, branching=3, overlap=3, seed=5)
