@@ -103,6 +103,10 @@ typedef struct {
   long** ss_index;       /* [K] s(s+1)/2 slab offsets (seperator_diagonal) */
   int* ss_count;         /* [K] */
   double* temporaries;   /* max separator size */
+  /* LDLT mode (kkt_solver.cc:180-193): per-supernode transpositions of Eigen::RLDLT */
+  int* transpositions;   /* [N], local indices inside each supernode */
+  int factored_ldlt;     /* last factorization was BlockLDLTInPlace */
+  int regularized;       /* a pivot was clamped to +-1e-9 */
 } cxo_workspace;
 
 cxo_workspace* cxo_workspace_new(int K, const ivec* path, const int* supernode_size);
@@ -111,6 +115,13 @@ void cxo_workspace_free(cxo_workspace* w);
 /* ---------- numeric kernels ---------- */
 /* block_triangular_operations.cc:184-219 ; returns 1 on success */
 int cxo_block_cholesky(cxo_workspace* w);
+/* BlockLDLTInPlace :315-349 with Eigen::RLDLT (RLDLT.h:294-431); returns 1 when no pivot was
+ * regularised */
+int cxo_block_ldlt(cxo_workspace* w);
+/* SolveInPlaceLDLT: ApplyBlockInverseOfMD :265-299 then ApplyBlockInverseOfMTranspose :222-263 */
+void cxo_solve_ldlt(const cxo_workspace* w, double* y);
+/* rldlt_inplace<Lower>::unblocked RLDLT.h:298-431; returns 1 when no regularisation was used */
+int cxo_rldlt_inplace(int n, double* a, int lda, int* transpositions);
 /* :160-182 */
 void cxo_apply_block_inverse(const cxo_workspace* w, double* y);
 /* :114-151 */

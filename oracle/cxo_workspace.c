@@ -134,6 +134,7 @@ cxo_workspace* cxo_workspace_new(int K, const ivec* path, const int* supernode_s
 }
 
 void cxo_workspace_free(cxo_workspace* o) {
+  if (o) free(o->transpositions);
   if (!o) return;
   int nci = o->K - 1 > 0 ? o->K - 1 : 0;
   free(o->supernode_size);
@@ -271,6 +272,200 @@ void cxo_apply_block_inverse_of_transpose(const cxo_workspace* m, double* y) {
     }
   }
   if (m->supernode_size[0] > 0) trsv_lower_t(m->supernode_size[0], m->slab + m->diag_off[0], y);
+  free(start);
+}
+
+/* ------------------------------------------------------------------ LDLT path
+ * Eigen::RLDLT (conex/RLDLT.h:298-431): diagonal pivoting on the largest |diagonal| entry,
+ * left-looking column update, pivots with |d| <= 1e-9 clamped to +-1e-9.  Lower triangle only. */
+int cxo_rldlt_inplace(int n, double* a, int lda, int* tr) {
+#define M_(i, j) a[(size_t)(j) * lda + (i)]
+  const double reg = 1e-9;
+  int ret = 1;
+  if (n <= 1) {
+    if (n == 1) {
+      if (fabs(M_(0, 0)) < reg) M_(0, 0) = M_(0, 0) < 0 ? -reg : reg;
+      tr[0] = 0;
+    }
+    return 1; /* the size <= 1 branch reports success even when it clamps (RLDLT.h:311-330) */
+  }
+  double* temp = (double*)malloc(sizeof(double) * (size_t)n);
+  for (int k = 0; k < n; k++) {
+    int big = k; /* maxCoeff of |diag| over the trailing part: first maximum */
+    double best = fabs(M_(k, k));
+    for (int i = k + 1; i < n; i++)
+      if (fabs(M_(i, i)) > best) {
+        best = fabs(M_(i, i));
+        big = i;
+      }
+    tr[k] = big;
+    if (k != big) {
+      for (int j = 0; j < k; j++) { /* row(k).head(k) <-> row(big).head(k) */
+        double t = M_(k, j);
+        M_(k, j) = M_(big, j);
+        M_(big, j) = t;
+      }
+      for (int i = big + 1; i < n; i++) { /* col(k).tail(s) <-> col(big).tail(s) */
+        double t = M_(i, k);
+        M_(i, k) = M_(i, big);
+        M_(i, big) = t;
+      }
+      double t = M_(k, k);
+      M_(k, k) = M_(big, big);
+      M_(big, big) = t;
+      for (int i = k + 1; i < big; i++) {
+        double u = M_(i, k);
+        M_(i, k) = M_(big, i);
+        M_(big, i) = u;
+      }
+    }
+    int rs = n - k - 1;
+    if (k > 0) {
+      for (int j = 0; j < k; j++) temp[j] = M_(j, j) * M_(k, j); /* D(0:k) .* A10^T */
+      double dot = 0;
+      for (int j = 0; j < k; j++) dot += M_(k, j) * temp[j];
+      M_(k, k) -= dot;
+      for (int i = 0; i < rs; i++) { /* A21 -= A20 * temp */
+        double acc = 0;
+        for (int j = 0; j < k; j++) acc += M_(k + 1 + i, j) * temp[j];
+        M_(k + 1 + i, k) -= acc;
+      }
+    }
+    double akk = M_(k, k);
+    if (!(fabs(akk) > 1e-9)) {
+      ret = 0;
+      M_(k, k) = M_(k, k) < 0 ? -(1e-9) : (1e-9);
+      akk = M_(k, k);
+    }
+    for (int i = 0; i < rs; i++) M_(k + 1 + i, k) /= akk;
+  }
+  free(temp);
+  return ret;
+#undef M_
+}
+
+static void apply_transpositions(int n, const int* tr, double* y, int stride, int cols) {
+  for (int k = 0; k < n; k++)
+    if (tr[k] != k)
+      for (int c = 0; c < cols; c++) {
+        double t = y[(size_t)c * stride + k];
+        y[(size_t)c * stride + k] = y[(size_t)c * stride + tr[k]];
+        y[(size_t)c * stride + tr[k]] = t;
+      }
+}
+static void apply_transpositions_t(int n, const int* tr, double* y) {
+  for (int k = n - 1; k >= 0; k--)
+    if (tr[k] != k) {
+      double t = y[k];
+      y[k] = y[tr[k]];
+      y[tr[k]] = t;
+    }
+}
+static void trsv_unit_lower(int n, const double* L, double* y) {
+  for (int j = 0; j < n; j++) {
+    double yj = y[j];
+    for (int i = j + 1; i < n; i++) y[i] -= L[(size_t)j * n + i] * yj;
+  }
+}
+static void trsv_unit_lower_t(int n, const double* L, double* y) {
+  for (int j = n - 1; j >= 0; j--) {
+    double acc = y[j];
+    for (int i = j + 1; i < n; i++) acc -= L[(size_t)j * n + i] * y[i];
+    y[j] = acc;
+  }
+}
+
+/* BlockLDLTInPlace block_triangular_operations.cc:315-349 */
+int cxo_block_ldlt(cxo_workspace* C) {
+  int ok = 1, start = 0;
+  if (!C->transpositions) C->transpositions = (int*)calloc((size_t)(C->N > 0 ? C->N : 1), sizeof(int));
+  for (int i = 0; i < C->K; i++) {
+    int ns = C->supernode_size[i];
+    int s = C->separators[i].n;
+    double* D = C->slab + C->diag_off[i];
+    double* B = C->slab + C->offd_off[i];
+    int* tr = C->transpositions + start;
+    if (ns > 0 && !cxo_rldlt_inplace(ns, D, ns, tr)) ok = 0;
+    if (ns > 0 && s > 0) {
+      apply_transpositions(ns, tr, B, ns, s);                            /* off = P off */
+      for (int c = 0; c < s; c++) trsv_unit_lower(ns, D, B + (size_t)c * ns); /* L^{-1} */
+      for (int c = 0; c < s; c++)
+        for (int r = 0; r < ns; r++) B[(size_t)c * ns + r] = (1.0 / D[(size_t)r * ns + r]) * B[(size_t)c * ns + r];
+      int index = 0;
+      const long* ss = C->ss_index[i];
+      for (int k = 0; k < s; k++)
+        for (int j = k; j < s; j++) {
+          double dot = 0; /* temp.col(k).dot(off.col(j)), temp = D off */
+          for (int r = 0; r < ns; r++)
+            dot += (D[(size_t)r * ns + r] * B[(size_t)k * ns + r]) * B[(size_t)j * ns + r];
+          C->slab[ss[index++]] -= dot;
+        }
+    }
+    start += ns;
+  }
+  C->factored_ldlt = 1;
+  C->regularized = !ok;
+  return ok;
+}
+
+/* SolveInPlaceLDLT: inv(M D) then inv(M^T), M = P^T L */
+void cxo_solve_ldlt(const cxo_workspace* m, double* y) {
+  int K = m->K;
+  int* start = (int*)malloc(sizeof(int) * (size_t)(K + 1));
+  start[0] = 0;
+  for (int i = 0; i < K; i++) start[i + 1] = start[i] + m->supernode_size[i];
+  /* ApplyBlockInverseOfMD :265-299 */
+  for (int i = 0; i < K; i++) {
+    int ns = m->supernode_size[i];
+    if (i > 0) {
+      int nsp = m->supernode_size[i - 1], s = m->separators[i - 1].n;
+      if (nsp > 0 && s > 0) {
+        const double* B = m->slab + m->offd_off[i - 1];
+        const double* yp = y + start[i - 1];
+        for (int c = 0; c < s; c++) {
+          double t = 0;
+          for (int r = 0; r < nsp; r++) t += B[(size_t)c * nsp + r] * yp[r];
+          m->temporaries[c] = t;
+        }
+        for (int c = 0; c < s; c++) y[m->separators[i - 1].d[c]] -= m->temporaries[c];
+      }
+    }
+    if (ns > 0) {
+      apply_transpositions(ns, m->transpositions + start[i], y + start[i], ns, 1);
+      trsv_unit_lower(ns, m->slab + m->diag_off[i], y + start[i]);
+    }
+  }
+  for (int i = 0; i < K; i++) {
+    int ns = m->supernode_size[i];
+    const double* D = m->slab + m->diag_off[i];
+    for (int r = 0; r < ns; r++) y[start[i] + r] = (1.0 / D[(size_t)r * ns + r]) * y[start[i] + r];
+  }
+  /* ApplyBlockInverseOfMTranspose :222-263 */
+  if (K > 0 && m->supernode_size[K - 1] > 0) {
+    int nl = m->supernode_size[K - 1];
+    trsv_unit_lower_t(nl, m->slab + m->diag_off[K - 1], y + start[K - 1]);
+    apply_transpositions_t(nl, m->transpositions + start[K - 1], y + start[K - 1]);
+  }
+  for (int i = K - 2; i >= 0; i--) {
+    double* yp = y + start[i + 1];
+    for (int jc = 0; jc < m->col_int[i].n; jc++) {
+      int j = m->col_int[i].d[jc];
+      int nsj = m->supernode_size[j];
+      double* res = y + start[j];
+      const double* B = m->slab + m->offd_off[j];
+      for (int q = m->col_int_start[i].d[jc]; q < m->col_int_start[i].d[jc + 1]; q++) {
+        int pf = m->pair_first[i].d[q];
+        int ps = m->pair_second[i].d[q];
+        double w = yp[pf];
+        for (int r = 0; r < nsj; r++) res[r] -= B[(size_t)ps * nsj + r] * w;
+      }
+    }
+    int ns = m->supernode_size[i];
+    if (ns > 0) {
+      trsv_unit_lower_t(ns, m->slab + m->diag_off[i], y + start[i]);
+      apply_transpositions_t(ns, m->transpositions + start[i], y + start[i]);
+    }
+  }
   free(start);
 }
 

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects the round's rocprofv3 evidence on the GPU box (run through gpurun):
+#   tools/profile_round.sh r01
+# kernel-trace statistics of the default bench.py run, then one PMC pass per counter set (PMC
+# passes never share a run with other tracing, MI355X_MICROARCH.md HBM/rocprofv3 section).
+# Output lands in gpurun_out/<round>/; tools/summarize_profiles.py condenses it into profiles/.
+set -u
+ROUND=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$ROUND
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+python3 "$ROOT/bench.py" > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
+  python3 "$ROOT/bench.py" --no-cpu > "$OUT/bench_default_under_rocprof.log" 2>&1
+python3 "$ROOT/bench.py" --workload c2 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -o bench -- \
+  python3 "$ROOT/bench.py" --workload c2 --no-cpu --steps 50 > "$OUT/bench_c2_under_rocprof.log" 2>&1
+i=0
+for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU" \
+           "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"; do
+  i=$((i+1))
+  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/pmc_$i" -o p -- \
+    python3 "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu > "$OUT/pmc_$i.log" 2>&1
+done
+ls -R "$OUT" | head -60

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/<round>/ (written by tools/profile_round.sh) into profiles/<round>/.
+
+  python tools/summarize_profiles.py r01
+
+Copies the kernel statistics and bench lines, and averages every collected PMC counter per
+kernel.  HBM traffic of the dominant kernel = 2 x FETCH_SIZE + WRITE_SIZE: on gfx950 FETCH_SIZE
+counts 128-byte requests as 64 bytes (MI355X_MICROARCH.md, HBM / rocprofv3 section); both counters
+are reported in KB by rocprofv3.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", rnd)
+    dst = os.path.join(ROOT, "profiles", rnd)
+    os.makedirs(dst, exist_ok=True)
+    for name in ["bench_default.json", "bench_default_under_rocprof.log", "bench_c2.json",
+                 "bench_c2_under_rocprof.log"]:
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+    for sub, out in [("stats", "bench_default_kernel_stats.csv"), ("stats_c2", "bench_c2_kernel_stats.csv")]:
+        files = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+        if files:
+            shutil.copy(files[0], os.path.join(dst, out))
+    counters = {}
+    for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            c = counters.setdefault(k, {}).setdefault(r["Counter_Name"], [0.0, 0])
+            c[0] += float(r["Counter_Value"])
+            c[1] += 1
+    summary = {
+        "command": "rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py "
+                   "--steps 20 --warmup 3 --no-cpu (one pass per counter set, tools/profile_round.sh)",
+        "units": "FETCH_SIZE / WRITE_SIZE in KB as reported; gfx950: wide coalesced reads are "
+                 "under-reported 2x (MI355X_MICROARCH.md HBM section)",
+        "counters": {k: {c: {"mean": v[0] / v[1], "dispatches": v[1]} for c, v in d.items()}
+                     for k, d in counters.items()},
+    }
+    for k, d in counters.items():
+        if "lmi_schur_fused" in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            fetch = d["FETCH_SIZE"][0] / d["FETCH_SIZE"][1] * 1024
+            write = d["WRITE_SIZE"][0] / d["WRITE_SIZE"][1] * 1024
+            summary["lmi_schur_fused"] = {
+                "FETCH_SIZE_bytes_raw": fetch,
+                "FETCH_SIZE_bytes_corrected_x2": 2 * fetch,
+                "WRITE_SIZE_bytes": write,
+                "hbm_traffic_bytes_per_launch": 2 * fetch + write,
+                "algorithmic_bytes_per_launch": 72400000.0,
+            }
+    with open(os.path.join(dst, "pmc_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1, sort_keys=True)
+    print("wrote", dst, sorted(os.listdir(dst)))
+
+
+if __name__ == "__main__":
+    main()
