@@ -15,7 +15,8 @@ enum {
   CXO_LINEAR = 1,    /* LinearConstraint     linear_constraint.{h,cc} */
   CXO_SOC = 2,       /* SOCConstraint        soc_constraint.{h,cc} */
   CXO_STATIC = 3,    /* SupernodalAssemblerStatic supernodal_assembler.h:122-129 (fixed G) */
-  CXO_HERMITIAN = 4  /* HermitianPsdConstraint<Real|Complex|Quaternions> hermitian_psd.{h,cc} */
+  CXO_HERMITIAN = 4, /* HermitianPsdConstraint<Real|Complex|Quaternions> hermitian_psd.{h,cc} */
+  CXO_EQUALITY = 5   /* EqualityConstraints equality_constraint.{h,cc} (multipliers -> LDLT path) */
 };
 
 /* cone_program.h:17-38 */
@@ -56,6 +57,12 @@ int cxo_add_linear(cxo_program* p, int r, int m, const double* A, const double* 
                    const int* vars);
 /* A: (n+1) x m col-major, c: n+1 */
 int cxo_add_soc(cxo_program* p, int n, int m, const double* A, const double* c, const int* vars);
+/* A y[vars] = b with r rows: appends r multipliers to the KKT system (constraint_manager.h:66-90);
+ * the factorization switches to BlockLDLTInPlace (kkt_solver.cc:180-193).  dual size = r (lambda). */
+int cxo_add_equality(cxo_program* p, int r, int m, const double* A, const double* b,
+                     const int* vars);
+/* 1 when the last LDLT factorization clamped a pivot to +-1e-9 (kkt_solver.cc:190-192) */
+int cxo_factor_regularized(const cxo_program* p);
 /* Hermitian PSD cone over R (d=1), C (d=2) or H (d=4): A = m x d planes of n x n (column-major),
  * C = d planes.  W / dual variable: d planes.  hermitian_psd.h:41-116 */
 int cxo_add_hermitian(cxo_program* p, int n, int d, int m, const double* A, const double* C,

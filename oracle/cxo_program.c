@@ -74,6 +74,7 @@ struct cxo_program {
   int solved;
   int primal_infeasible;
   int dual_infeasible;
+  int dual_variable_start; /* constraint_manager.h:30,80: next multiplier id (>= num_vars) */
   unsigned long lanczos_calls; /* index of the next PrepareStep / eigenvalue query (start vectors) */
 };
 
@@ -126,6 +127,7 @@ void cxo_default_config(cxo_config* c) { /* cone_program.h:17-38 */
 cxo_program* cxo_program_new(int num_vars) {
   cxo_program* p = (cxo_program*)calloc(1, sizeof(cxo_program));
   p->num_vars = num_vars;
+  p->dual_variable_start = num_vars;
   p->b_scaling = 1;
   p->c_scaling = 1;
   return p;
@@ -243,6 +245,36 @@ int cxo_add_hermitian(cxo_program* p, int n, int d, int m, const double* A, cons
   c->temp1 = (double*)calloc(sz, sizeof(double)); /* WS */
   c->temp2 = (double*)calloc(sz, sizeof(double)); /* minus_s */
   return p->K - 1;
+}
+
+/* Program::AddConstraint(EqualityConstraints{A, b}, vars) -> ConstraintManager::
+ * AddEqualityConstraint (constraint_manager.h:66-90): the clique is vars followed by r fresh
+ * multiplier ids; A is r x m (column-major), the constraint is A y[vars] = b. */
+int cxo_add_equality(cxo_program* p, int r, int m, const double* A, const double* b,
+                     const int* vars) {
+  if (!vars && m != p->num_vars) return -1;
+  cxo_constraint* c = new_constraint(p, m, vars);
+  if (!c) return -1;
+  int k = p->K - 1, mt = m + r;
+  for (int i = 0; i < r; i++) {
+    iv_push(&p->cliques[k], p->dual_variable_start + i);
+    iv_push(&p->dual_vars[k], p->dual_variable_start + i);
+  }
+  p->dual_variable_start += r;
+  free(c->G_own);
+  free(c->AW);
+  free(c->AQc);
+  c->G_own = (double*)calloc((size_t)mt * mt, sizeof(double));
+  c->G = c->G_own;
+  c->AW = (double*)calloc((size_t)mt, sizeof(double));
+  c->AQc = (double*)calloc((size_t)mt, sizeof(double));
+  c->type = CXO_EQUALITY;
+  c->n = r;       /* number of equality rows = multipliers */
+  c->m = mt;      /* clique size seen by the KKT system */
+  c->A = dupd(A, (size_t)r * m);
+  c->C = dupd(b, (size_t)r);
+  c->W = (double*)calloc((size_t)(r > 0 ? r : 1), sizeof(double)); /* lambda_ */
+  return k;
 }
 
 int cxo_add_linear(cxo_program* p, int r, int m, const double* A, const double* cc,
@@ -401,6 +433,7 @@ int cxo_dual_size(const cxo_program* p, int i) {
   switch (c->type) {
     case CXO_LMI: return c->n * c->n;
     case CXO_HERMITIAN: return c->n * c->n * c->hd;
+    case CXO_EQUALITY: return c->n;
     case CXO_LINEAR: return c->n;
     case CXO_SOC: return c->n + 1;
     default: return 0;
@@ -515,10 +548,12 @@ static void schur_static(cxo_constraint* o) { /* supernodal_assembler.h:127 G = 
 }
 
 static void schur_hermitian(cxo_constraint* o);
+static void schur_equality(cxo_constraint* o);
 static void set_dense_data(cxo_constraint* o) {
   switch (o->type) {
     case CXO_LMI: schur_lmi(o); break;
     case CXO_HERMITIAN: schur_hermitian(o); break;
+    case CXO_EQUALITY: schur_equality(o); break;
     case CXO_LINEAR: schur_linear(o); break;
     case CXO_SOC: schur_soc(o); break;
     case CXO_STATIC: schur_static(o); break;
@@ -608,7 +643,25 @@ void cxo_get_residuals(const cxo_program* p, double* AW, double* AQc, double* sc
 }
 
 /* Factor kkt_solver.cc:172-199 (LLT branch) */
-int cxo_factor(cxo_program* p) { return cxo_block_cholesky(p->ws); }
+/* SupernodalKKTSolver::Factor kkt_solver.cc:172-199: Cholesky unless some constraint carries
+ * multipliers, then block LDLT (which always "succeeds"; regularisation is only recorded) */
+int cxo_factor(cxo_program* p) {
+  int use_cholesky = 1;
+  for (int i = 0; i < p->K; i++)
+    if (p->dual_vars[i].n > 0) {
+      use_cholesky = 0;
+      break;
+    }
+  if (use_cholesky) {
+    p->ws->factored_ldlt = 0;
+    return cxo_block_cholesky(p->ws);
+  }
+  cxo_block_ldlt(p->ws);
+  return 1;
+}
+
+/* factorization_regularized_ kkt_solver.cc:192 */
+int cxo_factor_regularized(const cxo_program* p) { return p->ws ? p->ws->regularized : 0; }
 
 /* SolveInPlace kkt_solver.cc:220-263 (no refinement): b_perm = Pt^T b ; solves ; b = Pt b_perm.
  * Pt.indices() = permutation_inverse, so (Pt^T b)(i) = b(permutation_inverse[i]). */
@@ -616,8 +669,12 @@ void cxo_solve_inplace(cxo_program* p, double* y) {
   int N = p->md->N;
   const int* pinv = p->md->permutation_inverse;
   for (int i = 0; i < N; i++) p->b_permuted[i] = y[pinv[i]];
-  cxo_apply_block_inverse(p->ws, p->b_permuted);
-  cxo_apply_block_inverse_of_transpose(p->ws, p->b_permuted);
+  if (p->ws->factored_ldlt) {
+    cxo_solve_ldlt(p->ws, p->b_permuted);
+  } else {
+    cxo_apply_block_inverse(p->ws, p->b_permuted);
+    cxo_apply_block_inverse_of_transpose(p->ws, p->b_permuted);
+  }
   for (int i = 0; i < N; i++) y[pinv[i]] = p->b_permuted[i];
 }
 
@@ -884,6 +941,24 @@ static void soc_weighted_eigs(cxo_constraint* o, const double* y, double c_weigh
 }
 
 /* Vars() cone_program.h:59-67 */
+/* ConstructSchurComplementSystem(EqualityConstraints*) equality_constraint.cc:14-30 (initialize):
+ * G = [0 A^T; A 0] over (clique variables, multipliers), AQc = [0; b], everything else zero */
+static void schur_equality(cxo_constraint* o) {
+  int r = o->n, mt = o->m, m = mt - r;
+  memset(o->G, 0, sizeof(double) * (size_t)mt * mt);
+  memset(o->AW, 0, sizeof(double) * (size_t)mt);
+  memset(o->AQc, 0, sizeof(double) * (size_t)mt);
+  for (int j = 0; j < m; j++)
+    for (int i = 0; i < r; i++) {
+      double a = o->A[(size_t)j * r + i];
+      o->G[(size_t)j * mt + (m + i)] = a; /* bottom-left  */
+      o->G[(size_t)(m + i) * mt + j] = a; /* top-right    */
+    }
+  for (int i = 0; i < r; i++) o->AQc[m + i] = o->C[i];
+  o->ip_wc = 0;
+  o->ip_cQc = 0;
+}
+
 /* ------------------------------------------------------------- Hermitian PSD over R / C / H */
 /* ConstructSchurComplementSystem(HermitianPsdConstraint<T>*) hermitian_psd.cc:171-230, initialize */
 static void schur_hermitian(cxo_constraint* o) {
@@ -1035,6 +1110,11 @@ void cxo_prepare_step(cxo_program* p, int affine, double c_weight, double e_weig
         break;
       case CXO_LINEAR: lin_prepare_step(c, affine, c_weight, e_weight, 1.0, z, &ni_sq, &ni_inf); break;
       case CXO_SOC: soc_prepare_step(c, c_weight, z, &ni_sq, &ni_inf); break;
+      case CXO_EQUALITY: /* equality_constraint.cc:32-37: lambda_ = y.tail(rows) */
+        for (int q = 0; q < c->n; q++) c->W[q] = z[c->m - c->n + q];
+        ni_sq = 0;
+        ni_inf = 0;
+        break;
       default: ni_sq = 0; ni_inf = 0; break;
     }
     if (ni_inf > norminfd) norminfd = ni_inf;
@@ -1163,6 +1243,7 @@ static int rank_of(const cxo_constraint* c) {
   switch (c->type) {
     case CXO_LMI: return c->n;
     case CXO_HERMITIAN: return c->n;
+    case CXO_EQUALITY: return 0;
     case CXO_LINEAR: return c->n;
     case CXO_SOC: return 2;
     default: return 0;

@@ -63,6 +63,7 @@ def lib():
         "cxo_add_linear": (C.c_int, [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
         "cxo_add_soc": (C.c_int, [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
         "cxo_add_static": (C.c_int, [vp, C.c_int, c_double_p, c_int_p]),
+        "cxo_add_equality": (C.c_int, [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
         "cxo_add_hermitian": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p,
                                         c_int_p]),
         "cxo_hc_multiply": (None, [C.c_int, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p,
@@ -220,6 +221,18 @@ class Program:
         r = self.L.cxo_add_hermitian(self.h, n, d, m, dp(a), dp(c), vp_)
         if r >= 0:
             self.cons.append(("herm", n, m, d))
+        return r
+
+    def add_equality(self, A, b, vars_=None):
+        """A y[vars] = b (EqualityConstraints{A, b}); appends A.shape[0] multipliers."""
+        A = np.asarray(A, dtype=np.float64)
+        r_, m = A.shape
+        a = colmajor(A)
+        bb = f64(np.asarray(b).ravel())
+        v, vp_ = self._vars(vars_)
+        r = self.L.cxo_add_equality(self.h, r_, m, dp(a), dp(bb), vp_)
+        if r >= 0:
+            self.cons.append(("eq", r_, m + r_))
         return r
 
     def add_linear(self, A, c, vars_=None):
