@@ -316,7 +316,8 @@ __global__ void __launch_bounds__(64) soc_take_step(VecGroup g, StepArgs sa) {
 struct StaticGroup {
   int m;
   int count;
-  const double* Gc;  // count x (m x m)
+  const double* Gc;    // count x (m x m)
+  const double* AQc0;  // count x m constant AQc (equality constraints: [0; b], equality_constraint.cc:14-30)
   const int* ids;
 };
 
@@ -327,7 +328,7 @@ __global__ void static_schur(StaticGroup g, Arena ar) {
   for (int q = threadIdx.x; q < mm; q += blockDim.x) G[q] = src[q];
   for (int q = threadIdx.x; q < g.m; q += blockDim.x) {
     ar.AWc[ar.r_off[id] + q] = 0;
-    ar.AQcc[ar.r_off[id] + q] = 0;
+    ar.AQcc[ar.r_off[id] + q] = g.AQc0[(size_t)mem * g.m + q];
   }
   if (threadIdx.x == 0) {
     ar.sc[2 * id] = 0;

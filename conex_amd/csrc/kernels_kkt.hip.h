@@ -974,6 +974,232 @@ tree_sweep_block(FactorPlan P, int base0, double* __restrict__ slab, double* __r
 }
 
 // ---------------------------------------------------------------------------------------
+// LDLT path (programs with equality constraints: multipliers make the KKT matrix indefinite).
+// Reference: BlockLDLTInPlace block_triangular_operations.cc:315-349 over Eigen::RLDLT
+// (RLDLT.h:298-431: diagonal pivoting on the largest |diagonal|, left-looking column update,
+// pivots with |d| <= 1e-9 clamped to +-1e-9), solves ApplyBlockInverseOfMD :265-299 and
+// ApplyBlockInverseOfMTranspose :222-263.  One workgroup per supernode, panel in LDS
+// [diag ns x ns | off ns x s | rhs ns | temp ns]; `tr` holds the transpositions (local indices)
+// of every supernode by first permuted index.  Published updates:
+//   U[k][j] = sum_r (D_r off[r][k]) off[r][j]   with off = D^-1 L^-1 P off
+//   t[c]    = sum_r off[r][c] b_r               with b = L^-1 P b (D^-1 is applied afterwards)
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256)
+tree_sweep_block_ldlt(FactorPlan P, int base0, double* __restrict__ slab, double* __restrict__ rhs,
+                      int* __restrict__ tr_all, int* __restrict__ regularized) {
+  extern __shared__ double lds[];
+  __shared__ double s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ int s_piv;
+  const SnRec R = LoadRec(P.rec, base0 + blockIdx.x);
+  const int ns = R.ns, s = R.nsep, tid = threadIdx.x, nt = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  double* D = slab + R.diag_off;
+  double* B = slab + R.offd_off;
+  double* sD = lds;
+  double* sB = sD + ns * ns;
+  double* sb = sB + ns * s;
+  double* temp = sb + ns;
+  int* str = reinterpret_cast<int*>(temp + ns);  // LDS copy of the transpositions
+  int* tr = tr_all + R.start;
+  if (MODE == 2) {
+    for (int q = tid; q < ns * ns; q += nt) sD[q] = D[q];
+    for (int i = tid; i < ns; i += nt) {
+      double acc = rhs[R.start + i];
+      for (int q = R.bs_beg; q < R.bs_end; q++) acc -= B[i + (size_t)P.bs_c[q] * ns] * rhs[P.bs_row[q]];
+      sb[i] = acc;
+    }
+    __syncthreads();
+    for (int k = ns - 1; k >= 0; k--) {  // unit-lower-transposed solve
+      const double yk = sb[k];
+      for (int i = tid; i < k; i += nt) sb[i] = fma(-sD[k + i * ns], yk, sb[i]);
+      __syncthreads();
+    }
+    if (tid == 0)
+      for (int k = ns - 1; k >= 0; k--) {  // P^T
+        const int t = tr[k];
+        if (t != k) {
+          const double v = sb[k];
+          sb[k] = sb[t];
+          sb[t] = v;
+        }
+      }
+    __syncthreads();
+    for (int i = tid; i < ns; i += nt) rhs[R.start + i] = sb[i];
+    return;
+  }
+  const bool with_matrix = MODE == 0;
+  const bool with_rhs = rhs != nullptr;
+  {
+    const int nd = ns * ns, total = nd + ns * s;
+    for (int q = tid; q < total; q += nt) lds[q] = q < nd ? D[q] : B[q - nd];
+    if (with_rhs)
+      for (int i = tid; i < ns; i += nt) sb[i] = rhs[R.start + i];
+  }
+  if (!with_matrix)
+    for (int i = tid; i < ns; i += nt) str[i] = tr[i];
+  __syncthreads();
+  if (with_matrix)
+    for (int t = R.tg_beg + tid; t < R.tg_end; t += nt) {
+      const int loc = P.tg_loc[t];
+      double acc = lds[loc];
+      const int q1 = P.tr_ptr[t + 1];
+      for (int q = P.tr_ptr[t]; q < q1; q++) acc -= P.upd[P.tr_src[q]];
+      lds[loc] = acc;
+    }
+  if (with_rhs)
+    for (int i = tid; i < ns; i += nt) {
+      double acc = sb[i];
+      const int q1 = P.fs_ptr[R.start + i + 1];
+      for (int q = P.fs_ptr[R.start + i]; q < q1; q++) acc -= P.updb[P.fs_src[q]];
+      sb[i] = acc;
+    }
+  __syncthreads();
+  if (with_matrix) {
+    if (ns == 1) {  // RLDLT.h:311-330: clamps without reporting
+      if (tid == 0) {
+        if (fabs(sD[0]) < 1e-9) sD[0] = sD[0] < 0 ? -1e-9 : 1e-9;
+        tr[0] = 0;
+        str[0] = 0;
+      }
+      __syncthreads();
+    } else {
+      for (int k = 0; k < ns; k++) {
+        // first largest |diagonal| of the trailing part
+        double best = -1.0;
+        int bi = k;
+        for (int i = k + tid; i < ns; i += nt) {
+          const double v = fabs(sD[i + i * ns]);
+          if (v > best) {
+            best = v;
+            bi = i;
+          }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+          const double ov = __shfl_xor(best, off, 64);
+          const int oi = __shfl_xor(bi, off, 64);
+          if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+          }
+        }
+        if (lane == 0) {
+          s_val[wave] = best;
+          s_idx[wave] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          double b = s_val[0];
+          int p = s_idx[0];
+          for (int w = 1; w < (nt >> 6); w++)
+            if (s_val[w] > b || (s_val[w] == b && s_idx[w] < p)) {
+              b = s_val[w];
+              p = s_idx[w];
+            }
+          s_piv = p;
+          tr[k] = p;
+          str[k] = p;
+        }
+        __syncthreads();
+        const int big = s_piv;
+        if (big != k) {  // symmetric transposition on the lower triangle (RLDLT.h:343-362)
+          for (int j = tid; j < k; j += nt) {
+            const double t = sD[k + j * ns];
+            sD[k + j * ns] = sD[big + j * ns];
+            sD[big + j * ns] = t;
+          }
+          for (int i = big + 1 + tid; i < ns; i += nt) {
+            const double t = sD[i + k * ns];
+            sD[i + k * ns] = sD[i + big * ns];
+            sD[i + big * ns] = t;
+          }
+          for (int i = k + 1 + tid; i < big; i += nt) {
+            const double t = sD[i + k * ns];
+            sD[i + k * ns] = sD[big + i * ns];
+            sD[big + i * ns] = t;
+          }
+          if (tid == 0) {
+            const double t = sD[k + k * ns];
+            sD[k + k * ns] = sD[big + big * ns];
+            sD[big + big * ns] = t;
+          }
+          __syncthreads();
+        }
+        for (int j = tid; j < k; j += nt) temp[j] = sD[j + j * ns] * sD[k + j * ns];
+        __syncthreads();
+        for (int i = k + tid; i < ns; i += nt) {  // row k: the pivot; rows > k: A21
+          double acc = 0;
+          for (int j = 0; j < k; j++) acc += sD[i + j * ns] * temp[j];
+          sD[i + k * ns] -= acc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          const double akk = sD[k + k * ns];
+          if (!(fabs(akk) > 1e-9)) {
+            sD[k + k * ns] = akk < 0 ? -1e-9 : 1e-9;
+            atomicExch(regularized, 1);
+          }
+        }
+        __syncthreads();
+        const double akk = sD[k + k * ns];
+        for (int i = k + 1 + tid; i < ns; i += nt) sD[i + k * ns] /= akk;
+        __syncthreads();
+      }
+    }
+  }
+  // extra columns: off block (factor sweep only) and rhs.  One thread per column:
+  // P, then the unit-lower solve; off additionally scaled by D^-1.
+  const int ext = s + (with_rhs ? 1 : 0), c0 = with_matrix ? 0 : s;
+  for (int c = c0 + tid; c < ext; c += nt) {
+    double* col = c < s ? sB + c * ns : sb;
+    for (int k = 0; k < ns; k++) {
+      const int t = str[k];
+      if (t != k) {
+        const double v = col[k];
+        col[k] = col[t];
+        col[t] = v;
+      }
+    }
+    for (int j = 0; j < ns; j++) {
+      const double cj = col[j];
+      for (int i = j + 1; i < ns; i++) col[i] -= sD[i + j * ns] * cj;
+    }
+    if (c < s)
+      for (int r = 0; r < ns; r++) col[r] = (1.0 / sD[r + r * ns]) * col[r];
+  }
+  __syncthreads();
+  if (with_matrix) {
+    for (int q = tid; q < ns * ns; q += nt)
+      if (q % ns >= q / ns) D[q] = sD[q];
+    for (int q = tid; q < ns * s; q += nt) B[q] = sB[q];
+    const int* dst = P.pub_dst + R.upd_off;
+    const int npairs = s * (s + 1) / 2;
+    for (int t = tid; t < npairs; t += nt) {
+      int k = 0, rem = t;
+      while (rem >= s - k) {
+        rem -= s - k;
+        k++;
+      }
+      const int j = k + rem;
+      double dot = 0;
+      for (int r = 0; r < ns; r++) dot += (sD[r + r * ns] * sB[r + k * ns]) * sB[r + j * ns];
+      P.upd[dst[t]] = dot;
+    }
+  }
+  if (with_rhs) {
+    const int* dst = P.pubb_dst + R.updb_off;
+    for (int c = tid; c < s; c += nt) {
+      double dot = 0;
+      for (int r = 0; r < ns; r++) dot += sB[r + c * ns] * sb[r];
+      P.updb[dst[c]] = dot;
+    }
+    __syncthreads();
+    for (int i = tid; i < ns; i += nt) rhs[R.start + i] = (1.0 / sD[i + i * ns]) * sb[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Multi-GPU exchange.  Buffer layout, all doubles:
 //   [ T slab entries (n_xs) | AW_T (n_xv) | AQc_T (n_xv) | fwd_T (n_xv) | <w,c> | <c,Qc> | fail | pad ]
 // pack:   fold this rank's subtree updates into its PARTIAL top blocks (pre-reduce pulls), then

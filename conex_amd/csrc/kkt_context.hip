@@ -31,6 +31,7 @@ namespace {
 struct ConstraintRec {
   int type = 0, n = 0, m = 0;
   int herm_d = 0;  // Hermitian PSD over R/C/H: number of real planes d; n is then d * order
+  int eq_rows = 0; // CXK_STATIC built from EqualityConstraints: number of multipliers (last clique entries)
   std::vector<double> A, C;
   int group = -1, member = -1;
 };
@@ -118,6 +119,11 @@ struct cxk_context {
   FactorPlan plan{};
   // index of the next PrepareStep / eigenvalue query (keys the Hermitian start vectors)
   unsigned long long lanczos_calls = 0;
+  // equality constraints: next multiplier id, LDLT state (kkt_solver.cc:180-193)
+  int dual_start = -1;
+  bool use_ldlt = false;
+  DevBuf<int> d_tr, d_reg;
+  std::vector<double> y_at_prepare;  // lambda_ = y.tail(rows) is latched by PrepareStep
   // timing of the dominant (dense-LMI Schur) kernel
   bool timing = false;
   int timing_period = 1, timing_tick = 0;  // hipEvents bracket every timing_period-th launch
@@ -216,6 +222,7 @@ StaticGroup MakeStatic(Group& g) {
   d.m = g.m;
   d.count = static_cast<int>(g.ids.size());
   d.Gc = g.A.p;
+  d.AQc0 = g.C.p;
   d.ids = g.dids.p;
   return d;
 }
@@ -709,7 +716,7 @@ int BuildPlans(cxk_context* ctx) {
         ctx->level_sn.push_back(e);
         if (ns[e] > 32 || nsep[e] > 16) ctx->level_big[l] = 1;
         ctx->chol_lds = std::max(ctx->chol_lds, sizeof(double) * ((size_t)ns[e] * ns[e] +
-                                                                   (size_t)ns[e] * nsep[e] + ns[e]));
+                                                                   (size_t)ns[e] * nsep[e] + 3 * (size_t)ns[e] + 2));
       }
     ctx->level_ptr[l + 1] = (int)ctx->level_sn.size();
   }
@@ -753,6 +760,7 @@ int BuildPlans(cxk_context* ctx) {
     int top = nlev;
     while (top > 0 && ctx->level_ptr[top] - ctx->level_ptr[top - 1] <= 8 && !ctx->level_big[top - 1]) top--;
     if (sharded) top = std::max(top, ctx->cut_level);
+    if (ctx->use_ldlt) top = nlev;  // LDLT sweeps run level by level, one workgroup per supernode
     ctx->top_level = top;
   }
   CXK_TRY(ctx->p_ns.upload(ns));
@@ -803,6 +811,9 @@ hipError_t RaiseLdsLimits() {
         reinterpret_cast<const void*>(&tree_sweep_block<0>),
         reinterpret_cast<const void*>(&tree_sweep_block<1>),
         reinterpret_cast<const void*>(&tree_sweep_block<2>),
+        reinterpret_cast<const void*>(&tree_sweep_block_ldlt<0>),
+        reinterpret_cast<const void*>(&tree_sweep_block_ldlt<1>),
+        reinterpret_cast<const void*>(&tree_sweep_block_ldlt<2>),
         reinterpret_cast<const void*>(&soc_schur),
     };
     for (const void* k : ks) {
@@ -936,6 +947,19 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
     grid = (maxcnt + waves - 1) / waves;
   }
   const bool is_top = le - lb > 1 || then_backward;
+  if (ctx->use_ldlt) {
+    CXK_DEMAND(!is_top, "internal error: LDLT sweeps are launched level by level");
+    double* r = (with_rhs || mode != 0) ? ctx->y.p : nullptr;
+    const int base = ctx->level_ptr[lb];
+    if (mode == 0)
+      tree_sweep_block_ldlt<0><<<maxcnt, 256, ctx->chol_lds, ctx->stream>>>(ctx->plan, base, ctx->slab.p, r, ctx->d_tr.p, ctx->d_reg.p);
+    else if (mode == 1)
+      tree_sweep_block_ldlt<1><<<maxcnt, 256, ctx->chol_lds, ctx->stream>>>(ctx->plan, base, ctx->slab.p, r, ctx->d_tr.p, ctx->d_reg.p);
+    else
+      tree_sweep_block_ldlt<2><<<maxcnt, 256, ctx->chol_lds, ctx->stream>>>(ctx->plan, base, ctx->slab.p, r, ctx->d_tr.p, ctx->d_reg.p);
+    CXK_TRY(hipGetLastError());
+    return CXK_SUCCESS;
+  }
   if (!is_top && ctx->level_big[lb]) {  // one workgroup per supernode
     double* r = (with_rhs || mode != 0) ? ctx->y.p : nullptr;
     const int base = ctx->level_ptr[lb];
@@ -969,6 +993,7 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
 // Bottom-up pass (mode 0 factor or mode 1 forward), optionally continuing straight into the
 // top-down backward pass.  The narrow top of the tree is one launch.
 int LaunchTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
+  if (ctx->use_ldlt && mode == 0) CXK_TRY(hipMemsetAsync(ctx->d_reg.p, 0, sizeof(int), ctx->stream));
   const int nlev = (int)ctx->level_ptr.size() - 1;
   const int top = ctx->top_level;
   for (int l = 0; l < top; l++)
@@ -1117,6 +1142,45 @@ int cxk_add_static(cxk_context* ctx, int m, const double* G, const int* vars) {
   return AddConstraint(ctx, std::move(r), vars);
 }
 
+int cxk_add_equality(cxk_context* ctx, int rows, int m, const double* A, const double* b,
+                     const int* vars) {
+  if (!ctx || rows < 1 || m < 1 || !A || !b) return -1;
+  const int mt = m + rows;
+  ConstraintRec r;
+  r.type = CXK_STATIC;  // constant Schur block [0 A^T; A 0], constant AQc = [0; b]
+  r.n = 0;
+  r.m = m;              // AddConstraint validates the user variables; multipliers appended below
+  r.eq_rows = rows;
+  r.A.assign((size_t)mt * mt, 0.0);
+  r.C.assign((size_t)mt, 0.0);
+  for (int j = 0; j < m; j++)
+    for (int i = 0; i < rows; i++) {
+      const double a = A[(size_t)j * rows + i];
+      r.A[(size_t)j * mt + (m + i)] = a;
+      r.A[(size_t)(m + i) * mt + j] = a;
+    }
+  for (int i = 0; i < rows; i++) r.C[m + i] = b[i];
+  const int id = AddConstraint(ctx, std::move(r), vars);
+  if (id < 0) return id;
+  if (ctx->dual_start < 0) ctx->dual_start = ctx->num_vars;
+  for (int i = 0; i < rows; i++) {  // constraint_manager.h:66-90
+    ctx->cliques[id].push_back(ctx->dual_start + i);
+    ctx->dual_vars[id].push_back(ctx->dual_start + i);
+  }
+  ctx->dual_start += rows;
+  ctx->cons[id].m = mt;
+  return id;
+}
+
+int cxk_factor_regularized(cxk_context* ctx, int* flag) {
+  if (!ctx || !flag) return CXK_FAILURE;
+  *flag = 0;
+  if (!ctx->use_ldlt || !ctx->d_reg.p) return CXK_SUCCESS;
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(flag, ctx->d_reg.p, sizeof(int), hipMemcpyDeviceToHost));
+  return CXK_SUCCESS;
+}
+
 int cxk_num_constraints(const cxk_context* ctx) { return ctx ? (int)ctx->cons.size() : 0; }
 
 int cxk_set_shard(cxk_context* ctx, int rank, int world_size) {
@@ -1192,6 +1256,7 @@ int cxk_finalize(cxk_context* ctx) {
         break;
       case CXK_STATIC:
         a_sz = (size_t)g.m * g.m;
+        c_sz = (size_t)g.m;  // constant AQc (zeros for a quadratic-cost block)
         break;
     }
     std::vector<double> hA(a_sz * cnt), hC(c_sz * cnt);
@@ -1233,6 +1298,14 @@ int cxk_finalize(cxk_context* ctx) {
   CXK_TRY(ctx->red_out.alloc(4));
   CXK_TRY(ctx->scal_out.alloc(8));
   CXK_TRY(ctx->d_fail.alloc(1));
+  ctx->use_ldlt = false;
+  for (const IntList& dv : ctx->dual_vars)
+    if (!dv.empty()) ctx->use_ldlt = true;  // kkt_solver.cc:180-186
+  if (ctx->use_ldlt) {
+    CXK_DEMAND(ctx->world == 1, "equality constraints (LDLT path) are single-GPU for now");
+    CXK_TRY(ctx->d_tr.alloc(N));
+    CXK_TRY(ctx->d_reg.alloc(1));
+  }
   {
     // per-constraint step outputs; constraints without a cone (constant blocks) keep the
     // reference's defaults: StepInfo {0,0}; WeightedSlackEigenvalues {min=DBL_MAX,max=-DBL_MAX,0,0}
@@ -1308,6 +1381,7 @@ int cxk_dual_size(const cxk_context* ctx, int i) {
     case CXK_LMI: return c.herm_d ? (c.n / c.herm_d) * (c.n / c.herm_d) * c.herm_d : c.n * c.n;
     case CXK_LINEAR: return c.n;
     case CXK_SOC: return c.n + 1;
+    case CXK_STATIC: return c.eq_rows;  // lambda_ of an equality block; 0 for a quadratic cost
     default: return 0;
   }
 }
@@ -1333,6 +1407,13 @@ int cxk_get_W(cxk_context* ctx, int i, double* out) {
   const ConstraintRec& c = ctx->cons[i];
   const size_t sz = (size_t)cxk_dual_size(ctx, i);
   if (sz == 0) return CXK_SUCCESS;
+  if (c.type == CXK_STATIC) {  // multipliers latched by the last PrepareStep (equality_constraint.cc:32-37)
+    CXK_DEMAND(!ctx->y_at_prepare.empty(), "no PrepareStep has run yet");
+    const IntList& cl = ctx->cliques[i];
+    for (int q = 0; q < c.eq_rows; q++)
+      out[q] = ctx->y_at_prepare[ctx->md.permutation[cl[cl.size() - c.eq_rows + q]]];
+    return CXK_SUCCESS;
+  }
   CXK_TRY(hipStreamSynchronize(ctx->stream));
   if (c.herm_d) {  // device holds the real representation; the interface speaks planes
     const size_t NN = (size_t)c.n * c.n;
@@ -1352,7 +1433,7 @@ int cxk_set_W(cxk_context* ctx, int i, const double* in) {
   CXK_DEMAND(i >= 0 && i < (int)ctx->cons.size() && ctx->cons[i].group >= 0, "invalid constraint");
   const ConstraintRec& c = ctx->cons[i];
   const size_t sz = (size_t)cxk_dual_size(ctx, i);
-  if (sz == 0) return CXK_SUCCESS;
+  if (sz == 0 || c.type == CXK_STATIC) return CXK_SUCCESS;  // multipliers are outputs only
   CXK_TRY(hipStreamSynchronize(ctx->stream));
   if (c.herm_d) {
     const size_t NN = (size_t)c.n * c.n;
@@ -1496,6 +1577,11 @@ int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_wei
           MakeVec(g), sa);
   }
   CXK_TRY(hipGetLastError());
+  if (ctx->use_ldlt) {  // lambda_ = y.tail(rows) (equality_constraint.cc:32-37)
+    ctx->y_at_prepare.resize(ctx->md.N);
+    CXK_TRY(hipStreamSynchronize(ctx->stream));
+    CXK_TRY(hipMemcpy(ctx->y_at_prepare.data(), ctx->y.p, sizeof(double) * ctx->md.N, hipMemcpyDeviceToHost));
+  }
   if (affine) return CXK_SUCCESS;
   reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), 0, ctx->info2.p, ctx->d_mask.p,
                                                ctx->red_out.p);

@@ -35,6 +35,8 @@ _SIGNATURES = {
     "cxk_add_lmi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
     "cxk_add_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
     "cxk_add_soc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
+    "cxk_add_equality": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
+    "cxk_factor_regularized": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "cxk_add_hermitian": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p,
                                     c_int_p]),
     "cxk_add_static": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_int_p]),
@@ -189,6 +191,23 @@ class KktContext:
         if r >= 0:
             self.cons.append(("herm", n, m, d))
         return r
+
+    def add_equality(self, A, b, vars_=None):
+        """A y[vars] = b; appends A.shape[0] multipliers and switches the solver to LDLT."""
+        A = np.asarray(A, dtype=np.float64)
+        rows, m = A.shape
+        a = _colmajor(A)
+        bb = np.ascontiguousarray(np.asarray(b, dtype=np.float64).ravel())
+        keep, vp = self._vars(vars_)
+        r = self.L.cxk_add_equality(self.h, rows, m, _dp(a), _dp(bb), vp)
+        if r >= 0:
+            self.cons.append(("eq", rows, m + rows))
+        return r
+
+    def factor_regularized(self):
+        f = C.c_int(0)
+        self._check(self.L.cxk_factor_regularized(self.h, C.byref(f)), "cxk_factor_regularized")
+        return f.value
 
     def add_soc(self, A, c, vars_=None):
         A = np.asarray(A, dtype=np.float64)

@@ -59,6 +59,17 @@ int cxk_add_lmi(cxk_context* ctx, int n, int m, const double* A /* m x (n x n) *
  * Lanczos, hermitian_psd.cc:10-91).  d = 8 (octonions) is rejected. */
 int cxk_add_hermitian(cxk_context* ctx, int n, int d, int m, const double* A, const double* C,
                       const int* vars);
+/* Program::AddConstraint(EqualityConstraints{A, b}, vars) -> ConstraintManager::
+ * AddEqualityConstraint (constraint_manager.h:66-90, equality_constraint.{h,cc}): A y[vars] = b,
+ * A rows x m column-major.  Appends `rows` multipliers to the KKT system (cxk_system_size grows);
+ * the Schur block is the constant [0 A^T; A 0] with AQc = [0; b].  Any equality switches
+ * cxk_factor / the solves to the LDLT path (BlockLDLTInPlace block_triangular_operations.cc:
+ * 315-349 over Eigen::RLDLT, RLDLT.h:298-431; kkt_solver.cc:180-193): factor always reports ok,
+ * cxk_factor_regularized tells whether a pivot was clamped to +-1e-9.  cxk_get_W returns the
+ * multipliers latched by the last cxk_prepare_step (lambda_, equality_constraint.cc:32-37). */
+int cxk_add_equality(cxk_context* ctx, int rows, int m, const double* A /* rows x m */,
+                     const double* b /* rows */, const int* vars);
+int cxk_factor_regularized(cxk_context* ctx, int* flag);
 int cxk_add_linear(cxk_context* ctx, int rows, int m, const double* A /* rows x m */,
                    const double* c /* rows */, const int* vars);
 int cxk_add_soc(cxk_context* ctx, int n, int m, const double* A /* (n+1) x m */,

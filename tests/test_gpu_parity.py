@@ -221,6 +221,69 @@ def test_hermitian_affine_update_and_identity():
         assert rel(k.get_W(i), o.get_W(i)) <= 1e-13
 
 
+# --------------------------------------------------------------------- equalities / LDLT (B8, B10)
+def eq_pair(seed, kind):
+    """LP or chordal-LMI program plus equality blocks, built identically on both sides."""
+    rng = np.random.default_rng(seed)
+    if kind == "lp":
+        nv = 8
+        A = rng.uniform(-1, 1, (14, nv))
+        c = np.abs(rng.uniform(0.5, 1.5, 14))
+        eqs = [(rng.uniform(-1, 1, (3, nv)), rng.uniform(-1, 1, 3), None)]
+        b = rng.uniform(-1, 1, nv)
+
+        def build(cls, **kw):
+            p = cls(nv, **kw)
+            p.add_linear(A, c)
+            for Ae, be, v in eqs:
+                p.add_equality(Ae, be, v)
+            p.initialize()
+            return p
+        W = None
+    else:
+        prob = syn.lmi_problem(K=12, n=6, m=6, branching=3, overlap=2, seed=seed)
+        nv = prob["num_vars"]
+        b = prob["b"]
+        # one coupling equality on the root clique and two on leaf cliques
+        eqs = [(rng.uniform(-1, 1, (2, 6)), rng.uniform(-0.1, 0.1, 2), prob["cliques"][0]),
+               (rng.uniform(-1, 1, (1, 6)), rng.uniform(-0.1, 0.1, 1), prob["cliques"][7]),
+               (rng.uniform(-1, 1, (1, 3)), rng.uniform(-0.1, 0.1, 1), prob["cliques"][11][:3])]
+
+        def build(cls, **kw):
+            p = cls(nv, **kw)
+            for ci, cl in enumerate(prob["cliques"]):
+                p.add_lmi(prob["A"][ci], prob["C"][ci], cl)
+            for Ae, be, v in eqs:
+                p.add_equality(Ae, be, v)
+            p.initialize()
+            return p
+        W = syn.scaling_points(12, 6, seed=seed + 1)
+    o, k = build(ol.Program), build(KktContext, device=0)
+    if W is not None:
+        for i in range(len(W)):
+            o.set_W(i, W[i])
+            k.set_W(i, W[i])
+    return o, k, b
+
+
+@pytest.mark.parametrize("kind,seed", [("lp", 1), ("lp", 2), ("lmi", 3), ("lmi", 4)])
+def test_equality_constraints_ldlt_newton_step(kind, seed):
+    """Multipliers make the KKT matrix indefinite: block LDLT with diagonal pivoting
+    (BlockLDLTInPlace over Eigen::RLDLT) and its solves, against the oracle."""
+    o, k, b = eq_pair(seed, kind)
+    assert k.N == o.N > len(b)
+    check_newton_step(o, k, b, check_update=(kind == "lmi"))
+    assert k.factor_regularized() == 0
+
+
+def test_equality_multipliers_are_latched_by_prepare_step():
+    o, k, b = eq_pair(5, "lp")
+    y = np.random.default_rng(1).uniform(-1, 1, o.N)
+    o.prepare_step(y, 0.3, 1.0)
+    k.prepare_step(y, 0.3, 1.0)
+    assert np.array_equal(k.get_W(1), o.get_W(1)) and len(k.get_W(1)) == 3
+
+
 # --------------------------------------------------------------------- LP (C1)
 def test_c1_lp_newton_steps():
     prob = syn.lp_problem(rows=20, num_vars=10)
