@@ -42,7 +42,7 @@ bool Verbose() {
   return g_verbose == 1;
 }
 
-enum ConeKind { kLmi, kLinear, kSoc, kQuadCost };
+enum ConeKind { kLmi, kLinear, kSoc, kQuadCost, kEquality };
 
 struct Cone {
   ConeKind kind = kLmi;
@@ -204,6 +204,14 @@ int BuildContext(Program* p) {
       case kQuadCost:
         id = cxk_add_static(p->ctx, m, c.A.data(), c.vars.data());
         break;
+      case kEquality: {
+        std::vector<double> A((size_t)c.order * m, 0.0);
+        for (int j = 0; j < m && j < c.cols; j++)
+          std::copy(c.A.begin() + (size_t)j * c.order, c.A.begin() + (size_t)(j + 1) * c.order,
+                    A.begin() + (size_t)j * c.order);
+        id = cxk_add_equality(p->ctx, c.order, m, A.data(), c.c.data(), c.vars.data());
+        break;
+      }
     }
     CONEX_DEMAND(id >= 0, "constraint rejected while building the device program");
   }
@@ -575,15 +583,18 @@ int CONEX_AddLinearInequalities(void* x, const double* A, int Ar, int Ac, const 
   Program* p = static_cast<Program*>(x);
   if (!p || Ar != num_lb || Ar != num_ub) return -1;
   // PreprocessLinearInequality linear_constraint.cc:14-46
-  std::vector<std::vector<double>> rows;
-  std::vector<double> rhs;
+  std::vector<std::vector<double>> rows, eq_rows;
+  std::vector<double> rhs, eq_rhs;
   for (int i = 0; i < Ar; i++) {
     double n2 = 0;
     for (int j = 0; j < Ac; j++) n2 += A[i + (size_t)j * Ar] * A[i + (size_t)j * Ar];
-    if (lb[i] == ub[i]) {
-      fprintf(stderr, "%s line %d: %s\n", __FILE__, __LINE__,
-              "equality rows (lb == ub) need the LDLT path, which is not on the device yet.");
-      return -1;
+    if (lb[i] == ub[i]) {  // equality row: scaled like the others, goes to EqualityConstraints
+      const double scale = 1.0 / std::sqrt(n2 + ub[i] * ub[i]);
+      std::vector<double> r(Ac);
+      for (int j = 0; j < Ac; j++) r[j] = scale * A[i + (size_t)j * Ar];
+      eq_rows.push_back(r);
+      eq_rhs.push_back(scale * ub[i]);
+      continue;
     }
     if (ub[i] < 1e8) {
       const double scale = 1.0 / std::sqrt(n2 + ub[i] * ub[i]);
@@ -614,6 +625,22 @@ int CONEX_AddLinearInequalities(void* x, const double* A, int Ar, int Ac, const 
     for (int i = 0; i < k.order; i++)
       for (int j = 0; j < Ac; j++) k.A[i + (size_t)j * k.order] = rows[i][j];
     k.c = rhs;
+    AddCone(p, std::move(k));
+  }
+  if (!eq_rows.empty()) {  // program.AddConstraint(EqualityConstraints(Aeq, beq)) conex.cc:209-211
+    if (p->num_vars == 0) {
+      p->num_vars = Ac;
+      p->linear_cost.assign(Ac, 0.0);
+    }
+    Cone k;
+    k.kind = kEquality;
+    k.order = static_cast<int>(eq_rows.size());
+    k.cols = Ac;
+    k.vars = AllVars(*p);
+    k.A.assign((size_t)k.order * Ac, 0.0);
+    for (int i = 0; i < k.order; i++)
+      for (int j = 0; j < Ac; j++) k.A[i + (size_t)j * k.order] = eq_rows[i][j];
+    k.c = eq_rhs;
     AddCone(p, std::move(k));
   }
   return -1;  // interfaces/conex.cc:213-214
@@ -749,6 +776,7 @@ CONEX_STATUS CONEX_UpdateLinearOperator(void* x, int constraint, double value, i
       break;
     }
     case kQuadCost:
+    case kEquality:  // constraint.h:13-18 default: not supported
       CONEX_DEMAND(false, "Constraint does not support updates of linear operator.");
   }
   p->dirty = true;
@@ -798,6 +826,8 @@ CONEX_STATUS CONEX_UpdateAffineTerm(void* x, int constraint, double value, int r
         k.A[row + (size_t)col * m] = value;
       }
       break;
+    case kEquality:  // constraint.h:20-24 default: not supported
+      CONEX_DEMAND(false, "Constraint does not support updates of affine term.");
   }
   p->dirty = true;
   return CONEX_SUCCESS;

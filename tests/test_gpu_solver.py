@@ -147,6 +147,39 @@ def test_octonion_lmi_is_rejected_loudly():
     L.CONEX_DeleteConeProgram(p)
 
 
+def test_linear_inequalities_with_equality_rows_take_the_ldlt_path():
+    """CONEX_AddLinearInequalities with lb == ub rows (interfaces/conex.cc:190-215,
+    PreprocessLinearInequality linear_constraint.cc:14-46): the equality rows become an
+    EqualityConstraints block with multipliers and the solver factors with LDLT.  Checked against
+    the oracle's restatement and the properties of equality_constraints_test.cc:11-52."""
+    rng = np.random.default_rng(21)
+    nv, nin, neq = 6, 12, 2
+    A = rng.uniform(-1, 1, (nin + neq, nv))
+    y_opt = rng.uniform(-1, 1, nv)
+    slack = np.r_[np.zeros(nin // 2), np.ones(nin - nin // 2)]
+    dual = np.r_[np.ones(nin // 2), np.zeros(nin - nin // 2)]
+    ub = np.r_[slack + A[:nin] @ y_opt, A[nin:] @ y_opt]
+    lb = np.r_[np.full(nin, -1e9), A[nin:] @ y_opt]          # last rows: lb == ub
+    cost = A[:nin].T @ dual
+    L = ca.api()
+    p = L.CONEX_CreateConeProgram()
+    assert L.CONEX_SetNumberOfVariables(p, nv) == 0
+    assert L.CONEX_AddLinearInequalities(p, ca.dp(ca.colmajor(A)), nin + neq, nv, ca.dp(lb), nin + neq,
+                                         ca.dp(ub), nin + neq) == -1          # conex.cc:213-214
+    ok, y = _maximize(L, p, cost)
+    # oracle: same preprocessing by hand
+    sc = 1.0 / np.sqrt(np.sum(A * A, axis=1) + ub * ub)
+    o = ol.Program(nv)
+    o.add_linear(A[:nin] * sc[:nin, None], ub[:nin] * sc[:nin])
+    o.add_equality(A[nin:] * sc[nin:, None], ub[nin:] * sc[nin:])
+    oko, yo = o.solve(cost)
+    assert ok == oko == 1
+    assert np.allclose(y, yo, rtol=1e-7, atol=1e-9)
+    assert np.linalg.norm(A[nin:] @ y - ub[nin:]) <= 1e-5
+    assert np.linalg.norm(y - y_opt) <= 1e-4
+    L.CONEX_DeleteConeProgram(p)
+
+
 def test_sdp_mixed_literal():
     """test_sdp.cc:13-59: S == ones(2,2) to 1e-6."""
     L = ca.api()
