@@ -764,35 +764,60 @@ __device__ inline void BackwardSupernodeLds(const FactorPlan& P, int p,
 }
 
 // MODE 0: factor (+ forward if rhs), MODE 1: forward only, MODE 2: backward.
-// TOP = false: one level per launch, positions [base0, base0 + cnt0) of the level lists, one
-// wavefront per supernode.  TOP = true: levels [lb, le) ascending (MODE 0/1; MODE 2 walks the
-// range downwards), optionally continuing into the backward sweep, in ONE workgroup: levels are
-// then separated by a workgroup barrier instead of a kernel boundary.
+// TOP = false: one level per launch, positions [base0, base0 + cnt0) of the level-ordered
+// records, one wavefront per supernode.
+// TOP = true: a RANGE of `nl` consecutive levels per launch.  Workgroup g sweeps one connected
+// piece of the elimination forest restricted to those levels (a subtree, or the whole top of
+// the tree): its records are stored level by level, wg_lev[g * (nl + 1) + l] is the first
+// position of its level l.  Levels inside the workgroup are separated by a workgroup barrier
+// instead of a kernel boundary; MODE 0/1 walk them upwards and (then_backward) straight back
+// down, MODE 2 walks them downwards.  The records of the piece are prefetched into LDS with one
+// load at kernel start, so a level step pays one memory round trip (its data) instead of two.
 // The kernel is specialised per (MODE, TOP) so that each instance keeps only the plan fields it
 // uses in SGPRs.
+constexpr int kRangeMaxRecs = 96;  // records of one workgroup's piece held in LDS (12 KB)
+
 template <int MODE, bool TOP>
 __global__ void __launch_bounds__(512)
-tree_sweep(FactorPlan P, const int* __restrict__ level_ptr, int base0, int cnt0, int lb, int le,
-           int then_backward, double* __restrict__ slab, double* __restrict__ rhs,
+tree_sweep(FactorPlan P, const SnRec* __restrict__ recs, const int* __restrict__ wg_lev, int base0,
+           int cnt0, int nl, int then_backward, double* __restrict__ slab, double* __restrict__ rhs,
            int* __restrict__ fail, int lds_per_wave) {
   extern __shared__ double lds[];
+  __shared__ int s_rec[TOP ? kRangeMaxRecs * 32 : 32];
   // wave-uniform values are forced into SGPRs: otherwise every loop bound / lane select below
   // is treated as divergent (waterfall loops around v_readlane, vector address arithmetic)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   double* my = lds + (size_t)wave * lds_per_wave;
-  CXK_STAMP_SELECT(lb, MODE);
+  CXK_STAMP_SELECT(TOP ? 1 : 0, MODE);
   CXK_STAMP(6);
   CXK_STAMPB(0);
-  if constexpr (!TOP) {
-    le = lb + 1;
+  const int* lp = nullptr;
+  int first = base0;
+  bool prefetched = false;
+  if constexpr (TOP) {
+    lp = wg_lev + (size_t)blockIdx.x * (nl + 1);
+    first = lp[0];
+    const int nrec = lp[nl] - first;
+    prefetched = nrec <= kRangeMaxRecs;  // a long narrow top (chain-shaped trees) reads from HBM
+    if (prefetched) {
+      const int* src = reinterpret_cast<const int*>(recs + first);
+      for (int q = threadIdx.x; q < nrec * 32; q += blockDim.x) s_rec[q] = src[q];
+    }
+    __syncthreads();
+  } else {
+    nl = 1;
     then_backward = 0;
   }
+  auto load_rec = [&](int pos) -> SnRec {
+    if (TOP && prefetched) return LoadRec(reinterpret_cast<const SnRec*>(s_rec), pos - first);
+    return LoadRec(recs, pos);
+  };
   if constexpr (MODE != 2) {
-    for (int l = lb; l < le; l++) {
-      const int base = (!TOP || l == lb) ? base0 : level_ptr[l];
-      const int cnt = (!TOP || l == lb) ? cnt0 : level_ptr[l + 1] - base;
-      for (int idx = blockIdx.x * nw + wave; idx < cnt; idx += gridDim.x * nw) {
-        const SnRec R = LoadRec(P.rec, base + idx);
+    for (int l = 0; l < nl; l++) {
+      const int base = TOP ? lp[l] : base0;
+      const int cnt = TOP ? lp[l + 1] - base : cnt0;
+      for (int idx = (TOP ? 0 : blockIdx.x * nw) + wave; idx < cnt; idx += (TOP ? 1 : gridDim.x) * nw) {
+        const SnRec R = load_rec(base + idx);
         const int ns = R.ns, s = R.nsep;
         if constexpr (MODE == 0) {
           if (ns <= 16 && s <= 8)
@@ -816,11 +841,11 @@ tree_sweep(FactorPlan P, const int* __restrict__ level_ptr, int base0, int cnt0,
     }
   }
   if (MODE == 2 || (TOP && then_backward)) {
-    for (int l = le - 1; l >= lb; l--) {
-      const int base = (!TOP || l == lb) ? base0 : level_ptr[l];
-      const int cnt = (!TOP || l == lb) ? cnt0 : level_ptr[l + 1] - base;
-      for (int idx = blockIdx.x * nw + wave; idx < cnt; idx += gridDim.x * nw) {
-        const SnRec R = LoadRec(P.rec, base + idx);
+    for (int l = nl - 1; l >= 0; l--) {
+      const int base = TOP ? lp[l] : base0;
+      const int cnt = TOP ? lp[l + 1] - base : cnt0;
+      for (int idx = (TOP ? 0 : blockIdx.x * nw) + wave; idx < cnt; idx += (TOP ? 1 : gridDim.x) * nw) {
+        const SnRec R = load_rec(base + idx);
         const int ns = R.ns, s = R.nsep;
         if (ns <= 16 && s <= 8)
           BackwardSupernodeRows<16, 8>(P, R, slab, rhs);
