@@ -1287,6 +1287,84 @@ static double mu_from_divergence(cxo_program* p, const double* AQc_s, double c_w
   if (g_verbose) printf(#name ": %.2e, ", (double)(val));
 
 /* conex::Solve cone_program.cc:235-552 */
+/* PerformLineSearch(LinearConstraint*) + FindMinimumMu linear_constraint.cc:48-103.
+ * Returns failure (1) when the admissible interval is empty. */
+static int lin_line_search(cxo_constraint* o, double c0_weight, double c1_weight, double dinfmax,
+                           const double* y0, const double* y1, double* lower, double* upper) {
+  int r = o->n;
+  double* d0 = o->temp1;
+  double* d1 = o->temp2;
+  lin_negative_slack(o, c0_weight, y0, d0);
+  for (int i = 0; i < r; i++) d0[i] = d0[i] * o->W[i];
+  for (int i = 0; i < r; i++) d0[i] += 1;
+  lin_negative_slack(o, c1_weight, y1, d1);
+  for (int i = 0; i < r; i++) d1[i] = d1[i] * o->W[i];
+  for (int i = 0; i < r; i++) d1[i] += 1;
+  for (int i = 0; i < r; i++) d1[i] = d1[i] - d0[i];
+  double ub = *upper, lb = *lower;
+  for (int i = 0; i < r; i++) {
+    double ubi = (dinfmax - d0[i]) / d1[i];
+    double lbi = (-dinfmax - d0[i]) / d1[i];
+    if (lbi > ubi) {
+      double t = ubi;
+      ubi = lbi;
+      lbi = t;
+    }
+    if (ubi < ub || i == 0) ub = ubi;
+    if (lbi > lb || i == 0) lb = lbi;
+  }
+  *upper = ub;
+  *lower = lb;
+  return lb > ub;
+}
+
+/* ComputeMuFromLineSearch cone_program.cc:118-160.  y0 is the caller's iterate vector and is
+ * overwritten, as in the reference. */
+static double mu_from_line_search(cxo_program* p, double dinf_upper_bound, const double* AQc_s,
+                                  double c_weight, const double* b_s, double* y0) {
+  int N = p->md->N;
+  for (int q = 0; q < N; q++) y0[q] = -2 * p->sysAW[q];
+  cxo_solve_inplace(p, y0);
+  double* y1 = (double*)malloc(sizeof(double) * (size_t)N);
+  for (int q = 0; q < N; q++) y1[q] = AQc_s[q] + b_s[q] - 2 * p->sysAW[q];
+  cxo_solve_inplace(p, y1);
+  double c0 = c_weight * 0, c1 = c_weight * 1;
+  double out_lb = -DBL_MAX, out_ub = DBL_MAX;
+  int maxm = 1;
+  for (int i = 0; i < p->K; i++)
+    if (p->c[i].m > maxm) maxm = p->c[i].m;
+  double* z1 = (double*)malloc(sizeof(double) * (size_t)maxm);
+  double* z2 = (double*)malloc(sizeof(double) * (size_t)maxm);
+  double result = 0;
+  int failed = 0;
+  for (int i = 0; i < p->K && !failed; i++) {
+    cxo_constraint* c = &p->c[i];
+    gather_vars(p, i, y0, z1);
+    gather_vars(p, i, y1, z2);
+    double lb = -DBL_MAX, ub = DBL_MAX; /* LineSearchOutput output_i */
+    switch (c->type) {
+      case CXO_LINEAR: failed = lin_line_search(c, c0, c1, dinf_upper_bound, z1, z2, &lb, &ub); break;
+      case CXO_STATIC:   /* quadratic_cost.cc:59-65 */
+      case CXO_EQUALITY: /* equality_constraint.h:49-54 */
+        break;
+      default: /* constraint.h:24-28: "Constraint does not support line search." -> failure */
+        failed = 1;
+        break;
+    }
+    if (failed) break;
+    if (lb > out_lb) out_lb = lb;
+    if (ub < out_ub) out_ub = ub;
+  }
+  if (failed)
+    result = -1;
+  else
+    result = out_lb <= out_ub ? out_ub : -1;
+  free(y1);
+  free(z1);
+  free(z2);
+  return result;
+}
+
 int cxo_solve(cxo_program* p, const double* bin, const cxo_config* cfg, double* yout) {
   int m = p->num_vars;
   p->solved = 0;
@@ -1297,9 +1375,14 @@ int cxo_solve(cxo_program* p, const double* bin, const cxo_config* cfg, double* 
     for (int i = 0; i < m; i++) yout[i] = bin[i] * INFINITY;
     return 0;
   }
-  if (cfg->enable_line_search) {
-    fprintf(stderr, "conex oracle: line search not restated\n");
-    return 0;
+  { /* cone_program.cc:237-240: quadratic costs need the line search and no rescaling */
+    int quad = 0;
+    for (int i = 0; i < p->K; i++)
+      if (p->c[i].type == CXO_STATIC) quad = 1;
+    if (quad && !(cfg->enable_line_search && !cfg->enable_rescaling)) {
+      fprintf(stderr, "Must enable line search and disable rescaling for problems with quadratic costs.\n");
+      return 0;
+    }
   }
   /* Initialize :78-112 */
   if (!p->initialized || cfg->initialization_mode == 0) {
@@ -1379,7 +1462,11 @@ int cxo_solve(cxo_program* p, const double* bin, const cxo_config* cfg, double* 
         AQc_s[q] = p->sysAQc[q] * cs;
         b_s[q] = b[q] * bs;
       }
-      temp = mu_from_divergence(p, AQc_s, cs, b_s, cfg, rankK, y);
+      if (cfg->enable_line_search) { /* cone_program.cc:376-384 */
+        temp = mu_from_line_search(p, cfg->dinf_upper_bound, AQc_s, cs, b_s, y);
+        if (temp < 0) temp = inv_sqrt_mu;
+      }
+      if (temp < 0) temp = mu_from_divergence(p, AQc_s, cs, b_s, cfg, rankK, y);
       if (temp > 0)
         inv_sqrt_mu = temp;
       else

@@ -491,3 +491,56 @@ def test_lp_dense_random(oracle):
         assert slack @ x >= -eps
         mu = 1.0 / (cfg.inv_sqrt_mu_max ** 2)
         assert slack @ x <= (mu + np.sqrt(eps)) * nc
+
+
+# ----------------------------------------------------------------- quadratic cost / line search
+def qp_with_solution(n, num_ineqs, seed):
+    """quadratic_objective_test.cc:95-125 ProblemDataWithSolution (seeded numpy instead of rand())."""
+    rng = np.random.default_rng(seed)
+    lam = np.zeros(num_ineqs)
+    slack = np.zeros(num_ineqs)
+    lam[:n] = np.linspace(1, n, n)
+    slack[n:] = 1.0
+    x = rng.uniform(-1, 1, n)
+    W = np.eye(n)
+    A = rng.uniform(-1, 1, (num_ineqs, n))
+    b = slack - A @ x
+    c = A.T @ lam - W @ x
+    return dict(W=W, A=A, b=b, c=c, x=x, slack=slack)
+
+
+def qp_config(cfg):
+    """quadratic_objective_test.cc:142-157"""
+    cfg.enable_line_search = 1
+    cfg.initial_centering_steps_coldstart = 0
+    cfg.enable_rescaling = 0
+    cfg.inv_sqrt_mu_max = 2e5
+    cfg.max_iterations = 30
+    cfg.final_centering_tolerance = 1.05
+    cfg.final_centering_steps = 0
+    cfg.minimum_mu = 0
+    cfg.kkt_error_tolerance = 1e45
+    cfg.dinf_upper_bound = 1
+    cfg.prepare_dual_variables = 1
+    return cfg
+
+
+@pytest.mark.parametrize("n,num_ineqs", [(5, 10), (10, 20), (50, 70)])
+def test_random_qp_line_search(oracle, n, num_ineqs):  # quadratic_objective_test.cc:159-175
+    d = qp_with_solution(n, num_ineqs, seed=n)
+    p = ol.Program(n)
+    p.add_static(d["W"], list(range(n)))
+    p.add_linear(-d["A"], d["b"], list(range(n)))
+    ok, y = p.solve(-d["c"], qp_config(ol.default_config()))   # AddLinearCost(c): Solve maximises -c'x
+    assert ok == 1
+    assert np.linalg.norm(y - d["x"]) <= 1e-9
+    assert np.linalg.norm(d["A"] @ y + d["b"] - d["slack"]) <= 1e-9
+
+
+def test_quadratic_cost_demands_line_search(oracle):
+    d = qp_with_solution(5, 10, seed=1)
+    p = ol.Program(5)
+    p.add_static(d["W"], list(range(5)))
+    p.add_linear(-d["A"], d["b"], list(range(5)))
+    ok, _ = p.solve(-d["c"])                                  # default config: refused
+    assert ok == 0
