@@ -70,6 +70,74 @@ __global__ void __launch_bounds__(256) linear_schur(VecGroup g, Arena ar) {
   }
 }
 
+// PerformLineSearch(LinearConstraint*) + FindMinimumMu (linear_constraint.cc:48-103):
+//   d0 = e + w o (A y0 - c k0),  delta = (e + w o (A y1 - c k1)) - d0,
+//   per row the interval of t with |d0 + t delta| <= dinfmax; out[2 id] = max lower end,
+//   out[2 id + 1] = min upper end (the caller treats lower > upper as failure).
+struct LineSearchArgs {
+  const double* y0;     // permuted solve of -2 AW
+  const double* y1;     // permuted solve of AQc c_s + b b_s - 2 AW
+  const int* cl_ptr;
+  const int* cl_perm;
+  double c0_weight, c1_weight, dinfmax;
+  double* out;          // [2 K]
+};
+
+__global__ void __launch_bounds__(256) linear_line_search(VecGroup g, LineSearchArgs a) {
+  extern __shared__ double lds[];
+  __shared__ double red[8];
+  const int r = g.len, m = g.m;
+  const int mem = blockIdx.x, id = g.ids[mem];
+  const double* A = g.A + (size_t)mem * r * m;
+  const double* c = g.c + (size_t)mem * r;
+  const double* w = g.W + (size_t)mem * r;
+  double* s0 = lds;
+  double* s1 = lds + m;
+  for (int q = threadIdx.x; q < m; q += blockDim.x) {
+    const int v = a.cl_perm[a.cl_ptr[id] + q];
+    s0[q] = a.y0[v];
+    s1[q] = a.y1[v];
+  }
+  __syncthreads();
+  double ub = 1.7976931348623157e308, lb = -1.7976931348623157e308;
+  for (int k = threadIdx.x; k < r; k += blockDim.x) {
+    double t0 = 0, t1 = 0;
+    for (int j = 0; j < m; j++) {
+      t0 = fma(A[k + (size_t)j * r], s0[j], t0);
+      t1 = fma(A[k + (size_t)j * r], s1[j], t1);
+    }
+    t0 -= c[k] * a.c0_weight;
+    t1 -= c[k] * a.c1_weight;
+    const double d0 = t0 * w[k] + 1, d1 = t1 * w[k] + 1;
+    const double delta = d1 - d0;
+    double ubi = (a.dinfmax - d0) / delta, lbi = (-a.dinfmax - d0) / delta;
+    if (lbi > ubi) {
+      const double t = ubi;
+      ubi = lbi;
+      lbi = t;
+    }
+    ub = fmin(ub, ubi);
+    lb = fmax(lb, lbi);
+  }
+  lb = WaveMax(lb);
+  ub = -WaveMax(-ub);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[wave] = lb;
+    red[4 + wave] = ub;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+    for (int q = 1; q < nw; q++) {
+      lb = fmax(lb, red[q]);
+      ub = fmin(ub, red[4 + q]);
+    }
+    a.out[2 * id] = lb;
+    a.out[2 * id + 1] = ub;
+  }
+}
+
 // mode 0 PrepareStep, mode 1 GetWeightedSlackEigenvalues
 template <int MODE>
 __global__ void __launch_bounds__(256) linear_prepare(VecGroup g, StepArgs sa) {

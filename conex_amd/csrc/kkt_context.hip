@@ -132,6 +132,7 @@ struct cxk_context {
   int dual_start = -1;
   bool use_ldlt = false;
   DevBuf<int> d_tr, d_reg;
+  DevBuf<double> y2;  // second solve vector of the line search
   std::vector<double> y_at_prepare;  // lambda_ = y.tail(rows) is latched by PrepareStep
   // timing of the dominant (dense-LMI Schur) kernel
   bool timing = false;
@@ -1651,6 +1652,56 @@ int cxk_solve_rhs(cxk_context* ctx, double cb, double cq, double cw) {
   build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, cb, cq, cw, ctx->b.p, ctx->AQc.p,
                                                            ctx->AW.p, ctx->y.p);
   return LaunchTree(ctx, 1, true, true);
+}
+
+// ComputeMuFromLineSearch cone_program.cc:118-160.  *result = the admissible inv_sqrt_mu, or -1
+// when a cone does not support the line search (everything but linear, quadratic-cost and
+// equality blocks: constraint.h:24-28) or the interval is empty.  Overwrites y (as the reference
+// overwrites its iterate vector).
+int cxk_line_search(cxk_context* ctx, double dinf_upper_bound, double b_scaling, double c_scaling,
+                    double* result) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_DEMAND(result != nullptr, "null output");
+  CXK_DEMAND(ctx->world == 1, "line search is single-GPU for now");
+  const int N = ctx->md.N, K = (int)ctx->cons.size();
+  if (ctx->y2.n != (size_t)N) CXK_TRY(ctx->y2.alloc(N));
+  build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, 0.0, 0.0, -2.0, ctx->b.p, ctx->AQc.p,
+                                                           ctx->AW.p, ctx->y.p);
+  if (LaunchTree(ctx, 1, true, true)) return CXK_FAILURE;
+  CXK_TRY(hipMemcpyAsync(ctx->y2.p, ctx->y.p, sizeof(double) * N, hipMemcpyDeviceToDevice, ctx->stream));
+  build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, b_scaling, c_scaling, -2.0, ctx->b.p,
+                                                           ctx->AQc.p, ctx->AW.p, ctx->y.p);
+  if (LaunchTree(ctx, 1, true, true)) return CXK_FAILURE;
+  LineSearchArgs a;
+  a.y0 = ctx->y2.p;
+  a.y1 = ctx->y.p;
+  a.cl_ptr = ctx->cl_ptr.p;
+  a.cl_perm = ctx->cl_perm.p;
+  a.c0_weight = c_scaling * 0;
+  a.c1_weight = c_scaling * 1;
+  a.dinfmax = dinf_upper_bound;
+  a.out = ctx->info2.p;
+  for (Group& g : ctx->groups) {
+    const int cnt = (int)g.ids.size();
+    if (cnt == 0 || g.type != CXK_LINEAR) continue;
+    linear_line_search<<<cnt, 256, sizeof(double) * 2 * g.m, ctx->stream>>>(MakeVec(g), a);
+  }
+  CXK_TRY(hipGetLastError());
+  std::vector<double> out((size_t)2 * K);
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(out.data(), ctx->info2.p, sizeof(double) * 2 * K, hipMemcpyDeviceToHost));
+  double lb = -DBL_MAX, ub = DBL_MAX;
+  *result = -1;
+  for (int i = 0; i < K; i++) {
+    const ConstraintRec& c = ctx->cons[i];
+    if (c.type == CXK_STATIC) continue;          // quadratic cost / equality: no restriction
+    if (c.type != CXK_LINEAR) return CXK_SUCCESS;  // unsupported cone: failure (-1)
+    if (out[2 * i] > out[2 * i + 1]) return CXK_SUCCESS;
+    lb = std::max(lb, out[2 * i]);
+    ub = std::min(ub, out[2 * i + 1]);
+  }
+  if (lb <= ub) *result = ub;
+  return CXK_SUCCESS;
 }
 
 int cxk_step_scalars(cxk_context* ctx, double* out6) {

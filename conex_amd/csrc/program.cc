@@ -317,16 +317,6 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     for (int i = 0; i < m; i++) yout[i] = -p->linear_cost[i] * std::numeric_limits<double>::infinity();
     return 0;
   }
-  if (cfg.enable_line_search) {
-    // The line-search mu rule (cone_program.cc:118-160) is not on the device yet; the reference
-    // falls back to the divergence rule whenever a cone reports failure, which is what happens
-    // here for every call.  Programs with quadratic costs rely on it and are rejected below.
-    if (p->contains_quadratic_costs) {
-      fprintf(stderr, "%s line %d: Solver terminating with error: line-search failed.\n", __FILE__,
-              __LINE__);
-      return 1;
-    }
-  }
   if (cfg.kkt_solver != 0 || cfg.iterative_refinement_iterations != 0) {
     fprintf(stderr,
             "conex: kkt_solver/iterative_refinement options need the dense KKT matrix and are not "
@@ -412,7 +402,18 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     }
     if (update_mu) {
       double temp = -1;
-      if (MuFromDivergence(p, cfg, rankK, &temp)) return 0;
+      if (cfg.enable_line_search) {  // cone_program.cc:376-384
+        if (cxk_line_search(ctx, cfg.dinf_upper_bound, b_scaling, c_scaling, &temp)) return 0;
+        if (temp < 0) temp = inv_sqrt_mu;
+      }
+      if (temp < 0) {
+        if (p->contains_quadratic_costs) {
+          fprintf(stderr, "%s line %d: Solver terminating with error: line-search failed.\n", __FILE__,
+                  __LINE__);
+          return 1;
+        }
+        if (MuFromDivergence(p, cfg, rankK, &temp)) return 0;
+      }
       if (temp > 0)
         inv_sqrt_mu = temp;
       else

@@ -176,6 +176,14 @@ int cxk_shard_info(const cxk_context* ctx, int* cut_level, int* num_levels, long
 int cxk_assemble_local(cxk_context* ctx);
 int cxk_finish_assemble(cxk_context* ctx);
 
+/* ComputeMuFromLineSearch (cone_program.cc:118-160) with PerformLineSearch / FindMinimumMu of the
+ * linear cone (linear_constraint.cc:48-103): two solves with the current factorization (right-hand
+ * sides -2 AW and AQc c_s + b b_s - 2 AW), per-row admissible interval of the step, reduced over
+ * constraints.  *result = inv_sqrt_mu candidate, or -1 (a cone without line-search support --
+ * constraint.h:24-28 -- or an empty interval).  Overwrites y. */
+int cxk_line_search(cxk_context* ctx, double dinf_upper_bound, double b_scaling, double c_scaling,
+                    double* result);
+
 /* ---- isolated batched fp64 GEMM on the matrix pipe ----------------------------------------
  * C[b] = alpha op(A[b]) op(B[b]) + beta C[b], packed column-major host buffers (A is M x K, or
  * K x M when ta; B is K x N, or N x K when tb).  This is the kernel behind the large-order LMI

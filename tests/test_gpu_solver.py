@@ -180,6 +180,52 @@ def test_linear_inequalities_with_equality_rows_take_the_ldlt_path():
     L.CONEX_DeleteConeProgram(p)
 
 
+@pytest.mark.parametrize("n,num_ineqs", [(5, 10), (10, 20), (50, 70)])
+def test_random_qp_with_line_search_through_conex_h(n, num_ineqs):
+    """quadratic_objective_test.cc:142-175 (RandomQP Small / Medium / Large): quadratic cost +
+    linear inequalities, line-search mu rule (cone_program.cc:118-160), against the known optimum
+    and the oracle's iteration count."""
+    rng = np.random.default_rng(n)
+    lam, slack = np.zeros(num_ineqs), np.zeros(num_ineqs)
+    lam[:n] = np.linspace(1, n, n)
+    slack[n:] = 1.0
+    x = rng.uniform(-1, 1, n)
+    A = rng.uniform(-1, 1, (num_ineqs, n))
+    b = slack - A @ x
+    c = A.T @ lam - x                               # W = I
+    L = ca.api()
+    p = L.CONEX_CreateConeProgram()
+    assert L.CONEX_SetNumberOfVariables(p, n) == 0
+    W = np.eye(n)
+    assert L.CONEX_AddQuadraticCost(p, ca.dp(ca.colmajor(W)), n, n) == 0
+    assert L.CONEX_AddDenseLinearConstraint(p, ca.dp(ca.colmajor(-A)), num_ineqs, n, ca.dp(b), num_ineqs) == 1
+    cfg = ca.default_config()
+    cfg.enable_line_search = 1
+    cfg.initial_centering_steps_coldstart = 0
+    cfg.enable_rescaling = 0
+    cfg.inv_sqrt_mu_max = 2e5
+    cfg.max_iterations = 30
+    cfg.final_centering_tolerance = 1.05
+    cfg.final_centering_steps = 0
+    cfg.minimum_mu = 0
+    cfg.kkt_error_tolerance = 1e45
+    cfg.dinf_upper_bound = 1
+    cfg.prepare_dual_variables = 1
+    ok, y = _maximize(L, p, -c, cfg)                # Solve maximises b'y with b = -linear_cost
+    assert ok == 1
+    assert np.linalg.norm(y - x) <= 1e-9
+    assert np.linalg.norm(A @ y + b - slack) <= 1e-9
+    o = ol.Program(n)
+    o.add_static(W, list(range(n)))
+    o.add_linear(-A, b, list(range(n)))
+    oko, yo = o.solve(-c, _sync_cfg(cfg))
+    assert oko == 1 and np.allclose(y, yo, rtol=1e-9, atol=1e-11)
+    st = ca.IterationStats()
+    L.CONEX_GetIterationStats(p, C.byref(st), -1)
+    assert st.iteration_number == o.num_iterations() - 1
+    L.CONEX_DeleteConeProgram(p)
+
+
 def test_sdp_mixed_literal():
     """test_sdp.cc:13-59: S == ones(2,2) to 1e-6."""
     L = ca.api()
