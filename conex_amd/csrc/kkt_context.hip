@@ -20,6 +20,7 @@
 #include "kernels_cone.hip.h"
 #include "kernels_gemm.hip.h"
 #include "kernels_kkt.hip.h"
+#include "kernels_kkt_big.hip.h"
 #include "kernels_lmi.hip.h"
 #include "kernels_lmi_fused.hip.h"
 #include "kernels_lmi_large.hip.h"
@@ -104,6 +105,11 @@ struct cxk_context {
   size_t chol_lds = 0, solve_lds = 0;  // bytes of LDS staging one supernode needs
   int top_level = 0;                   // levels [top_level, nlev) run inside one workgroup
   std::vector<unsigned char> level_big;  // level holds a supernode beyond the wave-per-supernode kernels
+  // supernodes whose panel exceeds LDS sit at the END of their level list and are swept one by
+  // one through the blocked HBM path (kernels_kkt_big.hip.h); level_nh = count of the others
+  std::vector<int> level_nh;
+  std::vector<SnRec> h_recs;  // host copy of the level-ordered records
+  DevBuf<double> big_ws;
   // Level ranges below the top that are swept by one launch each: workgroup g of range r sweeps
   // one connected piece of the elimination forest restricted to levels [lo, hi)
   struct SweepRange {
@@ -720,15 +726,31 @@ int BuildPlans(cxk_context* ctx) {
   ctx->level_sn.clear();
   ctx->chol_lds = 8;
   ctx->level_big.assign(nlev, 0);
+  ctx->level_nh.assign(nlev, 0);
+  size_t big_ws = 0;
+  auto panel_bytes = [&](int e) {
+    return sizeof(double) * ((size_t)ns[e] * ns[e] + (size_t)ns[e] * nsep[e] + 3 * (size_t)ns[e] + 2);
+  };
   for (int l = 0; l < nlev; l++) {
+    std::vector<int> huge;
     for (int e = 0; e < K; e++)
       if (ns[e] > 0 && ctx->t_level[e] == l && block_wanted(e)) {
-        ctx->level_sn.push_back(e);
         if (ns[e] > 32 || nsep[e] > 16) ctx->level_big[l] = 1;
-        ctx->chol_lds = std::max(ctx->chol_lds, sizeof(double) * ((size_t)ns[e] * ns[e] +
-                                                                   (size_t)ns[e] * nsep[e] + 3 * (size_t)ns[e] + 2));
+        if (panel_bytes(e) > kLdsLimit) {
+          huge.push_back(e);
+          big_ws = std::max(big_ws, (size_t)nsep[e] * nsep[e] + nsep[e] + 1);
+          continue;
+        }
+        ctx->level_sn.push_back(e);
+        ctx->chol_lds = std::max(ctx->chol_lds, panel_bytes(e));
       }
+    ctx->level_nh[l] = (int)ctx->level_sn.size() - ctx->level_ptr[l];
+    for (int e : huge) ctx->level_sn.push_back(e);
     ctx->level_ptr[l + 1] = (int)ctx->level_sn.size();
+  }
+  if (big_ws > 0) {
+    CXK_DEMAND(!sharded, "supernodes beyond LDS are single-GPU for now");
+    CXK_TRY(ctx->big_ws.alloc(big_ws));
   }
   CXK_DEMAND(ctx->chol_lds <= kLdsLimit,
              "supernode too large for the LDS-resident block Cholesky (blocked path not built yet)");
@@ -765,6 +787,7 @@ int BuildPlans(cxk_context* ctx) {
     }
     CXK_TRY(ctx->p_rec.upload(recs));
     h_recs = recs;
+    ctx->h_recs = recs;
   }
   // narrow top of the tree: trailing levels that hold few supernodes are swept by one workgroup
   // (levels separated by a workgroup barrier instead of a kernel boundary); never below the cut
@@ -1028,12 +1051,28 @@ int LaunchGather(cxk_context* ctx, bool with_rhs, double k, double bs, double cs
   return CXK_SUCCESS;
 }
 
+// Supernodes of level l whose panel exceeds LDS: blocked HBM path, one at a time.
+int LaunchHuge(cxk_context* ctx, int l, int mode, bool with_rhs) {
+  const int first = ctx->level_ptr[l] + ctx->level_nh[l], last = ctx->level_ptr[l + 1];
+  if (first == last) return CXK_SUCCESS;
+  CXK_DEMAND(!ctx->use_ldlt, "equality constraints with supernodes beyond LDS: blocked LDLT is not built");
+  double* rhs = (with_rhs || mode != 0) ? ctx->y.p : nullptr;
+  for (int pos = first; pos < last; pos++)
+    CXK_TRY(BigSupernodeSweep(ctx->plan, ctx->h_recs[pos], mode, ctx->slab.p, rhs, ctx->d_fail.p,
+                              ctx->big_ws.p, ctx->stream));
+  return CXK_SUCCESS;
+}
+
 // One sweep launch over levels [lb, le).  mode 0 factor(+forward), 1 forward, 2 backward.
 int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, bool with_rhs) {
   const int per_wave = (int)(ctx->chol_lds / sizeof(double));
   const int wmax = std::max(1, std::min<int>(8, (int)(kLdsLimit / std::max<size_t>(ctx->chol_lds, 8))));
+  if (le - lb == 1 && !then_backward && ctx->level_nh[lb] < ctx->level_ptr[lb + 1] - ctx->level_ptr[lb]) {
+    if (LaunchHuge(ctx, lb, mode, with_rhs)) return CXK_FAILURE;
+    if (ctx->level_nh[lb] == 0) return CXK_SUCCESS;
+  }
   int maxcnt = 0;
-  for (int l = lb; l < le; l++) maxcnt = std::max(maxcnt, ctx->level_ptr[l + 1] - ctx->level_ptr[l]);
+  for (int l = lb; l < le; l++) maxcnt = std::max(maxcnt, le - lb == 1 ? ctx->level_nh[l] : ctx->level_ptr[l + 1] - ctx->level_ptr[l]);
   if (maxcnt == 0) return CXK_SUCCESS;
   int waves, grid;
   if (le - lb > 1 || then_backward) {
@@ -1077,8 +1116,8 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
 #define CXK_SWEEP(MODE, TOP)                                                                   \
   tree_sweep<MODE, TOP><<<grid, waves * 64, lds, ctx->stream>>>(                               \
       ctx->plan, ctx->p_rec.p, ctx->d_level_ptr.p + lb, ctx->level_ptr[lb],                    \
-      ctx->level_ptr[lb + 1] - ctx->level_ptr[lb], le - lb, then_backward ? 1 : 0, ctx->slab.p, rhs, \
-      ctx->d_fail.p, per_wave)
+      is_top ? ctx->level_ptr[lb + 1] - ctx->level_ptr[lb] : maxcnt, le - lb, then_backward ? 1 : 0, \
+      ctx->slab.p, rhs, ctx->d_fail.p, per_wave)
   if (mode == 0) {
     if (is_top) CXK_SWEEP(0, true); else CXK_SWEEP(0, false);
   } else if (mode == 1) {

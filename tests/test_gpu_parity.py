@@ -153,6 +153,22 @@ def test_mid_size_supernodes_and_lds_resident_orders(K, n, m, b_, ov):
     check_newton_step(o, k, prob["b"], lanczos_tol=1e-7)
 
 
+def test_huge_supernodes_take_the_blocked_hbm_path():
+    """Panels beyond LDS (> ~140 columns): blocked right-looking Cholesky in HBM, 32-column panels,
+    SYRK / GEMM / TRSM updates on the fp64 MFMA GEMM (kernels_kkt_big.hip.h)."""
+    # (a) dense LP with 300 variables: one 300 x 300 supernode
+    prob = syn.lp_problem(rows=400, num_vars=300, seed=8)
+    o, k = make_pair(prob, "lp")
+    check_newton_step(o, k, prob["b"], inv_sqrt_mu=0.4)
+    # (b) LMI tree with 200-variable cliques: leaves 140 + 60 separators, root 200
+    prob = syn.lmi_problem(K=3, n=24, m=200, branching=2, overlap=60, seed=9)   # 24*25/2 >= 200
+    W = syn.scaling_points(3, 24, seed=5)
+    o, k = make_pair(prob, "lmi", W)
+    sizes = o.supernode_sizes()
+    assert max(sizes) == 200 and min(sizes) == 140
+    check_newton_step(o, k, prob["b"], check_update=False)
+
+
 def test_lmi_identity_start_and_iterations():
     """Three IPM iterations from W = I through both paths stay in lock-step."""
     prob = syn.lmi_problem(K=20, n=8, m=8, branching=3, overlap=3, seed=5)
