@@ -131,55 +131,56 @@ __global__ void __launch_bounds__(256) lmi_schur_generic(LmiGroup g, Arena ar) {
   }
 }
 
-// Eigenvalue range of a symmetric tridiagonal (implicit QL); single thread. d,e are clobbered.
-__device__ inline void TridiagMinMax(int n, double* d, double* e, double* mn, double* mx) {
-  e[n - 1] = 0;
-  for (int l = 0; l < n; l++) {
-    int iter = 0, m;
-    do {
-      for (m = l; m < n - 1; m++) {
-        const double dd = fabs(d[m]) + fabs(d[m + 1]);
-        if (fabs(e[m]) <= 2.2204460492503131e-16 * dd) break;
-      }
-      if (m != l) {
-        if (iter++ == 200) break;
-        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-        double r = hypot(g, 1.0);
-        g = d[m] - d[l] + e[l] / (g + (g >= 0 ? fabs(r) : -fabs(r)));
-        double s = 1.0, c = 1.0, p = 0.0;
-        int i;
-        for (i = m - 1; i >= l; i--) {
-          double f = s * e[i];
-          const double b = c * e[i];
-          r = hypot(f, g);
-          e[i + 1] = r;
-          if (r == 0.0) {
-            d[i + 1] -= p;
-            e[m] = 0.0;
-            break;
-          }
-          s = f / r;
-          c = g / r;
-          g = d[i + 1] - p;
-          r = (d[i] - g) * s + 2.0 * c * b;
-          p = s * r;
-          d[i + 1] = g + p;
-          g = c * r - b;
-        }
-        if (r == 0.0 && i >= l) continue;
-        d[l] -= p;
-        e[l] = g;
-        e[m] = 0.0;
-      }
-    } while (m != l);
+// Extreme eigenvalues of a symmetric tridiagonal (the Jacobi matrix of the Lanczos run) by
+// 32-way multisection on Sturm counts, executed by ONE wavefront: lanes 0-31 bracket the smallest
+// eigenvalue, lanes 32-63 the largest; every round each lane evaluates one shift, a ballot picks
+// the sub-interval (x* = inf{x : #eigenvalues below x >= target}), 12 rounds shrink the Gershgorin
+// interval by 33^12 > 2^60.  Replaces the sequential QL iteration (which cost ~100 us per launch
+// on one lane); the reference only consumes min / max of
+// SelfAdjointEigenSolver::computeFromTridiagonal (approximate_eigenvalues.cc:232-238), and both
+// methods are accurate to a few ulps of the matrix norm.  d, e are read-only (LDS).
+__device__ inline void TridiagMinMaxWave(int n, const double* d, const double* e, double* mn, double* mx) {
+  const int lane = threadIdx.x & 63;
+  if (n == 1) {
+    if (lane == 0) *mn = *mx = d[0];
+    return;
   }
-  double lo = d[0], hi = d[0];
-  for (int i = 1; i < n; i++) {
-    lo = fmin(lo, d[i]);
-    hi = fmax(hi, d[i]);
+  double glo = 1.7976931348623157e308, ghi = -1.7976931348623157e308;
+  for (int i = lane; i < n; i += 64) {
+    const double r = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i < n - 1 ? fabs(e[i]) : 0.0);
+    glo = fmin(glo, d[i] - r);
+    ghi = fmax(ghi, d[i] + r);
   }
-  *mn = lo;
-  *mx = hi;
+  glo = -WaveMax(-glo);
+  ghi = WaveMax(ghi);
+  const double pad = (ghi - glo) * 1e-12 + 1e-300;  // count(glo - pad) = 0, count(ghi + pad) = n
+  double a = glo - pad, b = ghi + pad;
+  const int half = lane >> 5, sub = lane & 31;
+  const int target = half == 0 ? 1 : n;
+  for (int round = 0; round < 12; round++) {
+    const double w = b - a;
+    const double x = a + w * ((sub + 1) * (1.0 / 33.0));
+    int c = 0;
+    double q = d[0] - x;
+    c += q < 0.0;
+    for (int i = 1; i < n; i++) {
+      if (fabs(q) < 1e-290) q = q < 0.0 ? -1e-290 : 1e-290;
+      double r = __builtin_amdgcn_rcp(q);
+      r = fma(fma(-q, r, 1.0), r, r);  // one Newton step: only the sign of the pivot matters
+      q = (d[i] - x) - e[i - 1] * e[i - 1] * r;
+      c += q < 0.0;
+    }
+    const unsigned long long m = __ballot(c >= target);
+    const unsigned int mh = half ? (unsigned int)(m >> 32) : (unsigned int)(m & 0xffffffffull);
+    const int first = mh ? __ffs(mh) - 1 : 32;  // first probe at or beyond x*
+    const double na = a + w * (first * (1.0 / 33.0));
+    const double nb = first == 32 ? b : a + w * ((first + 1) * (1.0 / 33.0));
+    a = na;
+    b = nb;
+  }
+  const double val = 0.5 * (a + b);
+  if (lane == 0) *mn = val;
+  if (lane == 32) *mx = val;
 }
 
 // Two-sided Lanczos on WS with V = [W r, r] run by wave 0; result (min,max eigenvalue of the
@@ -269,7 +270,8 @@ __device__ inline void LanczosWave0(int n, const double* sWS, const double* sW, 
       U1[i] = u1;
     }
   }
-  if (lane == 0) TridiagMinMax(cnt + 1, alpha, beta, &out[0], &out[1]);
+  WaveSync();  // alpha / beta were written by lane 0
+  TridiagMinMaxWave(cnt + 1, alpha, beta, &out[0], &out[1]);
 }
 
 struct StepArgs {

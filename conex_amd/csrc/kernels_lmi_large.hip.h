@@ -349,7 +349,8 @@ __global__ void __launch_bounds__(512) lmi_large_spectrum(LmiGroup g, StepArgs s
     }
     __syncthreads();
   }
-  if (tid == 0) TridiagMinMax(cnt + 1, alpha, beta, &red[8], &red[9]);
+  __syncthreads();  // alpha / beta complete
+  if (tid < 64) TridiagMinMaxWave(cnt + 1, alpha, beta, &red[8], &red[9]);
   // tr(WS WS) and tr(WS)
   double t2 = 0, t1 = 0;
   for (int q = tid; q < nn; q += blockDim.x) {
