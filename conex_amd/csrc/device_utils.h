@@ -8,17 +8,57 @@ namespace cxk {
 
 constexpr int kWave = 64;
 
+// Cross-lane exchange steps of the 64-lane butterfly without LDS traffic (ds_bpermute costs a
+// full LDS round trip per step): xor 1 / xor 2 are DPP quad permutes, the 4- and 8-lane steps use
+// row_half_mirror / row_mirror (after the previous steps every lane of a quad / half-row already
+// holds the same partial, so any quad-to-quad / half-to-half exchange is the butterfly partner),
+// the 16- and 32-lane steps use gfx950's v_permlane16_swap / v_permlane32_swap.  The operand pairs
+// are exactly those of the xor butterfly, so sums are bit-identical to it.
+template <int CTRL>
+__device__ __forceinline__ double DppMove(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+struct RowPair {
+  double a, b;
+};
+__device__ __forceinline__ RowPair Swap16(double v) {  // a = [r0 r0 r2 r2], b = [r1 r1 r3 r3]
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const u2 l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const u2 h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return {__hiloint2double(h.x, l.x), __hiloint2double(h.y, l.y)};
+}
+__device__ __forceinline__ RowPair Swap32(double v) {  // a = [lower lower], b = [upper upper]
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const u2 l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const u2 h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return {__hiloint2double(h.x, l.x), __hiloint2double(h.y, l.y)};
+}
+
 // Sum over the 64 lanes of a wavefront; every lane returns the total.
 __device__ __forceinline__ double WaveSum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-  return v;
+  v += DppMove<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += DppMove<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += DppMove<0x141>(v);  // row_half_mirror
+  v += DppMove<0x140>(v);  // row_mirror
+  RowPair p = Swap16(v);
+  v = p.a + p.b;
+  p = Swap32(v);
+  return p.a + p.b;
 }
 
 __device__ __forceinline__ double WaveMax(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, kWave));
-  return v;
+  v = fmax(v, DppMove<0xB1>(v));
+  v = fmax(v, DppMove<0x4E>(v));
+  v = fmax(v, DppMove<0x141>(v));
+  v = fmax(v, DppMove<0x140>(v));
+  RowPair p = Swap16(v);
+  v = fmax(p.a, p.b);
+  p = Swap32(v);
+  return fmax(p.a, p.b);
 }
 
 // Block-wide sum in a fixed (deterministic) order. `scratch` holds >= blockDim/64 doubles.

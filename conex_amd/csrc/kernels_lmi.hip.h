@@ -309,11 +309,35 @@ __global__ void __launch_bounds__(256) lmi_prepare_generic(LmiGroup g, StepArgs 
   for (int q = threadIdx.x; q < nn; q += blockDim.x) sW[q] = Wg[q];
   __syncthreads();
   // minus_s = sum_i y_i A_i - k C   (dense_lmi_constraint.cc:8-27)
-  for (int q = threadIdx.x; q < nn; q += blockDim.x) {
-    double s = 0;
-    for (int i = 0; i < m; i++) s += sy[i] * A[(size_t)i * nn + q];
-    s -= sa.c_weight * Cm[q];
-    sS[q] = s;
+  if ((nn & 1) == 0) {
+    // A is streamed once more here (m n^2 doubles per constraint): 16-byte loads, eight matrices
+    // in flight per thread; the sum over i keeps the reference's order
+    const int half = nn >> 1;
+    for (int q2 = threadIdx.x; q2 < half; q2 += blockDim.x) {
+      double s0 = 0, s1 = 0;
+      const double2* base = reinterpret_cast<const double2*>(A) + q2;
+      for (int i0 = 0; i0 < m; i0 += 8) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          v[u] = (i0 + u < m) ? base[(size_t)(i0 + u) * half] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (i0 + u < m) {
+            s0 += sy[i0 + u] * v[u].x;
+            s1 += sy[i0 + u] * v[u].y;
+          }
+      }
+      sS[2 * q2] = s0 - sa.c_weight * Cm[2 * q2];
+      sS[2 * q2 + 1] = s1 - sa.c_weight * Cm[2 * q2 + 1];
+    }
+  } else {
+    for (int q = threadIdx.x; q < nn; q += blockDim.x) {
+      double s = 0;
+      for (int i = 0; i < m; i++) s += sy[i] * A[(size_t)i * nn + q];
+      s -= sa.c_weight * Cm[q];
+      sS[q] = s;
+    }
   }
   __syncthreads();
   LdsGemm(n, sW, sS, sWS);  // WS = W * minus_s
