@@ -134,12 +134,12 @@ __global__ void __launch_bounds__(256) lmi_schur_generic(LmiGroup g, Arena ar) {
 // Extreme eigenvalues of a symmetric tridiagonal (the Jacobi matrix of the Lanczos run) by
 // 32-way multisection on Sturm counts, executed by ONE wavefront: lanes 0-31 bracket the smallest
 // eigenvalue, lanes 32-63 the largest; every round each lane evaluates one shift, a ballot picks
-// the sub-interval (x* = inf{x : #eigenvalues below x >= target}), 12 rounds shrink the Gershgorin
-// interval by 33^12 > 2^60.  Replaces the sequential QL iteration (which cost ~100 us per launch
+// the sub-interval (x* = inf{x : #eigenvalues below x >= target}), 10 rounds shrink the Gershgorin
+// interval by 33^10 > 2^50.  Replaces the sequential QL iteration (which cost ~100 us per launch
 // on one lane); the reference only consumes min / max of
 // SelfAdjointEigenSolver::computeFromTridiagonal (approximate_eigenvalues.cc:232-238), and both
 // methods are accurate to a few ulps of the matrix norm.  d, e are read-only (LDS).
-__device__ inline void TridiagMinMaxWave(int n, const double* d, const double* e, double* mn, double* mx) {
+__device__ __forceinline__ void TridiagMinMaxWave(int n, const double* d, const double* e, double* mn, double* mx) {
   const int lane = threadIdx.x & 63;
   if (n == 1) {
     if (lane == 0) *mn = *mx = d[0];
@@ -157,12 +157,13 @@ __device__ inline void TridiagMinMaxWave(int n, const double* d, const double* e
   double a = glo - pad, b = ghi + pad;
   const int half = lane >> 5, sub = lane & 31;
   const int target = half == 0 ? 1 : n;
-  for (int round = 0; round < 12; round++) {
+  for (int round = 0; round < 10; round++) {
     const double w = b - a;
     const double x = a + w * ((sub + 1) * (1.0 / 33.0));
     int c = 0;
     double q = d[0] - x;
     c += q < 0.0;
+#pragma unroll 4
     for (int i = 1; i < n; i++) {
       if (fabs(q) < 1e-290) q = q < 0.0 ? -1e-290 : 1e-290;
       double r = __builtin_amdgcn_rcp(q);
@@ -188,7 +189,7 @@ __device__ inline void TridiagMinMaxWave(int n, const double* d, const double* e
 // herm = false: AsymmetricLanczos of approximate_eigenvalues.cc (absolute break 1e-6, divisions);
 // herm = true: MatrixAlgebra<d>::ApproximateEigenvalues of jordan_matrix_algebra.cc:386-452
 // (break relative to <U,U> of the first step, normalisations by reciprocal multiply).
-__device__ inline void LanczosWave0(int n, const double* sWS, const double* sW, const double* r,
+__device__ __forceinline__ void LanczosWave0(int n, const double* sWS, const double* sW, const double* r,
                                     int num_iter, double* vec, double* ab, double* out,
                                     bool herm = false) {
   if (threadIdx.x >= 64) return;
@@ -286,11 +287,13 @@ struct StepArgs {
   unsigned long long call;  // index of this PrepareStep / eigenvalue query (Hermitian start vectors)
 };
 
-// mode 0: PrepareStep ; mode 1: GetWeightedSlackEigenvalues
-template <int MODE>
+// mode 0: PrepareStep ; mode 1: GetWeightedSlackEigenvalues.  NF > 0 fixes the order at compile
+// time (the helpers are force-inlined, so their loops unroll and the index arithmetic folds: a
+// lone wavefront issues one dependent instruction per ~8 cycles, instruction count is latency).
+template <int MODE, int NF = 0>
 __global__ void __launch_bounds__(256) lmi_prepare_generic(LmiGroup g, StepArgs sa) {
   extern __shared__ double lds[];
-  const int n = g.n, m = g.m, nn = n * n;
+  const int n = NF > 0 ? NF : g.n, m = g.m, nn = n * n;
   double* sW = lds;
   double* sS = sW + nn;
   double* sWS = sS + nn;
@@ -316,13 +319,14 @@ __global__ void __launch_bounds__(256) lmi_prepare_generic(LmiGroup g, StepArgs 
     for (int q2 = threadIdx.x; q2 < half; q2 += blockDim.x) {
       double s0 = 0, s1 = 0;
       const double2* base = reinterpret_cast<const double2*>(A) + q2;
-      for (int i0 = 0; i0 < m; i0 += 8) {
-        double2 v[8];
+      constexpr int kBatch = 20;  // one memory round trip for the C4 shape (m = 20)
+      for (int i0 = 0; i0 < m; i0 += kBatch) {
+        double2 v[kBatch];
 #pragma unroll
-        for (int u = 0; u < 8; u++)
+        for (int u = 0; u < kBatch; u++)
           v[u] = (i0 + u < m) ? base[(size_t)(i0 + u) * half] : make_double2(0.0, 0.0);
 #pragma unroll
-        for (int u = 0; u < 8; u++)
+        for (int u = 0; u < kBatch; u++)
           if (i0 + u < m) {
             s0 += sy[i0 + u] * v[u].x;
             s1 += sy[i0 + u] * v[u].y;
@@ -406,9 +410,10 @@ __global__ void __launch_bounds__(256) lmi_prepare_generic(LmiGroup g, StepArgs 
 }
 
 // W <- sym( pade33( (WS + e I) * alpha ) * W )
+template <int NF = 0>
 __global__ void __launch_bounds__(256) lmi_take_step_generic(LmiGroup g, StepArgs sa) {
   extern __shared__ double lds[];
-  const int n = g.n, nn = n * n;
+  const int n = NF > 0 ? NF : g.n, nn = n * n;
   double* sW = lds;
   double* sX = sW + nn;
   double* sV = sX + nn;

@@ -914,9 +914,9 @@ hipError_t RaiseLdsLimits() {
     const int lim = (int)kLdsLimit;
     const void* ks[] = {
         reinterpret_cast<const void*>(&lmi_schur_generic),
-        reinterpret_cast<const void*>(&lmi_prepare_generic<0>),
-        reinterpret_cast<const void*>(&lmi_prepare_generic<1>),
-        reinterpret_cast<const void*>(&lmi_take_step_generic),
+        reinterpret_cast<const void*>(&lmi_prepare_generic<0, 0>),
+        reinterpret_cast<const void*>(&lmi_prepare_generic<1, 0>),
+        reinterpret_cast<const void*>(&lmi_take_step_generic<0>),
         reinterpret_cast<const void*>(&tree_sweep<0, false>),
         reinterpret_cast<const void*>(&tree_sweep<0, true>),
         reinterpret_cast<const void*>(&tree_sweep<1, false>),
@@ -1796,7 +1796,10 @@ int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_wei
     if (g.type == CXK_LMI && g.large)
       CXK_TRY(LmiLargePrepare(MakeLmi(g), sa, MakeLargeWs(g), 0, ctx->stream));
     else if (g.type == CXK_LMI)
-      lmi_prepare_generic<0><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
+      if (g.n == 20)
+        lmi_prepare_generic<0, 20><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
+      else
+        lmi_prepare_generic<0, 0><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
     else if (g.type == CXK_LINEAR)
       linear_prepare<0><<<cnt, 256, sizeof(double) * g.m, ctx->stream>>>(MakeVec(g), sa);
     else if (g.type == CXK_SOC)
@@ -1827,7 +1830,10 @@ int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_siz
     if (g.type == CXK_LMI && g.large)
       CXK_TRY(LmiLargeTakeStep(MakeLmi(g), sa, MakeLargeWs(g), ctx->stream));
     else if (g.type == CXK_LMI)
-      lmi_take_step_generic<<<cnt, 256, LmiTakeLds(g.n), ctx->stream>>>(MakeLmi(g), sa);
+      if (g.n == 20)
+        lmi_take_step_generic<20><<<cnt, 256, LmiTakeLds(g.n), ctx->stream>>>(MakeLmi(g), sa);
+      else
+        lmi_take_step_generic<0><<<cnt, 256, LmiTakeLds(g.n), ctx->stream>>>(MakeLmi(g), sa);
     else if (g.type == CXK_LINEAR)
       linear_take_step<<<GridFor((size_t)cnt * g.n, 256), 256, 0, ctx->stream>>>(MakeVec(g), sa);
     else if (g.type == CXK_SOC)
@@ -1847,7 +1853,10 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
     if (g.type == CXK_LMI && g.large)
       CXK_TRY(LmiLargePrepare(MakeLmi(g), sa, MakeLargeWs(g), 1, ctx->stream));
     else if (g.type == CXK_LMI)
-      lmi_prepare_generic<1><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
+      if (g.n == 20)
+        lmi_prepare_generic<1, 20><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
+      else
+        lmi_prepare_generic<1, 0><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
     else if (g.type == CXK_LINEAR)
       linear_prepare<1><<<cnt, 256, sizeof(double) * g.m, ctx->stream>>>(MakeVec(g), sa);
     else if (g.type == CXK_SOC)
