@@ -224,6 +224,7 @@ __global__ void __launch_bounds__((FusedCfg<N, M>::THREADS)) lmi_schur_fused(Lmi
   double* G = ar.G + ar.g_off[id];
   double* AW = ar.AWc + ar.r_off[id];
   double* AQc = ar.AQcc + ar.r_off[id];
+  const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;  // Hermitian cones: tr over the real representation
   for (int idx = threadIdx.x; idx < M1 * M1; idx += blockDim.x) {
     const int ii = idx / M1, jj = idx - ii * M1;
     if (jj > ii) continue;
@@ -233,6 +234,7 @@ __global__ void __launch_bounds__((FusedCfg<N, M>::THREADS)) lmi_schur_fused(Lmi
     double s = 0;
 #pragma unroll
     for (int w = 0; w < WAVES; w++) s += buf[w * NT * 256 + off];
+    s *= osc;
     if (ii < M)
       G[ii + (size_t)jj * M] = s;
     else if (jj < M)
@@ -244,6 +246,7 @@ __global__ void __launch_bounds__((FusedCfg<N, M>::THREADS)) lmi_schur_fused(Lmi
     double s = 0;
 #pragma unroll
     for (int q = 0; q < N; q++) s += sDiag[ii * N + q];
+    s *= osc;
     if (ii < M)
       AW[ii] = s;
     else
@@ -251,21 +254,27 @@ __global__ void __launch_bounds__((FusedCfg<N, M>::THREADS)) lmi_schur_fused(Lmi
   }
 }
 
-inline bool LmiFusedSupports(int n, int m) { return n == 20 && m == 20; }
+// Shapes with a compiled instance: the benchmark shape (20, 20) and (24, 24) -- BASELINE config 5's
+// complex Hermitian cones of order 12 over 24 variables in their real representation.
+inline bool LmiFusedSupports(int n, int m) { return (n == 20 && m == 20) || (n == 24 && m == 24); }
+
+template <int N, int M>
+inline hipError_t LaunchLmiSchurFusedT(const LmiGroup& g, const Arena& ar, hipStream_t stream) {
+  using Cfg = FusedCfg<N, M>;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lmi_schur_fused<N, M>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  lmi_schur_fused<N, M><<<g.count, Cfg::THREADS, Cfg::LDS, stream>>>(g, ar);
+  return hipGetLastError();
+}
 
 inline hipError_t LaunchLmiSchurFused(const LmiGroup& g, const Arena& ar, hipStream_t stream) {
-  if (g.n == 20 && g.m == 20) {
-    using Cfg = FusedCfg<20, 20>;
-    static bool configured = false;
-    if (!configured) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lmi_schur_fused<20, 20>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
-      if (e != hipSuccess) return e;
-      configured = true;
-    }
-    lmi_schur_fused<20, 20><<<g.count, Cfg::THREADS, Cfg::LDS, stream>>>(g, ar);
-    return hipGetLastError();
-  }
+  if (g.n == 20 && g.m == 20) return LaunchLmiSchurFusedT<20, 20>(g, ar, stream);
+  if (g.n == 24 && g.m == 24) return LaunchLmiSchurFusedT<24, 24>(g, ar, stream);
   return hipErrorNotSupported;
 }
 

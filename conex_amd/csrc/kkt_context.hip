@@ -1421,7 +1421,7 @@ int cxk_finalize(cxk_context* ctx) {
         a_sz = (size_t)g.m * g.n * g.n;
         c_sz = w_sz = (size_t)g.n * g.n;
         g.large = !(LmiTakeLds(g.n) <= kLdsLimit && LmiPrepareLds(g.n, g.m) <= kLdsLimit);
-        g.fused = !g.large && !g.herm_d && LmiFusedSupports(g.n, g.m);
+        g.fused = !g.large && LmiFusedSupports(g.n, g.m);
         break;
       case CXK_LINEAR:
         a_sz = (size_t)g.n * g.m;

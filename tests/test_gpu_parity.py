@@ -111,7 +111,7 @@ def check_newton_step(o, k, b, inv_sqrt_mu=0.7, bs=0.9, cs=0.8, check_update=Tru
 
 # --------------------------------------------------------------------- LMI
 @pytest.mark.parametrize("K,n,m,b_,ov", [(1, 4, 3, 8, 1), (9, 6, 6, 8, 2), (30, 20, 20, 8, 5),
-                                          (40, 7, 9, 3, 4), (12, 33, 5, 2, 2)])
+                                          (40, 7, 9, 3, 4), (12, 33, 5, 2, 2), (11, 24, 24, 3, 6)])
 def test_lmi_newton_step(K, n, m, b_, ov):
     prob = syn.lmi_problem(K=K, n=n, m=m, branching=b_, overlap=ov, seed=100 + K)
     W = syn.scaling_points(K, n, seed=7 + K)
@@ -200,7 +200,7 @@ def test_lmi_affine_update():
 
 # --------------------------------------------------------------------- Hermitian PSD over R/C/H
 @pytest.mark.parametrize("d", [1, 2, 4])
-@pytest.mark.parametrize("K,n,m,b_,ov", [(1, 3, 2, 2, 1), (7, 6, 5, 2, 2), (3, 12, 8, 2, 3)])
+@pytest.mark.parametrize("K,n,m,b_,ov", [(1, 3, 2, 2, 1), (7, 6, 5, 2, 2), (3, 12, 8, 2, 3), (5, 12, 24, 2, 4)])
 def test_hermitian_newton_step(d, K, n, m, b_, ov):
     """B2 / C7: HermitianPsdConstraint<Real|Complex|Quaternions> (hermitian_psd.cc) against the
     plane-by-plane oracle.  The device runs the real representation of order d n on the LMI
