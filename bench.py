@@ -40,11 +40,11 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(prob, W, budget_s=12.0):
+def cpu_baseline(prob, W, budget_s=12.0, kind="lmi"):
     """The oracle (plain-C port of the reference path, 1 thread) on the same workload."""
     import oracle_lib as ol
     from conex_amd import synthetic as syn
-    o = syn.build(ol.Program, prob, "lmi")
+    o = syn.build(ol.Program, prob, kind)
     for i in range(o.K):
         o.set_W(i, W[i])
     t0 = time.perf_counter()
@@ -66,9 +66,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--K", type=int, default=1000)
-    ap.add_argument("--workload", choices=["c4", "c2"], default="c4",
-                    help="c4 (default, the metric's config): 1000 LMIs n=20; c2: one LMI n=200 m=50 "
-                         "(BASELINE config 2, MFMA-bound assembly; extra measurement, single GPU)")
+    ap.add_argument("--workload", choices=["c4", "c2", "c3", "c5"], default="c4",
+                    help="c4 (default, the metric's config): 1000 LMIs n=20; extras, single GPU: "
+                         "c2 one LMI n=200 m=50 (MFMA-bound assembly); c3 5000 second-order cones in a "
+                         "chain (no tree parallelism: latency-bound sweeps); c5 mixed complex Hermitian "
+                         "+ SOC tree, N = 50k")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--event-period", type=int, default=8,
                     help="hipEvent-bracket every P-th launch of the dominant kernel in the timed region")
@@ -90,19 +92,37 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl")
 
+    kind = "lmi"
+    if args.workload != "c4" and world > 1:
+        raise SystemExit("the extra workloads are single-GPU measurements")
     if args.workload == "c2":
-        if world > 1:
-            raise SystemExit("config 2 is one constraint: it does not shard (replicas only)")
         args.K, n_order, m_vars = 1, 200, 50
         prob = syn.lmi_problem(K=1, n=200, m=50, branching=2, overlap=1)
+        W = syn.scaling_points(args.K, n_order)
+    elif args.workload == "c3":
+        kind, args.K, n_order, m_vars = "soc", 5000, 10, 10
+        prob = syn.soc_problem(K=5000, dim=10, m=10, overlap=2)
+        W = syn.soc_scaling_points(5000, 10)
+    elif args.workload == "c5":
+        kind, n_order, m_vars = "mixed", 12, 24
+        prob = syn.mixed_problem()
+        args.K = len(prob["cliques"])
+        W = syn.mixed_scaling_points(prob)
     else:
         n_order, m_vars = 20, 20
         prob = syn.lmi_problem(K=args.K, n=20, m=20, branching=8, overlap=5)
-    W = syn.scaling_points(args.K, n_order)
+        W = syn.scaling_points(args.K, n_order)
     stream = torch.cuda.current_stream().cuda_stream
     ctx = KktContext(prob["num_vars"], device=local_rank, stream=stream)
     for c, cl in enumerate(prob["cliques"]):
-        ctx.add_lmi(prob["A"][c], prob["C"][c], cl)
+        if kind == "lmi":
+            ctx.add_lmi(prob["A"][c], prob["C"][c], cl)
+        elif kind == "soc":
+            ctx.add_soc(prob["A"][c], prob["c"][c], cl)
+        elif prob["kinds"][c] == "herm":
+            ctx.add_hermitian(prob["A"][c], prob["C"][c], cl)
+        else:
+            ctx.add_soc(prob["A"][c], prob["C"][c], cl)
     if world > 1:
         ctx.set_shard(rank, world)
     ctx.initialize()
@@ -152,9 +172,11 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": ("Newton KKT-solves/sec (assemble+factor+solve), 1000x(20x20) PSD blocks, fp64"
-                       if args.workload == "c4" else
-                       "Newton KKT-solves/sec (assemble+factor+solve), one 200x200 PSD block m=50, fp64"),
+            "metric": {"c4": "Newton KKT-solves/sec (assemble+factor+solve), 1000x(20x20) PSD blocks, fp64",
+                       "c2": "Newton KKT-solves/sec (assemble+factor+solve), one 200x200 PSD block m=50, fp64",
+                       "c3": "Newton KKT-solves/sec (assemble+factor+solve), 5000 second-order cones dim 10 (chain), fp64",
+                       "c5": "Newton KKT-solves/sec (assemble+factor+solve), 1600 complex 12x12 PSD + 3000 SOC, fp64",
+                       }[args.workload],
             "value": args.steps / elapsed,
             "unit": "KKT-solves/s",
             "n_gpus": world,
@@ -166,9 +188,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": ("BASELINE config 4: chordal SDP, 1000 dense LMIs n=20 m=20, "
-                                    "8-ary clique tree overlap 5, N=15005") if args.workload == "c4"
-                       else "BASELINE config 2: one dense LMI n=200, m=50 (profile_sdp.cc shape)",
+            "config": {"workload": {"c4": "BASELINE config 4: chordal SDP, 1000 dense LMIs n=20 m=20, "
+                                          "8-ary clique tree overlap 5, N=15005",
+                                    "c2": "BASELINE config 2: one dense LMI n=200, m=50 (profile_sdp.cc shape)",
+                                    "c3": "BASELINE config 3: 5000 SOC dim 10, chain overlap 2, N=40002",
+                                    "c5": "BASELINE config 5: 1600 complex Hermitian PSD order 12 (m=24) + 3000 SOC "
+                                          "dim 10, 8-ary clique tree overlap 4, N=50004"}[args.workload],
                        "K": args.K, "n": n_order, "m": m_vars, "N": ctx.N,
                        "parallelism": (f"elimination-subtree sharding x{world}, one RCCL all-reduce "
                                        f"of {exch.numel() * 8} B per solve") if world > 1
@@ -177,7 +202,14 @@ def main():
         }
         if nsamp > 0 and kern_ms > 0:
             gbs = abytes / (kern_ms * 1e-3) / 1e9
-            if args.workload == "c2":
+            if args.workload in ("c3", "c5"):
+                out["roofline"] = {"bound": "hbm", "kernel": "Hermitian assembly (lmi_schur_fused<24,24>)",
+                                   "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
+                                   "kernel_samples": nsamp, "algorithmic_bytes": abytes,
+                                   "note": "bytes of the order-24 real representation the kernel streams; the "
+                                           "plane-wise reference data are half of that"}
+            elif args.workload == "c2":
                 tf = aflops / (kern_ms * 1e-3) / 1e12
                 out["roofline"] = {"bound": "mfma", "kernel": "lmi assembly (gemm_f64_mfma x3 + finalize)",
                                    "achieved": tf, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
@@ -196,7 +228,7 @@ def main():
                                "algorithmic_bytes": abytes, "algorithmic_gflop": aflops / 1e9,
                                "achieved_tflops": aflops / (kern_ms * 1e-3) / 1e12}
         if not args.no_cpu and world == 1:
-            cb, yo = cpu_baseline(prob, W)
+            cb, yo = cpu_baseline(prob, W, kind=kind)
             out["cpu_baseline"] = cb
             out["config"]["direction_rel_err_vs_cpu"] = float(
                 np.linalg.norm(y - yo) / np.linalg.norm(yo))

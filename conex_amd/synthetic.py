@@ -153,6 +153,64 @@ def hc_multiply(X, Y):
     return Z
 
 
+def mixed_problem(K=4600, herm_every=(8, 23), branching=8, overlap=4, seed=SEED):
+    """C5 shape: a clique tree mixing complex Hermitian PSD cones of order 12 over 24
+    variables with second-order cones of dimension 10 over 10 variables; node c is Hermitian when
+    c % herm_every[1] < herm_every[0] (about 1600 of 4600), every child shares `overlap` of its
+    parent's own variables.  Returns dict(kinds, A, C, cliques, num_vars, b)."""
+    rng = np.random.default_rng(seed)
+    kinds = ["herm" if c % herm_every[1] < herm_every[0] else "soc" for c in range(K)]
+    size = [24 if k == "herm" else 10 for k in kinds]
+    start = [0] * K                       # first own (fresh) variable of node c
+    cliques = [list(range(size[0]))]
+    nxt = size[0]
+    for c in range(1, K):
+        p = (c - 1) // branching
+        fresh_p = size[p] - (overlap if p > 0 else 0)
+        own_p = start[p] if p > 0 else 0
+        groups = max(1, fresh_p // overlap)
+        g = (c - 1) % groups
+        shared = [own_p + overlap * g + t for t in range(overlap)]
+        fresh = size[c] - overlap
+        start[c] = nxt
+        cliques.append(shared + list(range(nxt, nxt + fresh)))
+        nxt += fresh
+    A, Cm = [], []
+    b = np.zeros(nxt)
+    for c in range(K):
+        if kinds[c] == "herm":
+            a = np.stack([random_hermitian(rng, 2, 12) for _ in range(24)])
+            cm = np.zeros((2, 12, 12))
+            cm[0] = np.eye(12)
+            b[cliques[c]] += 0.5 * np.trace(a[:, 0], axis1=1, axis2=2)
+        else:
+            a = rng.uniform(-1, 1, (11, 10))
+            cm = np.zeros(11)
+            cm[0] = 1.0
+            b[cliques[c]] += a.T @ cm
+        A.append(a)
+        Cm.append(cm)
+    return dict(kinds=kinds, A=A, C=Cm, cliques=cliques, num_vars=nxt, b=b)
+
+
+def mixed_scaling_points(prob, seed=SEED + 5):
+    rng = np.random.default_rng(seed)
+    W = []
+    for k in prob["kinds"]:
+        if k == "herm":
+            H = random_hermitian(rng, 2, 12) * 0.1
+            H[0] += np.eye(12)
+            w = hc_multiply(H, H)
+            w[0] = 0.5 * (w[0] + w[0].T)
+            w[1] = 0.5 * (w[1] - w[1].T)
+        else:
+            w = np.zeros(11)
+            w[1:] = rng.uniform(-0.3, 0.3, 10)
+            w[0] = np.linalg.norm(w[1:]) + rng.uniform(0.5, 1.5)
+        W.append(w)
+    return W
+
+
 def build(ctx_cls, prob, kind="lmi", **kw):
     """Instantiate `ctx_cls(num_vars, **kw)` (oracle Program or KktContext) from a problem dict."""
     if kind == "lmi":
@@ -163,6 +221,11 @@ def build(ctx_cls, prob, kind="lmi", **kw):
         p = ctx_cls(prob["num_vars"], **kw)
         for c, cl in enumerate(prob["cliques"]):
             assert p.add_hermitian(prob["A"][c], prob["C"][c], cl) == c
+    elif kind == "mixed":
+        p = ctx_cls(prob["num_vars"], **kw)
+        for c, cl in enumerate(prob["cliques"]):
+            add = p.add_hermitian if prob["kinds"][c] == "herm" else p.add_soc
+            assert add(prob["A"][c], prob["C"][c], cl) == c
     elif kind == "soc":
         p = ctx_cls(prob["num_vars"], **kw)
         for c, cl in enumerate(prob["cliques"]):

@@ -300,6 +300,15 @@ def test_equality_multipliers_are_latched_by_prepare_step():
     assert np.array_equal(k.get_W(1), o.get_W(1)) and len(k.get_W(1)) == 3
 
 
+# --------------------------------------------------------------------- mixed Hermitian + SOC (C5, reduced)
+def test_c5_mixed_hermitian_soc_newton_step():
+    prob = syn.mixed_problem(K=230, seed=31)
+    assert prob["kinds"].count("herm") == 80
+    W = syn.mixed_scaling_points(prob, seed=32)
+    o, k = make_pair(prob, "mixed", W)
+    check_newton_step(o, k, prob["b"], inv_sqrt_mu=0.5)
+
+
 # --------------------------------------------------------------------- LP (C1)
 def test_c1_lp_newton_steps():
     prob = syn.lp_problem(rows=20, num_vars=10)
