@@ -72,6 +72,8 @@ def main():
                          "chain (no tree parallelism: latency-bound sweeps); c5 mixed complex Hermitian "
                          "+ SOC tree, N = 50k")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--soc-tree", type=int, default=0,
+                    help="with --workload c3: arrange the cones in a b-ary clique tree instead of a chain")
     ap.add_argument("--event-period", type=int, default=8,
                     help="hipEvent-bracket every P-th launch of the dominant kernel in the timed region")
     args = ap.parse_args()
@@ -101,7 +103,7 @@ def main():
         W = syn.scaling_points(args.K, n_order)
     elif args.workload == "c3":
         kind, args.K, n_order, m_vars = "soc", 5000, 10, 10
-        prob = syn.soc_problem(K=5000, dim=10, m=10, overlap=2)
+        prob = syn.soc_problem(K=5000, dim=10, m=10, overlap=2, tree=args.soc_tree)
         W = syn.soc_scaling_points(5000, 10)
     elif args.workload == "c5":
         kind, n_order, m_vars = "mixed", 12, 24
@@ -174,7 +176,8 @@ def main():
         out = {
             "metric": {"c4": "Newton KKT-solves/sec (assemble+factor+solve), 1000x(20x20) PSD blocks, fp64",
                        "c2": "Newton KKT-solves/sec (assemble+factor+solve), one 200x200 PSD block m=50, fp64",
-                       "c3": "Newton KKT-solves/sec (assemble+factor+solve), 5000 second-order cones dim 10 (chain), fp64",
+                       "c3": "Newton KKT-solves/sec (assemble+factor+solve), 5000 second-order cones dim 10 ("
+                             + (f"{args.soc_tree}-ary tree" if args.soc_tree else "chain") + "), fp64",
                        "c5": "Newton KKT-solves/sec (assemble+factor+solve), 1600 complex 12x12 PSD + 3000 SOC, fp64",
                        }[args.workload],
             "value": args.steps / elapsed,
@@ -191,7 +194,7 @@ def main():
             "config": {"workload": {"c4": "BASELINE config 4: chordal SDP, 1000 dense LMIs n=20 m=20, "
                                           "8-ary clique tree overlap 5, N=15005",
                                     "c2": "BASELINE config 2: one dense LMI n=200, m=50 (profile_sdp.cc shape)",
-                                    "c3": "BASELINE config 3: 5000 SOC dim 10, chain overlap 2, N=40002",
+                                    "c3": "BASELINE config 3: 5000 SOC dim 10, overlap 2, " + (f"{args.soc_tree}-ary clique tree" if args.soc_tree else "chain (N=40002)"),
                                     "c5": "BASELINE config 5: 1600 complex Hermitian PSD order 12 (m=24) + 3000 SOC "
                                           "dim 10, 8-ary clique tree overlap 4, N=50004"}[args.workload],
                        "K": args.K, "n": n_order, "m": m_vars, "N": ctx.N,

@@ -378,7 +378,14 @@ struct ElimSteps {
       double root, inv;
       SqrtAndInverse(d, root, inv);
       a[J] = (lane == J) ? root : a[J] * inv;
-      if constexpr (NSMAX == 16 && SMAX <= 16) {
+      if constexpr (NSMAX + SMAX <= 16) {
+        // the whole panel (supernode rows + separator rows) sits in ONE 16-lane DPP row:
+        // row_newbcast:c delivers L[c][J] (c < NSMAX) and L[sep c - NSMAX][J] directly
+        double naj = -a[J];
+        double dummy = 0.0;
+        DppOperandFence(dummy, naj, a[J]);
+        DppColumns<LEN, J + 1, NSMAX + SMAX, 0>::run(a, a[J], naj);
+      } else if constexpr (NSMAX == 16 && SMAX <= 16) {
         // supernode rows fill DPP row 0, separator rows start DPP row 1.  L[c][J] (c < 16) is
         // lane c of row 0: with row 0 mirrored into row 1 a row_newbcast DPP operand delivers it
         // to both rows; L[sep c][J] is lane c of row 1, only row 1 needs the trailing block.
@@ -820,7 +827,9 @@ tree_sweep(FactorPlan P, const SnRec* __restrict__ recs, const int* __restrict__
         const SnRec R = load_rec(base + idx);
         const int ns = R.ns, s = R.nsep;
         if constexpr (MODE == 0) {
-          if (ns <= 16 && s <= 8)
+          if (ns <= 8 && s <= 8)
+            FactorSupernodeRows<8, 8>(P, R, slab, rhs, fail, my);
+          else if (ns <= 16 && s <= 8)
             FactorSupernodeRows<16, 8>(P, R, slab, rhs, fail, my);
           else if (ns <= 24 && s == 0)
             FactorSupernodeRows<24, 0>(P, R, slab, rhs, fail, my);
@@ -847,7 +856,9 @@ tree_sweep(FactorPlan P, const SnRec* __restrict__ recs, const int* __restrict__
       for (int idx = (TOP ? 0 : blockIdx.x * nw) + wave; idx < cnt; idx += (TOP ? 1 : gridDim.x) * nw) {
         const SnRec R = load_rec(base + idx);
         const int ns = R.ns, s = R.nsep;
-        if (ns <= 16 && s <= 8)
+        if (ns <= 8 && s <= 8)
+          BackwardSupernodeRows<8, 8>(P, R, slab, rhs);
+        else if (ns <= 16 && s <= 8)
           BackwardSupernodeRows<16, 8>(P, R, slab, rhs);
         else if (ns <= 24 && s <= 8)
           BackwardSupernodeRows<24, 8>(P, R, slab, rhs);

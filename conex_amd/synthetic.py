@@ -76,10 +76,14 @@ def lp_problem(rows=20, num_vars=10, seed=SEED):
     return dict(A=A, c=c, b=A.T @ x0)
 
 
-def soc_problem(K=5000, dim=10, m=10, overlap=2, seed=SEED):
-    """C3: K second-order cones in R^{dim+1}, chain overlap."""
+def soc_problem(K=5000, dim=10, m=10, overlap=2, seed=SEED, tree=0):
+    """C3: K second-order cones in R^{dim+1}; chain overlap (the reference-style C3), or with
+    tree > 0 a `tree`-ary clique tree (SURVEY 8d's variant with tree parallelism)."""
     rng = np.random.default_rng(seed)
-    cliques, num_vars = chain_cliques(K, m, overlap)
+    if tree:
+        cliques, num_vars = tree_cliques(K, tree, m, overlap)
+    else:
+        cliques, num_vars = chain_cliques(K, m, overlap)
     A = rng.uniform(-1, 1, (K, dim + 1, m))
     c = np.zeros((K, dim + 1))
     c[:, 0] = 1.0
