@@ -1,5 +1,6 @@
-// Supernodal KKT kernels: deterministic gather-assembly of the slab, level-scheduled
-// left-looking block Cholesky, and level-scheduled block triangular solves.
+// Supernodal KKT kernels: deterministic gather-assembly of the slab, level-scheduled block
+// Cholesky / LDLT (right-looking inside a supernode, published updates pulled by ancestors),
+// and level-scheduled block triangular solves.
 //
 // Reference semantics reproduced here (summation ORDER included, so results do not depend
 // on scheduling):

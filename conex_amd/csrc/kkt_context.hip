@@ -753,7 +753,7 @@ int BuildPlans(cxk_context* ctx) {
     CXK_TRY(ctx->big_ws.alloc(big_ws));
   }
   CXK_DEMAND(ctx->chol_lds <= kLdsLimit,
-             "supernode too large for the LDS-resident block Cholesky (blocked path not built yet)");
+             "internal error: a supernode routed to the LDS kernels does not fit LDS");
   CXK_TRY(ctx->d_level_sn.upload(ctx->level_sn));
   CXK_TRY(ctx->d_level_ptr.upload(ctx->level_ptr));
   std::vector<SnRec> h_recs;
