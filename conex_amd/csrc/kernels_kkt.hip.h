@@ -386,17 +386,19 @@ struct ElimSteps {
         double dummy = 0.0;
         DppOperandFence(dummy, naj, a[J]);
         DppColumns<LEN, J + 1, NSMAX + SMAX, 0>::run(a, a[J], naj);
-      } else if constexpr (NSMAX <= 32 && SMAX == 0) {
-        // no separator rows (tree roots): rows fill DPP rows 0 and 1.  Row 0 mirrored into row 1
-        // serves the columns c < 16, row 1 mirrored into row 0 the columns c >= 16.
+      } else if constexpr (NSMAX + SMAX <= 32 && NSMAX != 16) {
+        // the panel (supernode rows, then separator rows at lanes NSMAX..) fills DPP rows 0 and 1.
+        // Row 0 mirrored into row 1 serves the columns whose owner lane is < 16, row 1 mirrored
+        // into row 0 the columns whose owner lane is >= 16.
         const RowPair xp = Swap16(a[J]);
         double x0 = xp.a, x1 = xp.b;
         double naj = -a[J];
         DppOperandFence(x0, x1, naj);
-        constexpr int kLo0 = (J + 1 < 16) ? J + 1 : 16, kLo1 = (NSMAX < 16) ? NSMAX : 16;
+        constexpr int kEnd = NSMAX + SMAX;
+        constexpr int kLo0 = (J + 1 < 16) ? J + 1 : 16, kLo1 = (kEnd < 16) ? kEnd : 16;
         constexpr int kHi0 = (J + 1 > 16) ? J + 1 : 16;
         DppColumns<LEN, kLo0, kLo1, 0>::run(a, x0, naj);
-        DppColumns<LEN, kHi0, NSMAX, 16>::run(a, x1, naj);
+        DppColumns<LEN, kHi0, kEnd, 16>::run(a, x1, naj);
       } else if constexpr (NSMAX == 16 && SMAX <= 16) {
         // supernode rows fill DPP row 0, separator rows start DPP row 1.  L[c][J] (c < 16) is
         // lane c of row 0: with row 0 mirrored into row 1 a row_newbcast DPP operand delivers it
