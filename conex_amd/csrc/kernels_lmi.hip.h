@@ -56,12 +56,41 @@ struct Arena {
 };
 
 // out(n x n) = X(n x n) * Y(n x n), all in LDS, column-major. Caller syncs.
+// From order 32 up each thread owns a 2 x 2 block of the product (rows r, r+1; columns c, c+1):
+// four LDS reads feed four FMAs instead of eight reads -- the plain one-output-per-thread form is
+// LDS-issue bound there.  Every output is still one fma chain over k = 0..n-1 (same rounding as before).
 __device__ __forceinline__ void LdsGemm(int n, const double* X, const double* Y, double* out) {
-  for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
-    const int r = idx % n, c = idx / n;
-    double s = 0;
-    for (int k = 0; k < n; k++) s = fma(X[r + k * n], Y[k + c * n], s);
-    out[idx] = s;
+  if (n * n < 4 * (int)blockDim.x) {  // small orders: one output per thread keeps every lane busy
+    for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+      const int r = idx % n, c = idx / n;
+      double s = 0;
+      for (int k = 0; k < n; k++) s = fma(X[r + k * n], Y[k + c * n], s);
+      out[idx] = s;
+    }
+    return;
+  }
+  const int hr = (n + 1) >> 1;  // row pairs (and column pairs)
+  for (int idx = threadIdx.x; idx < hr * hr; idx += blockDim.x) {
+    const int r = 2 * (idx % hr), c = 2 * (idx / hr);
+    const bool r1 = r + 1 < n, c1 = c + 1 < n;
+    const double* x = X + r;
+    const double* y0 = Y + (size_t)c * n;
+    const double* y1 = Y + (size_t)(c1 ? c + 1 : c) * n;
+    double s00 = 0, s10 = 0, s01 = 0, s11 = 0;
+    for (int k = 0; k < n; k++) {
+      const double xa = x[k * n], xb = r1 ? x[k * n + 1] : 0.0;
+      const double ya = y0[k], yb = y1[k];
+      s00 = fma(xa, ya, s00);
+      s10 = fma(xb, ya, s10);
+      s01 = fma(xa, yb, s01);
+      s11 = fma(xb, yb, s11);
+    }
+    out[r + (size_t)c * n] = s00;
+    if (r1) out[r + 1 + (size_t)c * n] = s10;
+    if (c1) {
+      out[r + (size_t)(c + 1) * n] = s01;
+      if (r1) out[r + 1 + (size_t)(c + 1) * n] = s11;
+    }
   }
 }
 

@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -72,6 +73,9 @@ struct Group {
   bool fused = false;
   // orders beyond the LDS-resident kernels: HBM-resident matrices + MFMA GEMM pipeline
   bool large = false;
+  // assembly through the batched MFMA GEMM pipeline (always when `large`; also for LDS-resident
+  // orders >= 32 without a fused instance, where it measured 1.5-2.7x faster than the LDS kernel)
+  bool schur_gemm = false;
   DevBuf<double> ws_main, ws_gf, ws_part;
   int splits = 1;
 };
@@ -994,7 +998,7 @@ int LaunchSchur(cxk_context* ctx) {
           ctx->ev_used++;
           CXK_TRY(hipEventRecord(e0, ctx->stream));
         }
-        if (g.large) {
+        if (g.schur_gemm) {
           CXK_TRY(LmiLargeSchur(MakeLmi(g), ar, MakeLargeWs(g), ctx->stream));
         } else if (g.fused) {
           CXK_TRY(LaunchLmiSchurFused(MakeLmi(g), ar, ctx->stream));
@@ -1422,6 +1426,8 @@ int cxk_finalize(cxk_context* ctx) {
         c_sz = w_sz = (size_t)g.n * g.n;
         g.large = !(LmiTakeLds(g.n) <= kLdsLimit && LmiPrepareLds(g.n, g.m) <= kLdsLimit);
         g.fused = !g.large && LmiFusedSupports(g.n, g.m);
+        g.schur_gemm = g.large || (!g.fused && g.n >= 32 &&
+                                   cnt * 2 * ((size_t)g.m + 1) * g.n * g.n * sizeof(double) <= ((size_t)8 << 30));
         break;
       case CXK_LINEAR:
         a_sz = (size_t)g.n * g.m;
@@ -1448,7 +1454,7 @@ int cxk_finalize(cxk_context* ctx) {
     CXK_TRY(g.T1.alloc(w_sz * cnt));
     CXK_TRY(g.T2.alloc(g.type == CXK_LINEAR ? w_sz * cnt : 0));
     CXK_TRY(g.dids.upload(g.ids));
-    if (g.large) {
+    if (g.schur_gemm) {
       const size_t nn = (size_t)g.n * g.n, m1 = (size_t)g.m + 1;
       // split-K of the contraction: enough workgroups to fill the chip, at most one K step each
       const int ksteps = (int)((nn + kGemmBK - 1) / kGemmBK);
