@@ -25,6 +25,7 @@ struct LmiLargeWs {
   double* Gf;    // count x (m+1)^2       contraction result (lower triangle)
   double* part;  // splits x count x (m+1)^2 split-K partials
   double* tmp;   // count x 8 x n^2       step temporaries (aliases P: never live together)
+  int* piv;      // count x n             pivot rows of the Pade LU
   int splits;
 };
 
@@ -115,21 +116,50 @@ __global__ void __launch_bounds__(256) lmi_large_pade_system(int n, const double
   }
 }
 
-// Partial-pivot LU of the n x n left half of aug carrying the n right-hand sides, then back
-// substitution; the solution E overwrites the right half.  One workgroup per constraint, matrix in
-// HBM / L2 (Eigen PartialPivLU semantics: first largest |entry| of the column is the pivot).
-__global__ void __launch_bounds__(1024) lmi_large_lu_solve(int n, double* __restrict__ aug_all) {
-  double* aug = aug_all + (size_t)blockIdx.x * 2 * n * n;
-  __shared__ double s_val[16];
-  __shared__ int s_idx[16];
+// Y = (X/4 + I) + T * 0.125 with T = X (X/4): the degree-2 Taylor head of DoExponentialMap
+// (exponential_map.cc:23-37); Xq = X * 1.0 / 4.0 is produced by lmi_large_quarter.
+__global__ void __launch_bounds__(256) lmi_large_quarter(int n, const double* __restrict__ X, double* __restrict__ Xq) {
+  const int nn = n * n;
+  const size_t base = (size_t)blockIdx.y * nn;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x)
+    Xq[base + q] = X[base + q] * 1.0 / 4.0;
+}
+__global__ void __launch_bounds__(256) lmi_large_taylor_head(int n, const double* __restrict__ Xq,
+                                                             const double* __restrict__ T, double* __restrict__ Y) {
+  const int nn = n * n;
+  const size_t base = (size_t)blockIdx.y * nn;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x)
+    Y[base + q] = (Xq[base + q] + ((q % n == q / n) ? 1.0 : 0.0)) + T[base + q] * 0.125;
+}
+
+// ---- blocked partial-pivot LU of the Pade system, batched over the constraints of a group ----
+// aug (n x 2n per constraint, column-major, ld = n) = [ V - U | V + U ]; the solution E of
+// (V - U) E = V + U overwrites the right half.  Eigen::PartialPivLU semantics (first largest
+// |entry| of the column is the pivot; exponential_map_pade.cc:23-32): 32-column panels are
+// factored with pivoting inside one workgroup (panel in LDS), the row swaps and the triangular
+// solves run column-parallel, every O(n^3) update is the batched fp64 MFMA GEMM.
+constexpr int kLuNB = 32;
+
+// Panel factorization: rows k0..n-1, columns k0..k0+nb-1.  grid = constraints.
+__global__ void __launch_bounds__(256) lu_panel(double* __restrict__ aug_all, int n, int k0, int nb,
+                                                int* __restrict__ piv_all) {
+  extern __shared__ double pan[];  // rows x nb, column-major, ld = rows
+  __shared__ double s_val[4];
+  __shared__ int s_idx[4];
   __shared__ int s_piv;
-  const int n2 = 2 * n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  for (int k = 0; k < n; k++) {
-    // pivot search: first index of the maximum |aug[i][k]|, i >= k
+  double* aug = aug_all + (size_t)blockIdx.x * 2 * n * n;
+  int* piv = piv_all + (size_t)blockIdx.x * n;
+  const int rows = n - k0, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  for (int q = tid; q < rows * nb; q += nt) {
+    const int i = q % rows, j = q / rows;
+    pan[q] = aug[(k0 + i) + (size_t)(k0 + j) * n];
+  }
+  __syncthreads();
+  for (int j = 0; j < nb; j++) {
     double best = -1.0;
-    int bi = k;
-    for (int i = k + tid; i < n; i += blockDim.x) {
-      const double v = fabs(aug[i + (size_t)k * n]);
+    int bi = j;
+    for (int i = j + tid; i < rows; i += nt) {
+      const double v = fabs(pan[i + j * rows]);
       if (v > best) {
         best = v;
         bi = i;
@@ -151,61 +181,177 @@ __global__ void __launch_bounds__(1024) lmi_large_lu_solve(int n, double* __rest
     if (tid == 0) {
       double b = s_val[0];
       int p = s_idx[0];
-      for (int w = 1; w < nw; w++)
+      for (int w = 1; w < (nt >> 6); w++)
         if (s_val[w] > b || (s_val[w] == b && s_idx[w] < p)) {
           b = s_val[w];
           p = s_idx[w];
         }
       s_piv = p;
+      piv[k0 + j] = k0 + p;
     }
     __syncthreads();
-    const int piv = s_piv;
-    if (piv != k) {
-      for (int c = tid; c < n2; c += blockDim.x) {
-        const double t = aug[k + (size_t)c * n];
-        aug[k + (size_t)c * n] = aug[piv + (size_t)c * n];
-        aug[piv + (size_t)c * n] = t;
+    const int p = s_piv;
+    if (p != j) {
+      for (int c = tid; c < nb; c += nt) {
+        const double t = pan[j + c * rows];
+        pan[j + c * rows] = pan[p + c * rows];
+        pan[p + c * rows] = t;
       }
       __syncthreads();
     }
-    const double d = aug[k + (size_t)k * n];
-    for (int i = k + 1 + tid; i < n; i += blockDim.x) aug[i + (size_t)k * n] /= d;
+    const double d = pan[j + j * rows];
+    for (int i = j + 1 + tid; i < rows; i += nt) pan[i + j * rows] /= d;
     __syncthreads();
-    const int rows = n - k - 1, cols = n2 - k - 1;
-    for (int idx = tid; idx < rows * cols; idx += blockDim.x) {
-      const int i = k + 1 + idx % rows, c = k + 1 + idx / rows;
-      aug[i + (size_t)c * n] -= aug[i + (size_t)k * n] * aug[k + (size_t)c * n];
+    const int rr = rows - j - 1, cc = nb - j - 1;
+    for (int idx = tid; idx < rr * cc; idx += nt) {
+      const int i = j + 1 + idx % rr, c = j + 1 + idx / rr;
+      pan[i + c * rows] -= pan[i + j * rows] * pan[j + c * rows];
     }
     __syncthreads();
   }
-  // back substitution on all right-hand sides, one pivot row per step
-  double* rhs = aug + (size_t)n * n;
-  for (int j = n - 1; j >= 0; j--) {
-    const double d = aug[j + (size_t)j * n];
-    for (int c = tid; c < n; c += blockDim.x) rhs[j + (size_t)c * n] /= d;
-    __syncthreads();
-    for (int idx = tid; idx < j * n; idx += blockDim.x) {
-      const int i = idx % j, c = idx / j;
-      rhs[i + (size_t)c * n] -= aug[i + (size_t)j * n] * rhs[j + (size_t)c * n];
-    }
-    __syncthreads();
+  for (int q = tid; q < rows * nb; q += nt) {
+    const int i = q % rows, j = q / rows;
+    aug[(k0 + i) + (size_t)(k0 + j) * n] = pan[q];
   }
 }
 
-// Y = (X/4 + I) + T * 0.125 with T = X (X/4): the degree-2 Taylor head of DoExponentialMap
-// (exponential_map.cc:23-37); Xq = X * 1.0 / 4.0 is produced by lmi_large_quarter.
-__global__ void __launch_bounds__(256) lmi_large_quarter(int n, const double* __restrict__ X, double* __restrict__ Xq) {
-  const int nn = n * n;
-  const size_t base = (size_t)blockIdx.y * nn;
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x)
-    Xq[base + q] = X[base + q] * 1.0 / 4.0;
+// Columns outside the panel (0..k0-1 and k0+nb..2n-1): apply the panel's row swaps, then for the
+// columns to the right the unit-lower solve x <- L11^-1 x.  grid = (column blocks, constraints).
+// One thread per column; NB is the compile-time block size (registers with static indices; the
+// ragged last block takes the NB = 0 run-time form).
+template <int NB>
+__global__ void __launch_bounds__(256) lu_swap_trsm(double* __restrict__ aug_all, int n, int k0, int nb_rt,
+                                                    const int* __restrict__ piv_all) {
+  __shared__ double L[kLuNB * kLuNB];
+  __shared__ int sp[kLuNB];
+  const int nb = NB > 0 ? NB : nb_rt;
+  double* aug = aug_all + (size_t)blockIdx.y * 2 * n * n;
+  const int* piv = piv_all + (size_t)blockIdx.y * n;
+  for (int q = threadIdx.x; q < nb * nb; q += blockDim.x) {
+    const int i = q % nb, j = q / nb;
+    L[i + j * nb] = aug[(k0 + i) + (size_t)(k0 + j) * n];
+  }
+  if (threadIdx.x < nb) sp[threadIdx.x] = piv[k0 + threadIdx.x];
+  __syncthreads();
+  const int ncols = 2 * n - nb;
+  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < ncols; w += gridDim.x * blockDim.x) {
+    const int c = w < k0 ? w : w + nb;
+    double* col = aug + (size_t)c * n;
+    for (int j = 0; j < nb; j++) {
+      const int p = sp[j];
+      if (p != k0 + j) {
+        const double t = col[k0 + j];
+        col[k0 + j] = col[p];
+        col[p] = t;
+      }
+    }
+    if (c >= k0 + nb) {
+      if constexpr (NB > 0) {
+        double x[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) x[i] = col[k0 + i];
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+#pragma unroll
+          for (int j = 0; j < i; j++) x[i] -= L[i + j * NB] * x[j];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) col[k0 + i] = x[i];
+      } else {
+        for (int i = 0; i < nb; i++) {
+          double acc = col[k0 + i];
+          for (int j = 0; j < i; j++) acc -= L[i + j * nb] * col[k0 + j];
+          col[k0 + i] = acc;
+        }
+      }
+    }
+  }
 }
-__global__ void __launch_bounds__(256) lmi_large_taylor_head(int n, const double* __restrict__ Xq,
-                                                             const double* __restrict__ T, double* __restrict__ Y) {
-  const int nn = n * n;
-  const size_t base = (size_t)blockIdx.y * nn;
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x)
-    Y[base + q] = (Xq[base + q] + ((q % n == q / n) ? 1.0 : 0.0)) + T[base + q] * 0.125;
+
+// Right-hand-side block rows k0..k0+nb-1 <- U11^-1 (those rows); one thread per RHS column.
+template <int NB>
+__global__ void __launch_bounds__(256) lu_backsolve_block(double* __restrict__ aug_all, int n, int k0, int nb_rt) {
+  __shared__ double U[kLuNB * kLuNB];
+  const int nb = NB > 0 ? NB : nb_rt;
+  double* aug = aug_all + (size_t)blockIdx.y * 2 * n * n;
+  for (int q = threadIdx.x; q < nb * nb; q += blockDim.x) {
+    const int i = q % nb, j = q / nb;
+    U[i + j * nb] = aug[(k0 + i) + (size_t)(k0 + j) * n];
+  }
+  __syncthreads();
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+    double* col = aug + (size_t)(n + c) * n + k0;
+    if constexpr (NB > 0) {
+      double x[NB];
+#pragma unroll
+      for (int i = 0; i < NB; i++) x[i] = col[i];
+#pragma unroll
+      for (int i = NB - 1; i >= 0; i--) {
+#pragma unroll
+        for (int j = i + 1; j < NB; j++) x[i] -= U[i + j * NB] * x[j];
+        x[i] = x[i] / U[i + i * NB];
+      }
+#pragma unroll
+      for (int i = 0; i < NB; i++) col[i] = x[i];
+    } else {
+      for (int i = nb - 1; i >= 0; i--) {
+        double acc = col[i];
+        for (int j = i + 1; j < nb; j++) acc -= U[i + j * nb] * col[j];
+        col[i] = acc / U[i + i * nb];
+      }
+    }
+  }
+}
+
+inline hipError_t LmiLargeLuSolve(int n, int count, double* aug, int* piv, hipStream_t st) {
+  const int64_t an = 2 * (int64_t)n * n;
+  hipError_t e;
+  auto gemm = [&](int M, int N, int K, const double* A, const double* B, double* C) {
+    GemmArgs g{};
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.A = A;
+    g.lda = n;
+    g.sA1 = an;
+    g.B = B;
+    g.ldb = n;
+    g.sB1 = an;
+    g.C = C;
+    g.ldc = n;
+    g.sC1 = an;
+    g.inner = 1;
+    g.alpha = -1.0;
+    g.beta = 1.0;
+    g.splits = 1;
+    return LaunchGemm(g, false, false, count, st);
+  };
+  for (int k0 = 0; k0 < n; k0 += kLuNB) {
+    const int nb = std::min(kLuNB, n - k0), below = n - k0 - nb;
+    lu_panel<<<count, 256, sizeof(double) * (size_t)(n - k0) * nb, st>>>(aug, n, k0, nb, piv);
+    if (nb == kLuNB)
+      lu_swap_trsm<kLuNB><<<dim3((2 * n - nb + 63) / 64, count), 64, 0, st>>>(aug, n, k0, nb, piv);
+    else
+      lu_swap_trsm<0><<<dim3((2 * n - nb + 63) / 64, count), 64, 0, st>>>(aug, n, k0, nb, piv);
+    if (below > 0) {  // A22 -= L21 U12 over all columns to the right (incl. the right-hand sides)
+      if ((e = gemm(below, 2 * n - k0 - nb, nb, aug + (k0 + nb) + (size_t)k0 * n,
+                    aug + k0 + (size_t)(k0 + nb) * n, aug + (k0 + nb) + (size_t)(k0 + nb) * n)) != hipSuccess)
+        return e;
+    }
+  }
+  const int nblk = (n + kLuNB - 1) / kLuNB;
+  for (int kb = nblk - 1; kb >= 0; kb--) {
+    const int k0 = kb * kLuNB, nb = std::min(kLuNB, n - k0);
+    if (nb == kLuNB)
+      lu_backsolve_block<kLuNB><<<dim3((n + 63) / 64, count), 64, 0, st>>>(aug, n, k0, nb);
+    else
+      lu_backsolve_block<0><<<dim3((n + 63) / 64, count), 64, 0, st>>>(aug, n, k0, nb);
+    if (k0 > 0) {  // RHS[0:k0, :] -= U[0:k0, k0:k0+nb] E_blk
+      if ((e = gemm(k0, n, nb, aug + (size_t)k0 * n, aug + k0 + (size_t)n * n, aug + (size_t)n * n)) != hipSuccess)
+        return e;
+    }
+  }
+  return hipGetLastError();
 }
 
 // W = (T + T^T) / 2
@@ -233,11 +379,21 @@ __global__ void __launch_bounds__(256) lmi_large_affine(int n, double e, const d
 __device__ inline void BlockGemvBoth(int n, const double* __restrict__ M, const double* x0, const double* x1,
                                      double* y0, double* y1) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  // y0 = M x0: thread per row, eight independent loads in flight (the matrix comes from L2)
   for (int i = tid; i < n; i += blockDim.x) {
     double s = 0;
-    for (int k = 0; k < n; k++) s = fma(M[i + (size_t)k * n], x0[k], s);
+    int k = 0;
+    for (; k + 8 <= n; k += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = M[i + (size_t)(k + u) * n];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s = fma(v[u], x0[k + u], s);
+    }
+    for (; k < n; k++) s = fma(M[i + (size_t)k * n], x0[k], s);
     y0[i] = s;
   }
+  // y1 = M^T x1: wave per column, coalesced along the column
   for (int i = wave; i < n; i += nw) {
     double s = 0;
     for (int k = lane; k < n; k += 64) s = fma(M[k + (size_t)i * n], x1[k], s);
@@ -521,7 +677,7 @@ inline hipError_t LmiLargeTakeStep(const LmiGroup& g, const StepArgs& sa, const 
   GemmArgs b = SquareGemm(n, X, nn, T4, nn, U, nn);
   if ((e = LaunchGemm(b, false, false, count, st)) != hipSuccess) return e;
   lmi_large_pade_system<<<eg, 256, 0, st>>>(n, X2, U, aug);
-  lmi_large_lu_solve<<<count, 1024, 0, st>>>(n, aug);
+  if ((e = LmiLargeLuSolve(n, count, aug, ws.piv, st)) != hipSuccess) return e;
   GemmArgs c = SquareGemm(n, aug + nn, 2 * nn, g.W, nn, EW, nn);
   if ((e = LaunchGemm(c, false, false, count, st)) != hipSuccess) return e;
   lmi_large_symmetrize<<<eg, 256, 0, st>>>(n, EW, g.W);

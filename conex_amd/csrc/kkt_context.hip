@@ -77,6 +77,7 @@ struct Group {
   // orders >= 32 without a fused instance, where it measured 1.5-2.7x faster than the LDS kernel)
   bool schur_gemm = false;
   DevBuf<double> ws_main, ws_gf, ws_part;
+  DevBuf<int> ws_piv;
   int splits = 1;
 };
 
@@ -278,6 +279,7 @@ LmiLargeWs MakeLargeWs(Group& g) {
   w.tmp = g.ws_main.p;
   w.Gf = g.ws_gf.p;
   w.part = g.ws_part.p;
+  w.piv = g.ws_piv.p;
   w.splits = g.splits;
   return w;
 }
@@ -1462,6 +1464,7 @@ int cxk_finalize(cxk_context* ctx) {
       g.splits = std::max(1, std::min(std::max(1, ksteps / 8), (int)((512 + cnt * tiles - 1) / (cnt * tiles))));
       CXK_TRY(g.ws_main.alloc(cnt * std::max(2 * m1 * nn, 8 * nn)));
       CXK_TRY(g.ws_gf.alloc(cnt * m1 * m1));
+      CXK_TRY(g.ws_piv.alloc(cnt * (size_t)g.n));
       CXK_TRY(g.ws_part.alloc(g.splits > 1 ? (size_t)g.splits * cnt * m1 * m1 : 0));
     }
   }
