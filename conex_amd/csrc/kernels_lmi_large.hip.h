@@ -140,78 +140,98 @@ __global__ void __launch_bounds__(256) lmi_large_taylor_head(int n, const double
 // solves run column-parallel, every O(n^3) update is the batched fp64 MFMA GEMM.
 constexpr int kLuNB = 32;
 
-// Panel factorization: rows k0..n-1, columns k0..k0+nb-1.  grid = constraints.
-__global__ void __launch_bounds__(256) lu_panel(double* __restrict__ aug_all, int n, int k0, int nb,
-                                                int* __restrict__ piv_all) {
-  extern __shared__ double pan[];  // rows x nb, column-major, ld = rows
-  __shared__ double s_val[4];
-  __shared__ int s_idx[4];
-  __shared__ int s_piv;
+// Panel factorization: rows k0..n-1, columns k0..k0+nb-1.  grid = constraints, one THREAD PER
+// ROW with the row's nb <= 32 panel entries in registers (static indices: the column loop is
+// unrolled).  Per column: block-wide arg-max of |a[j]| over rows >= j (first maximum), the pivot
+// row and row j trade places through two LDS lines, the pivot row doubles as the broadcast
+// operand of the rank-1 update.  Three barriers per column, no LDS-resident panel (rows <= 1024).
+struct LuPanelShared {
+  double line[2][kLuNB];
+  double s_val[16];
+  int s_idx[16];
+  int s_piv;
+};
+
+// Column steps J .. NB-1 by compile-time recursion (every register index is an immediate).
+template <int NB, int J>
+struct LuPanelSteps {
+  static __device__ __forceinline__ void run(double (&a)[NB], LuPanelShared& sh, int* piv, int k0, int nb,
+                                             int i, bool has) {
+    if constexpr (J < NB) {
+      if (J < nb) {  // uniform
+        const int lane = i & 63, wave = i >> 6, nw = blockDim.x >> 6;
+        double best = (has && i >= J) ? fabs(a[J]) : -1.0;
+        int bi = i;
+        for (int off = 32; off > 0; off >>= 1) {
+          const double ov = __shfl_xor(best, off, 64);
+          const int oi = __shfl_xor(bi, off, 64);
+          if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+          }
+        }
+        if (lane == 0) {
+          sh.s_val[wave] = best;
+          sh.s_idx[wave] = bi;
+        }
+        __syncthreads();
+        if (i == 0) {
+          double b = sh.s_val[0];
+          int p = sh.s_idx[0];
+          for (int w = 1; w < nw; w++)
+            if (sh.s_val[w] > b || (sh.s_val[w] == b && sh.s_idx[w] < p)) {
+              b = sh.s_val[w];
+              p = sh.s_idx[w];
+            }
+          sh.s_piv = p;
+          piv[k0 + J] = k0 + p;
+        }
+        __syncthreads();
+        const int p = sh.s_piv;
+        if (i == p) {
+#pragma unroll
+          for (int c = 0; c < NB; c++) sh.line[0][c] = a[c];
+        }
+        if (i == J && p != J) {
+#pragma unroll
+          for (int c = 0; c < NB; c++) sh.line[1][c] = a[c];
+        }
+        __syncthreads();
+        if (i == J) {
+#pragma unroll
+          for (int c = 0; c < NB; c++) a[c] = sh.line[0][c];
+        } else if (i == p) {
+#pragma unroll
+          for (int c = 0; c < NB; c++) a[c] = sh.line[1][c];
+        }
+        if (has && i > J) {
+          const double l = a[J] / sh.line[0][J];
+          a[J] = l;
+#pragma unroll
+          for (int c = J + 1; c < NB; c++) a[c] -= l * sh.line[0][c];
+        }
+      }
+      LuPanelSteps<NB, J + 1>::run(a, sh, piv, k0, nb, i, has);
+    }
+  }
+};
+
+template <int NB>
+__global__ void __launch_bounds__(1024) lu_panel(double* __restrict__ aug_all, int n, int k0, int nb,
+                                                 int* __restrict__ piv_all) {
+  __shared__ LuPanelShared sh;
   double* aug = aug_all + (size_t)blockIdx.x * 2 * n * n;
   int* piv = piv_all + (size_t)blockIdx.x * n;
-  const int rows = n - k0, tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
-  for (int q = tid; q < rows * nb; q += nt) {
-    const int i = q % rows, j = q / rows;
-    pan[q] = aug[(k0 + i) + (size_t)(k0 + j) * n];
-  }
-  __syncthreads();
-  for (int j = 0; j < nb; j++) {
-    double best = -1.0;
-    int bi = j;
-    for (int i = j + tid; i < rows; i += nt) {
-      const double v = fabs(pan[i + j * rows]);
-      if (v > best) {
-        best = v;
-        bi = i;
-      }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ov = __shfl_xor(best, off, 64);
-      const int oi = __shfl_xor(bi, off, 64);
-      if (ov > best || (ov == best && oi < bi)) {
-        best = ov;
-        bi = oi;
-      }
-    }
-    if (lane == 0) {
-      s_val[wave] = best;
-      s_idx[wave] = bi;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double b = s_val[0];
-      int p = s_idx[0];
-      for (int w = 1; w < (nt >> 6); w++)
-        if (s_val[w] > b || (s_val[w] == b && s_idx[w] < p)) {
-          b = s_val[w];
-          p = s_idx[w];
-        }
-      s_piv = p;
-      piv[k0 + j] = k0 + p;
-    }
-    __syncthreads();
-    const int p = s_piv;
-    if (p != j) {
-      for (int c = tid; c < nb; c += nt) {
-        const double t = pan[j + c * rows];
-        pan[j + c * rows] = pan[p + c * rows];
-        pan[p + c * rows] = t;
-      }
-      __syncthreads();
-    }
-    const double d = pan[j + j * rows];
-    for (int i = j + 1 + tid; i < rows; i += nt) pan[i + j * rows] /= d;
-    __syncthreads();
-    const int rr = rows - j - 1, cc = nb - j - 1;
-    for (int idx = tid; idx < rr * cc; idx += nt) {
-      const int i = j + 1 + idx % rr, c = j + 1 + idx / rr;
-      pan[i + c * rows] -= pan[i + j * rows] * pan[j + c * rows];
-    }
-    __syncthreads();
-  }
-  for (int q = tid; q < rows * nb; q += nt) {
-    const int i = q % rows, j = q / rows;
-    aug[(k0 + i) + (size_t)(k0 + j) * n] = pan[q];
+  const int rows = n - k0, i = threadIdx.x;
+  const bool has = i < rows;
+  double a[NB];
+#pragma unroll
+  for (int c = 0; c < NB; c++) a[c] = (has && c < nb) ? aug[(k0 + i) + (size_t)(k0 + c) * n] : 0.0;
+  LuPanelSteps<NB, 0>::run(a, sh, piv, k0, nb, i, has);
+  if (has) {
+#pragma unroll
+    for (int c = 0; c < NB; c++)
+      if (c < nb) aug[(k0 + i) + (size_t)(k0 + c) * n] = a[c];
   }
 }
 
@@ -304,6 +324,7 @@ __global__ void __launch_bounds__(256) lu_backsolve_block(double* __restrict__ a
 }
 
 inline hipError_t LmiLargeLuSolve(int n, int count, double* aug, int* piv, hipStream_t st) {
+  if (n > 1024) return hipErrorNotSupported;  // one panel row per thread
   const int64_t an = 2 * (int64_t)n * n;
   hipError_t e;
   auto gemm = [&](int M, int N, int K, const double* A, const double* B, double* C) {
@@ -328,7 +349,10 @@ inline hipError_t LmiLargeLuSolve(int n, int count, double* aug, int* piv, hipSt
   };
   for (int k0 = 0; k0 < n; k0 += kLuNB) {
     const int nb = std::min(kLuNB, n - k0), below = n - k0 - nb;
-    lu_panel<<<count, 256, sizeof(double) * (size_t)(n - k0) * nb, st>>>(aug, n, k0, nb, piv);
+    {
+      const int threads = std::min(1024, ((n - k0 + 63) / 64) * 64);
+      lu_panel<kLuNB><<<count, threads, 0, st>>>(aug, n, k0, nb, piv);
+    }
     if (nb == kLuNB)
       lu_swap_trsm<kLuNB><<<dim3((2 * n - nb + 63) / 64, count), 64, 0, st>>>(aug, n, k0, nb, piv);
     else
