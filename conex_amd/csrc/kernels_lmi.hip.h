@@ -34,6 +34,27 @@ struct LmiGroup {
   int herm_d;
 };
 
+// Safeguard on the Lanczos estimates (not in the reference).  The unreorthogonalised two-sided
+// Lanczos of approximate_eigenvalues.cc:178-239 turns into noise once the Krylov space is nearly
+// invariant: beta^2 then hovers around the 1e-6 break threshold, the next vectors are rounding
+// error divided by beta, and a Ritz value far outside the spectrum can come out (seen at iteration
+// 8 of the C4 solve: -52 for a spectrum in [-1.67, -0.32]; which run gets hit depends on summation
+// order, the CPU restatement has the same failure mode on other inputs).  The eigenvalues of W S
+// are real (W S is similar to W^1/2 S W^1/2), so with t1 = tr(WS), t2 = tr(WS WS) Samuelson's
+// inequality bounds every one of them by  t1/n +- sqrt((n-1) (t2/n - (t1/n)^2)).  Ritz values of
+// a healthy run lie inside the spectrum and are untouched; only provably wrong ones are clamped.
+__device__ __forceinline__ void ClampToSpectrumBound(int n, double t1, double t2, double* mn, double* mx) {
+  const double mean = t1 / n;
+  double var = t2 / n - mean * mean;
+  if (!(var > 0.0)) var = 0.0;
+  const double half = sqrt((n - 1) * var);
+  const double lo = mean - half, hi = mean + half;
+  if (!(*mn >= lo)) *mn = lo;  // also catches NaN
+  if (!(*mn <= hi)) *mn = hi;
+  if (!(*mx <= hi)) *mx = hi;
+  if (!(*mx >= lo)) *mx = lo;
+}
+
 // Stateless generator shared with the oracle (oracle/cxo_hermitian.c cxo_hc_random): the
 // reference's start vector is libc rand() and unpinned.
 __device__ __forceinline__ double HcRandom(unsigned long long id, unsigned long long call,
@@ -419,7 +440,8 @@ __global__ void __launch_bounds__(256) lmi_prepare_generic(LmiGroup g, StepArgs 
   t1 = BlockSum(t1, red);
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double mn = red[4], mx = red[5];
+    double mn = red[4], mx = red[5];
+    ClampToSpectrumBound(n, t1, t2, &mn, &mx);
     if (g.herm_d > 1) {  // traces over the real representation are d x the reference's
       t2 /= g.herm_d;
       t1 /= g.herm_d;

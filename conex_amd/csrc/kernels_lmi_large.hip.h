@@ -543,7 +543,8 @@ __global__ void __launch_bounds__(512) lmi_large_spectrum(LmiGroup g, StepArgs s
   t1 = BlockSum(t1, red);
   __syncthreads();
   if (tid == 0) {
-    const double mn = red[8], mx = red[9];
+    double mn = red[8], mx = red[9];
+    ClampToSpectrumBound(n, t1, t2, &mn, &mx);
     if (g.herm_d > 1) {
       t2 /= g.herm_d;
       t1 /= g.herm_d;

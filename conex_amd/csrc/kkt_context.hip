@@ -1829,6 +1829,14 @@ int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_wei
   return CXK_SUCCESS;
 }
 
+/* per-constraint outputs of the last cxk_prepare_step: {normsqrd, norminfd} for each constraint */
+int cxk_get_step_info(cxk_context* ctx, double* out2k) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(out2k, ctx->info2.p, sizeof(double) * 2 * ctx->cons.size(), hipMemcpyDeviceToHost));
+  return CXK_SUCCESS;
+}
+
 int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_size) {
   if (CheckReady(ctx)) return CXK_FAILURE;
   if (affine) return CXK_SUCCESS;  // the affine update is applied inside PrepareStep

@@ -176,6 +176,10 @@ int cxk_shard_info(const cxk_context* ctx, int* cut_level, int* num_levels, long
 int cxk_assemble_local(cxk_context* ctx);
 int cxk_finish_assemble(cxk_context* ctx);
 
+/* per-constraint {normsqrd, norminfd} of the last cxk_prepare_step (the StepInfo info_i of
+ * cone_program.h:69-90 before the reduction); diagnostics and tests */
+int cxk_get_step_info(cxk_context* ctx, double* out2k);
+
 /* ComputeMuFromLineSearch (cone_program.cc:118-160) with PerformLineSearch / FindMinimumMu of the
  * linear cone (linear_constraint.cc:48-103): two solves with the current factorization (right-hand
  * sides -2 AW and AQc c_s + b b_s - 2 AW), per-row admissible interval of the step, reduced over

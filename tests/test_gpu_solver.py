@@ -226,6 +226,34 @@ def test_random_qp_with_line_search_through_conex_h(n, num_ineqs):
     L.CONEX_DeleteConeProgram(p)
 
 
+def test_c4_full_ipm_solve_through_conex_h():
+    """The headline program (1000 LMIs of order 20, N = 15005) solved end to end by CONEX_Maximize
+    on the GPU and by the oracle's restatement of conex::Solve: same optimum.  The iteration
+    counts agree when both Lanczos runs stay healthy; the unreorthogonalised recurrence is
+    noise-dominated near convergence, so a small difference is tolerated."""
+    from conex_amd import synthetic as syn
+    prob = syn.lmi_problem()
+    L = ca.api()
+    p = L.CONEX_CreateConeProgram()
+    nv = prob["num_vars"]
+    assert L.CONEX_SetNumberOfVariables(p, nv) == 0
+    for c, cl in enumerate(prob["cliques"]):
+        a, cm = ca.colmajor(prob["A"][c]), ca.colmajor(prob["C"][c])
+        v = np.ascontiguousarray(cl, dtype=np.int64)
+        assert L.CONEX_AddSparseLMIConstraint(p, ca.dp(a), 20, 20, 20, ca.dp(cm), 20, 20,
+                                              v.ctypes.data_as(C.POINTER(C.c_long)), 20) == c
+    ok, y = _maximize(L, p, prob["b"])
+    st = ca.IterationStats()
+    L.CONEX_GetIterationStats(p, C.byref(st), -1)
+    o = syn.build(ol.Program, prob, "lmi")
+    oko, yo = o.solve(prob["b"])
+    assert ok == 1 and oko == 1
+    assert abs((st.iteration_number + 1) - o.num_iterations()) <= 3
+    assert abs(prob["b"] @ y - prob["b"] @ yo) <= 1e-6 * abs(prob["b"] @ yo)
+    assert np.linalg.norm(y - yo) <= 1e-3 * np.linalg.norm(yo)
+    L.CONEX_DeleteConeProgram(p)
+
+
 def test_sdp_mixed_literal():
     """test_sdp.cc:13-59: S == ones(2,2) to 1e-6."""
     L = ca.api()
