@@ -32,6 +32,16 @@ struct LmiGroup {
   // Taylor-squaring exponential and the eigenvalue estimates its random-start Lanczos
   // (hermitian_psd.cc:10-91, exponential_map.cc:15-43, jordan_matrix_algebra.cc:386-452).
   int herm_d;
+  // Sparse groups (kernels_lmi_sparse.hip.h): A is not stored densely.  Nonzeros (both triangles)
+  // matrix-major -- entries of (member, i) at [sp_eptr[mem*m+i], sp_eptr[mem*m+i+1]), sp_erc =
+  // row | col << 16 -- and position-major for the slack: entries of (member, position q) at
+  // [sp_pptr[mem*n*n+q], ...), variable index ascending.  All null for dense groups.
+  const int* sp_eptr;
+  const int* sp_erc;
+  const double* sp_eval;
+  const int* sp_pptr;
+  const int* sp_pvar;
+  const double* sp_pval;
 };
 
 // Safeguard on the Lanczos estimates (not in the reference).  The unreorthogonalised two-sided
@@ -362,7 +372,16 @@ __global__ void __launch_bounds__(256) lmi_prepare_generic(LmiGroup g, StepArgs 
   for (int q = threadIdx.x; q < nn; q += blockDim.x) sW[q] = Wg[q];
   __syncthreads();
   // minus_s = sum_i y_i A_i - k C   (dense_lmi_constraint.cc:8-27)
-  if ((nn & 1) == 0) {
+  if (g.sp_pptr) {
+    // sparse group: one thread per position sums its nonzeros in the reference's order of i
+    // (the skipped terms are exact zeros)
+    const int* pp = g.sp_pptr + (size_t)mem * nn;
+    for (int q = threadIdx.x; q < nn; q += blockDim.x) {
+      double s = 0;
+      for (int e = pp[q]; e < pp[q + 1]; e++) s += sy[g.sp_pvar[e]] * g.sp_pval[e];
+      sS[q] = s - sa.c_weight * Cm[q];
+    }
+  } else if ((nn & 1) == 0) {
     // A is streamed once more here (m n^2 doubles per constraint): 16-byte loads, eight matrices
     // in flight per thread; the sum over i keeps the reference's order
     const int half = nn >> 1;

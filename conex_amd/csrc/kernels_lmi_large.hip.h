@@ -73,6 +73,15 @@ __global__ void __launch_bounds__(256) lmi_large_slack(LmiGroup g, StepArgs sa, 
   __syncthreads();
   const double* A = g.A + (size_t)mem * m * nn;
   const double* Cm = g.C + (size_t)mem * nn;
+  if (g.sp_pptr) {  // sparse group: nonzeros of each position, variable index ascending
+    const int* pp = g.sp_pptr + (size_t)mem * nn;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x) {
+      double s = 0;
+      for (int e = pp[q]; e < pp[q + 1]; e++) s += sy[g.sp_pvar[e]] * g.sp_pval[e];
+      S[(size_t)mem * nn + q] = s - sa.c_weight * Cm[q];
+    }
+    return;
+  }
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nn; q += gridDim.x * blockDim.x) {
     double s = 0;
     for (int i = 0; i < m; i++) s += sy[i] * A[(size_t)i * nn + q];

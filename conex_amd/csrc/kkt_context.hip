@@ -24,6 +24,7 @@
 #include "kernels_kkt_big.hip.h"
 #include "kernels_lmi.hip.h"
 #include "kernels_lmi_fused.hip.h"
+#include "kernels_lmi_sparse.hip.h"
 #include "kernels_lmi_large.hip.h"
 #include "symbolic.h"
 
@@ -37,6 +38,7 @@ struct ConstraintRec {
   int eq_rows = 0; // CXK_STATIC built from EqualityConstraints: number of multipliers (last clique entries)
   std::vector<double> A, C;
   int group = -1, member = -1;
+  bool sparse = false;  // LMI evaluated from its nonzeros (kernels_lmi_sparse.hip.h)
 };
 
 template <typename T>
@@ -79,6 +81,11 @@ struct Group {
   DevBuf<double> ws_main, ws_gf, ws_part;
   DevBuf<int> ws_piv;
   int splits = 1;
+  // sparse LMI groups: nonzeros matrix-major and position-major instead of the dense A
+  bool sparse = false, sp_wave = false;
+  int sp_chunks = 1;
+  DevBuf<int> sp_eptr, sp_erc, sp_pptr, sp_pvar;
+  DevBuf<double> sp_eval, sp_pval;
 };
 
 }  // namespace
@@ -223,6 +230,12 @@ LmiGroup MakeLmi(Group& g) {
   d.T1 = g.T1.p;
   d.ids = g.dids.p;
   d.herm_d = g.herm_d;
+  d.sp_eptr = g.sparse ? g.sp_eptr.p : nullptr;
+  d.sp_erc = g.sparse ? g.sp_erc.p : nullptr;
+  d.sp_eval = g.sparse ? g.sp_eval.p : nullptr;
+  d.sp_pptr = g.sparse ? g.sp_pptr.p : nullptr;
+  d.sp_pvar = g.sparse ? g.sp_pvar.p : nullptr;
+  d.sp_pval = g.sparse ? g.sp_pval.p : nullptr;
   return d;
 }
 VecGroup MakeVec(Group& g) {
@@ -936,6 +949,8 @@ hipError_t RaiseLdsLimits() {
         reinterpret_cast<const void*>(&tree_sweep_block_ldlt<1>),
         reinterpret_cast<const void*>(&tree_sweep_block_ldlt<2>),
         reinterpret_cast<const void*>(&soc_schur),
+        reinterpret_cast<const void*>(&lmi_schur_sparse<true, true>),
+        reinterpret_cast<const void*>(&lmi_schur_sparse<true, false>),
     };
     for (const void* k : ks) {
       hipFuncAttributes attr;
@@ -979,6 +994,83 @@ ExchangeArgs MakeExchange(cxk_context* ctx, double k, double bs, double cs) {
   return a;
 }
 
+// Entry lists of a sparse LMI group (kernels_lmi_sparse.hip.h) from the dense host matrices.
+int UploadSparseLmi(cxk_context* ctx, Group& g) {
+  const size_t cnt = g.ids.size(), nn = (size_t)g.n * g.n;
+  const int n = g.n, m = g.m;
+  std::vector<int> eptr(cnt * m + 1, 0), erc, pptr(cnt * nn + 1, 0), pvar;
+  std::vector<double> eval, pval;
+  for (size_t k = 0; k < cnt; k++) {
+    const ConstraintRec& c = ctx->cons[g.ids[k]];
+    for (int i = 0; i < m; i++) {
+      const double* M = c.A.data() + (size_t)i * nn;
+      for (int col = 0; col < n; col++)
+        for (int row = 0; row < n; row++) {
+          const double v = M[row + (size_t)col * n];
+          if (v != 0.0) {
+            erc.push_back(row | (col << 16));
+            eval.push_back(v);
+          }
+        }
+      CXK_DEMAND(eval.size() < ((size_t)1 << 31), "sparse LMI group: too many nonzeros");
+      eptr[k * m + i + 1] = (int)eval.size();
+    }
+    for (size_t q = 0; q < nn; q++) {
+      for (int i = 0; i < m; i++) {
+        const double v = c.A[(size_t)i * nn + q];
+        if (v != 0.0) {
+          pvar.push_back(i);
+          pval.push_back(v);
+        }
+      }
+      pptr[k * nn + q + 1] = (int)pval.size();
+    }
+  }
+  // work split: a wavefront per pair once a pair averages >= 64 terms; enough workgroups to
+  // fill the chip when the group is small
+  const double per_mat = cnt * (size_t)m ? (double)eval.size() / (double)(cnt * m) : 0.0;
+  g.sp_wave = per_mat * per_mat >= 64.0;
+  const double pairs = 0.5 * m * (m + 1.0);
+  const double per_block = g.sp_wave ? 4.0 * 16.0 : 256.0 * 4.0;  // pairs one workgroup takes in stride
+  int chunks = (int)std::ceil(pairs / per_block);
+  const int cap = (int)std::max<size_t>(1, 2048 / std::max<size_t>(cnt, 1));
+  g.sp_chunks = std::max(1, std::min(chunks, cap));
+  CXK_TRY(g.sp_eptr.upload(eptr));
+  CXK_TRY(g.sp_erc.upload(erc));
+  CXK_TRY(g.sp_eval.upload(eval));
+  CXK_TRY(g.sp_pptr.upload(pptr));
+  CXK_TRY(g.sp_pvar.upload(pvar));
+  CXK_TRY(g.sp_pval.upload(pval));
+  return CXK_SUCCESS;
+}
+
+// Sparse LMI group: X = W C W (LDS for small orders, two GEMMs otherwise), then the nonzero sums.
+hipError_t LaunchLmiSchurSparse(Group& g, const Arena& ar, hipStream_t st) {
+  const LmiGroup d = MakeLmi(g);
+  const int n = g.n;
+  const dim3 grid(d.count, g.sp_chunks);
+  if (!g.large && LmiSparseLds(n) <= kLdsLimit) {
+    if (g.sp_wave)
+      lmi_schur_sparse<true, true><<<grid, 256, LmiSparseLds(n), st>>>(d, ar, nullptr);
+    else
+      lmi_schur_sparse<true, false><<<grid, 256, LmiSparseLds(n), st>>>(d, ar, nullptr);
+    return hipGetLastError();
+  }
+  const int64_t nn = (int64_t)n * n;
+  double* CW = g.ws_main.p;                          // count x nn
+  double* X = g.ws_main.p + (size_t)d.count * nn;    // count x nn
+  hipError_t e;
+  GemmArgs a = SquareGemm(n, d.C, nn, d.W, nn, CW, nn);
+  if ((e = LaunchGemm(a, false, false, d.count, st)) != hipSuccess) return e;
+  a = SquareGemm(n, d.W, nn, CW, nn, X, nn);
+  if ((e = LaunchGemm(a, false, false, d.count, st)) != hipSuccess) return e;
+  if (g.sp_wave)
+    lmi_schur_sparse<false, true><<<grid, 256, 0, st>>>(d, ar, X);
+  else
+    lmi_schur_sparse<false, false><<<grid, 256, 0, st>>>(d, ar, X);
+  return hipGetLastError();
+}
+
 int LaunchSchur(cxk_context* ctx) {
   Arena ar = MakeArena(ctx);
   for (Group& g : ctx->groups) {
@@ -1000,7 +1092,9 @@ int LaunchSchur(cxk_context* ctx) {
           ctx->ev_used++;
           CXK_TRY(hipEventRecord(e0, ctx->stream));
         }
-        if (g.schur_gemm) {
+        if (g.sparse) {
+          CXK_TRY(LaunchLmiSchurSparse(g, ar, ctx->stream));
+        } else if (g.schur_gemm) {
           CXK_TRY(LmiLargeSchur(MakeLmi(g), ar, MakeLargeWs(g), ctx->stream));
         } else if (g.fused) {
           CXK_TRY(LaunchLmiSchurFused(MakeLmi(g), ar, ctx->stream));
@@ -1405,7 +1499,15 @@ int cxk_finalize(cxk_context* ctx) {
   for (int i = 0; i < K; i++) {
     ConstraintRec& c = ctx->cons[i];
     if (!ctx->owned[i]) continue;
-    auto key = std::make_tuple(c.type, c.n, c.m, c.herm_d);
+    if (c.type == CXK_LMI) {
+      // sparse evaluation when it pays (CXK_SPARSE_LMI=0 / 1 forces never / always: tests)
+      double nnz = 0;
+      for (double v : c.A) nnz += (v != 0.0);
+      const char* force = getenv("CXK_SPARSE_LMI");
+      c.sparse = force ? (atoi(force) != 0) : LmiSparsePays(c.n, c.m, nnz);
+      if (c.n > 65535) c.sparse = false;  // packed row | col << 16
+    }
+    auto key = std::make_tuple(c.type, c.n, c.m, c.herm_d + (c.sparse ? 16 : 0));
     auto it = gmap.find(key);
     if (it == gmap.end()) {
       it = gmap.emplace(key, (int)ctx->groups.size()).first;
@@ -1414,6 +1516,7 @@ int cxk_finalize(cxk_context* ctx) {
       ctx->groups.back().n = c.n;
       ctx->groups.back().m = c.m;
       ctx->groups.back().herm_d = c.herm_d;
+      ctx->groups.back().sparse = c.sparse;
     }
     c.group = it->second;
     c.member = (int)ctx->groups[it->second].ids.size();
@@ -1427,9 +1530,9 @@ int cxk_finalize(cxk_context* ctx) {
         a_sz = (size_t)g.m * g.n * g.n;
         c_sz = w_sz = (size_t)g.n * g.n;
         g.large = !(LmiTakeLds(g.n) <= kLdsLimit && LmiPrepareLds(g.n, g.m) <= kLdsLimit);
-        g.fused = !g.large && LmiFusedSupports(g.n, g.m);
-        g.schur_gemm = g.large || (!g.fused && g.n >= 32 &&
-                                   cnt * 2 * ((size_t)g.m + 1) * g.n * g.n * sizeof(double) <= ((size_t)8 << 30));
+        g.fused = !g.sparse && !g.large && LmiFusedSupports(g.n, g.m);
+        g.schur_gemm = !g.sparse && (g.large || (!g.fused && g.n >= 32 &&
+                                   cnt * 2 * ((size_t)g.m + 1) * g.n * g.n * sizeof(double) <= ((size_t)8 << 30)));
         break;
       case CXK_LINEAR:
         a_sz = (size_t)g.n * g.m;
@@ -1444,10 +1547,14 @@ int cxk_finalize(cxk_context* ctx) {
         c_sz = (size_t)g.m;  // constant AQc (zeros for a quadratic-cost block)
         break;
     }
+    if (g.type == CXK_LMI && g.sparse) {
+      if (UploadSparseLmi(ctx, g)) return CXK_FAILURE;
+      a_sz = 0;  // no dense copy of A on the device
+    }
     std::vector<double> hA(a_sz * cnt), hC(c_sz * cnt);
     for (size_t k = 0; k < cnt; k++) {
       const ConstraintRec& c = ctx->cons[g.ids[k]];
-      std::copy(c.A.begin(), c.A.end(), hA.begin() + k * a_sz);
+      if (a_sz) std::copy(c.A.begin(), c.A.end(), hA.begin() + k * a_sz);
       std::copy(c.C.begin(), c.C.end(), hC.begin() + k * c_sz);
     }
     CXK_TRY(g.A.upload(hA));
@@ -1456,6 +1563,11 @@ int cxk_finalize(cxk_context* ctx) {
     CXK_TRY(g.T1.alloc(w_sz * cnt));
     CXK_TRY(g.T2.alloc(g.type == CXK_LINEAR ? w_sz * cnt : 0));
     CXK_TRY(g.dids.upload(g.ids));
+    if (g.type == CXK_LMI && g.sparse && (g.large || LmiSparseLds(g.n) > kLdsLimit)) {
+      const size_t nn = (size_t)g.n * g.n;
+      CXK_TRY(g.ws_main.alloc(cnt * 8 * nn));  // step temporaries; C W and W C W during assembly
+      CXK_TRY(g.ws_piv.alloc(cnt * (size_t)g.n));
+    }
     if (g.schur_gemm) {
       const size_t nn = (size_t)g.n * g.n, m1 = (size_t)g.m + 1;
       // split-K of the contraction: enough workgroups to fill the chip, at most one K step each
@@ -2073,6 +2185,13 @@ int cxk_gemm_f64(int device, int ta, int tb, int M, int N, int K, int batch, con
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return CXK_SUCCESS;
+}
+
+int cxk_count_sparse_lmi(const cxk_context* ctx) {
+  if (!ctx || !ctx->finalized) return -1;
+  int k = 0;
+  for (size_t i = 0; i < ctx->cons.size(); i++) k += ctx->cons[i].type == CXK_LMI && ctx->owned[i] && ctx->cons[i].sparse;
+  return k;
 }
 
 int cxk_assembly_work(const cxk_context* ctx, double* bytes, double* flops) {

@@ -86,6 +86,7 @@ _SIGNATURES = {
     "cxk_assemble_local": (C.c_int, [C.c_void_p]),
     "cxk_finish_assemble": (C.c_int, [C.c_void_p]),
     "cxk_assembly_work": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "cxk_count_sparse_lmi": (C.c_int, [C.c_void_p]),
     "cxk_kernel_time": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     "cxk_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
 }
@@ -462,6 +463,10 @@ class KktContext:
 
     def finish_assemble(self):
         self._check(self.L.cxk_finish_assemble(self.h), "cxk_finish_assemble")
+
+    def count_sparse_lmi(self):
+        """Constraints on the sparse-LMI evaluation path (cxk_count_sparse_lmi)."""
+        return self.L.cxk_count_sparse_lmi(self.h)
 
     def assembly_work(self):
         b = C.c_double()

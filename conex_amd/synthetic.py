@@ -54,6 +54,36 @@ def lmi_problem(K=1000, n=20, m=20, branching=8, overlap=5, seed=SEED):
     return dict(A=A, C=Cm, cliques=cliques, num_vars=num_vars, b=b, n=n, m=m)
 
 
+def sparsify(prob, density, seed=SEED + 7):
+    """Zero all but about `density` of the entries of every A_i of an lmi_problem / hermitian_problem
+    (symmetric pattern, the diagonal of the first plane kept with the same probability plus one
+    guaranteed diagonal entry so that tr A_i != 0); b is recomputed.  Mirrors programs built entry
+    by entry through CONEX_UpdateLinearOperator (hermitian_psd.cc:249-275)."""
+    rng = np.random.default_rng(seed)
+    A = prob["A"].copy()
+    herm = A.ndim == 5
+    K, m, n = A.shape[0], A.shape[1], A.shape[-1]
+    for c in range(K):
+        for i in range(m):
+            keep = np.triu(rng.uniform(size=(n, n)) < density)
+            keep[rng.integers(n), rng.integers(n)] = True
+            keep = np.triu(keep) | np.triu(keep).T | np.tril(keep) | np.tril(keep).T
+            d = rng.integers(n)
+            keep[d, d] = True
+            A[c, i] = A[c, i] * keep          # broadcasts over the planes of a Hermitian matrix
+            diag = A[c, i, 0] if herm else A[c, i]
+            if diag[d, d] == 0.0:
+                diag[d, d] = 0.5
+    out = dict(prob)
+    out["A"] = A
+    b = np.zeros(prob["num_vars"])
+    for c in range(K):
+        tr = np.trace(A[c, :, 0], axis1=1, axis2=2) if herm else np.trace(A[c], axis1=1, axis2=2)
+        b[prob["cliques"][c]] += 0.5 * tr
+    out["b"] = b
+    return out
+
+
 def scaling_points(K, n, seed=SEED + 1, scale=0.3):
     """W_c = expm(scale * sym(R)): symmetric positive definite, W != I."""
     rng = np.random.default_rng(seed)

@@ -200,6 +200,13 @@ int cxk_gemm_f64(int device, int ta, int tb, int M, int N, int K, int batch, con
                  const double* B, double* C, double alpha, double beta, int lower_only, int splits,
                  int reps, double* avg_ms);
 
+/* Number of (owned) LMI / Hermitian constraints evaluated from their nonzeros instead of dense
+ * matrices (kernels_lmi_sparse.hip.h).  The C-ABI fills matrix inequalities
+ * entry by entry (CONEX_UpdateLinearOperator, hermitian_psd.cc:249-275), so their A_i are
+ * typically very sparse; cxk_initialize picks the sparse evaluation per constraint when
+ * 4 (sum nnz)^2 <= 4 n^3 (m+1) + n^2 m^2.  Results equal the dense path's to rounding. */
+int cxk_count_sparse_lmi(const cxk_context* ctx);
+
 /* ---- timing / roofline accounting -------------------------------------- */
 /* algorithmic bytes and flops of one dense-LMI assembly launch (SURVEY 8d formulas) */
 int cxk_assembly_work(const cxk_context* ctx, double* bytes, double* flops);

@@ -1,0 +1,115 @@
+"""Sparse-LMI evaluation path (kernels_lmi_sparse.hip.h) against the CPU oracle.
+
+The reference has no sparse code path: it multiplies the full matrices whatever their content
+(dense_lmi_constraint.cc:72-103, hermitian_psd.cc:171-230), so the oracle on the densified data
+IS the expected result; the HIP path evaluates the same sums from the nonzeros only.  Bars as in
+test_gpu_parity.py (Schur blocks 1e-13, direction 1e-10, updates 1e-11).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conex_amd import KktContext
+from conex_amd import synthetic as syn
+from test_gpu_parity import check_newton_step, make_pair, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def force_sparse(monkeypatch):
+    monkeypatch.setenv("CXK_SPARSE_LMI", "1")
+
+
+@pytest.fixture
+def force_dense(monkeypatch):
+    monkeypatch.setenv("CXK_SPARSE_LMI", "0")
+
+
+@pytest.mark.parametrize("K,n,m,b_,ov,density", [(1, 4, 3, 8, 1, 0.3), (9, 6, 6, 8, 2, 0.2),
+                                                (30, 20, 20, 8, 5, 0.02), (12, 33, 17, 3, 4, 0.01),
+                                                (6, 24, 40, 2, 10, 0.015)])
+def test_sparse_lmi_newton_step(K, n, m, b_, ov, density):
+    prob = syn.sparsify(syn.lmi_problem(K=K, n=n, m=m, branching=b_, overlap=ov), density)
+    o, k = make_pair(prob, "lmi", syn.scaling_points(K, n))
+    if density <= 0.05:
+        assert k.count_sparse_lmi() == K      # chosen by the cost rule, not forced
+    check_newton_step(o, k, prob["b"])
+
+
+@pytest.mark.parametrize("K,n,m", [(5, 12, 9), (3, 20, 20)])
+def test_sparse_kernels_on_dense_data(force_sparse, K, n, m):
+    """Every entry nonzero: the wavefront-per-pair form of the kernel, same sums as the dense path."""
+    prob = syn.lmi_problem(K=K, n=n, m=m, branching=2, overlap=3)
+    o, k = make_pair(prob, "lmi", syn.scaling_points(K, n))
+    assert k.count_sparse_lmi() == K
+    check_newton_step(o, k, prob["b"])
+
+
+def test_sparse_and_dense_paths_agree(monkeypatch):
+    prob = syn.sparsify(syn.lmi_problem(K=40, n=20, m=20, branching=8, overlap=5), 0.02)
+    W = syn.scaling_points(40, 20)
+    ys = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("CXK_SPARSE_LMI", force)
+        k = syn.build(KktContext, prob, "lmi", device=0)
+        assert k.count_sparse_lmi() == (40 if force == "1" else 0)
+        for i in range(40):
+            k.set_W(i, W[i])
+        k.set_cost(prob["b"])
+        k.kkt_solve_async(0.7, 0.9, 0.8)
+        assert k.sync()
+        ys.append(k.get_y())
+    assert rel(ys[1], ys[0]) <= 1e-12
+
+
+@pytest.mark.parametrize("K,n,m,density,ritz_tol", [(1, 70, 12, 0.004, 2e-3), (2, 128, 30, 0.002, np.inf),
+                                                    (1, 300, 60, 0.0005, np.inf)])
+def test_sparse_large_order(K, n, m, density, ritz_tol):
+    """Orders beyond LDS: W and W C W are read from HBM, PrepareStep / TakeStep take the GEMM path.
+
+    With a slack of the form (sparse - k I) the reference's unreorthogonalised Lanczos breaks down
+    early (beta^2 near its 1e-6 threshold) and its extreme Ritz values are noise at the larger
+    orders -- the oracle's own estimate misses the true spectrum of the n = 128 case by 30 % of its
+    width, and the dense GPU path differs from it just as the sparse one does -- so those two
+    estimates are not compared there; slack, traces, norms and the updated W are."""
+    prob = syn.sparsify(syn.lmi_problem(K=K, n=n, m=m, branching=2, overlap=2), density)
+    o, k = make_pair(prob, "lmi", syn.scaling_points(K, n, scale=0.1))
+    assert k.count_sparse_lmi() == K
+    check_newton_step(o, k, prob["b"], lanczos_tol=ritz_tol)
+
+
+@pytest.mark.parametrize("d", [2, 4])
+def test_sparse_hermitian(d):
+    K, n, m = 6, 8, 10
+    prob = syn.sparsify(syn.hermitian_problem(K=K, n=n, d=d, m=m, branching=2, overlap=3), 0.03 if d == 2 else 0.005)
+    o, k = make_pair(prob, "herm", syn.hermitian_scaling_points(K, n, d))
+    assert k.count_sparse_lmi() == K
+    check_newton_step(o, k, prob["b"])
+
+
+def test_sparse_iterations_track_the_oracle():
+    """Three full Newton iterations (assemble, factor, direction, PrepareStep, TakeStep)."""
+    K, n, m = 20, 16, 12
+    prob = syn.sparsify(syn.lmi_problem(K=K, n=n, m=m, branching=3, overlap=3), 0.03)
+    o, k = make_pair(prob, "lmi", syn.scaling_points(K, n, scale=0.1))
+    assert k.count_sparse_lmi() == K
+    for _ in range(3):
+        check_newton_step(o, k, prob["b"])
+    for i in range(K):
+        assert rel(k.get_W(i), o.get_W(i)) <= 1e-10
+
+
+def test_sparse_runs_are_bit_reproducible():
+    prob = syn.sparsify(syn.lmi_problem(K=50, n=20, m=20, branching=8, overlap=5), 0.02)
+    W = syn.scaling_points(50, 20)
+    k = syn.build(KktContext, prob, "lmi", device=0)
+    for i in range(50):
+        k.set_W(i, W[i])
+    k.set_cost(prob["b"])
+    ys = []
+    for _ in range(2):
+        k.kkt_solve_async(0.7, 0.9, 0.8)
+        assert k.sync()
+        ys.append(k.get_y().copy())
+    assert np.array_equal(ys[0], ys[1])
