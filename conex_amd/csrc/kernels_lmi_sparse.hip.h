@@ -7,149 +7,268 @@
 //
 //   G(i,j) = tr(W A_i W A_j) = sum_{(r,c,a) in A_i} sum_{(p,q,b) in A_j} a b W[c,p] W[q,r]
 //   AW(i)  = tr(A_i W)       = sum_{(r,c,a) in A_i} a W[c,r]
-//   AQc(i) = tr(A_i W C W)   = sum_{(r,c,a) in A_i} a X[c,r],   X = W C W (dense, C is dense)
-//   <w,c>  = sum C o W,  <c,Qc> = sum C o X
+//   AQc(i) = G(i, C),  <c,Qc> = G(C, C),  <w,c> = AW(C)       (C = matrix number m)
 //
 // (dense_lmi_constraint.cc:72-103, hermitian_psd.cc:171-230) are evaluated from the nonzeros:
 // O((sum nnz)^2) instead of O(n^3 m + n^2 m^2), and the m n^2 stream of A disappears from HBM
-// (the dense A is never uploaded).  Values equal the dense path's up to summation order
-// (tolerance parity, tests/test_gpu_sparse.py); every sum has a fixed order: bit-reproducible.
+// (the dense A is never uploaded).  A dense affine term C (more than 64 nonzeros) does not join
+// the pair sums: X = W C W is formed densely instead (LDS for small orders, two GEMM launches
+// otherwise) and AQc(i) = sum a X[c,r], <c,Qc> = sum C o X, <w,c> = sum C o W.
+// Values equal the dense path's up to summation order (tolerance parity,
+// tests/test_gpu_sparse.py); every sum has a fixed order: bit-reproducible.
 //
-// Entry lists hold BOTH triangles of every A_i (the trace inner products above run over the
-// full matrix).  Layout per group: entries of (member, i) at [eptr[mem*m+i], eptr[mem*m+i+1]),
-// erc = row | col << 16, eval = value.  The slack of PrepareStep uses a second, position-major
-// copy (kernels_lmi.hip.h / kernels_lmi_large.hip.h: sp_pptr / sp_pvar / sp_pval) so that every
+// Entry lists hold BOTH triangles of every matrix (the trace inner products above run over the
+// full matrix).  Layout per group, m1 = m + 1 lists per member: entries of (member, i) at
+// [eptr[mem*m1+i], eptr[mem*m1+i+1]), erc = row | col << 16, eval = value; list m is C (empty
+// when C takes the dense route).  The slack of PrepareStep uses a second, position-major copy
+// (kernels_lmi.hip.h / kernels_lmi_large.hip.h: sp_pptr / sp_pvar / sp_pval) so that every
 // entry of sum_i y_i A_i is accumulated by one thread in the reference's order of i.
 #pragma once
 #include "kernels_lmi.hip.h"
 
 namespace cxk {
 
-// Sparse evaluation costs about 2 (sum nnz)^2 multiply-adds at a fraction of the dense kernels'
-// efficiency; it is chosen when that is at least 2x fewer operations than the dense formula.
-inline bool LmiSparsePays(int n, int m, double nnz_a) {
+// The pair sums cost about (sum nnz)^2 / 2 terms; a term is four scattered reads (entry pair, two
+// W elements).  Measured term rates on MI355X against the dense kernels' flop rates give the
+// break-even ratios below (dense flops per sparse term): ~80 where W sits in LDS and the dense
+// side is the fused kernel, ~40 for the other LDS-resident shapes, ~700 beyond LDS (W read from
+// L2/HBM, dense side on the MFMA GEMM pipeline).
+inline bool LmiSparsePays(int n, int m, double nnz_a, bool lds_resident, bool fused) {
   const double dense = 4.0 * n * n * n * (m + 1.0) + (double)n * n * m * m;
-  return 4.0 * nnz_a * nnz_a <= dense;
+  const double per_term = lds_resident ? (fused ? 80.0 : 40.0) : 700.0;
+  return 0.5 * nnz_a * nnz_a * per_term <= dense;
 }
 
 __device__ __forceinline__ void PairFromIndex(long long t, int* i, int* j) {
   // t = i (i + 1) / 2 + j, 0 <= j <= i
-  long long ii = (long long)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  long long ii = (long long)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
   while (ii * (ii + 1) / 2 > t) ii--;
   while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
   *i = (int)ii;
   *j = (int)(t - ii * (ii + 1) / 2);
 }
 
-// grid (count, chunks).  SMALL: W (and X = W C W, computed here by chunk 0) live in LDS;
-// otherwise W is read from HBM/L2 and X comes from two GEMM launches (Xg: count x n^2).
-// WAVE_PER_PAIR: a wavefront splits the nnz_i x nnz_j terms of one pair (heavier matrices);
-// otherwise one thread sums one pair.
-template <bool SMALL, bool WAVE_PER_PAIR>
-__global__ void __launch_bounds__(256) lmi_schur_sparse(LmiGroup g, Arena ar, const double* __restrict__ Xg) {
+#ifdef CXK_DEBUG_STAMPS
+__device__ long long g_sparse_stamp[8];
+#define SPSTAMP(i) do { if (blockIdx.x == 500 && blockIdx.y == 0 && threadIdx.x == 0) g_sparse_stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SPSTAMP(i) do { } while (0)
+#endif
+
+struct SparseLaunch {
+  const double* Xg;  // count x n^2: W C W from the GEMM path (large orders with a dense C), else null
+  int emax;          // entries reserved in LDS per workgroup (STAGE)
+  int cdense;        // C takes the dense route
+};
+
+// Sum over a group of LPP consecutive lanes (LPP a power of two <= 64) in a fixed butterfly order;
+// every lane of the group receives the total.
+template <int LPP>
+__device__ __forceinline__ double GroupSum(double v) {
+#pragma unroll
+  for (int d = LPP >> 1; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// Sum of the ni x nj terms of one pair shared by LP consecutive lanes (lane `sub` of the group
+// takes terms sub, sub + LP, ...; q = (ei - bi) nj + (ej - bj)), four terms in flight per lane: a
+// term is two dependent hops (the entries, then the W elements they name).  Every lane of the
+// group returns the total (fixed order: bit-reproducible).
+template <int LP>
+__device__ __forceinline__ double PairSum(const int* erc, const double* eval, const double* W, int n, int bi,
+                                          int ni, int bj, int nj, int sub) {
+  double s = 0;
+  if (ni > 0 && nj > 0) {
+    int ei = bi + sub / nj, ej = bj + sub % nj;
+    const int di = LP / nj, dj = LP % nj, ei_end = bi + ni, ej_end = bj + nj;
+    while (ei < ei_end) {
+      int xi[4], xj[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        ok[u] = ei < ei_end;
+        xi[u] = ok[u] ? ei : bi;
+        xj[u] = ok[u] ? ej : bj;
+        ei += di;
+        ej += dj;
+        if (ej >= ej_end) {
+          ej -= nj;
+          ei++;
+        }
+      }
+      int rc[4], pq[4];
+      double a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        rc[u] = erc[xi[u]];
+        pq[u] = erc[xj[u]];
+        a[u] = eval[xi[u]];
+        b[u] = eval[xj[u]];
+      }
+      double w0[4], w1[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int r = rc[u] & 0xffff, c = rc[u] >> 16, p = pq[u] & 0xffff, qq = pq[u] >> 16;
+        w0[u] = W[c + (size_t)p * n];
+        w1[u] = W[qq + (size_t)r * n];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const double term = (a[u] * b[u]) * (w0[u] * w1[u]);
+        s += ok[u] ? term : 0.0;
+      }
+    }
+  }
+  return GroupSum<LP>(s);
+}
+
+// grid (count, chunks of the pair range).
+// SMALL: W (and, for a dense C, X = W C W computed by chunk 0) live in LDS; otherwise W is read
+// from HBM/L2.  LPP lanes share the nnz_i x nnz_j terms of one pair (1: a thread per pair, for
+// the sparsest lists; 64: a wavefront per pair) -- a term is two dependent LDS hops (entry, then
+// the W elements it names), so the terms of a lane are issued four at a time.  STAGE: the
+// constraint's entry list is copied to LDS first: a sweep reads entries at unrelated addresses,
+// which costs a cache line per lane from L1/L2 but only bank conflicts from LDS.
+template <bool SMALL, int LPP, bool STAGE>
+__global__ void __launch_bounds__(256) lmi_schur_sparse(LmiGroup g, Arena ar, SparseLaunch L) {
   extern __shared__ double lds[];
-  const int n = g.n, m = g.m, nn = n * n;
+  const int n = g.n, m = g.m, m1 = m + 1, nn = n * n;
   const int mem = blockIdx.x, id = g.ids[mem];
   const double* Cm = g.C + (size_t)mem * nn;
   const double* Wg = g.W + (size_t)mem * nn;
-  const int* eptr = g.sp_eptr + (size_t)mem * m;
-  const int* erc = g.sp_erc;
-  const double* eval = g.sp_eval;
-  double* G = ar.G + ar.g_off[id];
+  const int* gptr = g.sp_eptr + (size_t)mem * m1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;
   const bool first = blockIdx.y == 0;
+  const bool cdense = L.cdense != 0;
+  // LDS: [W | C P X (dense C)] (SMALL), entry values, entry row/col, list pointers
+  double* sW = lds;
+  double* s_val = lds + (SMALL ? (cdense ? 4 : 1) * (size_t)nn : 0);
+  int* s_rc = reinterpret_cast<int*>(s_val + (STAGE ? L.emax : 0));
+  int* s_ptr = s_rc + (STAGE ? L.emax : 0);
+  SPSTAMP(0);
+  const int e0 = gptr[0];
+  for (int q = threadIdx.x; q <= m1; q += blockDim.x) s_ptr[q] = gptr[q] - (STAGE ? e0 : 0);
+  const int* erc = g.sp_erc;
+  const double* eval = g.sp_eval;
+  if (STAGE) {
+    const int cnt = gptr[m1] - e0;
+    for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+      s_val[q] = g.sp_eval[e0 + q];
+      s_rc[q] = g.sp_erc[e0 + q];
+    }
+    erc = s_rc;
+    eval = s_val;
+  }
   const double* W = Wg;
-  const double* X = Xg ? Xg + (size_t)mem * nn : nullptr;
   if (SMALL) {
-    double* sW = lds;
     for (int q = threadIdx.x; q < nn; q += blockDim.x) sW[q] = Wg[q];
     W = sW;
-    if (first) {
-      double* sC = sW + nn;
-      double* sP = sC + nn;
-      double* sX = sP + nn;
-      for (int q = threadIdx.x; q < nn; q += blockDim.x) sC[q] = Cm[q];
-      __syncthreads();
-      LdsGemm(n, sC, sW, sP);  // C W
-      __syncthreads();
-      LdsGemm(n, sW, sP, sX);  // W C W
-      X = sX;
-    }
-    __syncthreads();
   }
+  __syncthreads();
+  SPSTAMP(1);
   if (first) {
-    // residual vectors: one wavefront per variable
-    for (int i = wave; i < m; i += nwaves) {
-      double aw = 0, aq = 0;
-      for (int e = eptr[i] + lane; e < eptr[i + 1]; e += 64) {
-        const int rc = erc[e], r = rc & 0xffff, c = rc >> 16;
-        const double a = eval[e];
-        aw = fma(a, W[c + (size_t)r * n], aw);
-        aq = fma(a, X[c + (size_t)r * n], aq);
+    if (cdense) {
+      const double* X = L.Xg ? L.Xg + (size_t)mem * nn : nullptr;
+      const double* Cs = Cm;
+      if (SMALL) {
+        double* sC = sW + nn;
+        double* sP = sC + nn;
+        double* sX = sP + nn;
+        for (int q = threadIdx.x; q < nn; q += blockDim.x) sC[q] = Cm[q];
+        __syncthreads();
+        LdsGemm(n, sC, sW, sP);  // C W
+        __syncthreads();
+        LdsGemm(n, sW, sP, sX);  // W C W
+        __syncthreads();
+        X = sX;
+        Cs = sC;
       }
-      aw = WaveSum(aw);
-      aq = WaveSum(aq);
-      if (lane == 0) {
-        ar.AWc[ar.r_off[id] + i] = aw * osc;
-        ar.AQcc[ar.r_off[id] + i] = aq * osc;
+      for (int i = wave; i < m; i += nwaves) {  // AQc(i) = sum a X[c,r]
+        double aq = 0;
+        for (int e = s_ptr[i] + lane; e < s_ptr[i + 1]; e += 64) {
+          const int rc = erc[e], r = rc & 0xffff, c = rc >> 16;
+          aq = fma(eval[e], X[c + (size_t)r * n], aq);
+        }
+        aq = WaveSum(aq);
+        if (lane == 0) ar.AQcc[ar.r_off[id] + i] = aq * osc;
       }
-    }
-    if (wave == 0) {
       double wc = 0, cq = 0;
-      for (int q = lane; q < nn; q += 64) {
-        const double c = Cm[q];
+      for (int q = threadIdx.x; q < nn; q += blockDim.x) {
+        const double c = Cs[q];
         wc = fma(c, W[q], wc);
         cq = fma(c, X[q], cq);
       }
-      wc = WaveSum(wc);
-      cq = WaveSum(cq);
-      if (lane == 0) {
+      double* red = reinterpret_cast<double*>(s_ptr + ((m1 + 3) & ~1));
+      wc = BlockSum(wc, red);
+      cq = BlockSum(cq, red + 8);
+      if (threadIdx.x == 0) {
         ar.sc[2 * id] = wc * osc;
         ar.sc[2 * id + 1] = cq * osc;
       }
     }
-  }
-  const long long pairs = (long long)m * (m + 1) / 2;
-  const long long per = (pairs + gridDim.y - 1) / gridDim.y;
-  const long long t0 = per * blockIdx.y, t1 = (t0 + per < pairs) ? t0 + per : pairs;
-  if (WAVE_PER_PAIR) {
-    for (long long t = t0 + wave; t < t1; t += nwaves) {
-      int i, j;
-      PairFromIndex(t, &i, &j);
-      const int bi = eptr[i], ni = eptr[i + 1] - bi, bj = eptr[j], nj = eptr[j + 1] - bj;
-      double s = 0;
-      const long long terms = (long long)ni * nj;
-      for (long long q = lane; q < terms; q += 64) {
-        const int ei = bi + (int)(q / nj), ej = bj + (int)(q % nj);
-        const int rc = erc[ei], r = rc & 0xffff, c = rc >> 16;
-        const int pq = erc[ej], p = pq & 0xffff, qq = pq >> 16;
-        s = fma(eval[ei] * eval[ej], W[c + (size_t)p * n] * W[qq + (size_t)r * n], s);
+    // AW(i) = sum a W[c,r]; list m (sparse C) gives <w,c>
+    const int lists = cdense ? m : m1;
+    constexpr int LPV = LPP < 8 ? 8 : LPP;  // lanes per list
+    for (int i = threadIdx.x / LPV; i < lists; i += blockDim.x / LPV) {
+      double aw = 0;
+      for (int e = s_ptr[i] + (threadIdx.x % LPV); e < s_ptr[i + 1]; e += LPV) {
+        const int rc = erc[e], r = rc & 0xffff, c = rc >> 16;
+        aw = fma(eval[e], W[c + (size_t)r * n], aw);
       }
-      s = WaveSum(s);
-      if (lane == 0) G[i + (size_t)j * m] = s * osc;
-    }
-  } else {
-    for (long long t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
-      int i, j;
-      PairFromIndex(t, &i, &j);
-      const int bi = eptr[i], ei1 = eptr[i + 1], bj = eptr[j], ej1 = eptr[j + 1];
-      double s = 0;
-      for (int ei = bi; ei < ei1; ei++) {
-        const int rc = erc[ei], r = rc & 0xffff, c = rc >> 16;
-        const double a = eval[ei];
-        const double* Wc = W + c;               // W[c, p] = W[c + p n]
-        const double* Wr = W + (size_t)r * n;   // W[q, r] = W[q + r n]
-        for (int ej = bj; ej < ej1; ej++) {
-          const int pq = erc[ej], p = pq & 0xffff, qq = pq >> 16;
-          s = fma(a * eval[ej], Wc[(size_t)p * n] * Wr[qq], s);
-        }
+      aw = GroupSum<LPV>(aw);
+      if (threadIdx.x % LPV == 0) {
+        if (i < m)
+          ar.AWc[ar.r_off[id] + i] = aw * osc;
+        else
+          ar.sc[2 * id] = aw * osc;
       }
-      G[i + (size_t)j * m] = s * osc;
     }
   }
+  SPSTAMP(2);
+  // pair sums among the A_i: LPP lanes per pair, the pair range dealt to the chunks
+  double* G = ar.G + ar.g_off[id];
+  {
+    const long long pairs = (long long)m * (m + 1) / 2;
+    const long long per = (pairs + gridDim.y - 1) / gridDim.y;
+    const long long t0 = per * blockIdx.y, t1 = (t0 + per < pairs) ? t0 + per : pairs;
+    const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP, ngrp = blockDim.x / LPP;
+    for (long long t = t0 + grp; t < t1; t += ngrp) {
+      int i, j;
+      PairFromIndex(t, &i, &j);
+      const int bi = s_ptr[i], bj = s_ptr[j];
+      const double s = PairSum<LPP>(erc, eval, W, n, bi, s_ptr[i + 1] - bi, bj, s_ptr[j + 1] - bj, sub);
+      if (sub == 0) G[i + (size_t)j * m] = s * osc;
+    }
+  }
+  // row m (a sparse C, at most 64 nonzeros): AQc(j) = G(C, A_j), <c,Qc> = G(C, C) -- the longest
+  // lists of the constraint, a wavefront per pair
+  if (!cdense) {
+    const int bc = s_ptr[m], nc = s_ptr[m1] - bc;
+    for (int j = blockIdx.y * nwaves + wave; j <= m; j += gridDim.y * nwaves) {
+      const int bj = s_ptr[j];
+      const double s = PairSum<64>(erc, eval, W, n, bc, nc, bj, s_ptr[j + 1] - bj, lane);
+      if (lane == 0) {
+        if (j < m)
+          ar.AQcc[ar.r_off[id] + j] = s * osc;
+        else
+          ar.sc[2 * id + 1] = s * osc;
+      }
+    }
+  }
+#ifdef CXK_DEBUG_STAMPS
+  SPSTAMP(3);
+  __syncthreads();
+  SPSTAMP(4);
+#endif
 }
 
-inline size_t LmiSparseLds(int n) { return sizeof(double) * 4 * (size_t)n * n; }
+// bytes of LDS: matrices, staged entries, list pointers (+ block-reduction scratch)
+inline size_t LmiSparseLds(int n, int m, bool small, bool cdense, int emax_staged) {
+  size_t b = small ? sizeof(double) * (cdense ? 4 : 1) * (size_t)n * n : 0;
+  b += (size_t)emax_staged * 12;
+  b += sizeof(int) * (size_t)((m + 1 + 3) & ~1) + sizeof(double) * 16;
+  return b;
+}
 
 }  // namespace cxk

@@ -82,8 +82,11 @@ struct Group {
   DevBuf<int> ws_piv;
   int splits = 1;
   // sparse LMI groups: nonzeros matrix-major and position-major instead of the dense A
-  bool sparse = false, sp_wave = false;
-  int sp_chunks = 1;
+  bool sparse = false;
+  int sp_lpp = 1;                  // lanes sharing one (i, j) pair sum
+  int sp_chunks = 1, sp_emax = 0;  // sp_emax: most nonzeros in one constraint
+  bool sp_cdense = false;          // dense affine term: X = W C W instead of pair sums with C
+  bool sp_small = false;           // W (and X) of a constraint fit in LDS
   DevBuf<int> sp_eptr, sp_erc, sp_pptr, sp_pvar;
   DevBuf<double> sp_eval, sp_pval;
 };
@@ -949,8 +952,6 @@ hipError_t RaiseLdsLimits() {
         reinterpret_cast<const void*>(&tree_sweep_block_ldlt<1>),
         reinterpret_cast<const void*>(&tree_sweep_block_ldlt<2>),
         reinterpret_cast<const void*>(&soc_schur),
-        reinterpret_cast<const void*>(&lmi_schur_sparse<true, true>),
-        reinterpret_cast<const void*>(&lmi_schur_sparse<true, false>),
     };
     for (const void* k : ks) {
       hipFuncAttributes attr;
@@ -997,24 +998,34 @@ ExchangeArgs MakeExchange(cxk_context* ctx, double k, double bs, double cs) {
 // Entry lists of a sparse LMI group (kernels_lmi_sparse.hip.h) from the dense host matrices.
 int UploadSparseLmi(cxk_context* ctx, Group& g) {
   const size_t cnt = g.ids.size(), nn = (size_t)g.n * g.n;
-  const int n = g.n, m = g.m;
-  std::vector<int> eptr(cnt * m + 1, 0), erc, pptr(cnt * nn + 1, 0), pvar;
+  const int n = g.n, m = g.m, m1 = m + 1;
+  // a dense affine term stays out of the pair sums (X = W C W is formed instead)
+  g.sp_cdense = false;
+  for (size_t k = 0; k < cnt; k++) {
+    size_t nz = 0;
+    for (double v : ctx->cons[g.ids[k]].C) nz += (v != 0.0);
+    if (nz > 64) g.sp_cdense = true;  // (C, C) alone would be nz^2 terms on one wavefront
+  }
+  std::vector<int> eptr(cnt * m1 + 1, 0), erc, pptr(cnt * nn + 1, 0), pvar;
   std::vector<double> eval, pval;
+  g.sp_emax = 0;
   for (size_t k = 0; k < cnt; k++) {
     const ConstraintRec& c = ctx->cons[g.ids[k]];
-    for (int i = 0; i < m; i++) {
-      const double* M = c.A.data() + (size_t)i * nn;
-      for (int col = 0; col < n; col++)
-        for (int row = 0; row < n; row++) {
-          const double v = M[row + (size_t)col * n];
-          if (v != 0.0) {
-            erc.push_back(row | (col << 16));
-            eval.push_back(v);
+    for (int i = 0; i < m1; i++) {
+      const double* M = i < m ? c.A.data() + (size_t)i * nn : c.C.data();
+      if (i < m || !g.sp_cdense)
+        for (int col = 0; col < n; col++)
+          for (int row = 0; row < n; row++) {
+            const double v = M[row + (size_t)col * n];
+            if (v != 0.0) {
+              erc.push_back(row | (col << 16));
+              eval.push_back(v);
+            }
           }
-        }
       CXK_DEMAND(eval.size() < ((size_t)1 << 31), "sparse LMI group: too many nonzeros");
-      eptr[k * m + i + 1] = (int)eval.size();
+      eptr[k * m1 + i + 1] = (int)eval.size();
     }
+    g.sp_emax = std::max(g.sp_emax, eptr[k * m1 + m1] - eptr[k * m1]);
     for (size_t q = 0; q < nn; q++) {
       for (int i = 0; i < m; i++) {
         const double v = c.A[(size_t)i * nn + q];
@@ -1026,12 +1037,14 @@ int UploadSparseLmi(cxk_context* ctx, Group& g) {
       pptr[k * nn + q + 1] = (int)pval.size();
     }
   }
-  // work split: a wavefront per pair once a pair averages >= 64 terms; enough workgroups to
-  // fill the chip when the group is small
-  const double per_mat = cnt * (size_t)m ? (double)eval.size() / (double)(cnt * m) : 0.0;
-  g.sp_wave = per_mat * per_mat >= 64.0;
-  const double pairs = 0.5 * m * (m + 1.0);
-  const double per_block = g.sp_wave ? 4.0 * 16.0 : 256.0 * 4.0;  // pairs one workgroup takes in stride
+  g.sp_small = !g.large && LmiSparseLds(n, m, true, g.sp_cdense, 0) <= kLdsLimit;
+  // work split: lanes per pair from the average number of terms of a pair (each lane takes four
+  // terms at a time); enough workgroups to fill the chip when the group is small
+  const double per_mat = cnt ? (double)eval.size() / (double)(cnt * m1) : 0.0;
+  const double avg_terms = per_mat * per_mat;
+  g.sp_lpp = avg_terms <= 8 ? 1 : avg_terms <= 64 ? 4 : avg_terms <= 1024 ? 16 : 64;
+  const double pairs = 0.5 * m1 * (m1 + 1.0);
+  const double per_block = (256.0 / g.sp_lpp) * 4.0;  // pairs one workgroup takes in stride
   int chunks = (int)std::ceil(pairs / per_block);
   const int cap = (int)std::max<size_t>(1, 2048 / std::max<size_t>(cnt, 1));
   g.sp_chunks = std::max(1, std::min(chunks, cap));
@@ -1044,31 +1057,59 @@ int UploadSparseLmi(cxk_context* ctx, Group& g) {
   return CXK_SUCCESS;
 }
 
-// Sparse LMI group: X = W C W (LDS for small orders, two GEMMs otherwise), then the nonzero sums.
+// Sparse LMI group: the nonzero sums; a dense C first needs X = W C W (LDS for small orders, two
+// GEMMs otherwise).
+template <bool SMALL, int LPP>
+hipError_t LaunchLmiSparseKernelL(Group& g, const LmiGroup& d, const Arena& ar, const double* X, hipStream_t st) {
+  const dim3 grid(d.count, g.sp_chunks);
+  const int emax = (g.sp_emax + 1) & ~1;  // keeps the arrays behind it 8-byte aligned
+  const bool stage = LmiSparseLds(g.n, g.m, SMALL, g.sp_cdense, emax) <= kLdsLimit;
+  const size_t lds = LmiSparseLds(g.n, g.m, SMALL, g.sp_cdense, stage ? emax : 0);
+  SparseLaunch L;
+  L.Xg = X;
+  L.emax = stage ? emax : 0;
+  L.cdense = g.sp_cdense;
+  auto raise = [&](const void* k) -> hipError_t {  // dynamic LDS beyond 64 KB needs the attribute
+    return lds > 64 * 1024 ? hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit)
+                           : hipSuccess;
+  };
+  hipError_t e;
+  if (stage) {
+    if ((e = raise(reinterpret_cast<const void*>(&lmi_schur_sparse<SMALL, LPP, true>))) != hipSuccess) return e;
+    lmi_schur_sparse<SMALL, LPP, true><<<grid, 256, lds, st>>>(d, ar, L);
+  } else {
+    if ((e = raise(reinterpret_cast<const void*>(&lmi_schur_sparse<SMALL, LPP, false>))) != hipSuccess) return e;
+    lmi_schur_sparse<SMALL, LPP, false><<<grid, 256, lds, st>>>(d, ar, L);
+  }
+  return hipGetLastError();
+}
+
+template <bool SMALL>
+hipError_t LaunchLmiSparseKernel(Group& g, const LmiGroup& d, const Arena& ar, const double* X, hipStream_t st) {
+  switch (g.sp_lpp) {
+    case 1: return LaunchLmiSparseKernelL<SMALL, 1>(g, d, ar, X, st);
+    case 4: return LaunchLmiSparseKernelL<SMALL, 4>(g, d, ar, X, st);
+    case 16: return LaunchLmiSparseKernelL<SMALL, 16>(g, d, ar, X, st);
+    default: return LaunchLmiSparseKernelL<SMALL, 64>(g, d, ar, X, st);
+  }
+}
+
 hipError_t LaunchLmiSchurSparse(Group& g, const Arena& ar, hipStream_t st) {
   const LmiGroup d = MakeLmi(g);
   const int n = g.n;
-  const dim3 grid(d.count, g.sp_chunks);
-  if (!g.large && LmiSparseLds(n) <= kLdsLimit) {
-    if (g.sp_wave)
-      lmi_schur_sparse<true, true><<<grid, 256, LmiSparseLds(n), st>>>(d, ar, nullptr);
-    else
-      lmi_schur_sparse<true, false><<<grid, 256, LmiSparseLds(n), st>>>(d, ar, nullptr);
-    return hipGetLastError();
+  if (g.sp_small) return LaunchLmiSparseKernel<true>(g, d, ar, nullptr, st);
+  double* X = nullptr;
+  if (g.sp_cdense) {
+    const int64_t nn = (int64_t)n * n;
+    double* CW = g.ws_main.p;                  // count x nn
+    X = g.ws_main.p + (size_t)d.count * nn;    // count x nn
+    hipError_t e;
+    GemmArgs a = SquareGemm(n, d.C, nn, d.W, nn, CW, nn);
+    if ((e = LaunchGemm(a, false, false, d.count, st)) != hipSuccess) return e;
+    a = SquareGemm(n, d.W, nn, CW, nn, X, nn);
+    if ((e = LaunchGemm(a, false, false, d.count, st)) != hipSuccess) return e;
   }
-  const int64_t nn = (int64_t)n * n;
-  double* CW = g.ws_main.p;                          // count x nn
-  double* X = g.ws_main.p + (size_t)d.count * nn;    // count x nn
-  hipError_t e;
-  GemmArgs a = SquareGemm(n, d.C, nn, d.W, nn, CW, nn);
-  if ((e = LaunchGemm(a, false, false, d.count, st)) != hipSuccess) return e;
-  a = SquareGemm(n, d.W, nn, CW, nn, X, nn);
-  if ((e = LaunchGemm(a, false, false, d.count, st)) != hipSuccess) return e;
-  if (g.sp_wave)
-    lmi_schur_sparse<false, true><<<grid, 256, 0, st>>>(d, ar, X);
-  else
-    lmi_schur_sparse<false, false><<<grid, 256, 0, st>>>(d, ar, X);
-  return hipGetLastError();
+  return LaunchLmiSparseKernel<false>(g, d, ar, X, st);
 }
 
 int LaunchSchur(cxk_context* ctx) {
@@ -1504,7 +1545,9 @@ int cxk_finalize(cxk_context* ctx) {
       double nnz = 0;
       for (double v : c.A) nnz += (v != 0.0);
       const char* force = getenv("CXK_SPARSE_LMI");
-      c.sparse = force ? (atoi(force) != 0) : LmiSparsePays(c.n, c.m, nnz);
+      const bool lds_resident = LmiTakeLds(c.n) <= kLdsLimit && LmiPrepareLds(c.n, c.m) <= kLdsLimit;
+      c.sparse = force ? (atoi(force) != 0)
+                       : LmiSparsePays(c.n, c.m, nnz, lds_resident, LmiFusedSupports(c.n, c.m));
       if (c.n > 65535) c.sparse = false;  // packed row | col << 16
     }
     auto key = std::make_tuple(c.type, c.n, c.m, c.herm_d + (c.sparse ? 16 : 0));
@@ -1563,7 +1606,7 @@ int cxk_finalize(cxk_context* ctx) {
     CXK_TRY(g.T1.alloc(w_sz * cnt));
     CXK_TRY(g.T2.alloc(g.type == CXK_LINEAR ? w_sz * cnt : 0));
     CXK_TRY(g.dids.upload(g.ids));
-    if (g.type == CXK_LMI && g.sparse && (g.large || LmiSparseLds(g.n) > kLdsLimit)) {
+    if (g.type == CXK_LMI && g.sparse && (g.large || !g.sp_small)) {
       const size_t nn = (size_t)g.n * g.n;
       CXK_TRY(g.ws_main.alloc(cnt * 8 * nn));  // step temporaries; C W and W C W during assembly
       CXK_TRY(g.ws_piv.alloc(cnt * (size_t)g.n));
@@ -2213,6 +2256,9 @@ int cxk_assembly_work(const cxk_context* ctx, double* bytes, double* flops) {
 #ifdef CXK_DEBUG_STAMPS
 int cxk_debug_fused_stamps(long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamp), 64 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+int cxk_debug_sparse_stamps(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sparse_stamp), 8 * sizeof(long long)) == hipSuccess ? 0 : 1;
 }
 int cxk_debug_stamps(long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cxk_stamp), 32 * sizeof(long long)) == hipSuccess ? 0 : 1;

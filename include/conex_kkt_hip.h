@@ -203,8 +203,10 @@ int cxk_gemm_f64(int device, int ta, int tb, int M, int N, int K, int batch, con
 /* Number of (owned) LMI / Hermitian constraints evaluated from their nonzeros instead of dense
  * matrices (kernels_lmi_sparse.hip.h).  The C-ABI fills matrix inequalities
  * entry by entry (CONEX_UpdateLinearOperator, hermitian_psd.cc:249-275), so their A_i are
- * typically very sparse; cxk_initialize picks the sparse evaluation per constraint when
- * 4 (sum nnz)^2 <= 4 n^3 (m+1) + n^2 m^2.  Results equal the dense path's to rounding. */
+ * typically very sparse; cxk_initialize picks the sparse evaluation per constraint when its
+ * (sum nnz)^2 / 2 terms cost less than the dense formula 4 n^3 (m+1) + n^2 m^2 (measured
+ * break-even ratios in kernels_lmi_sparse.hip.h; CXK_SPARSE_LMI=0/1 in the environment forces
+ * never/always).  Results equal the dense path's to rounding. */
 int cxk_count_sparse_lmi(const cxk_context* ctx);
 
 /* ---- timing / roofline accounting -------------------------------------- */

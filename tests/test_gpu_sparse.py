@@ -29,12 +29,35 @@ def force_dense(monkeypatch):
 @pytest.mark.parametrize("K,n,m,b_,ov,density", [(1, 4, 3, 8, 1, 0.3), (9, 6, 6, 8, 2, 0.2),
                                                 (30, 20, 20, 8, 5, 0.02), (12, 33, 17, 3, 4, 0.01),
                                                 (6, 24, 40, 2, 10, 0.015)])
-def test_sparse_lmi_newton_step(K, n, m, b_, ov, density):
+def test_sparse_lmi_newton_step(force_sparse, K, n, m, b_, ov, density):
     prob = syn.sparsify(syn.lmi_problem(K=K, n=n, m=m, branching=b_, overlap=ov), density)
     o, k = make_pair(prob, "lmi", syn.scaling_points(K, n))
-    if density <= 0.05:
-        assert k.count_sparse_lmi() == K      # chosen by the cost rule, not forced
+    assert k.count_sparse_lmi() == K
     check_newton_step(o, k, prob["b"])
+
+
+@pytest.mark.parametrize("K,n,m,density,expect", [(10, 20, 20, 0.001, True), (10, 20, 20, 0.05, False),
+                                                  (4, 48, 12, 0.004, True), (4, 48, 12, 0.2, False),
+                                                  (1, 128, 100, 0.0002, True), (1, 128, 30, 0.01, False)])
+def test_cost_rule_picks_the_path(K, n, m, density, expect):
+    """cxk_initialize chooses the sparse evaluation only where it measured faster than the dense
+    kernels (kernels_lmi_sparse.hip.h: LmiSparsePays); either way the step matches the oracle."""
+    prob = syn.sparsify(syn.lmi_problem(K=K, n=n, m=m, branching=2, overlap=2), density)
+    o, k = make_pair(prob, "lmi", syn.scaling_points(K, n, scale=0.1))
+    assert k.count_sparse_lmi() == (K if expect else 0)
+    check_newton_step(o, k, prob["b"], check_update=False)
+
+
+@pytest.mark.parametrize("K,n,m,density", [(7, 20, 20, 0.02), (2, 70, 12, 0.004)])
+def test_sparse_lmi_with_dense_affine_term(force_sparse, K, n, m, density):
+    """C with more than 2n nonzeros stays out of the pair sums: X = W C W is formed densely
+    (in LDS, or by two GEMM launches beyond LDS-resident orders)."""
+    prob = syn.sparsify(syn.lmi_problem(K=K, n=n, m=m, branching=2, overlap=2), density)
+    rng = np.random.default_rng(5)
+    prob["C"] = prob["C"] + 0.05 * np.stack([syn.random_sym(rng, n) for _ in range(K)])
+    o, k = make_pair(prob, "lmi", syn.scaling_points(K, n, scale=0.1))
+    assert k.count_sparse_lmi() == K
+    check_newton_step(o, k, prob["b"], lanczos_tol=2e-3 if n > 60 else None)
 
 
 @pytest.mark.parametrize("K,n,m", [(5, 12, 9), (3, 20, 20)])
@@ -65,7 +88,7 @@ def test_sparse_and_dense_paths_agree(monkeypatch):
 
 @pytest.mark.parametrize("K,n,m,density,ritz_tol", [(1, 70, 12, 0.004, 2e-3), (2, 128, 30, 0.002, np.inf),
                                                     (1, 300, 60, 0.0005, np.inf)])
-def test_sparse_large_order(K, n, m, density, ritz_tol):
+def test_sparse_large_order(force_sparse, K, n, m, density, ritz_tol):
     """Orders beyond LDS: W and W C W are read from HBM, PrepareStep / TakeStep take the GEMM path.
 
     With a slack of the form (sparse - k I) the reference's unreorthogonalised Lanczos breaks down
@@ -80,7 +103,7 @@ def test_sparse_large_order(K, n, m, density, ritz_tol):
 
 
 @pytest.mark.parametrize("d", [2, 4])
-def test_sparse_hermitian(d):
+def test_sparse_hermitian(force_sparse, d):
     K, n, m = 6, 8, 10
     prob = syn.sparsify(syn.hermitian_problem(K=K, n=n, d=d, m=m, branching=2, overlap=3), 0.03 if d == 2 else 0.005)
     o, k = make_pair(prob, "herm", syn.hermitian_scaling_points(K, n, d))
@@ -88,7 +111,7 @@ def test_sparse_hermitian(d):
     check_newton_step(o, k, prob["b"])
 
 
-def test_sparse_iterations_track_the_oracle():
+def test_sparse_iterations_track_the_oracle(force_sparse):
     """Three full Newton iterations (assemble, factor, direction, PrepareStep, TakeStep)."""
     K, n, m = 20, 16, 12
     prob = syn.sparsify(syn.lmi_problem(K=K, n=n, m=m, branching=3, overlap=3), 0.03)
@@ -100,7 +123,7 @@ def test_sparse_iterations_track_the_oracle():
         assert rel(k.get_W(i), o.get_W(i)) <= 1e-10
 
 
-def test_sparse_runs_are_bit_reproducible():
+def test_sparse_runs_are_bit_reproducible(force_sparse):
     prob = syn.sparsify(syn.lmi_problem(K=50, n=20, m=20, branching=8, overlap=5), 0.02)
     W = syn.scaling_points(50, 20)
     k = syn.build(KktContext, prob, "lmi", device=0)
