@@ -2,9 +2,11 @@
 // factorization and solves, driven from the host one supernode at a time.  Same mathematics as
 // the in-kernel paths (reference BlockCholeskyInPlace block_triangular_operations.cc:184-219 and
 // the block solves :114-182), organised as a right-looking blocked Cholesky with 32-column
-// panels: small LDS kernels factor / solve the 32 x 32 diagonal blocks, every O(n^3) update is a
-// batched fp64 MFMA GEMM (kernels_gemm.hip.h):
-//     L21  = A21 L11^-T            (big_trsm_rows)
+// panels: one kernel per panel factors the 32 x 32 diagonal block (every workgroup redundantly,
+// row per lane in registers: no dependent launch) and solves its rows, every O(n^3) update is
+// a batched fp64 MFMA GEMM (kernels_gemm.hip.h); the triangular solves with the factored block
+// stream it once through ONE workgroup (big_solve_fwd / big_solve_bwd):
+//     L21  = A21 L11^-T            (big_panel)
 //     A22 -= L21 L21^T             (GEMM NT, lower only)          -- the SYRK of north_star
 //     off[k-block,:] = L11^-1 off[k-block,:]; off[below,:] -= L21 off[k-block,:]   (GEMM NN)
 //     U = off^T off, t = off^T b   (GEMM TN), scattered to the consumer slots
@@ -42,99 +44,159 @@ __global__ void __launch_bounds__(256) big_pull(FactorPlan P, SnRec R, double* _
     }
 }
 
-// In-place Cholesky of the nb x nb diagonal block at (k0, k0); one workgroup.
-__global__ void __launch_bounds__(256) big_diag(double* __restrict__ D, int ns, int k0, int nb,
-                                                int* __restrict__ fail) {
-  __shared__ double L[kBigNB * kBigNB];
-  __shared__ int bad;
-  const int tid = threadIdx.x;
-  if (tid == 0) bad = 0;
-  for (int q = tid; q < nb * nb; q += blockDim.x) {
-    const int i = q % nb, j = q / nb;
-    L[i + j * nb] = D[(k0 + i) + (size_t)(k0 + j) * ns];
-  }
-  __syncthreads();
-  for (int k = 0; k < nb; k++) {
-    const double d = L[k + k * nb];
-    double root, inv;
-    SqrtAndInverse(d, root, inv);
-    if (!(d > 0.0) && tid == 0) bad = 1;
-    __syncthreads();
-    for (int i = k + tid; i < nb; i += blockDim.x) L[i + k * nb] = (i == k) ? root : L[i + k * nb] * inv;
-    __syncthreads();
-    const int rows = nb - k - 1;
-    for (int idx = tid; idx < rows * rows; idx += blockDim.x) {
-      const int i = k + 1 + idx % rows, j = k + 1 + idx / rows;
-      if (j <= i) L[i + j * nb] = fma(-L[i + k * nb], L[j + k * nb], L[i + j * nb]);
+// Panel step of the blocked factorization; one WAVEFRONT per workgroup, one work item per lane.
+// Every wavefront factors the nb x nb diagonal block at (k0, k0) itself -- row per lane, the
+// register elimination of the small-supernode kernels (ElimSteps) -- so the triangular solves
+// below it need no second, dependent launch and no LDS: L[j][i] reaches the FMAs as a scalar
+// (v_readlane of column i at lane j).  Workgroup 0 stores the factor.  Work items: rows
+// r >= k0 + nb of the panel ( x <- x L11^-T ) and columns c of the off block
+// ( off[k-block, c] <- L11^-1 off[k-block, c] ), the 32 unknowns of an item in registers.
+__global__ void __launch_bounds__(64) big_panel(double* __restrict__ D, double* __restrict__ B, int ns, int s,
+                                                int k0, int nb, int* __restrict__ fail) {
+  constexpr int NB = kBigNB;
+  const int lane = threadIdx.x;
+  double a[NB + 1];  // a[j] = L[lane][j] (lanes >= nb: unit rows)
+  {
+    const bool row = lane < nb;
+    const double* src = D + (k0 + (row ? lane : 0)) + (size_t)k0 * ns;
+#pragma unroll
+    for (int j = 0; j < NB; j++) a[j] = (row && j <= lane) ? src[(size_t)(j < nb ? j : 0) * ns] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NB; j++)
+      if (j >= nb && lane == j) a[j] = 1.0;  // padding pivots
+    a[NB] = 0.0;
+    bool bad = false;
+    ElimSteps<NB, 0, 0>::run(a, lane, bad);
+    if (bad && lane == 0) atomicExch(fail, 1);
+    if (blockIdx.x == 0 && row) {
+      double* dst = D + (k0 + lane) + (size_t)k0 * ns;
+#pragma unroll
+      for (int j = 0; j < NB; j++)
+        if (j <= lane) dst[(size_t)j * ns] = a[j];
     }
-    __syncthreads();
   }
-  if (bad) {
-    if (tid == 0) atomicExch(fail, 1);
-    return;
-  }
-  for (int q = tid; q < nb * nb; q += blockDim.x) {
-    const int i = q % nb, j = q / nb;
-    if (i >= j) D[(k0 + i) + (size_t)(k0 + j) * ns] = L[i + j * nb];
-  }
-}
-
-// Work items: rows r > k0 + nb - 1 of the panel ( x <- x L11^-T ), columns c of the off block
-// ( off[k-block, c] <- L11^-1 off[k-block, c] ) and, last, the right-hand side block.
-__global__ void __launch_bounds__(256) big_trsm(double* __restrict__ D, double* __restrict__ B,
-                                                double* __restrict__ rhs, int ns, int s, int k0, int nb,
-                                                int with_matrix) {
-  __shared__ double L[kBigNB * kBigNB];
-  __shared__ double dinv[kBigNB];
-  for (int q = threadIdx.x; q < nb * nb; q += blockDim.x) {
-    const int i = q % nb, j = q / nb;
-    L[i + j * nb] = D[(k0 + i) + (size_t)(k0 + j) * ns];
-  }
-  __syncthreads();
-  if (threadIdx.x < nb) dinv[threadIdx.x] = 1.0 / L[threadIdx.x + threadIdx.x * nb];
-  __syncthreads();
   const int below = ns - k0 - nb;
-  const int n_rows = with_matrix ? below : 0, n_cols = with_matrix ? s : 0;
-  const int total = n_rows + n_cols + (rhs ? 1 : 0);
-  for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += gridDim.x * blockDim.x) {
-    double x[kBigNB];
-    if (w < n_rows) {  // row of A21: x L11^T = a
-      const int r = k0 + nb + w;
-      for (int j = 0; j < nb; j++) {
-        double acc = D[r + (size_t)(k0 + j) * ns];
-        for (int i = 0; i < j; i++) acc = fma(-x[i], L[j + i * nb], acc);
-        x[j] = acc * dinv[j];
-      }
-      for (int j = 0; j < nb; j++) D[r + (size_t)(k0 + j) * ns] = x[j];
-    } else {           // column of the off block or the right-hand side: L11 y = b
-      double* col = (w < n_rows + n_cols) ? B + (size_t)(w - n_rows) * ns + k0 : rhs + k0;
-      for (int i = 0; i < nb; i++) {
-        double acc = col[i];
-        for (int j = 0; j < i; j++) acc = fma(-L[i + j * nb], x[j], acc);
-        x[i] = acc * dinv[i];
-      }
-      for (int i = 0; i < nb; i++) col[i] = x[i];
-    }
+  const int w = blockIdx.x * 64 + lane;
+  const bool is_row = w < below, is_col = !is_row && w < below + s;
+  // element e of the item: rows step by ns (a row of A21), off columns by 1
+  double* base = is_row ? D + (k0 + nb + w) + (size_t)k0 * ns
+                        : B + (size_t)(is_col ? w - below : 0) * ns + k0;
+  const size_t st = is_row ? (size_t)ns : 1;
+  double x[NB];
+#pragma unroll
+  for (int j = 0; j < NB; j++) x[j] = ((is_row || is_col) && j < nb) ? base[j * st] : 0.0;
+  // both kinds of item are forward substitutions with L11: x_j = (x_j - sum_{i<j} L[j][i] x_i) / L[j][j]
+#pragma unroll
+  for (int j = 0; j < NB; j++) {
+    double acc = x[j];
+#pragma unroll
+    for (int i = 0; i < j; i++) acc = fma(-x[i], ReadLane(a[i], j), acc);
+    x[j] = acc / ReadLane(a[j], j);
+  }
+  if (is_row || is_col) {
+#pragma unroll
+    for (int j = 0; j < NB; j++)
+      if (j < nb) base[j * st] = x[j];
   }
 }
 
-// rhs block <- L11^-T rhs block (back substitution step); one workgroup, one thread solves.
-__global__ void __launch_bounds__(64) big_rhs_block_t(const double* __restrict__ D, double* __restrict__ rhs,
-                                                      int ns, int k0, int nb) {
-  __shared__ double L[kBigNB * kBigNB];
-  for (int q = threadIdx.x; q < nb * nb; q += blockDim.x) {
-    const int i = q % nb, j = q / nb;
-    L[i + j * nb] = D[(k0 + i) + (size_t)(k0 + j) * ns];
-  }
+// b <- L^-1 b for the factored diagonal block of a big supernode: ONE workgroup streams L once,
+// panel by panel (b lives in LDS): wavefront 0 solves the 32 x 32 block (row per lane in
+// registers), then every thread updates its rows below with the panel's 32 solved values.
+__global__ void __launch_bounds__(1024) big_solve_fwd(const double* __restrict__ D, double* __restrict__ b,
+                                                      int ns) {
+  constexpr int NB = kBigNB;
+  extern __shared__ double sb[];  // ns
+  __shared__ double yk[NB];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < ns; i += blockDim.x) sb[i] = b[i];
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double* b = rhs + k0;
-    for (int k = nb - 1; k >= 0; k--) {
-      double acc = b[k];
-      for (int i = k + 1; i < nb; i++) acc = fma(-L[i + k * nb], b[i], acc);
-      b[k] = acc * (1.0 / L[k + k * nb]);
+  for (int k0 = 0; k0 < ns; k0 += NB) {
+    const int nb = ns - k0 < NB ? ns - k0 : NB, below = ns - k0 - nb;
+    if (threadIdx.x < 64) {
+      const bool row = lane < nb;
+      double l[NB];
+      const double* src = D + (k0 + (row ? lane : 0)) + (size_t)k0 * ns;
+#pragma unroll
+      for (int j = 0; j < NB; j++) l[j] = (row && j <= lane) ? src[(size_t)(j < nb ? j : 0) * ns] : (j == lane ? 1.0 : 0.0);
+      double v = row ? sb[k0 + lane] : 0.0;
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        const double yj = ReadLane(v, j) / ReadLane(l[j], j);
+        if (lane == j)
+          v = yj;
+        else if (lane > j)
+          v = fma(-l[j], yj, v);
+      }
+      if (row) {
+        sb[k0 + lane] = v;
+        yk[lane] = v;
+      } else if (lane < NB) {
+        yk[lane] = 0.0;
+      }
     }
+    __syncthreads();
+    for (int r = threadIdx.x; r < below; r += blockDim.x) {
+      const double* rowp = D + (k0 + nb + r) + (size_t)k0 * ns;
+      double v[NB];
+#pragma unroll
+      for (int j = 0; j < NB; j++) v[j] = rowp[(size_t)(j < nb ? j : 0) * ns];
+      double acc = sb[k0 + nb + r];
+#pragma unroll
+      for (int j = 0; j < NB; j++) acc = fma(-v[j], yk[j], acc);  // yk is zero beyond nb
+      sb[k0 + nb + r] = acc;
+    }
+    __syncthreads();
   }
+  for (int i = threadIdx.x; i < ns; i += blockDim.x) b[i] = sb[i];
+}
+
+// b <- L^-T b, panels from the last to the first: the 32 dot products L21^T x_below are split
+// over the 1024 threads (32 consecutive rows per column group: coalesced), reduced in a fixed
+// order, then wavefront 0 solves the transposed 32 x 32 block (column per lane in registers).
+__global__ void __launch_bounds__(1024) big_solve_bwd(const double* __restrict__ D, double* __restrict__ b,
+                                                      int ns) {
+  constexpr int NB = kBigNB;
+  extern __shared__ double sb[];  // ns
+  __shared__ double part[NB];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < ns; i += blockDim.x) sb[i] = b[i];
+  __syncthreads();
+  const int nblk = (ns + NB - 1) / NB;
+  for (int kb = nblk - 1; kb >= 0; kb--) {
+    const int k0 = kb * NB, nb = ns - k0 < NB ? ns - k0 : NB, below = ns - k0 - nb;
+    {
+      const int j = threadIdx.x >> 5, sub = threadIdx.x & 31;  // 32 column groups of 32 lanes
+      double acc = 0.0;
+      if (j < nb) {
+        const double* colp = D + (k0 + nb) + (size_t)(k0 + j) * ns;
+        for (int r = sub; r < below; r += 32) acc = fma(colp[r], sb[k0 + nb + r], acc);
+      }
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+      if (sub == 0) part[j] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const bool colv = lane < nb;
+      double c[NB];  // c[k] = L[k0+k][k0+lane], k >= lane
+      const double* src = D + k0 + (size_t)(k0 + (colv ? lane : 0)) * ns;
+#pragma unroll
+      for (int k = 0; k < NB; k++) c[k] = (colv && k >= lane && k < nb) ? src[k] : (k == lane ? 1.0 : 0.0);
+      double v = colv ? sb[k0 + lane] - part[lane] : 0.0;
+#pragma unroll
+      for (int k = NB - 1; k >= 0; k--) {
+        const double xk = ReadLane(v, k) / ReadLane(c[k], k);
+        if (lane == k)
+          v = xk;
+        else if (lane < k)
+          v = fma(-c[k], xk, v);
+      }
+      if (colv) sb[k0 + lane] = v;
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < ns; i += blockDim.x) b[i] = sb[i];
 }
 
 // b_i -= sum_q off[i, c_q] y[row_q]  (separator terms of the back substitution)
@@ -202,30 +264,33 @@ inline hipError_t BigSupernodeSweep(const FactorPlan& P, const SnRec& R, int mod
   double* B = slab + R.offd_off;
   double* b = rhs ? rhs + R.start : nullptr;
   hipError_t e;
+  const size_t solve_lds = sizeof(double) * (size_t)ns;
+  if (solve_lds > 150 * 1024) return hipErrorNotSupported;  // right-hand side block held in LDS
+  static bool configured = false;
+  if (!configured) {
+    const int lim = 150 * 1024;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&big_solve_fwd),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lim)) != hipSuccess)
+      return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&big_solve_bwd),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lim)) != hipSuccess)
+      return e;
+    configured = true;
+  }
   if (mode == 2) {
     big_backsep<<<(ns + 255) / 256, 256, 0, st>>>(P, R, slab, rhs);
-    const int nblk = (ns + kBigNB - 1) / kBigNB;
-    for (int kb = nblk - 1; kb >= 0; kb--) {
-      const int k0 = kb * kBigNB, nb = std::min(kBigNB, ns - k0), below = ns - k0 - nb;
-      if (below > 0) {  // b_blk -= L21^T b_below
-        GemmArgs g = BigGemm(nb, 1, below, D + (k0 + nb) + (size_t)k0 * ns, ns, b + k0 + nb, below, b + k0, nb,
-                             -1.0, 1.0, 0);
-        if ((e = LaunchGemm(g, true, false, 1, st)) != hipSuccess) return e;
-      }
-      big_rhs_block_t<<<1, 64, 0, st>>>(D, b, ns, k0, nb);
-    }
+    big_solve_bwd<<<1, 1024, solve_lds, st>>>(D, b, ns);
     return hipGetLastError();
   }
   const int with_matrix = mode == 0;
   if (R.tg_end > R.tg_beg || rhs) big_pull<<<64, 256, 0, st>>>(P, R, slab, rhs, with_matrix);
-  for (int k0 = 0; k0 < ns; k0 += kBigNB) {
-    const int nb = std::min(kBigNB, ns - k0), below = ns - k0 - nb;
-    if (with_matrix) big_diag<<<1, 256, 0, st>>>(D, ns, k0, nb, fail);
-    const int items = (with_matrix ? below + s : 0) + (rhs ? 1 : 0);
-    if (items > 0) big_trsm<<<(items + 255) / 256, 256, 0, st>>>(D, B, b, ns, s, k0, nb, with_matrix);
-    if (below > 0) {
-      const double* L21 = D + (k0 + nb) + (size_t)k0 * ns;
-      if (with_matrix) {
+  if (with_matrix)
+    for (int k0 = 0; k0 < ns; k0 += kBigNB) {
+      const int nb = std::min(kBigNB, ns - k0), below = ns - k0 - nb;
+      const int items = below + s;
+      big_panel<<<std::max(1, (items + 63) / 64), 64, 0, st>>>(D, B, ns, s, k0, nb, fail);
+      if (below > 0) {
+        const double* L21 = D + (k0 + nb) + (size_t)k0 * ns;
         GemmArgs g1 = BigGemm(below, below, nb, L21, ns, L21, ns, D + (k0 + nb) + (size_t)(k0 + nb) * ns, ns,
                               -1.0, 1.0, 1);
         if ((e = LaunchGemm(g1, false, true, 1, st)) != hipSuccess) return e;
@@ -234,12 +299,8 @@ inline hipError_t BigSupernodeSweep(const FactorPlan& P, const SnRec& R, int mod
           if ((e = LaunchGemm(g2, false, false, 1, st)) != hipSuccess) return e;
         }
       }
-      if (rhs) {
-        GemmArgs g3 = BigGemm(below, 1, nb, L21, ns, b + k0, nb, b + k0 + nb, below, -1.0, 1.0, 0);
-        if ((e = LaunchGemm(g3, false, false, 1, st)) != hipSuccess) return e;
-      }
     }
-  }
+  if (rhs) big_solve_fwd<<<1, 1024, solve_lds, st>>>(D, b, ns);
   if (s > 0) {
     double* U = ws;
     double* t = ws + (size_t)s * s;

@@ -56,10 +56,37 @@ __device__ long long g_sparse_stamp[8];
 #endif
 
 struct SparseLaunch {
-  const double* Xg;  // count x n^2: W C W from the GEMM path (large orders with a dense C), else null
-  int emax;          // entries reserved in LDS per workgroup (STAGE)
-  int cdense;        // C takes the dense route
+  const double* Xg;    // count x n^2: W C W from the GEMM path (large orders with a dense C), else null
+  const double* part;  // count x npart x 2: partial sums of <w,c>, <c,Qc> (lmi_dense_c_scalars)
+  int npart;
+  int emax;            // entries reserved in LDS per workgroup (STAGE)
+  int cdense;          // C takes the dense route
 };
+
+// Dense C beyond LDS-resident orders: partial sums of <w,c> = sum C o W and <c,Qc> = sum C o X over
+// slices of the n^2 positions; grid (npart, count).  The sparse kernel adds them in block order.
+__global__ void __launch_bounds__(256) lmi_dense_c_scalars(LmiGroup g, const double* __restrict__ Xg,
+                                                           double* __restrict__ part) {
+  __shared__ double red[16];
+  const int nn = g.n * g.n, mem = blockIdx.y;
+  const double* Cm = g.C + (size_t)mem * nn;
+  const double* Wg = g.W + (size_t)mem * nn;
+  const double* X = Xg + (size_t)mem * nn;
+  const int per = (nn + gridDim.x - 1) / gridDim.x;
+  const int q0 = per * blockIdx.x, q1 = q0 + per < nn ? q0 + per : nn;
+  double wc = 0, cq = 0;
+  for (int q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
+    const double c = Cm[q];
+    wc = fma(c, Wg[q], wc);
+    cq = fma(c, X[q], cq);
+  }
+  wc = BlockSum(wc, red);
+  cq = BlockSum(cq, red + 8);
+  if (threadIdx.x == 0) {
+    part[((size_t)mem * gridDim.x + blockIdx.x) * 2] = wc;
+    part[((size_t)mem * gridDim.x + blockIdx.x) * 2 + 1] = cq;
+  }
+}
 
 // Sum over a group of LPP consecutive lanes (LPP a power of two <= 64) in a fixed butterfly order;
 // every lane of the group receives the total.
@@ -167,35 +194,23 @@ __global__ void __launch_bounds__(256) lmi_schur_sparse(LmiGroup g, Arena ar, Sp
   }
   __syncthreads();
   SPSTAMP(1);
-  if (first) {
-    if (cdense) {
-      const double* X = L.Xg ? L.Xg + (size_t)mem * nn : nullptr;
-      const double* Cs = Cm;
-      if (SMALL) {
-        double* sC = sW + nn;
-        double* sP = sC + nn;
-        double* sX = sP + nn;
-        for (int q = threadIdx.x; q < nn; q += blockDim.x) sC[q] = Cm[q];
-        __syncthreads();
-        LdsGemm(n, sC, sW, sP);  // C W
-        __syncthreads();
-        LdsGemm(n, sW, sP, sX);  // W C W
-        __syncthreads();
-        X = sX;
-        Cs = sC;
-      }
-      for (int i = wave; i < m; i += nwaves) {  // AQc(i) = sum a X[c,r]
-        double aq = 0;
-        for (int e = s_ptr[i] + lane; e < s_ptr[i + 1]; e += 64) {
-          const int rc = erc[e], r = rc & 0xffff, c = rc >> 16;
-          aq = fma(eval[e], X[c + (size_t)r * n], aq);
-        }
-        aq = WaveSum(aq);
-        if (lane == 0) ar.AQcc[ar.r_off[id] + i] = aq * osc;
-      }
+  // dense C: X = W C W (LDS product here for small orders, GEMM launches before this kernel otherwise)
+  const double* X = (cdense && L.Xg) ? L.Xg + (size_t)mem * nn : nullptr;
+  if (cdense && SMALL) {
+    double* sC = sW + nn;
+    double* sP = sC + nn;
+    double* sX = sP + nn;
+    for (int q = threadIdx.x; q < nn; q += blockDim.x) sC[q] = Cm[q];
+    __syncthreads();
+    LdsGemm(n, sC, sW, sP);  // C W
+    __syncthreads();
+    LdsGemm(n, sW, sP, sX);  // W C W
+    __syncthreads();
+    X = sX;
+    if (first) {
       double wc = 0, cq = 0;
       for (int q = threadIdx.x; q < nn; q += blockDim.x) {
-        const double c = Cs[q];
+        const double c = sC[q];
         wc = fma(c, W[q], wc);
         cq = fma(c, X[q], cq);
       }
@@ -207,21 +222,39 @@ __global__ void __launch_bounds__(256) lmi_schur_sparse(LmiGroup g, Arena ar, Sp
         ar.sc[2 * id + 1] = cq * osc;
       }
     }
-    // AW(i) = sum a W[c,r]; list m (sparse C) gives <w,c>
+  } else if (cdense && first && threadIdx.x == 0) {
+    // <w,c>, <c,Qc>: partial sums of lmi_dense_c_scalars, added in block order
+    double wc = 0, cq = 0;
+    for (int k = 0; k < L.npart; k++) {
+      wc += L.part[((size_t)mem * L.npart + k) * 2];
+      cq += L.part[((size_t)mem * L.npart + k) * 2 + 1];
+    }
+    ar.sc[2 * id] = wc * osc;
+    ar.sc[2 * id + 1] = cq * osc;
+  }
+  {
+    // AW(i) = sum a W[c,r] (list m, a sparse C, gives <w,c>) and, for a dense C, AQc(i) = sum a X[c,r]:
+    // LPV lanes per list, the lists dealt to all chunks
     const int lists = cdense ? m : m1;
-    constexpr int LPV = LPP < 8 ? 8 : LPP;  // lanes per list
-    for (int i = threadIdx.x / LPV; i < lists; i += blockDim.x / LPV) {
-      double aw = 0;
+    constexpr int LPV = LPP < 8 ? 8 : LPP;
+    const int gpb = blockDim.x / LPV;
+    for (int i = blockIdx.y * gpb + threadIdx.x / LPV; i < lists; i += gridDim.y * gpb) {
+      double aw = 0, aq = 0;
       for (int e = s_ptr[i] + (threadIdx.x % LPV); e < s_ptr[i + 1]; e += LPV) {
         const int rc = erc[e], r = rc & 0xffff, c = rc >> 16;
-        aw = fma(eval[e], W[c + (size_t)r * n], aw);
+        const double a = eval[e];
+        aw = fma(a, W[c + (size_t)r * n], aw);
+        if (cdense) aq = fma(a, X[c + (size_t)r * n], aq);
       }
       aw = GroupSum<LPV>(aw);
+      if (cdense) aq = GroupSum<LPV>(aq);
       if (threadIdx.x % LPV == 0) {
-        if (i < m)
+        if (i < m) {
           ar.AWc[ar.r_off[id] + i] = aw * osc;
-        else
+          if (cdense) ar.AQcc[ar.r_off[id] + i] = aq * osc;
+        } else {
           ar.sc[2 * id] = aw * osc;
+        }
       }
     }
   }

@@ -1059,6 +1059,8 @@ int UploadSparseLmi(cxk_context* ctx, Group& g) {
 
 // Sparse LMI group: the nonzero sums; a dense C first needs X = W C W (LDS for small orders, two
 // GEMMs otherwise).
+constexpr int kSparseCParts = 64;  // slices of the <w,c>, <c,Qc> sums of a dense C beyond LDS orders
+
 template <bool SMALL, int LPP>
 hipError_t LaunchLmiSparseKernelL(Group& g, const LmiGroup& d, const Arena& ar, const double* X, hipStream_t st) {
   const dim3 grid(d.count, g.sp_chunks);
@@ -1067,6 +1069,8 @@ hipError_t LaunchLmiSparseKernelL(Group& g, const LmiGroup& d, const Arena& ar, 
   const size_t lds = LmiSparseLds(g.n, g.m, SMALL, g.sp_cdense, stage ? emax : 0);
   SparseLaunch L;
   L.Xg = X;
+  L.part = g.ws_part.p;
+  L.npart = kSparseCParts;
   L.emax = stage ? emax : 0;
   L.cdense = g.sp_cdense;
   auto raise = [&](const void* k) -> hipError_t {  // dynamic LDS beyond 64 KB needs the attribute
@@ -1108,6 +1112,7 @@ hipError_t LaunchLmiSchurSparse(Group& g, const Arena& ar, hipStream_t st) {
     if ((e = LaunchGemm(a, false, false, d.count, st)) != hipSuccess) return e;
     a = SquareGemm(n, d.W, nn, CW, nn, X, nn);
     if ((e = LaunchGemm(a, false, false, d.count, st)) != hipSuccess) return e;
+    lmi_dense_c_scalars<<<dim3(kSparseCParts, d.count), 256, 0, st>>>(d, X, g.ws_part.p);
   }
   return LaunchLmiSparseKernel<false>(g, d, ar, X, st);
 }
@@ -1609,6 +1614,7 @@ int cxk_finalize(cxk_context* ctx) {
     if (g.type == CXK_LMI && g.sparse && (g.large || !g.sp_small)) {
       const size_t nn = (size_t)g.n * g.n;
       CXK_TRY(g.ws_main.alloc(cnt * 8 * nn));  // step temporaries; C W and W C W during assembly
+      CXK_TRY(g.ws_part.alloc(cnt * 2 * kSparseCParts));
       CXK_TRY(g.ws_piv.alloc(cnt * (size_t)g.n));
     }
     if (g.schur_gemm) {
