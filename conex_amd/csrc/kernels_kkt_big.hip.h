@@ -44,6 +44,28 @@ __global__ void __launch_bounds__(256) big_pull(FactorPlan P, SnRec R, double* _
     }
 }
 
+// Steps I .. NB-1 of the register forward substitution of big_panel (compile-time recursion:
+// register indices and DPP controls are immediates).
+template <int NB, int I>
+struct BigPanelSolve {
+  static __device__ __forceinline__ void run(const double (&a)[NB + 1], double (&x)[NB], double dinv) {
+    if constexpr (I < NB) {
+      x[I] *= ReadLane(dinv, I);
+      if constexpr (I + 1 < NB) {
+        const RowPair cp = Swap16(a[I]);  // a = rows 0/2 everywhere (L[0..15][I]), b = rows 1/3 (L[16..31][I])
+        double c0 = cp.a, c1 = cp.b;
+        double nx = -x[I];
+        DppOperandFence(c0, c1, nx);
+        constexpr int kLo0 = (I + 1 < 16) ? I + 1 : 16;
+        constexpr int kHi0 = (I + 1 > 16) ? I + 1 : 16;
+        DppColumns<NB, kLo0, 16, 0>::run(x, c0, nx);
+        DppColumns<NB, kHi0, NB, 16>::run(x, c1, nx);
+      }
+      BigPanelSolve<NB, I + 1>::run(a, x, dinv);
+    }
+  }
+};
+
 // Panel step of the blocked factorization; one WAVEFRONT per workgroup, one work item per lane.
 // Every wavefront factors the nb x nb diagonal block at (k0, k0) itself -- row per lane, the
 // register elimination of the small-supernode kernels (ElimSteps) -- so the triangular solves
@@ -55,49 +77,64 @@ __global__ void __launch_bounds__(64) big_panel(double* __restrict__ D, double* 
                                                 int k0, int nb, int* __restrict__ fail) {
   constexpr int NB = kBigNB;
   const int lane = threadIdx.x;
-  double a[NB + 1];  // a[j] = L[lane][j] (lanes >= nb: unit rows)
+  const int l32 = lane & 31;  // lanes 32..63 mirror lanes 0..31 through the elimination: every
+                              // 16-lane DPP row then holds half of a column of L (see the solves)
+  double a[NB + 1];           // a[j] = L[l32][j] (rows >= nb: unit rows)
+#ifdef CXK_DEBUG_STAMPS
+#define BPSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && k0 == 64) g_cxk_stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BPSTAMP(i) do { } while (0)
+#endif
+  BPSTAMP(0);
+  const bool row = l32 < nb;
   {
-    const bool row = lane < nb;
-    const double* src = D + (k0 + (row ? lane : 0)) + (size_t)k0 * ns;
+    const double* src = D + (k0 + (row ? l32 : 0)) + (size_t)k0 * ns;
 #pragma unroll
-    for (int j = 0; j < NB; j++) a[j] = (row && j <= lane) ? src[(size_t)(j < nb ? j : 0) * ns] : 0.0;
-#pragma unroll
-    for (int j = 0; j < NB; j++)
-      if (j >= nb && lane == j) a[j] = 1.0;  // padding pivots
-    a[NB] = 0.0;
-    bool bad = false;
-    ElimSteps<NB, 0, 0>::run(a, lane, bad);
-    if (bad && lane == 0) atomicExch(fail, 1);
-    if (blockIdx.x == 0 && row) {
-      double* dst = D + (k0 + lane) + (size_t)k0 * ns;
-#pragma unroll
-      for (int j = 0; j < NB; j++)
-        if (j <= lane) dst[(size_t)j * ns] = a[j];
-    }
+    for (int j = 0; j < NB; j++) a[j] = (row && j <= l32) ? src[(size_t)(j < nb ? j : 0) * ns] : 0.0;
   }
+  // this lane's work item, loaded while the elimination runs: element e at base[e * st]
+  // (a row of A21 steps by ns, a column of the off block by 1)
   const int below = ns - k0 - nb;
   const int w = blockIdx.x * 64 + lane;
   const bool is_row = w < below, is_col = !is_row && w < below + s;
-  // element e of the item: rows step by ns (a row of A21), off columns by 1
   double* base = is_row ? D + (k0 + nb + w) + (size_t)k0 * ns
                         : B + (size_t)(is_col ? w - below : 0) * ns + k0;
   const size_t st = is_row ? (size_t)ns : 1;
   double x[NB];
 #pragma unroll
   for (int j = 0; j < NB; j++) x[j] = ((is_row || is_col) && j < nb) ? base[j * st] : 0.0;
-  // both kinds of item are forward substitutions with L11: x_j = (x_j - sum_{i<j} L[j][i] x_i) / L[j][j]
 #pragma unroll
-  for (int j = 0; j < NB; j++) {
-    double acc = x[j];
+  for (int j = 0; j < NB; j++)
+    if (j >= nb && l32 == j) a[j] = 1.0;  // padding pivots
+  a[NB] = 0.0;
+  bool bad = false;
+  BPSTAMP(1);
+  ElimSteps<NB, 0, 0>::run(a, l32, bad);
+  BPSTAMP(2);
+  if (bad && lane == 0) atomicExch(fail, 1);
+  if (blockIdx.x == 0 && row && lane < NB) {
+    double* dst = D + (k0 + lane) + (size_t)k0 * ns;
 #pragma unroll
-    for (int i = 0; i < j; i++) acc = fma(-x[i], ReadLane(a[i], j), acc);
-    x[j] = acc / ReadLane(a[j], j);
+    for (int j = 0; j < NB; j++)
+      if (j <= lane) dst[(size_t)j * ns] = a[j];
   }
+  BPSTAMP(3);
+  // Both kinds of item are forward substitutions with L11: x_j = (x_j - sum_{i<j} L[j][i] x_i) / L[j][j],
+  // column by column: once x_i is final every later unknown takes its term (i ascending per unknown).
+  // L[j][i] is lane j of column a[i]: with DPP rows 0/2 (1/3) mirrored into every row it reaches
+  // the fma as a row_newbcast operand -- one instruction per term, as in the elimination itself.
+  double diag = 1.0;
+#pragma unroll
+  for (int j = 0; j < NB; j++) diag = (l32 == j) ? a[j] : diag;
+  const double dinv = 1.0 / diag;  // lane j: 1 / L[j][j]
+  BigPanelSolve<NB, 0>::run(a, x, dinv);
+  BPSTAMP(4);
   if (is_row || is_col) {
 #pragma unroll
     for (int j = 0; j < NB; j++)
       if (j < nb) base[j * st] = x[j];
   }
+  BPSTAMP(5);
 }
 
 // b <- L^-1 b for the factored diagonal block of a big supernode: ONE workgroup streams L once,
@@ -120,9 +157,13 @@ __global__ void __launch_bounds__(1024) big_solve_fwd(const double* __restrict__
 #pragma unroll
       for (int j = 0; j < NB; j++) l[j] = (row && j <= lane) ? src[(size_t)(j < nb ? j : 0) * ns] : (j == lane ? 1.0 : 0.0);
       double v = row ? sb[k0 + lane] : 0.0;
+      double diag = 1.0;
+#pragma unroll
+      for (int j = 0; j < NB; j++) diag = (lane == j) ? l[j] : diag;
+      const double dinv = 1.0 / diag;
 #pragma unroll
       for (int j = 0; j < NB; j++) {
-        const double yj = ReadLane(v, j) / ReadLane(l[j], j);
+        const double yj = ReadLane(v, j) * ReadLane(dinv, j);
         if (lane == j)
           v = yj;
         else if (lane > j)
@@ -184,9 +225,13 @@ __global__ void __launch_bounds__(1024) big_solve_bwd(const double* __restrict__
 #pragma unroll
       for (int k = 0; k < NB; k++) c[k] = (colv && k >= lane && k < nb) ? src[k] : (k == lane ? 1.0 : 0.0);
       double v = colv ? sb[k0 + lane] - part[lane] : 0.0;
+      double diag = 1.0;
+#pragma unroll
+      for (int k = 0; k < NB; k++) diag = (lane == k) ? c[k] : diag;
+      const double dinv = 1.0 / diag;
 #pragma unroll
       for (int k = NB - 1; k >= 0; k--) {
-        const double xk = ReadLane(v, k) / ReadLane(c[k], k);
+        const double xk = ReadLane(v, k) * ReadLane(dinv, k);
         if (lane == k)
           v = xk;
         else if (lane < k)
