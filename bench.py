@@ -66,12 +66,14 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--K", type=int, default=1000)
-    ap.add_argument("--workload", choices=["c4", "c2", "c3", "c5", "c4s"], default="c4",
+    ap.add_argument("--workload", choices=["c4", "c2", "c3", "c5", "c4s", "maxcut"], default="c4",
                     help="c4 (default, the metric's config): 1000 LMIs n=20; extras, single GPU: "
                          "c2 one LMI n=200 m=50 (MFMA-bound assembly); c3 5000 second-order cones in a "
                          "chain (no tree parallelism: latency-bound sweeps); c5 mixed complex Hermitian "
                          "+ SOC tree, N = 50k; c4s the C4 structure with sparse A_i (--density), the "
-                         "sparse-LMI evaluation path")
+                         "sparse-LMI evaluation path; maxcut one LMI of order --maxcut-n with one-nonzero "
+                         "A_i (sparse assembly + one big supernode)")
+    ap.add_argument("--maxcut-n", type=int, default=200)
     ap.add_argument("--density", type=float, default=0.005,
                     help="with --workload c4s: fraction of the entries of every A_i that is nonzero")
     ap.add_argument("--no-cpu", action="store_true")
@@ -108,6 +110,10 @@ def main():
         kind, args.K, n_order, m_vars = "soc", 5000, 10, 10
         prob = syn.soc_problem(K=5000, dim=10, m=10, overlap=2, tree=args.soc_tree)
         W = syn.soc_scaling_points(5000, 10)
+    elif args.workload == "maxcut":
+        args.K, n_order, m_vars = 1, args.maxcut_n, args.maxcut_n
+        prob = syn.maxcut_problem(args.maxcut_n)
+        W = syn.scaling_points(1, n_order, scale=0.05)
     elif args.workload == "c5":
         kind, n_order, m_vars = "mixed", 12, 24
         prob = syn.mixed_problem()
@@ -181,6 +187,7 @@ def main():
         out = {
             "metric": {"c4": "Newton KKT-solves/sec (assemble+factor+solve), 1000x(20x20) PSD blocks, fp64",
                        "c4s": "Newton KKT-solves/sec (assemble+factor+solve), 1000x(20x20) PSD blocks with sparse A_i, fp64",
+                       "maxcut": f"Newton KKT-solves/sec (assemble+factor+solve), max-cut SDP n=m={args.maxcut_n}, fp64",
                        "c2": "Newton KKT-solves/sec (assemble+factor+solve), one 200x200 PSD block m=50, fp64",
                        "c3": "Newton KKT-solves/sec (assemble+factor+solve), 5000 second-order cones dim 10 ("
                              + (f"{args.soc_tree}-ary tree" if args.soc_tree else "chain") + "), fp64",
@@ -199,6 +206,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": {"c4": "BASELINE config 4: chordal SDP, 1000 dense LMIs n=20 m=20, "
                                           "8-ary clique tree overlap 5, N=15005",
+                                    "maxcut": f"max-cut relaxation: one LMI of order {args.maxcut_n} over {args.maxcut_n} "
+                                              f"variables, A_i = -e_i e_i^T ({ctx.count_sparse_lmi()} constraint on the "
+                                              "sparse path), one dense supernode",
                                     "c4s": f"config 4 structure with sparse A_i (density {args.density}, "
                                            f"{ctx.count_sparse_lmi()} of {args.K} constraints on the sparse path)",
                                     "c2": "BASELINE config 2: one dense LMI n=200, m=50 (profile_sdp.cc shape)",
@@ -213,7 +223,17 @@ def main():
         }
         if nsamp > 0 and kern_ms > 0:
             gbs = abytes / (kern_ms * 1e-3) / 1e9
-            if args.workload == "c4s":
+            if args.workload == "maxcut":
+                n_ = float(args.maxcut_n)
+                sbytes = 8.0 * (3 * n_ * n_ + n_ * (n_ + 1) / 2)   # W, C, X = W C W, G
+                gbs = sbytes / (kern_ms * 1e-3) / 1e9
+                out["roofline"] = {"bound": "hbm", "kernel": "sparse LMI assembly (2 GEMM + lmi_schur_sparse)",
+                                   "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
+                                   "kernel_samples": nsamp, "algorithmic_bytes": sbytes,
+                                   "note": "the dense evaluation of the same constraint streams "
+                                           f"{8 * n_ ** 3 / 1e6:.0f} MB and does {4 * n_ ** 4 / 1e9:.0f} GFLOP"}
+            elif args.workload == "c4s":
                 nnz = float(np.count_nonzero(prob["A"]))
                 sbytes = 12.0 * nnz + args.K * 8.0 * (2 * 400 + 210 + 42)
                 gbs = sbytes / (kern_ms * 1e-3) / 1e9

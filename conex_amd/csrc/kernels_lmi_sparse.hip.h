@@ -31,11 +31,11 @@ namespace cxk {
 // The pair sums cost about (sum nnz)^2 / 2 terms; a term is four scattered reads (entry pair, two
 // W elements).  Measured term rates on MI355X against the dense kernels' flop rates give the
 // break-even ratios below (dense flops per sparse term): ~80 where W sits in LDS and the dense
-// side is the fused kernel, ~40 for the other LDS-resident shapes, ~700 beyond LDS (W read from
-// L2/HBM, dense side on the MFMA GEMM pipeline).
+// side is the fused kernel, ~40 for the other LDS-resident shapes, ~300 beyond LDS (W read from
+// L2/HBM, dense side on the MFMA GEMM pipeline at 25-40 TFLOP/s).
 inline bool LmiSparsePays(int n, int m, double nnz_a, bool lds_resident, bool fused) {
   const double dense = 4.0 * n * n * n * (m + 1.0) + (double)n * n * m * m;
-  const double per_term = lds_resident ? (fused ? 80.0 : 40.0) : 700.0;
+  const double per_term = lds_resident ? (fused ? 80.0 : 40.0) : 300.0;
   return 0.5 * nnz_a * nnz_a * per_term <= dense;
 }
 

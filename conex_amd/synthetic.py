@@ -84,6 +84,23 @@ def sparsify(prob, density, seed=SEED + 7):
     return out
 
 
+def maxcut_problem(n, edges_per_node=3, seed=SEED + 9):
+    """Max-cut relaxation  max -sum y  s.t.  Diag(y) - Q >= 0  (Q = graph Laplacian / 4) as ONE LMI
+    of order n over n variables: A_i = -e_i e_i^T (one nonzero each), C = -Q.  The Schur complement
+    is a dense n x n matrix: one supernode of n columns."""
+    rng = np.random.default_rng(seed)
+    Q = np.zeros((n, n))
+    for _ in range(edges_per_node * n):
+        i, j = rng.integers(n, size=2)
+        if i != j:
+            Q[i, j] = Q[j, i] = rng.uniform(0.2, 1.0)
+    Q = 0.25 * (np.diag(Q.sum(axis=1)) - Q)
+    A = np.zeros((1, n, n, n))
+    for i in range(n):
+        A[0, i, i, i] = -1.0
+    return dict(A=A, C=-Q[None], cliques=[list(range(n))], num_vars=n, b=-np.ones(n), n=n, m=n, Q=Q)
+
+
 def scaling_points(K, n, seed=SEED + 1, scale=0.3):
     """W_c = expm(scale * sym(R)): symmetric positive definite, W != I."""
     rng = np.random.default_rng(seed)
