@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--density", type=float, default=0.005,
                     help="with --workload c4s: fraction of the entries of every A_i that is nonzero")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--shard-path", action="store_true",
+                    help="run the sharded three-phase step (local / RCCL all-reduce / finish) even at "
+                         "world size 1: exercises the multi-GPU code path on a single-GPU box")
     ap.add_argument("--soc-tree", type=int, default=0,
                     help="with --workload c3: arrange the cones in a b-ary clique tree instead of a chain")
     ap.add_argument("--event-period", type=int, default=8,
@@ -95,9 +98,12 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.shard_path
+    if sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
 
     kind = "lmi"
     if args.workload != "c4" and world > 1:
@@ -136,20 +142,22 @@ def main():
             ctx.add_hermitian(prob["A"][c], prob["C"][c], cl)
         else:
             ctx.add_soc(prob["A"][c], prob["C"][c], cl)
-    if world > 1:
-        ctx.set_shard(rank, world)
+    if sharded:
+        # --shard-path on one GPU: rank 0 of a virtual 2-rank world (half the tree is missing from
+        # the exchange, so only timing and the plumbing are meaningful, not the direction)
+        ctx.set_shard(rank, world if world > 1 else 2)
     ctx.initialize()
     for i in range(ctx.K):
-        if world == 1 or ctx.owns(i):
+        if not sharded or ctx.owns(i):
             ctx.set_W(i, W[i])
     ctx.set_cost(prob["b"])
 
     exch = None
-    if world > 1:
+    if sharded:
         exch = ctx.exchange_tensor(torch)   # zero-copy view of the device exchange buffer
 
     def step():
-        if world == 1:
+        if not sharded:
             ctx.kkt_solve_async(0.7, 0.9, 0.8)
         else:
             ctx.kkt_local_async(0.7, 0.9, 0.8)      # own constraints + own subtrees
@@ -157,7 +165,7 @@ def main():
             ctx.kkt_finish_async(0.7, 0.9, 0.8)     # replicated top + own back-substitution
 
     def fence():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -174,14 +182,14 @@ def main():
     elapsed = time.perf_counter() - t0
     ok = ctx.sync() and ok
     ctx.enable_timing(False)
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     nsamp, kern_ms = ctx.kernel_time(reset=True)
     abytes, aflops = ctx.assembly_work()
-    y = ctx.get_y() if world == 1 else None
+    y = ctx.get_y() if not sharded else None
 
     if rank == 0:
         out = {
@@ -217,7 +225,7 @@ def main():
                                           "dim 10, 8-ary clique tree overlap 4, N=50004"}[args.workload],
                        "K": args.K, "n": n_order, "m": m_vars, "N": ctx.N,
                        "parallelism": (f"elimination-subtree sharding x{world}, one RCCL all-reduce "
-                                       f"of {exch.numel() * 8} B per solve") if world > 1
+                                       f"of {exch.numel() * 8} B per solve") if sharded
                        else "single GPU",
                        "factor_ok": bool(ok)},
         }
@@ -268,7 +276,7 @@ def main():
                                "kernel_ms": kern_ms, "kernel_samples": nsamp,
                                "algorithmic_bytes": abytes, "algorithmic_gflop": aflops / 1e9,
                                "achieved_tflops": aflops / (kern_ms * 1e-3) / 1e12}
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and not sharded:
             cb, yo = cpu_baseline(prob, W, kind=kind)
             out["cpu_baseline"] = cb
             out["config"]["direction_rel_err_vs_cpu"] = float(
@@ -276,7 +284,7 @@ def main():
         elif not args.no_cpu:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 
