@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -162,6 +163,14 @@ struct cxk_context {
   size_t ev_used = 0;
   double time_acc_ms = 0;
   int time_samples = 0;
+  // Host mailbox (pinned, device-visible): the scalars the IPM loop reads every iteration --
+  // reduced step info / eigenvalue bounds [0..3], step scalars [4..9], factor-failure flag [10],
+  // sequence number [11] -- are written by one tiny kernel at the end of the enqueued work and
+  // picked up by the host without a D2H copy.  seq counts enqueued producers; mb_seen is the
+  // value the mailbox carried when the host last waited for it.
+  double* mb = nullptr;
+  double* pin_y = nullptr;  // pinned staging of y for cxk_get_y
+  long long seq = 0, mb_seen = -1, factor_seq = -1, scal_seq = -1;
 };
 
 namespace {
@@ -1372,6 +1381,8 @@ void cxk_destroy(cxk_context* ctx) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
   }
+  if (ctx->mb) (void)hipHostFree(ctx->mb);
+  if (ctx->pin_y) (void)hipHostFree(ctx->pin_y);
   delete ctx;
 }
 
@@ -1809,19 +1820,82 @@ int cxk_assemble(cxk_context* ctx) {
   return cxk_finish_assemble(ctx);
 }
 
-int cxk_factor(cxk_context* ctx, int* ok) {
+__global__ void copy_doubles(int n, const double* __restrict__ src, double* __restrict__ dst) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+__global__ void mailbox_pack(const double* __restrict__ red, const double* __restrict__ scal,
+                             const int* __restrict__ fail, double seq, double* __restrict__ mb) {
+  const int t = threadIdx.x;
+  if (t < 4) mb[t] = red[t];
+  if (t >= 4 && t < 10) mb[t] = scal[t - 4];
+  if (t == 10) mb[10] = (double)*fail;
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) mb[11] = seq;
+}
+
+// Waits until everything enqueued so far has run and the mailbox carries its results.
+int SyncMailbox(cxk_context* ctx) {
+  if (!ctx->mb) {
+    CXK_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->mb), 16 * sizeof(double), hipHostMallocDefault));
+    for (int i = 0; i < 16; i++) ctx->mb[i] = 0.0;
+    ctx->mb[11] = -1.0;
+  }
+  const long long want = ++ctx->seq;
+  mailbox_pack<<<1, 64, 0, ctx->stream>>>(ctx->red_out.p, ctx->scal_out.p, ctx->d_fail.p, (double)want, ctx->mb);
+  CXK_TRY(hipGetLastError());
+  // spin on the sequence number (a stream synchronisation costs tens of microseconds of driver
+  // wake-up); the stream is polled now and then so that a failed launch cannot hang the host
+  volatile double* flag = ctx->mb + 11;
+  static const bool no_spin = getenv("CXK_NO_SPIN") != nullptr;
+  if (no_spin) CXK_TRY(hipStreamSynchronize(ctx->stream));
+  for (unsigned spins = 1;; spins++) {
+    if (*flag == (double)want) break;
+    if ((spins & 0xfff) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) {
+      CXK_TRY(hipStreamSynchronize(ctx->stream));
+      break;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  ctx->mb_seen = want;
+  return CXK_SUCCESS;
+}
+
+int cxk_factor_async(cxk_context* ctx) {
   if (CheckReady(ctx)) return CXK_FAILURE;
   CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));
   if (LaunchTree(ctx, 0, false, false)) return CXK_FAILURE;
+  ctx->factor_seq = ++ctx->seq;
+  return CXK_SUCCESS;
+}
+
+int cxk_factor_status(cxk_context* ctx, int* ok) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  if (ctx->mb_seen < ctx->factor_seq && SyncMailbox(ctx)) return CXK_FAILURE;
+  if (ok) *ok = ctx->mb ? (ctx->mb[10] == 0.0) : 1;
+  return CXK_SUCCESS;
+}
+
+int cxk_step_scalars_async(cxk_context* ctx) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  step_scalars<<<1, 1024, 0, ctx->stream>>>(ctx->md.N, ctx->b.p, ctx->AQc.p, ctx->y.p,
+                                            ctx->sys_sc.p, ctx->scal_out.p);
+  CXK_TRY(hipGetLastError());
+  ctx->scal_seq = ++ctx->seq;
+  return CXK_SUCCESS;
+}
+
+int cxk_factor(cxk_context* ctx, int* ok) {
+  if (cxk_factor_async(ctx)) return CXK_FAILURE;
   return cxk_sync(ctx, ok);
 }
 
 int cxk_sync(cxk_context* ctx, int* factor_ok) {
   if (CheckReady(ctx)) return CXK_FAILURE;
-  CXK_TRY(hipStreamSynchronize(ctx->stream));
-  int fail = 0;
-  CXK_TRY(hipMemcpy(&fail, ctx->d_fail.p, sizeof(int), hipMemcpyDeviceToHost));
-  if (factor_ok) *factor_ok = !fail;
+  if (SyncMailbox(ctx)) return CXK_FAILURE;
+  CXK_TRY(hipStreamSynchronize(ctx->stream));  // the stream is idle: cheap, and later host-side copies rely on it
+  if (factor_ok) *factor_ok = ctx->mb[10] == 0.0;
   // fold finished timing samples
   for (size_t k = 0; k < ctx->ev_used; k++) {
     float ms = 0;
@@ -1915,11 +1989,10 @@ int cxk_line_search(cxk_context* ctx, double dinf_upper_bound, double b_scaling,
 
 int cxk_step_scalars(cxk_context* ctx, double* out6) {
   if (CheckReady(ctx)) return CXK_FAILURE;
-  step_scalars<<<1, 1024, 0, ctx->stream>>>(ctx->md.N, ctx->b.p, ctx->AQc.p, ctx->y.p,
-                                            ctx->sys_sc.p, ctx->scal_out.p);
-  CXK_TRY(hipGetLastError());
-  CXK_TRY(hipStreamSynchronize(ctx->stream));
-  CXK_TRY(hipMemcpy(out6, ctx->scal_out.p, 6 * sizeof(double), hipMemcpyDeviceToHost));
+  if (ctx->scal_seq < 0 && cxk_step_scalars_async(ctx)) return CXK_FAILURE;  // not enqueued yet
+  if (ctx->mb_seen < ctx->scal_seq && SyncMailbox(ctx)) return CXK_FAILURE;
+  for (int i = 0; i < 6; i++) out6[i] = ctx->mb[4 + i];
+  ctx->scal_seq = -1;  // consumed: the next call computes them afresh
   return CXK_SUCCESS;
 }
 
@@ -1939,10 +2012,13 @@ int cxk_solve_inplace(cxk_context* ctx, double* yh) {
 int cxk_get_y(cxk_context* ctx, double* yh) {
   if (CheckReady(ctx)) return CXK_FAILURE;
   const int N = ctx->md.N;
-  std::vector<double> yp(N);
+  // a kernel writes y into pinned host memory: the first device-to-host hipMemcpy of a process
+  // pays milliseconds of copy-engine set-up, which would dominate a whole C4 solve
+  if (!ctx->pin_y) CXK_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->pin_y), sizeof(double) * (size_t)N, hipHostMallocDefault));
+  copy_doubles<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, ctx->y.p, ctx->pin_y);
+  CXK_TRY(hipGetLastError());
   CXK_TRY(hipStreamSynchronize(ctx->stream));
-  CXK_TRY(hipMemcpy(yp.data(), ctx->y.p, sizeof(double) * N, hipMemcpyDeviceToHost));
-  for (int i = 0; i < N; i++) yh[ctx->md.permutation_inverse[i]] = yp[i];
+  for (int i = 0; i < N; i++) yh[ctx->md.permutation_inverse[i]] = ctx->pin_y[i];
   return CXK_SUCCESS;
 }
 
@@ -1985,8 +2061,10 @@ int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_wei
   if (affine) return CXK_SUCCESS;
   reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), 0, ctx->info2.p, ctx->d_mask.p,
                                                ctx->red_out.p);
-  CXK_TRY(hipStreamSynchronize(ctx->stream));
-  CXK_TRY(hipMemcpy(info, ctx->red_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost));
+  ctx->seq++;
+  if (SyncMailbox(ctx)) return CXK_FAILURE;
+  info[0] = ctx->mb[0];
+  info[1] = ctx->mb[1];
   return CXK_SUCCESS;
 }
 
@@ -2044,8 +2122,9 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
   reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), 1, ctx->info4.p, ctx->d_mask.p,
                                                ctx->red_out.p);
   CXK_TRY(hipGetLastError());
-  CXK_TRY(hipStreamSynchronize(ctx->stream));
-  CXK_TRY(hipMemcpy(out, ctx->red_out.p, 4 * sizeof(double), hipMemcpyDeviceToHost));
+  ctx->seq++;
+  if (SyncMailbox(ctx)) return CXK_FAILURE;
+  for (int i = 0; i < 4; i++) out[i] = ctx->mb[i];
   return CXK_SUCCESS;
 }
 

@@ -14,6 +14,7 @@
 // Every fp64 vector/matrix operation of the loop is a cxk_* call; per iteration only the
 // scalars of cxk_step_scalars / cxk_prepare_step / cxk_weighted_slack_eigenvalues cross PCIe.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -323,6 +324,24 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
             "conex: kkt_solver/iterative_refinement options need the dense KKT matrix and are not "
             "available on the device path; using LLT without refinement.\n");
   }
+  // CONEX_PROFILE=1 in the environment: wall time of set-up, of the iteration loop and of the
+  // host side of each device call on stderr
+  const bool profile = getenv("CONEX_PROFILE") != nullptr;
+  double prof_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static const char* const prof_name[8] = {"assemble", "factor_async", "mu selection", "factor_status",
+                                           "newton_direction", "prepare_step", "step_scalars", "take_step"};
+#define TIMED(slot, expr)                                                                  \
+  [&]() {                                                                                  \
+    if (!profile) return (expr);                                                           \
+    const auto t0_ = std::chrono::steady_clock::now();                                     \
+    const auto r_ = (expr);                                                                \
+    prof_ms[slot] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count(); \
+    return r_;                                                                             \
+  }()
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since = [](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
   // Initialize :78-112
   if (!p->initialized || p->dirty || cfg.initialization_mode == 0) {
     if (p->dirty || !p->ctx) {
@@ -336,6 +355,8 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     p->initialized = true;
   }
   cxk_context* ctx = p->ctx;
+  if (profile) fprintf(stderr, "conex profile: set-up (symbolic analysis, plans, upload) %.2f ms\n", since(t_start));
+  const auto t_loop = std::chrono::steady_clock::now();
   p->sqrt_inv_mu.assign(std::max(cfg.max_iterations, 1), 0.0);
   p->num_iter = 0;
   p->stats_ready = true;
@@ -376,7 +397,7 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
         break;
       }
     }
-    if (cxk_assemble(ctx)) return 0;
+    if (TIMED(0, cxk_assemble(ctx))) return 0;
     if (i < 1 && cfg.enable_rescaling) {
       if (cfg.initialization_mode == 0) {
         double sc[6];
@@ -388,19 +409,25 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
       mu_target *= (b_scaling * c_scaling);
       inv_sqrt_mu_max = 1.0 / std::sqrt(mu_target);
     }
-    int ok = 0;
-    if (cxk_factor(ctx, &ok)) return 0;
-    if (!ok) {
+    // solver->Factor() :360.  The LLT flag travels back with the next host round trip of this
+    // iteration (mu selection or PrepareStep); everything enqueued in between only overwrites
+    // scratch state (y, the step temporaries), so acting on the flag there is equivalent.
+    if (TIMED(1, cxk_factor_async(ctx))) return 0;
+    enum { kOk, kRetry, kFailed };
+    auto factor_outcome = [&]() -> int {
+      int ok = 0;
+      if (TIMED(3, cxk_factor_status(ctx, &ok))) return kFailed;
+      if (ok) return kOk;
       if (i == 0 && cfg.initialization_mode == 1) {
         PRINTSTATUS("Aborting warmstart...");
         cxk_set_identity(ctx);
         warmstart_aborted = true;
-        continue;
+        return kRetry;
       }
       p->solved = 0;
       PRINTSTATUS("Factorization failed.");
-      return 0;
-    }
+      return kFailed;
+    };
     if (update_mu) {
       double temp = -1;
       if (cfg.enable_line_search) {  // cone_program.cc:376-384
@@ -413,7 +440,12 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
                   __LINE__);
           return 1;
         }
-        if (MuFromDivergence(p, cfg, rankK, &temp)) return 0;
+        if (TIMED(2, MuFromDivergence(p, cfg, rankK, &temp))) return 0;
+      }
+      {
+        const int fo = factor_outcome();  // free: the mu selection above has waited for the stream
+        if (fo == kRetry) continue;
+        if (fo == kFailed) return 0;
       }
       if (temp > 0)
         inv_sqrt_mu = temp;
@@ -424,21 +456,27 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     }
     ApplyLimits(&inv_sqrt_mu, std::sqrt(1.0 / (1e-15 + cfg.maximum_mu)), inv_sqrt_mu_max);
 
-    if (cxk_newton_direction(ctx, inv_sqrt_mu, b_scaling, c_scaling)) return 0;
+    if (TIMED(4, cxk_newton_direction(ctx, inv_sqrt_mu, b_scaling, c_scaling))) return 0;
+    if (TIMED(6, cxk_step_scalars_async(ctx))) return 0;  // by / cx of :439-446 need y only: same round trip
     e_weight = 1;
     c_weight = inv_sqrt_mu * c_scaling;
     double info[2];
-    if (cxk_prepare_step(ctx, 0, c_weight, e_weight, info)) return 0;
+    if (TIMED(5, cxk_prepare_step(ctx, 0, c_weight, e_weight, info))) return 0;
+    if (!update_mu) {
+      const int fo = factor_outcome();
+      if (fo == kRetry) continue;
+      if (fo == kFailed) return 0;
+    }
     step_size = 2.0 / (info[1] * info[1]);
     if (step_size > 1) step_size = 1;
     double sc[6];
-    if (cxk_step_scalars(ctx, sc)) return 0;
+    if (TIMED(6, cxk_step_scalars(ctx, sc))) return 0;
     if (i == 0 && cfg.initialization_mode == 1 && info[1] >= cfg.warmstart_abort_threshold) {
       PRINTSTATUS("Aborting warmstart...");
       cxk_set_identity(ctx);
       warmstart_aborted = true;
     } else {
-      if (cxk_take_step(ctx, 0, e_weight, step_size)) return 0;
+      if (TIMED(7, cxk_take_step(ctx, 0, e_weight, step_size))) return 0;
     }
     const double d_2 = std::sqrt(std::fabs(info[0]));
     const double d_inf = std::fabs(info[1]);
@@ -468,9 +506,18 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
       }
     }
   }
+  if (profile) fprintf(stderr, "conex profile: loop left after %.2f ms\n", since(t_loop));
   std::vector<double> y(N, 0.0);
   if (cxk_get_y(ctx, y.data())) return 0;
   for (int i = 0; i < m; i++) yout[i] = y[i];
+  if (profile) {
+    fprintf(stderr, "conex profile: %d iterations in %.2f ms (%.3f ms each)\n", p->num_iter, since(t_loop),
+            since(t_loop) / std::max(p->num_iter, 1));
+    for (int k = 0; k < 8; k++)
+      fprintf(stderr, "conex profile:   host time in %-18s %.3f ms per iteration\n", prof_name[k],
+              prof_ms[k] / std::max(p->num_iter, 1));
+  }
+#undef TIMED
 
   double mu = 1.0 / inv_sqrt_mu;
   mu *= mu;

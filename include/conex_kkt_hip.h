@@ -112,6 +112,17 @@ int cxk_set_W(cxk_context* ctx, int i, const double* in);     /* warm start impo
 int cxk_assemble(cxk_context* ctx);
 /* solver->Factor() kkt_solver.cc:172-199 (LLT mode). *ok = 1 success, 0 not PD. Syncs. */
 int cxk_factor(cxk_context* ctx, int* ok);
+/* The same without waiting: cxk_factor_async enqueues the factorization, cxk_factor_status
+ * returns its LLT flag -- at no cost when a later blocking call (cxk_prepare_step,
+ * cxk_weighted_slack_eigenvalues, cxk_step_scalars, cxk_sync) has already waited for the stream:
+ * every wait brings the flag, the reduced step info and the step scalars back together through
+ * one pinned host mailbox.  conex::Solve's per-iteration host round trips (cone_program.cc:360,
+ * 417, 439-446) collapse into one or two this way. */
+int cxk_factor_async(cxk_context* ctx);
+int cxk_factor_status(cxk_context* ctx, int* ok);
+/* enqueue the by / cx / norm reductions of cxk_step_scalars; the next cxk_step_scalars call
+ * returns them (waiting only if nothing has waited since) */
+int cxk_step_scalars_async(cxk_context* ctx);
 /* y_dev = inv_sqrt_mu*(b*b_scaling + AQc*c_scaling) - 2 AW  cone_program.cc:409-411,
  * followed by solver->SolveInPlace(&y) kkt_solver.cc:220-263.  No host sync. */
 int cxk_set_cost(cxk_context* ctx, const double* b /* num_vars, host */);
