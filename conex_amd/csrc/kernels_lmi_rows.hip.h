@@ -1,0 +1,152 @@
+// TakeStep for small dense LMIs, one WAVEFRONT per constraint, one matrix row per lane, everything
+// in registers (compiled for the benchmark order N = 20; 16 < N <= 32: a column spans two
+// 16-lane DPP rows).  Reference: TakeStep -> GeodesicUpdate with the Pade [3/3] exponential
+// (psd_constraint.cc:45-84, exponential_map_pade.cc:10-32):
+//     X = (WS + e I) * step;  A2 = X X;  U = X (A2 + 60 I);  V = 12 A2 + 120 I
+//     E = (V - U)^-1 (V + U);  W <- sym(E W)
+//
+// The matrix products are row-times-matrix sums  out[c] = sum_j row[j] M[j][c]  in which M[j][c] is
+// lane j's register c: it reaches the fma as a row_newbcast DPP operand (the mirror of DPP row 0
+// serves j < 16, the mirror of row 1 the rest), one instruction per term, j ascending -- the same
+// fma chains as the LDS kernel (lmi_take_step_generic) up to the linear solve.  The solve is a
+// Gauss-Jordan elimination with partial pivoting on [V - U | V + U]: the pivot row stays in its
+// lane (an implicit permutation), its entries reach the other rows by v_readlane.  The workgroup
+// kernel spends most of its 64 us at the C4 shape in barriers and in serial LDS chains (pivot
+// search, back substitution); this one needs no barrier at all.  Mathematically the same update;
+// the elimination order differs from an LU + triangular solves, so W agrees with the oracle to
+// rounding (tests/test_gpu_parity.py, <= 1e-11).
+#pragma once
+#include "kernels_kkt.hip.h"
+#include "kernels_lmi_fused.hip.h"
+
+namespace cxk {
+
+template <int N, int J>
+struct RowDotSteps {  // acc += sum_{j >= J} M[j][c] row[j]
+  static __device__ __forceinline__ void run(double& acc, double m0, double m1, const double (&row)[N]) {
+    if constexpr (J < N) {
+      if constexpr (J < 16)
+        FmaBcast<J>(acc, m0, row[J]);
+      else
+        FmaBcast<J - 16>(acc, m1, row[J]);
+      RowDotSteps<N, J + 1>::run(acc, m0, m1, row);
+    }
+  }
+};
+
+// out[c] = sum_j row[j] * M[j][c], M[j][c] = lane j's mat[c]; columns C .. N-1
+template <int N, int C>
+struct RowTimesMatrix {
+  static __device__ __forceinline__ void run(const double (&row)[N], const double (&mat)[N], double (&out)[N]) {
+    if constexpr (C < N) {
+      const RowPair mp = Swap16(mat[C]);  // a: DPP rows 0/2 everywhere, b: rows 1/3
+      double m0 = mp.a, m1 = mp.b, acc = 0.0;
+      DppOperandFence(m0, m1, acc);
+      RowDotSteps<N, 0>::run(acc, m0, m1, row);
+      out[C] = acc;
+      RowTimesMatrix<N, C + 1>::run(row, mat, out);
+    }
+  }
+};
+
+__device__ __forceinline__ double ReadLaneUniform(double v, int src) {  // src wave-uniform at run time
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+template <int N, int K, int C>
+struct GjColumns {  // aug[c] -= f * pivot_row[c], c = C .. 2N-1
+  static __device__ __forceinline__ void run(double (&aug)[2 * N], double f, int p) {
+    if constexpr (C < 2 * N) {
+      aug[C] = fma(-f, ReadLaneUniform(aug[C], p), aug[C]);
+      GjColumns<N, K, C + 1>::run(aug, f, p);
+    }
+  }
+};
+
+// Gauss-Jordan steps K .. N-1 with partial pivoting among the rows not used as pivots yet.
+template <int N, int K>
+struct GjSteps {
+  static __device__ __forceinline__ void run(double (&aug)[2 * N], int lane, bool& done, double& mypiv, int& myk) {
+    if constexpr (K < N) {
+      const bool cand = lane < N && !done;
+      const double mag = cand ? fabs(aug[K]) : -1.0;
+      const double best = WaveMax(mag);
+      unsigned long long bal = __ballot(cand && mag == best);
+      if (bal == 0) bal = __ballot(cand);  // NaN column: any remaining row (the result is NaN anyway)
+      const int p = __builtin_amdgcn_readfirstlane(__ffsll((long long)bal) - 1);
+      const double pk = ReadLaneUniform(aug[K], p);
+      const bool is_p = lane == p;
+      const double f = is_p ? 0.0 : aug[K] / pk;  // every other row, pivots of earlier steps included
+      if (is_p) {
+        done = true;
+        mypiv = aug[K];
+        myk = K;
+      }
+      GjColumns<N, K, K + 1>::run(aug, f, p);
+      GjSteps<N, K + 1>::run(aug, lane, done, mypiv, myk);
+    }
+  }
+};
+
+template <int N>
+__global__ void __launch_bounds__(256) lmi_take_step_rows(LmiGroup g, StepArgs sa) {
+  static_assert(N > 16 && N <= 32, "a column spans DPP rows 0 and 1");
+  __shared__ double sT[4][N * N];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int mem = blockIdx.x * 4 + wave;
+  if (mem >= g.count) return;  // wave-uniform; no workgroup barrier below
+  constexpr int NN = N * N;
+  double* Wg = g.W + (size_t)mem * NN;
+  const double* T1 = g.T1 + (size_t)mem * NN;
+  const bool row = lane < N;
+  const int r = row ? lane : 0;
+  double x[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double v = row ? T1[r + j * N] : 0.0;
+    if (row && j == r) v += sa.e_weight;
+    if (sa.step_size != 1.0) v *= sa.step_size;
+    x[j] = v;
+  }
+  double aug[2 * N];
+  {
+    double a2[N], t[N], u[N];
+    RowTimesMatrix<N, 0>::run(x, x, a2);  // A2 = X X
+#pragma unroll
+    for (int c = 0; c < N; c++) t[c] = a2[c] + ((row && c == r) ? 60.0 : 0.0);
+    RowTimesMatrix<N, 0>::run(x, t, u);   // U = X (A2 + 60 I)
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+      const double v = a2[c] * 12.0 + ((row && c == r) ? 120.0 : 0.0);
+      aug[c] = -u[c] + v;      // denominator
+      aug[N + c] = u[c] + v;   // numerator
+    }
+  }
+  bool done = false;
+  double mypiv = 1.0;
+  int myk = 0;
+  GjSteps<N, 0>::run(aug, lane, done, mypiv, myk);
+  // this lane now holds row myk of E = denominator^-1 numerator
+  double e[N], w[N], ew[N];
+#pragma unroll
+  for (int c = 0; c < N; c++) e[c] = aug[N + c] / mypiv;
+#pragma unroll
+  for (int c = 0; c < N; c++) w[c] = row ? Wg[r + c * N] : 0.0;  // lane j: row j of W
+  RowTimesMatrix<N, 0>::run(e, w, ew);  // row myk of E W
+  double* T = sT[wave];
+  if (row) {
+#pragma unroll
+    for (int c = 0; c < N; c++) T[myk + c * N] = ew[c];
+  }
+  WaveSync();
+  if (row) {
+#pragma unroll
+    for (int c = 0; c < N; c++) Wg[r + c * N] = (T[r + c * N] + T[c + r * N]) * 0.5;
+  }
+}
+
+inline bool LmiTakeStepRowsSupports(int n, int herm_d) { return n == 20 && herm_d == 0; }
+
+}  // namespace cxk

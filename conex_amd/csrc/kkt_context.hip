@@ -26,6 +26,7 @@
 #include "kernels_lmi.hip.h"
 #include "kernels_lmi_fused.hip.h"
 #include "kernels_lmi_sparse.hip.h"
+#include "kernels_lmi_rows.hip.h"
 #include "kernels_lmi_large.hip.h"
 #include "symbolic.h"
 
@@ -2085,11 +2086,15 @@ int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_siz
     if (cnt == 0) continue;
     if (g.type == CXK_LMI && g.large)
       CXK_TRY(LmiLargeTakeStep(MakeLmi(g), sa, MakeLargeWs(g), ctx->stream));
-    else if (g.type == CXK_LMI)
-      if (g.n == 20)
+    else if (g.type == CXK_LMI) {
+      static const bool lds_kernel = getenv("CXK_TAKE_STEP_LDS") != nullptr;  // A/B switch (tests, timing)
+      if (LmiTakeStepRowsSupports(g.n, g.herm_d) && !lds_kernel)
+        lmi_take_step_rows<20><<<(cnt + 3) / 4, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+      else if (g.n == 20)
         lmi_take_step_generic<20><<<cnt, 256, LmiTakeLds(g.n), ctx->stream>>>(MakeLmi(g), sa);
       else
         lmi_take_step_generic<0><<<cnt, 256, LmiTakeLds(g.n), ctx->stream>>>(MakeLmi(g), sa);
+    }
     else if (g.type == CXK_LINEAR)
       linear_take_step<<<GridFor((size_t)cnt * g.n, 256), 256, 0, ctx->stream>>>(MakeVec(g), sa);
     else if (g.type == CXK_SOC)
