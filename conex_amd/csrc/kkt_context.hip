@@ -1887,6 +1887,33 @@ int cxk_step_scalars_async(cxk_context* ctx) {
   return CXK_SUCCESS;
 }
 
+// Factor and solve in one sweep (the forward substitution rides in the elimination as in
+// cxk_kkt_solve_async): y <- K^-1 (cb b + cq AQc + cw AW).  With (k bs, k cs, -2) this is the Newton
+// direction, with (-bs, cs, 0) the right-hand side of ComputeMuFromDivergence (cone_program.cc:173-214).
+int cxk_factor_solve_async(cxk_context* ctx, double cb, double cq, double cw) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  const int N = ctx->md.N;
+  CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));
+  build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, cb, cq, cw, ctx->b.p, ctx->AQc.p, ctx->AW.p,
+                                                           ctx->y.p);
+  CXK_TRY(hipGetLastError());
+  if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;
+  ctx->factor_seq = ++ctx->seq;
+  return CXK_SUCCESS;
+}
+
+// cxk_factor_async + cxk_newton_direction in one upward pass: y <- K^-1 (k (b bs + AQc cs) - 2 AW).
+int cxk_factor_direction_async(cxk_context* ctx, double k, double bs, double cs) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  const int N = ctx->md.N;
+  CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));
+  build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p, ctx->y.p);
+  CXK_TRY(hipGetLastError());
+  if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;
+  ctx->factor_seq = ++ctx->seq;
+  return CXK_SUCCESS;
+}
+
 int cxk_factor(cxk_context* ctx, int* ok) {
   if (cxk_factor_async(ctx)) return CXK_FAILURE;
   return cxk_sync(ctx, ok);

@@ -271,10 +271,11 @@ Config FromApi(const CONEX_SolverConfiguration* c) {  // interfaces/conex.cc:65-
 }
 
 // ComputeMuFromDivergence cone_program.cc:173-214
-int MuFromDivergence(Program* p, const Config& cfg, int rankK, double* out) {
+int MuFromDivergence(Program* p, const Config& cfg, int rankK, double* out, bool solved_already = false) {
   cxk_context* ctx = p->ctx;
   const double bs = p->b_scaling, cs = p->c_scaling;
-  if (cxk_solve_rhs(ctx, -bs, cs, 0.0)) return 1;  // y = AQc*cs - b*bs ; SolveInPlace
+  // y = AQc*cs - b*bs ; SolveInPlace (already done when the factorization carried this right-hand side)
+  if (!solved_already && cxk_solve_rhs(ctx, -bs, cs, 0.0)) return 1;
   double e4[4];
   if (cxk_weighted_slack_eigenvalues(ctx, cs, e4)) return 1;
   Wse mp;
@@ -412,7 +413,22 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     // solver->Factor() :360.  The LLT flag travels back with the next host round trip of this
     // iteration (mu selection or PrepareStep); everything enqueued in between only overwrites
     // scratch state (y, the step temporaries), so acting on the flag there is equivalent.
-    if (TIMED(1, cxk_factor_async(ctx))) return 0;
+    // One upward pass serves the factorization and the first solve of the iteration: the
+    // right-hand side of the mu selection (ComputeMuFromDivergence) when mu is updated without a
+    // line search, the Newton direction itself when mu stays (its value is final before Factor()).
+    const bool fuse_mu_solve = update_mu && !cfg.enable_line_search;
+    const bool fuse_direction = !update_mu;
+    if (fuse_direction) {
+      if (initial_centering == 0) centering_steps++;
+      ApplyLimits(&inv_sqrt_mu, std::sqrt(1.0 / (1e-15 + cfg.maximum_mu)), inv_sqrt_mu_max);
+    }
+    if (fuse_mu_solve) {
+      if (TIMED(1, cxk_factor_solve_async(ctx, -b_scaling, c_scaling, 0.0))) return 0;
+    } else if (fuse_direction) {
+      if (TIMED(1, cxk_factor_direction_async(ctx, inv_sqrt_mu, b_scaling, c_scaling))) return 0;
+    } else {
+      if (TIMED(1, cxk_factor_async(ctx))) return 0;
+    }
     enum { kOk, kRetry, kFailed };
     auto factor_outcome = [&]() -> int {
       int ok = 0;
@@ -440,7 +456,7 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
                   __LINE__);
           return 1;
         }
-        if (TIMED(2, MuFromDivergence(p, cfg, rankK, &temp))) return 0;
+        if (TIMED(2, MuFromDivergence(p, cfg, rankK, &temp, fuse_mu_solve))) return 0;
       }
       {
         const int fo = factor_outcome();  // free: the mu selection above has waited for the stream
@@ -451,12 +467,10 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
         inv_sqrt_mu = temp;
       else
         inv_sqrt_mu *= .5;
-    } else {
-      if (initial_centering == 0) centering_steps++;
     }
     ApplyLimits(&inv_sqrt_mu, std::sqrt(1.0 / (1e-15 + cfg.maximum_mu)), inv_sqrt_mu_max);
 
-    if (TIMED(4, cxk_newton_direction(ctx, inv_sqrt_mu, b_scaling, c_scaling))) return 0;
+    if (!fuse_direction && TIMED(4, cxk_newton_direction(ctx, inv_sqrt_mu, b_scaling, c_scaling))) return 0;
     if (TIMED(6, cxk_step_scalars_async(ctx))) return 0;  // by / cx of :439-446 need y only: same round trip
     e_weight = 1;
     c_weight = inv_sqrt_mu * c_scaling;

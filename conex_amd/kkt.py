@@ -88,6 +88,8 @@ _SIGNATURES = {
     "cxk_assembly_work": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "cxk_count_sparse_lmi": (C.c_int, [C.c_void_p]),
     "cxk_factor_async": (C.c_int, [C.c_void_p]),
+    "cxk_factor_solve_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "cxk_factor_direction_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
     "cxk_factor_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "cxk_step_scalars_async": (C.c_int, [C.c_void_p]),
     "cxk_kernel_time": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),

@@ -119,6 +119,14 @@ int cxk_factor(cxk_context* ctx, int* ok);
  * one pinned host mailbox.  conex::Solve's per-iteration host round trips (cone_program.cc:360,
  * 417, 439-446) collapse into one or two this way. */
 int cxk_factor_async(cxk_context* ctx);
+/* factor and, in the same sweeps, solve  y <- K^-1 (cb b + cq AQc + cw AW)  (permuted b, residuals of
+ * the last cxk_assemble): one upward pass instead of factor + forward substitution.  (k bs, k cs, -2)
+ * gives the Newton direction of cxk_newton_direction, (-bs, cs, 0) the solve of
+ * ComputeMuFromDivergence (cone_program.cc:173-214).  LLT flag through cxk_factor_status. */
+int cxk_factor_solve_async(cxk_context* ctx, double cb, double cq, double cw);
+/* cxk_factor_async + cxk_newton_direction in one upward pass (same right-hand side formula
+ * y = k (b bs + AQc cs) - 2 AW, cone_program.cc:409-411) */
+int cxk_factor_direction_async(cxk_context* ctx, double k, double bs, double cs);
 int cxk_factor_status(cxk_context* ctx, int* ok);
 /* enqueue the by / cx / norm reductions of cxk_step_scalars; the next cxk_step_scalars call
  * returns them (waiting only if nothing has waited since) */
