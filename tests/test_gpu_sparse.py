@@ -136,3 +136,32 @@ def test_sparse_runs_are_bit_reproducible(force_sparse):
         assert k.sync()
         ys.append(k.get_y().copy())
     assert np.array_equal(ys[0], ys[1])
+
+
+@pytest.mark.parametrize("dense_c", [False, True])
+def test_sparse_assembly_with_empty_and_single_entry_matrices(force_sparse, dense_c):
+    """Edge lists: an all-zero A_i (empty list), a single diagonal entry, a single off-diagonal pair;
+    only the assembled blocks are compared (the Schur matrix is singular by construction)."""
+    K, n, m = 3, 9, 5
+    prob = syn.lmi_problem(K=K, n=n, m=m, branching=2, overlap=1)
+    A = np.zeros_like(prob["A"])
+    for c in range(K):
+        A[c, 1, 2, 2] = 1.5                      # one diagonal entry
+        A[c, 2, 0, 4] = A[c, 2, 4, 0] = -0.7     # one off-diagonal pair
+        A[c, 3] = prob["A"][c, 3]                # a dense matrix among them
+        A[c, 4, n - 1, n - 1] = 2.0
+    prob["A"] = A                                 # A[c, 0] stays empty
+    if dense_c:
+        rng = np.random.default_rng(3)
+        prob["C"] = prob["C"] + 0.1 * np.stack([syn.random_sym(rng, n) for _ in range(K)])
+    o, k = make_pair(prob, "lmi", syn.scaling_points(K, n))
+    assert k.count_sparse_lmi() == K
+    o.assemble()
+    k.assemble()
+    for i in range(K):
+        Go, AWo, AQo, sco = o.constraint_schur(i)
+        Gk, AWk, AQk, sck = k.constraint_schur(i)
+        assert np.allclose(np.tril(Gk), np.tril(Go), rtol=1e-13, atol=1e-15)
+        assert np.all(np.tril(Gk)[0] == 0.0) and np.all(np.tril(Gk)[:, 0] == 0.0)
+        assert np.allclose(AWk, AWo, rtol=1e-13, atol=1e-15) and np.allclose(AQk, AQo, rtol=1e-13, atol=1e-15)
+        assert np.allclose(sck, sco, rtol=1e-13, atol=1e-15)
