@@ -43,7 +43,12 @@ struct FusedCfg {
   static constexpr int LD = N + 1;                   // odd row stride
   static constexpr int MS = N * LD + (6 - (N * LD) % 4) % 4;  // smallest stride = 2 (mod 4)
   static constexpr int TI = (M1 + 15) / 16;          // 16-row tiles
-  static constexpr int NT = TI * (TI + 1) / 2;       // lower tile pairs
+  // 17 <= M1 <= 24: the lower triangle fits TWO 16 x 16 MFMA tiles instead of three -- tile 0 =
+  // rows R..M1-1 x columns 0..15 (R = M1 - 16), tile 1 = the symmetric block over the 2R matrices
+  // {0..R-1} u {16..M1-1}, which holds the pairs tile 0 misses (both < R, or both >= 16)
+  static constexpr bool TWO = (M1 > 16 && M1 <= 24);
+  static constexpr int R = M1 - 16;
+  static constexpr int NT = TWO ? 2 : TI * (TI + 1) / 2;  // accumulated tiles
   static constexpr int KSTEPS = N * N / 4;
   static constexpr size_t kRows = (size_t)M1 * MS;   // doubles: A, then P
   static constexpr size_t kW = (size_t)N * 32;       // padded copy of W
@@ -183,7 +188,22 @@ __global__ void __launch_bounds__((FusedCfg<N, M>::THREADS)) lmi_schur_fused(Lmi
   d4_t acc[NT];
 #pragma unroll
   for (int tt = 0; tt < NT; tt++) acc[tt] = (d4_t){0.0, 0.0, 0.0, 0.0};
-  {
+  if constexpr (Cfg::TWO) {
+    constexpr int R = Cfg::R;
+    const int il = lane & 15, kq = lane >> 4;
+    const int rowA = (R + il) * MS;                                      // tile 0 rows: matrices R .. M1-1
+    const int colA = il * MS;                                            // tile 0 columns: matrices 0 .. 15
+    const int setB = (il < R ? il : (il < 2 * R ? 16 + il - R : M1 - 1)) * MS;  // tile 1 rows = columns
+#pragma unroll 2
+    for (int ks = wave; ks < Cfg::KSTEPS; ks += WAVES) {
+      const int rr = ks / (N / 4), b0 = 4 * (ks % (N / 4));
+      const int ao = rr * LD + b0 + kq, bo = (b0 + kq) * LD + rr;
+      const double a0 = buf[rowA + ao], b0v = buf[colA + bo];
+      const double a1 = buf[setB + ao], b1v = buf[setB + bo];
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0v, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1v, acc[1], 0, 0, 0);
+    }
+  } else {
     const int il = lane & 15, kq = lane >> 4;
     int mrow[TI];
 #pragma unroll
@@ -228,9 +248,20 @@ __global__ void __launch_bounds__((FusedCfg<N, M>::THREADS)) lmi_schur_fused(Lmi
   for (int idx = threadIdx.x; idx < M1 * M1; idx += blockDim.x) {
     const int ii = idx / M1, jj = idx - ii * M1;
     if (jj > ii) continue;
-    const int I = ii >> 4, J = jj >> 4;
-    const int tt = I * (I + 1) / 2 + J;
-    const int off = tt * 256 + (ii & 15) * 16 + (jj & 15);
+    int off;
+    if constexpr (Cfg::TWO) {
+      constexpr int R = Cfg::R;
+      if (ii >= R && jj < 16)
+        off = (ii - R) * 16 + jj;                             // tile 0
+      else if (ii < R)
+        off = 256 + ii * 16 + jj;                             // tile 1, both among the first R
+      else
+        off = 256 + (R + ii - 16) * 16 + (R + jj - 16);       // tile 1, both >= 16
+    } else {
+      const int I = ii >> 4, J = jj >> 4;
+      const int tt = I * (I + 1) / 2 + J;
+      off = tt * 256 + (ii & 15) * 16 + (jj & 15);
+    }
     double s = 0;
 #pragma unroll
     for (int w = 0; w < WAVES; w++) s += buf[w * NT * 256 + off];
