@@ -124,6 +124,9 @@ int cxo_solve(cxo_program* p, const double* b, const cxo_config* cfg, double* y)
 int cxo_num_iterations(const cxo_program* p);
 void cxo_get_dual_variable(cxo_program* p, int i, double* out);
 void cxo_set_verbose(int v);
+/* 1: direct_update only when the supernode's positions are exactly 0..m-1 (fixes a reference defect
+ * on fill-in structures, see cxo_program.c); 0 (default): the reference's test as written */
+void cxo_set_strict_direct_update(int on);
 
 /* ---- stand-alone pieces for known-answer tests ---- */
 int cxo_path_in_tree(int x, int y, int n, const int* parent, const int* depth, int* path);

@@ -26,6 +26,19 @@
 static int g_verbose = 0;
 void cxo_set_verbose(int v) { g_verbose = v; }
 
+/* Reference defect, restated by default.  BindDiagonalBlock (supernodal_assembler.cc:72-91) turns
+ * on direct_update -- the constraint's Schur block G aliased onto the supernode's diagonal block
+ * -- when the supernode has as many variables as the constraint and their positions inside the
+ * constraint are strictly increasing.  It does not check that the first position is 0: with a
+ * fill-in variable (position -1, a variable the running-intersection fix assigned to this
+ * supernode although the constraint does not contain it) followed by positions 0, 1, .., m-2 the
+ * test passes, G lands one row/column off, and the constraint's last variable -- which sits in
+ * the separator -- never reaches its place.  The assembled matrix is then NOT sum_c P_c^T G_c P_c.
+ * cxo_set_strict_direct_update(1) adds the missing check (positions exactly 0..m-1); tests use it
+ * to show that the HIP path, which always scatters by position, equals the corrected reference. */
+static int g_strict_direct_update = 0;
+void cxo_set_strict_direct_update(int on) { g_strict_direct_update = on; }
+
 typedef struct {
   int type;
   int n;  /* LMI order / linear rows / SOC n (vector in R^{n+1}) */
@@ -370,6 +383,7 @@ int cxo_initialize(cxo_program* p) {
     const ivec* sn = &p->md->supernodes_pos[e];
     if (sn->n > 0 && c->m == sn->n) {
       int direct = 1;
+      if (g_strict_direct_update && sn->d[0] != 0) direct = 0;
       for (int q = 1; q < sn->n; q++)
         if (sn->d[q] <= sn->d[q - 1]) {
           direct = 0;

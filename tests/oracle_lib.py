@@ -103,6 +103,7 @@ def lib():
         "cxo_num_iterations": (C.c_int, [vp]),
         "cxo_get_dual_variable": (None, [vp, C.c_int, c_double_p]),
         "cxo_set_verbose": (None, [C.c_int]),
+        "cxo_set_strict_direct_update": (None, [C.c_int]),
         "cxo_default_config": (None, [C.POINTER(Config)]),
         "cxo_path_in_tree": (C.c_int, [C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p]),
         "cxo_pick_clique_order": (C.c_int, [C.c_int, c_int_p, c_int_p, C.c_int, c_int_p, c_int_p,
