@@ -477,6 +477,8 @@ int BuildPlans(cxk_context* ctx) {
     }
     return srcs[entry_of[off]];
   };
+  const char* quirks_env = getenv("CXK_REFERENCE_QUIRKS");
+  const bool quirks = quirks_env && atoi(quirks_env) != 0;
   for (int e = K - 1; e >= 0; e--) {
     const int i = md.clique_order[e];
     const int m = ctx->cons[i].m;
@@ -489,21 +491,32 @@ int BuildPlans(cxk_context* ctx) {
     const IntList& r = md.supernodes_pos[e];
     const IntList& s = md.separators_pos[e];
     const int nse = (int)r.size(), nsp = (int)s.size();
+    // The reference's direct_update test (BindDiagonalBlock, supernodal_assembler.cc:72-91) passes
+    // on a supernode whose positions are -1, 0, .., m-2 (a fill-in variable in front) and then
+    // writes G one row/column off and drops the separator terms -- a defect.
+    // By default blocks are scattered by position; CXK_REFERENCE_QUIRKS=1 reproduces the
+    // reference as written for callers that need its trajectories.
+    bool misplaced = false;
+    if (quirks && nse > 0 && m == nse && r[0] != 0) {
+      misplaced = true;
+      for (int q = 1; q < nse; q++) misplaced = misplaced && r[q] > r[q - 1];
+    }
     if (block_wanted(e)) {
       for (int j = 0; j < nse; j++)  // SetLowerTri
         for (int i2 = j; i2 < nse; i2++) {
           auto& v = entry(L.diag_off[e] + (int64_t)j * nse + i2);
           v.clear();
-          v.push_back(coeff(r[i2], r[j]));
+          v.push_back(misplaced ? coeff(i2, j) : coeff(r[i2], r[j]));
         }
       if (nse > 0)
         for (int j = 0; j < nsp; j++)  // Set
           for (int i2 = 0; i2 < nse; i2++) {
             auto& v = entry(L.offd_off[e] + (int64_t)j * nse + i2);
             v.clear();
-            v.push_back(coeff(r[i2], s[j]));
+            v.push_back(misplaced ? (int64_t)-1 : coeff(r[i2], s[j]));
           }
     }
+    if (misplaced) continue;  // UpdateBlocks returns before Scatter on a direct update
     int cnt = 0;
     for (int j = 0; j < nsp; j++)  // Scatter
       for (int i2 = j; i2 < nsp; i2++) {

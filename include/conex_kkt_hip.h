@@ -85,7 +85,11 @@ int cxk_set_shard(cxk_context* ctx, int rank, int world_size);
 
 /* Initialize(): symbolic analysis (SupernodalKKTSolver ctor kkt_solver.cc:104-116),
  * Bind (kkt_solver.h:26-33), workspace carve + SetIdentity (cone_program.cc:78-112),
- * upload of constant data, construction of device index tables and level schedule. */
+ * upload of constant data, construction of device index tables and level schedule.
+ * Environment read here: CXK_SPARSE_LMI=0/1 (force the dense / sparse LMI evaluation),
+ * CXK_REFERENCE_QUIRKS=1 (place a constraint's block where BindDiagonalBlock's unchecked
+ * direct_update test puts it on fill-in supernodes, supernodal_assembler.cc:72-91, instead of
+ * scattering it by position). */
 int cxk_finalize(cxk_context* ctx);
 
 /* ---- symbolic results (MatrixData supernodal_solver.h:18-29; bit-exact vs reference) */

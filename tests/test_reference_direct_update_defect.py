@@ -108,3 +108,21 @@ def test_hip_path_differs_from_the_reference_as_written_here():
     k.kkt_solve_async(0.3, 0.9, 0.8)
     assert ok_o == 1 and k.sync()
     assert rel(k.get_y(), yo) > 1e-4      # documented deviation: the reference's direction is off here
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [SEED, 2585])
+def test_reference_quirks_mode_reproduces_the_reference_as_written(monkeypatch, seed):
+    """CXK_REFERENCE_QUIRKS=1: the HIP path places the block where the reference does."""
+    from conex_amd import KktContext
+    monkeypatch.setenv("CXK_REFERENCE_QUIRKS", "1")
+    prob = random_program(seed)
+    o, k = build(ol.Program, prob), build(KktContext, prob, device=0)
+    o.assemble()
+    k.assemble()
+    assert np.abs(dense_from_slab(o, k.slab()) - dense_from_slab(o, o.slab())).max() <= 1e-12
+    ok_o, yo = o.kkt_solve(prob["b"], 0.3, 0.9, 0.8)
+    k.set_cost(prob["b"])
+    k.kkt_solve_async(0.3, 0.9, 0.8)
+    assert ok_o == 1 and k.sync()
+    assert rel(k.get_y(), yo) <= 1e-10
