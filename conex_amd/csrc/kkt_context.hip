@@ -27,7 +27,6 @@
 #include "kernels_lmi_fused.hip.h"
 #include "kernels_lmi_sparse.hip.h"
 #include "kernels_lmi_rows.hip.h"
-#include "kernels_kkt_top.hip.h"
 #include "kernels_lmi_large.hip.h"
 #include "symbolic.h"
 
@@ -135,12 +134,6 @@ struct cxk_context {
     DevBuf<int> wg_lev;  // [groups * (hi - lo + 1)] positions into rec_r
   };
   std::vector<std::unique_ptr<SweepRange>> ranges;
-  // the top levels as one dense factorization (kernels_kkt_top.hip.h), when they hold <= 64 columns
-  struct TopDense {
-    bool on = false;
-    TopDenseArgs args;
-    DevBuf<int> off, pl_ptr, pl_dst, pl_src, plb_ptr, plb_src;
-  } top_dense;
   DevBuf<SnRec> rec_r;   // records in (range, workgroup, level) order
   // device state
   DevBuf<double> G, AWc, AQcc, sc, slab, y, b, AW, AQc, sys_sc, info2, info4, red_out, scal_out;
@@ -717,7 +710,7 @@ int BuildPlans(cxk_context* ctx) {
   CXK_TRY(ctx->pub_dst.upload(pub_dst));
   CXK_TRY(ctx->pubb_dst.upload(pubb_dst));
   CXK_TRY(ctx->upd.alloc((size_t)slots + 1));
-  CXK_TRY(ctx->updb.alloc((size_t)slotsb + 2));  // + dump slot + a slot that stays 0.0
+  CXK_TRY(ctx->updb.alloc((size_t)slotsb + 1));
 
   // ---- exchange layout: [T slab entries | AW_T | AQc_T | fwd_T | <w,c> <c,Qc> fail]
   if (sharded) {
@@ -849,104 +842,6 @@ int BuildPlans(cxk_context* ctx) {
     if (sharded) top = std::max(top, ctx->cut_level);
     if (ctx->use_ldlt) top = nlev;  // LDLT sweeps run level by level, one workgroup per supernode
     ctx->top_level = top;
-  }
-  // ---- the top as one dense T x T factorization (single GPU, Cholesky): tables for
-  // tree_top_dense.  Rows = the variables of the top supernodes in elimination order.
-  ctx->top_dense.on = false;
-  if (!sharded && !ctx->use_ldlt && ctx->top_level < nlev && !getenv("CXK_NO_TOP_DENSE")) {
-    std::vector<int> tsn;
-    int T = 0;
-    bool ok = true;
-    for (int pos = ctx->level_ptr[ctx->top_level]; pos < ctx->level_ptr[nlev]; pos++) tsn.push_back(ctx->level_sn[pos]);
-    std::sort(tsn.begin(), tsn.end());
-    for (int e : tsn) T += ns[e];
-    for (int l = ctx->top_level; l < nlev; l++)
-      if (ctx->level_nh[l] != ctx->level_ptr[l + 1] - ctx->level_ptr[l]) ok = false;  // a panel beyond LDS
-    if (ok && !tsn.empty() && (int)tsn.size() <= kTopMaxSn && T <= kTopMaxCols && T > 0) {
-      TopDenseArgs& a = ctx->top_dense.args;
-      a.nt = (int)tsn.size();
-      a.T = T;
-      std::vector<int> is_top(K, -1), vrow(N, -1);
-      int row = 0, base = 0;
-      for (int k = 0; k < a.nt; k++) {
-        const int e = tsn[k];
-        is_top[e] = k;
-        a.ns[k] = ns[e];
-        a.nsep[k] = nsep[e];
-        a.start[k] = start[e];
-        a.row0[k] = row;
-        a.base[k] = base;
-        a.diag_off[k] = L.diag_off[e];
-        a.offd_off[k] = L.offd_off[e];
-        for (int i2 = 0; i2 < ns[e]; i2++) vrow[start[e] + i2] = row + i2;
-        row += ns[e];
-        base += ns[e] * ns[e] + ns[e] * nsep[e];
-      }
-      for (int k = 0; k < a.nt && ok; k++)  // separators of the top stay inside the top
-        for (int v : L.separators[tsn[k]])
-          if (vrow[v] < 0) ok = false;
-      if (ok && base <= kTopMaxCols * kTopMaxCols) {
-        std::vector<int> off((size_t)T * T, -1);
-        for (int k = 0; k < a.nt; k++) {
-          const int e = tsn[k], n = ns[e];
-          for (int jl = 0; jl < n; jl++) {
-            const int j = a.row0[k] + jl;
-            for (int rl = jl; rl < n; rl++) off[(size_t)(a.row0[k] + rl) * T + j] = a.base[k] + rl + jl * n;
-            const IntList& sp = L.separators[e];
-            for (int c = 0; c < (int)sp.size(); c++) off[(size_t)vrow[sp[c]] * T + j] = a.base[k] + n * n + jl + c * n;
-          }
-        }
-        // Updates from below the top arrive through the supernodes' consumer-ordered slots; slots
-        // fed from inside the top are never written in this mode (they hold 0.0).  Forward-solve
-        // values use explicit fixed-width lists (the forward-only sweeps do write the inner slots).
-        std::vector<int64_t> updb_off64(updb_off.begin(), updb_off.end());
-        auto producer = [&](const std::vector<int64_t>& offs, int64_t q) {
-          return (int)(std::upper_bound(offs.begin(), offs.end(), q) - offs.begin()) - 1;
-        };
-        int u_lds = 0, t_lds = 0;
-        std::vector<int> rhs_src((size_t)T * kTopRhsSrc, slotsb + 1);  // slotsb + 1: never written, 0.0
-        for (int k = 0; k < a.nt && ok; k++) {
-          const int e = tsn[k];
-          a.ubase[k] = (int)h_ubase[e];
-          a.m[k] = h_m[e];
-          a.tg_beg[k] = h_tg_ptr[e];
-          a.ntg[k] = h_tg_ptr[e + 1] - h_tg_ptr[e];
-          a.ubase_lds[k] = u_lds;
-          a.tg_lds[k] = t_lds;
-          u_lds += a.ntg[k] * a.m[k];
-          t_lds += a.ntg[k];
-          for (int i2 = 0; i2 < ns[e]; i2++) {
-            int cnt2 = 0;
-            for (int q : fs[start[e] + i2])
-              if (is_top[producer(updb_off64, q)] < 0) {
-                if (cnt2 == kTopRhsSrc) {
-                  ok = false;
-                  break;
-                }
-                rhs_src[(size_t)(a.row0[k] + i2) * kTopRhsSrc + cnt2++] = pubb_dst[q];
-              }
-          }
-        }
-        if (!ok || u_lds > kTopMaxImage || t_lds > kTopMaxImage) {
-          ok = false;
-        } else {
-          CXK_TRY(ctx->top_dense.off.upload(off));
-          CXK_TRY(ctx->top_dense.pl_src.upload(rhs_src));
-          a.top_off = ctx->top_dense.off.p;
-          a.rhs_src = ctx->top_dense.pl_src.p;
-        }
-        if (ok) {
-          for (const void* kf : {reinterpret_cast<const void*>(&tree_top_dense<32>),
-                                 reinterpret_cast<const void*>(&tree_top_dense<40>),
-                                 reinterpret_cast<const void*>(&tree_top_dense<48>),
-                                 reinterpret_cast<const void*>(&tree_top_dense<56>),
-                                 reinterpret_cast<const void*>(&tree_top_dense<64>)})
-            CXK_TRY(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTopDenseLds));
-        }
-        if (ok)
-        ctx->top_dense.on = true;
-      }
-    }
   }
   // ---- level ranges below the top: merge consecutive levels into one launch when every
   // connected piece of the forest restricted to them fits one workgroup (<= 8 supernodes per
@@ -1448,29 +1343,8 @@ int LaunchTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
   // way down, where a level step is a short back-substitution (measured: -30 % on C4).
   for (int l = 0; l < top; l++)
     if (LaunchSweep(ctx, l, l + 1, mode, false, with_rhs)) return CXK_FAILURE;
-  if (top < nlev) {
-    if (mode == 0 && ctx->top_dense.on) {
-      double* rhs = with_rhs ? ctx->y.p : nullptr;
-      const int wb = with_rhs && backward;
-      const TopDenseArgs& ta = ctx->top_dense.args;
-#define CXK_TOP_DENSE(TM) \
-  tree_top_dense<TM><<<1, 256, kTopDenseLds, ctx->stream>>>(ctx->plan, ta, ctx->slab.p, rhs, ctx->d_fail.p, with_rhs, wb)
-      if (ta.T <= 32)
-        CXK_TOP_DENSE(32);
-      else if (ta.T <= 40)
-        CXK_TOP_DENSE(40);
-      else if (ta.T <= 48)
-        CXK_TOP_DENSE(48);
-      else if (ta.T <= 56)
-        CXK_TOP_DENSE(56);
-      else
-        CXK_TOP_DENSE(64);
-#undef CXK_TOP_DENSE
-      CXK_TRY(hipGetLastError());
-    } else if (LaunchSweep(ctx, top, nlev, mode, backward, with_rhs)) {
-      return CXK_FAILURE;
-    }
-  }
+  if (top < nlev)
+    if (LaunchSweep(ctx, top, nlev, mode, backward, with_rhs)) return CXK_FAILURE;
   if (backward)
     for (auto it = order.rbegin(); it != order.rend(); ++it)
       if (it->second ? LaunchRange(ctx, *it->second, 2, true) : LaunchSweep(ctx, it->first, it->first + 1, 2, false, true))
