@@ -169,6 +169,29 @@ def test_huge_supernodes_take_the_blocked_hbm_path():
     check_newton_step(o, k, prob["b"], check_update=False)
 
 
+@pytest.mark.parametrize("num_vars,rows", [(141, 200), (193, 260), (257, 300), (321, 400)])
+def test_big_supernode_odd_sizes(num_vars, rows):
+    """One dense supernode whose size is not a multiple of the 32-column panel: the last panel is
+    ragged, the work items of big_panel do not fill their wavefronts, the streamed solves end on a
+    short block."""
+    prob = syn.lp_problem(rows=rows, num_vars=num_vars, seed=num_vars)
+    o, k = make_pair(prob, "lp")
+    check_newton_step(o, k, prob["b"], inv_sqrt_mu=0.4)
+
+
+@pytest.mark.parametrize("m,overlap", [(170, 21), (230, 45)])
+def test_big_supernodes_with_separators(m, overlap):
+    """Big leaves (m - overlap columns, `overlap` separator columns: the off block rides through
+    big_panel, U = off^T off goes to the parent) under a big root."""
+    n = 24 if m <= 200 else 28
+    prob = syn.lmi_problem(K=3, n=n, m=m, branching=2, overlap=overlap, seed=m)
+    W = syn.scaling_points(3, n, seed=5)
+    o, k = make_pair(prob, "lmi", W)
+    sizes = o.supernode_sizes()
+    assert max(sizes) == m and min(sizes) == m - overlap
+    check_newton_step(o, k, prob["b"], check_update=False)
+
+
 def test_lmi_identity_start_and_iterations():
     """Three IPM iterations from W = I through both paths stay in lock-step."""
     prob = syn.lmi_problem(K=20, n=8, m=8, branching=3, overlap=3, seed=5)
