@@ -369,23 +369,42 @@ __device__ __forceinline__ double EvenRowsToOddRows(double v) {
 
 // Elimination steps J .. NSMAX-1 of FactorSupernodeRows (compile-time recursion: every register
 // index, lane select and DPP control is an immediate).
+// Step J receives sqrt(d_J) and 1/sqrt(d_J) from step J-1, which starts that dependent chain
+// (readlane, v_rsq_f64, two Goldschmidt steps: ~130 cycles on a lone wavefront) as soon as column J
+// has taken its own update, so that the chain overlaps the remaining column updates of step J-1
+// instead of following them.  Same operations on the same values: results are unchanged.
 template <int NSMAX, int SMAX, int J>
 struct ElimSteps {
   static constexpr int LEN = NSMAX + SMAX + 1, RB = NSMAX + SMAX;
   static __device__ __forceinline__ void run(double (&a)[LEN], int lane, bool& bad) {
-    if constexpr (J < NSMAX) {
-      const double d = ReadLane(a[J], J);
+    if constexpr (J == 0 && NSMAX > 0) {
+      const double d = ReadLane(a[0], 0);
       bad |= !(d > 0.0);
       double root, inv;
       SqrtAndInverse(d, root, inv);
+      step(a, lane, bad, root, inv);
+    }
+  }
+  static __device__ __forceinline__ void step(double (&a)[LEN], int lane, bool& bad, double root, double inv) {
+    if constexpr (J < NSMAX) {
       a[J] = (lane == J) ? root : a[J] * inv;
+      double root1 = 1.0, inv1 = 1.0;
+      auto next_pivot = [&]() {  // column J+1 is final for step J+1 once it has taken column J's term
+        if constexpr (J + 1 < NSMAX) {
+          const double d1 = ReadLane(a[J + 1], J + 1);
+          bad |= !(d1 > 0.0);
+          SqrtAndInverse(d1, root1, inv1);
+        }
+      };
       if constexpr (NSMAX + SMAX <= 16) {
         // the whole panel (supernode rows + separator rows) sits in ONE 16-lane DPP row:
         // row_newbcast:c delivers L[c][J] (c < NSMAX) and L[sep c - NSMAX][J] directly
         double naj = -a[J];
         double dummy = 0.0;
         DppOperandFence(dummy, naj, a[J]);
-        DppColumns<LEN, J + 1, NSMAX + SMAX, 0>::run(a, a[J], naj);
+        DppColumns<LEN, J + 1, (J + 2 < NSMAX + SMAX ? J + 2 : NSMAX + SMAX), 0>::run(a, a[J], naj);
+        next_pivot();
+        DppColumns<LEN, J + 2, NSMAX + SMAX, 0>::run(a, a[J], naj);
       } else if constexpr (NSMAX + SMAX <= 32 && NSMAX != 16) {
         // the panel (supernode rows, then separator rows at lanes NSMAX..) fills DPP rows 0 and 1.
         // Row 0 mirrored into row 1 serves the columns whose owner lane is < 16, row 1 mirrored
@@ -395,8 +414,15 @@ struct ElimSteps {
         double naj = -a[J];
         DppOperandFence(x0, x1, naj);
         constexpr int kEnd = NSMAX + SMAX;
-        constexpr int kLo0 = (J + 1 < 16) ? J + 1 : 16, kLo1 = (kEnd < 16) ? kEnd : 16;
-        constexpr int kHi0 = (J + 1 > 16) ? J + 1 : 16;
+        // column J + 1 first, then the chain of the next pivot, then the rest
+        constexpr int n1 = (J + 2 < kEnd) ? J + 2 : kEnd;
+        if constexpr (J + 1 < 16)
+          DppColumns<LEN, J + 1, (n1 < 16 ? n1 : 16), 0>::run(a, x0, naj);
+        else
+          DppColumns<LEN, J + 1, n1, 16>::run(a, x1, naj);
+        next_pivot();
+        constexpr int kLo0 = (J + 2 < 16) ? J + 2 : 16, kLo1 = (kEnd < 16) ? kEnd : 16;
+        constexpr int kHi0 = (J + 2 > 16) ? J + 2 : 16;
         DppColumns<LEN, kLo0, kLo1, 0>::run(a, x0, naj);
         DppColumns<LEN, kHi0, kEnd, 16>::run(a, x1, naj);
       } else if constexpr (NSMAX == 16 && SMAX <= 16) {
@@ -406,18 +432,22 @@ struct ElimSteps {
         double x = EvenRowsToOddRows(a[J]);
         double naj = -a[J];
         DppOperandFence(x, naj, a[J]);
-        DppColumns<LEN, J + 1, NSMAX, 0>::run(a, x, naj);
+        DppColumns<LEN, J + 1, (J + 2 < NSMAX ? J + 2 : NSMAX), 0>::run(a, x, naj);
+        next_pivot();
+        DppColumns<LEN, J + 2, NSMAX, 0>::run(a, x, naj);
         DppColumns<LEN, NSMAX, NSMAX + SMAX, NSMAX>::run(a, a[J], naj);
       } else {
+        if constexpr (J + 1 < NSMAX + SMAX) a[J + 1] = fma(-ReadLane(a[J], J + 1), a[J], a[J + 1]);
+        next_pivot();
 #pragma unroll
-        for (int c = J + 1; c < NSMAX + SMAX; c++) a[c] = fma(-ReadLane(a[J], c), a[J], a[c]);
+        for (int c = J + 2; c < NSMAX + SMAX; c++) a[c] = fma(-ReadLane(a[J], c), a[J], a[c]);
       }
       const double yj = ReadLane(a[RB], J) * inv;
       if (lane > J)
         a[RB] = fma(-yj, a[J], a[RB]);
       else if (lane == J)
         a[RB] = yj;
-      ElimSteps<NSMAX, SMAX, J + 1>::run(a, lane, bad);
+      ElimSteps<NSMAX, SMAX, J + 1>::step(a, lane, bad, root1, inv1);
     }
   }
 };
