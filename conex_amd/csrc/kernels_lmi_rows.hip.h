@@ -147,6 +147,52 @@ __global__ void __launch_bounds__(256) lmi_take_step_rows(LmiGroup g, StepArgs s
   }
 }
 
+// The same for Hermitian cones (through their real representation of order N): the reference's
+// Taylor-squaring exponential  E = ((I + X/4 + X^2/32)^2)^2  (DoExponentialMap,
+// exponential_map.cc:15-43), then W <- sym(E W).  Five row-times-matrix products, no linear solve;
+// every product is the same fma chain as in lmi_take_step_generic's Hermitian branch.
+template <int N>
+__global__ void __launch_bounds__(256) lmi_take_step_rows_taylor(LmiGroup g, StepArgs sa) {
+  static_assert(N > 16 && N <= 32, "a column spans DPP rows 0 and 1");
+  __shared__ double sT[4][N * N];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int mem = blockIdx.x * 4 + wave;
+  if (mem >= g.count) return;
+  constexpr int NN = N * N;
+  double* Wg = g.W + (size_t)mem * NN;
+  const double* T1 = g.T1 + (size_t)mem * NN;
+  const bool row = lane < N;
+  const int r = row ? lane : 0;
+  double x[N], v[N], t[N], y[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double e = row ? T1[r + j * N] : 0.0;
+    if (row && j == r) e += sa.e_weight;
+    if (sa.step_size != 1.0) e *= sa.step_size;
+    x[j] = e;
+    v[j] = e * 1.0 / 4.0;
+  }
+  RowTimesMatrix<N, 0>::run(x, v, t);  // X (X/4)
+#pragma unroll
+  for (int c = 0; c < N; c++) y[c] = (v[c] + ((row && c == r) ? 1.0 : 0.0)) + t[c] * 0.125;
+  RowTimesMatrix<N, 0>::run(y, y, t);  // Y^2
+  RowTimesMatrix<N, 0>::run(t, t, y);  // Y^4 = E
+#pragma unroll
+  for (int c = 0; c < N; c++) v[c] = row ? Wg[r + c * N] : 0.0;  // lane j: row j of W
+  RowTimesMatrix<N, 0>::run(y, v, t);  // E W
+  double* T = sT[wave];
+  if (row) {
+#pragma unroll
+    for (int c = 0; c < N; c++) T[r + c * N] = t[c];
+  }
+  WaveSync();
+  if (row) {
+#pragma unroll
+    for (int c = 0; c < N; c++) Wg[r + c * N] = (T[r + c * N] + T[c + r * N]) * 0.5;
+  }
+}
+
 inline bool LmiTakeStepRowsSupports(int n, int herm_d) { return n == 20 && herm_d == 0; }
+inline bool LmiTakeStepTaylorRowsSupports(int n, int herm_d) { return n == 24 && herm_d > 0; }
 
 }  // namespace cxk
