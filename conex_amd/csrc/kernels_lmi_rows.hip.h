@@ -1,6 +1,6 @@
 // TakeStep for small dense LMIs, one WAVEFRONT per constraint, one matrix row per lane, everything
-// in registers (compiled for the benchmark order N = 20; 16 < N <= 32: a column spans two
-// 16-lane DPP rows).  Reference: TakeStep -> GeodesicUpdate with the Pade [3/3] exponential
+// in registers.  Compiled for register capacities N = 20 and 32 (the order n <= N is a run-time
+// value: rows and columns beyond n are padding); a column spans up to two 16-lane DPP rows.  Reference: TakeStep -> GeodesicUpdate with the Pade [3/3] exponential
 // (psd_constraint.cc:45-84, exponential_map_pade.cc:10-32):
 //     X = (WS + e I) * step;  A2 = X X;  U = X (A2 + 60 I);  V = 12 A2 + 120 I
 //     E = (V - U)^-1 (V + U);  W <- sym(E W)
@@ -42,7 +42,7 @@ struct RowTimesMatrix {
       const RowPair mp = Swap16(mat[C]);  // a: DPP rows 0/2 everywhere, b: rows 1/3
       double m0 = mp.a, m1 = mp.b, acc = 0.0;
       DppOperandFence(m0, m1, acc);
-      RowDotSteps<N, 0>::run(acc, m0, m1, row);
+      RowDotSteps<N, 0>::run(acc, m0, m1, row);  // rows / columns beyond the order hold zeros
       out[C] = acc;
       RowTimesMatrix<N, C + 1>::run(row, mat, out);
     }
@@ -68,9 +68,11 @@ struct GjColumns {  // aug[c] -= f * pivot_row[c], c = C .. 2N-1
 // Gauss-Jordan steps K .. N-1 with partial pivoting among the rows not used as pivots yet.
 template <int N, int K>
 struct GjSteps {
-  static __device__ __forceinline__ void run(double (&aug)[2 * N], int lane, bool& done, double& mypiv, int& myk) {
+  static __device__ __forceinline__ void run(double (&aug)[2 * N], int lane, int n, bool& done, double& mypiv,
+                                             int& myk) {
     if constexpr (K < N) {
-      const bool cand = lane < N && !done;
+      if (K >= n) return;  // wave-uniform: padding columns
+      const bool cand = lane < n && !done;
       const double mag = cand ? fabs(aug[K]) : -1.0;
       const double best = WaveMax(mag);
       unsigned long long bal = __ballot(cand && mag == best);
@@ -85,27 +87,27 @@ struct GjSteps {
         myk = K;
       }
       GjColumns<N, K, K + 1>::run(aug, f, p);
-      GjSteps<N, K + 1>::run(aug, lane, done, mypiv, myk);
+      GjSteps<N, K + 1>::run(aug, lane, n, done, mypiv, myk);
     }
   }
 };
 
 template <int N>
 __global__ void __launch_bounds__(256) lmi_take_step_rows(LmiGroup g, StepArgs sa) {
-  static_assert(N > 16 && N <= 32, "a column spans DPP rows 0 and 1");
+  static_assert(N <= 32, "a column spans DPP rows 0 and 1");
   __shared__ double sT[4][N * N];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mem = blockIdx.x * 4 + wave;
   if (mem >= g.count) return;  // wave-uniform; no workgroup barrier below
-  constexpr int NN = N * N;
-  double* Wg = g.W + (size_t)mem * NN;
-  const double* T1 = g.T1 + (size_t)mem * NN;
-  const bool row = lane < N;
+  const int n = g.n, nn = n * n;
+  double* Wg = g.W + (size_t)mem * nn;
+  const double* T1 = g.T1 + (size_t)mem * nn;
+  const bool row = lane < n;
   const int r = row ? lane : 0;
   double x[N];
 #pragma unroll
   for (int j = 0; j < N; j++) {
-    double v = row ? T1[r + j * N] : 0.0;
+    double v = (row && j < n) ? T1[r + j * n] : 0.0;
     if (row && j == r) v += sa.e_weight;
     if (sa.step_size != 1.0) v *= sa.step_size;
     x[j] = v;
@@ -127,23 +129,25 @@ __global__ void __launch_bounds__(256) lmi_take_step_rows(LmiGroup g, StepArgs s
   bool done = false;
   double mypiv = 1.0;
   int myk = 0;
-  GjSteps<N, 0>::run(aug, lane, done, mypiv, myk);
+  GjSteps<N, 0>::run(aug, lane, n, done, mypiv, myk);
   // this lane now holds row myk of E = denominator^-1 numerator
   double e[N], w[N], ew[N];
 #pragma unroll
   for (int c = 0; c < N; c++) e[c] = aug[N + c] / mypiv;
 #pragma unroll
-  for (int c = 0; c < N; c++) w[c] = row ? Wg[r + c * N] : 0.0;  // lane j: row j of W
+  for (int c = 0; c < N; c++) w[c] = (row && c < n) ? Wg[r + c * n] : 0.0;  // lane j: row j of W
   RowTimesMatrix<N, 0>::run(e, w, ew);  // row myk of E W
   double* T = sT[wave];
   if (row) {
 #pragma unroll
-    for (int c = 0; c < N; c++) T[myk + c * N] = ew[c];
+    for (int c = 0; c < N; c++)
+      if (c < n) T[myk + c * n] = ew[c];
   }
   WaveSync();
   if (row) {
 #pragma unroll
-    for (int c = 0; c < N; c++) Wg[r + c * N] = (T[r + c * N] + T[c + r * N]) * 0.5;
+    for (int c = 0; c < N; c++)
+      if (c < n) Wg[r + c * n] = (T[r + c * n] + T[c + r * n]) * 0.5;
   }
 }
 
@@ -153,20 +157,20 @@ __global__ void __launch_bounds__(256) lmi_take_step_rows(LmiGroup g, StepArgs s
 // every product is the same fma chain as in lmi_take_step_generic's Hermitian branch.
 template <int N>
 __global__ void __launch_bounds__(256) lmi_take_step_rows_taylor(LmiGroup g, StepArgs sa) {
-  static_assert(N > 16 && N <= 32, "a column spans DPP rows 0 and 1");
+  static_assert(N <= 32, "a column spans DPP rows 0 and 1");
   __shared__ double sT[4][N * N];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mem = blockIdx.x * 4 + wave;
   if (mem >= g.count) return;
-  constexpr int NN = N * N;
-  double* Wg = g.W + (size_t)mem * NN;
-  const double* T1 = g.T1 + (size_t)mem * NN;
-  const bool row = lane < N;
+  const int n = g.n, nn = n * n;
+  double* Wg = g.W + (size_t)mem * nn;
+  const double* T1 = g.T1 + (size_t)mem * nn;
+  const bool row = lane < n;
   const int r = row ? lane : 0;
   double x[N], v[N], t[N], y[N];
 #pragma unroll
   for (int j = 0; j < N; j++) {
-    double e = row ? T1[r + j * N] : 0.0;
+    double e = (row && j < n) ? T1[r + j * n] : 0.0;
     if (row && j == r) e += sa.e_weight;
     if (sa.step_size != 1.0) e *= sa.step_size;
     x[j] = e;
@@ -178,21 +182,22 @@ __global__ void __launch_bounds__(256) lmi_take_step_rows_taylor(LmiGroup g, Ste
   RowTimesMatrix<N, 0>::run(y, y, t);  // Y^2
   RowTimesMatrix<N, 0>::run(t, t, y);  // Y^4 = E
 #pragma unroll
-  for (int c = 0; c < N; c++) v[c] = row ? Wg[r + c * N] : 0.0;  // lane j: row j of W
+  for (int c = 0; c < N; c++) v[c] = (row && c < n) ? Wg[r + c * n] : 0.0;  // lane j: row j of W
   RowTimesMatrix<N, 0>::run(y, v, t);  // E W
   double* T = sT[wave];
   if (row) {
 #pragma unroll
-    for (int c = 0; c < N; c++) T[r + c * N] = t[c];
+    for (int c = 0; c < N; c++)
+      if (c < n) T[r + c * n] = t[c];
   }
   WaveSync();
   if (row) {
 #pragma unroll
-    for (int c = 0; c < N; c++) Wg[r + c * N] = (T[r + c * N] + T[c + r * N]) * 0.5;
+    for (int c = 0; c < N; c++)
+      if (c < n) Wg[r + c * n] = (T[r + c * n] + T[c + r * n]) * 0.5;
   }
 }
 
-inline bool LmiTakeStepRowsSupports(int n, int herm_d) { return n == 20 && herm_d == 0; }
-inline bool LmiTakeStepTaylorRowsSupports(int n, int herm_d) { return n == 24 && herm_d > 0; }
+inline bool LmiTakeStepRowsSupports(int n) { return n <= 32; }
 
 }  // namespace cxk

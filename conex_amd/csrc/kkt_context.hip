@@ -2128,10 +2128,20 @@ int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_siz
       CXK_TRY(LmiLargeTakeStep(MakeLmi(g), sa, MakeLargeWs(g), ctx->stream));
     else if (g.type == CXK_LMI) {
       static const bool lds_kernel = getenv("CXK_TAKE_STEP_LDS") != nullptr;  // A/B switch (tests, timing)
-      if (LmiTakeStepRowsSupports(g.n, g.herm_d) && !lds_kernel)
-        lmi_take_step_rows<20><<<(cnt + 3) / 4, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
-      else if (LmiTakeStepTaylorRowsSupports(g.n, g.herm_d) && !lds_kernel)
-        lmi_take_step_rows_taylor<24><<<(cnt + 3) / 4, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+      if (LmiTakeStepRowsSupports(g.n) && !lds_kernel) {
+        const int blocks = (cnt + 3) / 4;
+        if (g.herm_d == 0) {
+          if (g.n <= 20)
+            lmi_take_step_rows<20><<<blocks, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+          else
+            lmi_take_step_rows<32><<<blocks, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+        } else {
+          if (g.n <= 24)
+            lmi_take_step_rows_taylor<24><<<blocks, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+          else
+            lmi_take_step_rows_taylor<32><<<blocks, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+        }
+      }
       else if (g.n == 20)
         lmi_take_step_generic<20><<<cnt, 256, LmiTakeLds(g.n), ctx->stream>>>(MakeLmi(g), sa);
       else
