@@ -108,9 +108,12 @@ def test_world_size_2_gloo_exchange(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,K", [(2, 40), (3, 100), (8, 300)])
-def test_sharded_direction_equals_single_gpu(world, K):
+@pytest.mark.parametrize("world,K,sparse", [(2, 40, False), (3, 100, False), (8, 300, False), (4, 120, True)])
+def test_sharded_direction_equals_single_gpu(monkeypatch, world, K, sparse):
     prob = syn.lmi_problem(K=K, n=6, m=20, branching=8, overlap=5, seed=11)
+    if sparse:  # the shards assemble their constraints through the sparse-LMI kernels
+        prob = syn.sparsify(prob, 0.15)
+        monkeypatch.setenv("CXK_SPARSE_LMI", "1")
     W = syn.scaling_points(K, 6, seed=4)
     ref = syn.build(KktContext, prob, "lmi", device=0)
     for i in range(K):
