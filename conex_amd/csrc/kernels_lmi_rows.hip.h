@@ -198,6 +198,195 @@ __global__ void __launch_bounds__(256) lmi_take_step_rows_taylor(LmiGroup g, Ste
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// PrepareStep / GetWeightedSlackEigenvalues for dense LMIs of order N, one wavefront per
+// constraint (lmi_prepare_generic gives a constraint a 256-thread workgroup of which three
+// wavefronts idle through the Lanczos recurrence).  Every sum below is the sum the workgroup
+// kernel forms, in the same order -- the slack (i ascending), WS = W S (k ascending fma chains),
+// the Lanczos recurrence of LanczosWave0 with the matrix rows in registers and the vectors one
+// value per lane (matrix-vector products as row_newbcast DPP fma chains), the traces with the
+// workgroup kernel's partition into 256 partial sums -- so the results are bit-identical.
+template <int NR, int J>
+struct LanczosDot {  // acc += sum_{k >= J} row[k] * vec_k
+  static __device__ __forceinline__ void run(double& acc, double m0, double m1, const double (&row)[NR]) {
+    if constexpr (J < NR) {
+      if constexpr (J < 16)
+        FmaBcast<J>(acc, m0, row[J]);
+      else
+        FmaBcast<J - 16>(acc, m1, row[J]);
+      LanczosDot<NR, J + 1>::run(acc, m0, m1, row);
+    }
+  }
+};
+
+template <int NR>
+__device__ __forceinline__ double LanczosMatVec(const double (&row)[NR], double v) {
+  const RowPair mp = Swap16(v);  // a: DPP rows 0/2 everywhere (elements 0..15), b: rows 1/3 (16..31)
+  double m0 = mp.a, m1 = mp.b, acc = 0.0;
+  DppOperandFence(m0, m1, acc);
+  LanczosDot<NR, 0>::run(acc, m0, m1, row);
+  return acc;
+}
+
+// AsymmetricLanczos (approximate_eigenvalues.cc:178-239) as in LanczosWave0, non-Hermitian rules.
+template <int N>
+__device__ __forceinline__ void LanczosRows(const double (&ws)[N], const double (&wst)[N], const double (&w)[N],
+                                            double rvec, int lane, int num_iter, double* ab, double* out) {
+  const bool act = lane < N;
+  double* alpha = ab;
+  double* beta = ab + num_iter + 1;
+  // V.col(1) = r ; V.col(0) = W r
+  double v1 = act ? rvec : 0.0;
+  double v0 = LanczosMatVec<N>(w, v1);
+  const double nrm = sqrt(WaveSum(act ? fma(v0, v1, 0.0) : 0.0));
+  v0 = v0 / nrm;
+  v1 = v1 / nrm;
+  if (!act) v0 = v1 = 0.0;
+  double p0 = v0, p1 = v1, u0 = 0.0, u1 = 0.0;
+  int cnt = 0;
+  double beta_prev = 0;
+  for (int j = 0; j < num_iter; j++) {
+    if (j > 0) {
+      const double b2 = WaveSum(act ? fma(u0, u1, 0.0) : 0.0);
+      if (b2 < 1e-6) break;
+      beta_prev = sqrt(b2);
+      if (lane == 0) beta[j - 1] = beta_prev;
+      p0 = v0;
+      p1 = v1;
+      v0 = u0 / beta_prev;
+      v1 = u1 / beta_prev;
+      if (!act) v0 = v1 = 0.0;
+      cnt++;
+    }
+    u0 = LanczosMatVec<N>(ws, v0);   // WS V.col(0)
+    u1 = LanczosMatVec<N>(wst, v1);  // WS^T V.col(1)
+    const double a = WaveSum(act ? fma(v0, u1, 0.0) : 0.0);
+    if (lane == 0) alpha[j] = a;
+    u0 = u0 - a * v0;
+    u1 = u1 - a * v1;
+    if (j > 0) {
+      u0 -= beta_prev * p0;
+      u1 -= beta_prev * p1;
+    }
+  }
+  WaveSync();  // alpha / beta were written by lane 0
+  TridiagMinMaxWave(cnt + 1, alpha, beta, &out[0], &out[1]);
+}
+
+template <int MODE, int N>
+__global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa) {
+  static_assert(N > 16 && N <= 32 && (N * N) % 2 == 0, "two DPP rows; 16-byte chunks");
+  constexpr int NN = N * N, HALF = NN / 2, CH = (HALF + 63) / 64, ITERS = N / 2;
+  __shared__ double sM[4][NN];
+  __shared__ double sAB[4][2 * (ITERS + 2)];
+  __shared__ double sOut[4][2];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int mem = blockIdx.x * 4 + wave;
+  if (mem >= g.count) return;  // wave-uniform; no workgroup barrier below
+  const int id = g.ids[mem], m = g.m;
+  const double* Cm = g.C + (size_t)mem * NN;
+  const double* Wg = g.W + (size_t)mem * NN;
+  double* M = sM[wave];
+  // minus_s = sum_i y_i A_i - k C (dense_lmi_constraint.cc:8-27): lane l owns the 16-byte chunks l, l + 64, ..
+  const double yv = lane < m ? sa.y[sa.cl_perm[sa.cl_ptr[id] + lane]] : 0.0;
+  double2 acc[CH];
+#pragma unroll
+  for (int u = 0; u < CH; u++) acc[u] = make_double2(0.0, 0.0);
+  const double2* base = reinterpret_cast<const double2*>(g.A + (size_t)mem * m * NN);
+#pragma unroll 5
+  for (int i = 0; i < m; i++) {
+    const double yi = ReadLaneUniform(yv, i);
+#pragma unroll
+    for (int u = 0; u < CH; u++) {
+      const int e = lane + 64 * u;
+      if (e < HALF) {
+        const double2 v = base[(size_t)i * HALF + e];
+        acc[u].x += yi * v.x;
+        acc[u].y += yi * v.y;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < CH; u++) {
+    const int e = lane + 64 * u;
+    if (e < HALF) {
+      M[2 * e] = acc[u].x - sa.c_weight * Cm[2 * e];
+      M[2 * e + 1] = acc[u].y - sa.c_weight * Cm[2 * e + 1];
+    }
+  }
+  WaveSync();
+  const bool row = lane < N;
+  const int r = row ? lane : 0;
+  double s[N], w[N], ws[N], wst[N];
+#pragma unroll
+  for (int c = 0; c < N; c++) {
+    s[c] = row ? M[r + c * N] : 0.0;   // lane k: row k of minus_s
+    w[c] = row ? Wg[r + c * N] : 0.0;  // lane i: row i of W
+  }
+  RowTimesMatrix<N, 0>::run(w, s, ws);  // WS = W * minus_s, row per lane
+  WaveSync();
+  if (row) {
+    double* T1 = g.T1 + (size_t)mem * NN;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+      M[r + c * N] = ws[c];
+      if (MODE == 0) T1[r + c * N] = ws[c];
+    }
+  }
+  WaveSync();
+#pragma unroll
+  for (int c = 0; c < N; c++) wst[c] = row ? M[c + r * N] : 0.0;  // row of WS^T
+  // index of the first maximal diagonal entry of WS
+  double dval = 0.0;
+#pragma unroll
+  for (int c = 0; c < N; c++) dval = (lane == c) ? ws[c] : dval;
+  const double dmax = WaveMax(row ? dval : -1.7976931348623157e308);
+  const unsigned long long hit = __ballot(row && dval == dmax);
+  const int index = __builtin_amdgcn_readfirstlane(hit ? __ffsll((long long)hit) - 1 : 0);
+  // PrepareStep starts from WS.col(index), GetWeightedSlackEigenvalues from minus_s.col(index)
+  double rvec = 0.0;
+#pragma unroll
+  for (int c = 0; c < N; c++) rvec = (c == index) ? (MODE == 0 ? ws[c] : s[c]) : rvec;
+  LanczosRows<N>(ws, wst, w, rvec, lane, ITERS, sAB[wave], sOut[wave]);
+  // tr(WS WS) and tr(WS) with the workgroup kernel's partition: virtual thread t = 64 v + lane
+  // takes elements t and t + 256, the four wave sums are added in order
+  double t2 = 0.0, t1 = 0.0;
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    double p2 = 0.0, p1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int q = 64 * v + lane + 256 * k;
+      if (q < NN) {
+        const int a = q % N, b = q / N;
+        p2 = fma(M[q], M[b + a * N], p2);
+        if (a == b) p1 += M[q];
+      }
+    }
+    t2 += WaveSum(p2);
+    t1 += WaveSum(p1);
+  }
+  WaveSync();
+  if (lane == 0) {
+    double mn = sOut[wave][0], mx = sOut[wave][1];
+    ClampToSpectrumBound(N, t1, t2, &mn, &mx);
+    if (MODE == 0) {
+      const double l1 = fabs(sa.e_weight + mn), l2 = fabs(sa.e_weight + mx);
+      sa.info[2 * id] = t2 + 2 * t1 + N;
+      sa.info[2 * id + 1] = l1 < l2 ? l2 : l1;
+    } else {
+      sa.info[4 * id] = -mx;      // lambda_min
+      sa.info[4 * id + 1] = -mn;  // lambda_max
+      sa.info[4 * id + 2] = t2;
+      sa.info[4 * id + 3] = -t1;
+    }
+  }
+}
+
+inline bool LmiPrepareRowsSupports(int n, int m, int herm_d, bool sparse) {
+  return n == 20 && m <= 64 && herm_d == 0 && !sparse;
+}
+
 inline bool LmiTakeStepRowsSupports(int n) { return n <= 32; }
 
 }  // namespace cxk

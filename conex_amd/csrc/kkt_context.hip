@@ -2082,11 +2082,15 @@ int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_wei
     if (cnt == 0) continue;
     if (g.type == CXK_LMI && g.large)
       CXK_TRY(LmiLargePrepare(MakeLmi(g), sa, MakeLargeWs(g), 0, ctx->stream));
-    else if (g.type == CXK_LMI)
-      if (g.n == 20)
+    else if (g.type == CXK_LMI) {
+      static const bool lds_kernel = getenv("CXK_PREPARE_LDS") != nullptr;  // A/B switch (tests, timing)
+      if (!affine && !lds_kernel && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse))
+        lmi_prepare_rows<0, 20><<<(cnt + 3) / 4, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+      else if (g.n == 20)
         lmi_prepare_generic<0, 20><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
       else
         lmi_prepare_generic<0, 0><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
+    }
     else if (g.type == CXK_LINEAR)
       linear_prepare<0><<<cnt, 256, sizeof(double) * g.m, ctx->stream>>>(MakeVec(g), sa);
     else if (g.type == CXK_SOC)
@@ -2165,11 +2169,15 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
     if (cnt == 0) continue;
     if (g.type == CXK_LMI && g.large)
       CXK_TRY(LmiLargePrepare(MakeLmi(g), sa, MakeLargeWs(g), 1, ctx->stream));
-    else if (g.type == CXK_LMI)
-      if (g.n == 20)
+    else if (g.type == CXK_LMI) {
+      static const bool lds_kernel = getenv("CXK_PREPARE_LDS") != nullptr;
+      if (!lds_kernel && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse))
+        lmi_prepare_rows<1, 20><<<(cnt + 3) / 4, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+      else if (g.n == 20)
         lmi_prepare_generic<1, 20><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
       else
         lmi_prepare_generic<1, 0><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
+    }
     else if (g.type == CXK_LINEAR)
       linear_prepare<1><<<cnt, 256, sizeof(double) * g.m, ctx->stream>>>(MakeVec(g), sa);
     else if (g.type == CXK_SOC)
