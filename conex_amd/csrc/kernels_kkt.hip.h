@@ -85,9 +85,11 @@ __global__ void __launch_bounds__(256) assemble_gather(GatherArgs a) {
 }
 
 // y = k (b bs + AQc cs) - 2 AW   (cone_program.cc:409-411), all in permuted order
+// (reset: when not null, the factorization-failure flag cleared here instead of by a memset launch)
 __global__ void build_rhs(int N, double k, double bs, double cs, const double* __restrict__ b,
                           const double* __restrict__ AQc, const double* __restrict__ AW,
-                          double* __restrict__ y) {
+                          double* __restrict__ y, int* __restrict__ reset = nullptr) {
+  if (reset && blockIdx.x == 0 && threadIdx.x == 0) *reset = 0;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x)
     y[p] = k * (b[p] * bs + AQc[p] * cs) - 2 * AW[p];
 }
@@ -95,7 +97,8 @@ __global__ void build_rhs(int N, double k, double bs, double cs, const double* _
 // y = cb b + cq AQc + cw AW : every right-hand side of the IPM loop (cone_program.cc:181, 409-411, 504)
 __global__ void build_rhs_comb(int N, double cb, double cq, double cw, const double* __restrict__ b,
                                const double* __restrict__ AQc, const double* __restrict__ AW,
-                               double* __restrict__ y) {
+                               double* __restrict__ y, int* __restrict__ reset = nullptr) {
+  if (reset && blockIdx.x == 0 && threadIdx.x == 0) *reset = 0;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x)
     y[p] = cb * b[p] + cq * AQc[p] + cw * AW[p];
 }

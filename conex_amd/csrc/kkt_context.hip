@@ -1906,9 +1906,8 @@ int cxk_step_scalars_async(cxk_context* ctx) {
 int cxk_factor_solve_async(cxk_context* ctx, double cb, double cq, double cw) {
   if (CheckReady(ctx)) return CXK_FAILURE;
   const int N = ctx->md.N;
-  CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));
   build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, cb, cq, cw, ctx->b.p, ctx->AQc.p, ctx->AW.p,
-                                                           ctx->y.p);
+                                                           ctx->y.p, ctx->d_fail.p);
   CXK_TRY(hipGetLastError());
   if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;
   ctx->factor_seq = ++ctx->seq;
@@ -1919,8 +1918,8 @@ int cxk_factor_solve_async(cxk_context* ctx, double cb, double cq, double cw) {
 int cxk_factor_direction_async(cxk_context* ctx, double k, double bs, double cs) {
   if (CheckReady(ctx)) return CXK_FAILURE;
   const int N = ctx->md.N;
-  CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));
-  build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p, ctx->y.p);
+  build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p, ctx->y.p,
+                                                      ctx->d_fail.p);
   CXK_TRY(hipGetLastError());
   if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;
   ctx->factor_seq = ++ctx->seq;
