@@ -27,6 +27,7 @@
 #include "kernels_lmi_fused.hip.h"
 #include "kernels_lmi_sparse.hip.h"
 #include "kernels_lmi_rows.hip.h"
+#include "kernels_kkt_top.hip.h"
 #include "kernels_lmi_large.hip.h"
 #include "symbolic.h"
 
@@ -134,6 +135,13 @@ struct cxk_context {
     DevBuf<int> wg_lev;  // [groups * (hi - lo + 1)] positions into rec_r
   };
   std::vector<std::unique_ptr<SweepRange>> ranges;
+  // the top levels as one dense factorization (kernels_kkt_top.hip.h), when they hold <= 64 columns
+  struct TopDense {
+    bool on = false;
+    TopDenseArgs args;
+    DevBuf<int> off, pl_ptr, pl_dst, pl_src, plb_ptr, plb_src;
+  } top_dense;
+  int dense_level = 0;  // first level of the dense range (== nlev when off)
   DevBuf<SnRec> rec_r;   // records in (range, workgroup, level) order
   // device state
   DevBuf<double> G, AWc, AQcc, sc, slab, y, b, AW, AQc, sys_sc, info2, info4, red_out, scal_out;
@@ -710,7 +718,7 @@ int BuildPlans(cxk_context* ctx) {
   CXK_TRY(ctx->pub_dst.upload(pub_dst));
   CXK_TRY(ctx->pubb_dst.upload(pubb_dst));
   CXK_TRY(ctx->upd.alloc((size_t)slots + 1));
-  CXK_TRY(ctx->updb.alloc((size_t)slotsb + 1));
+  CXK_TRY(ctx->updb.alloc((size_t)slotsb + 2));  // + dump slot + a slot that stays 0.0
 
   // ---- exchange layout: [T slab entries | AW_T | AQc_T | fwd_T | <w,c> <c,Qc> fail]
   if (sharded) {
@@ -842,6 +850,125 @@ int BuildPlans(cxk_context* ctx) {
     if (sharded) top = std::max(top, ctx->cut_level);
     if (ctx->use_ldlt) top = nlev;  // LDLT sweeps run level by level, one workgroup per supernode
     ctx->top_level = top;
+  }
+  // ---- the top as one dense T x T factorization (single GPU, Cholesky): tables for
+  // tree_top_dense.  Rows = the variables of the top supernodes in elimination order.
+  // Used where the supernode-by-supernode kernels are weak: when the last levels hold a mid-size
+  // supernode (33..64 columns: otherwise a 256-thread workgroup with two barriers per column,
+  // 62 us for C2's 50-column root).  The dense range [dense_level, nlev) starts at such a level;
+  // for tops made of small supernodes (C4) the supernode-by-supernode top measured faster.
+  ctx->top_dense.on = false;
+  ctx->dense_level = nlev;
+  if (!sharded && !ctx->use_ldlt && !getenv("CXK_NO_TOP_DENSE")) {
+    int dt = -1;
+    {
+      int cols = 0, count = 0;
+      bool clean = true;
+      for (int l = nlev - 1; l >= 0 && clean; l--) {
+        if (ctx->level_nh[l] != ctx->level_ptr[l + 1] - ctx->level_ptr[l]) break;  // a panel beyond LDS
+        for (int pos = ctx->level_ptr[l]; pos < ctx->level_ptr[l + 1]; pos++) {
+          cols += ns[ctx->level_sn[pos]];
+          count++;
+        }
+        if (cols > kTopMaxCols || count > kTopMaxSn) break;
+        if (ctx->level_big[l]) dt = l;
+      }
+    }
+    std::vector<int> tsn;
+    int T = 0;
+    bool ok = dt >= 0;
+    if (ok) {
+      for (int pos = ctx->level_ptr[dt]; pos < ctx->level_ptr[nlev]; pos++) tsn.push_back(ctx->level_sn[pos]);
+      std::sort(tsn.begin(), tsn.end());
+      for (int e : tsn) T += ns[e];
+    }
+    if (ok && !tsn.empty() && (int)tsn.size() <= kTopMaxSn && T <= kTopMaxCols && T > 0) {
+      TopDenseArgs& a = ctx->top_dense.args;
+      a.nt = (int)tsn.size();
+      a.T = T;
+      std::vector<int> is_top(K, -1), vrow(N, -1);
+      int row = 0, base = 0;
+      for (int k = 0; k < a.nt; k++) {
+        const int e = tsn[k];
+        is_top[e] = k;
+        a.ns[k] = ns[e];
+        a.nsep[k] = nsep[e];
+        a.start[k] = start[e];
+        a.row0[k] = row;
+        a.base[k] = base;
+        a.diag_off[k] = L.diag_off[e];
+        a.offd_off[k] = L.offd_off[e];
+        for (int i2 = 0; i2 < ns[e]; i2++) vrow[start[e] + i2] = row + i2;
+        row += ns[e];
+        base += ns[e] * ns[e] + ns[e] * nsep[e];
+      }
+      for (int k = 0; k < a.nt && ok; k++)  // separators of the top stay inside the top
+        for (int v : L.separators[tsn[k]])
+          if (vrow[v] < 0) ok = false;
+      if (ok && base <= kTopMaxCols * kTopMaxCols) {
+        std::vector<int> off((size_t)T * T, -1);
+        for (int k = 0; k < a.nt; k++) {
+          const int e = tsn[k], n = ns[e];
+          for (int jl = 0; jl < n; jl++) {
+            const int j = a.row0[k] + jl;
+            for (int rl = jl; rl < n; rl++) off[(size_t)(a.row0[k] + rl) * T + j] = a.base[k] + rl + jl * n;
+            const IntList& sp = L.separators[e];
+            for (int c = 0; c < (int)sp.size(); c++) off[(size_t)vrow[sp[c]] * T + j] = a.base[k] + n * n + jl + c * n;
+          }
+        }
+        // Updates from below the top arrive through the supernodes' consumer-ordered slots; slots
+        // fed from inside the top are never written in this mode (they hold 0.0).  Forward-solve
+        // values use explicit fixed-width lists (the forward-only sweeps do write the inner slots).
+        std::vector<int64_t> updb_off64(updb_off.begin(), updb_off.end());
+        auto producer = [&](const std::vector<int64_t>& offs, int64_t q) {
+          return (int)(std::upper_bound(offs.begin(), offs.end(), q) - offs.begin()) - 1;
+        };
+        int u_lds = 0, t_lds = 0;
+        std::vector<int> rhs_src((size_t)T * kTopRhsSrc, slotsb + 1);  // slotsb + 1: never written, 0.0
+        for (int k = 0; k < a.nt && ok; k++) {
+          const int e = tsn[k];
+          a.ubase[k] = (int)h_ubase[e];
+          a.m[k] = h_m[e];
+          a.tg_beg[k] = h_tg_ptr[e];
+          a.ntg[k] = h_tg_ptr[e + 1] - h_tg_ptr[e];
+          a.ubase_lds[k] = u_lds;
+          a.tg_lds[k] = t_lds;
+          u_lds += a.ntg[k] * a.m[k];
+          t_lds += a.ntg[k];
+          for (int i2 = 0; i2 < ns[e]; i2++) {
+            int cnt2 = 0;
+            for (int q : fs[start[e] + i2])
+              if (is_top[producer(updb_off64, q)] < 0) {
+                if (cnt2 == kTopRhsSrc) {
+                  ok = false;
+                  break;
+                }
+                rhs_src[(size_t)(a.row0[k] + i2) * kTopRhsSrc + cnt2++] = pubb_dst[q];
+              }
+          }
+        }
+        if (!ok || u_lds > kTopMaxImage || t_lds > kTopMaxImage) {
+          ok = false;
+        } else {
+          CXK_TRY(ctx->top_dense.off.upload(off));
+          CXK_TRY(ctx->top_dense.pl_src.upload(rhs_src));
+          a.top_off = ctx->top_dense.off.p;
+          a.rhs_src = ctx->top_dense.pl_src.p;
+        }
+        if (ok) {
+          for (const void* kf : {reinterpret_cast<const void*>(&tree_top_dense<32>),
+                                 reinterpret_cast<const void*>(&tree_top_dense<40>),
+                                 reinterpret_cast<const void*>(&tree_top_dense<48>),
+                                 reinterpret_cast<const void*>(&tree_top_dense<56>),
+                                 reinterpret_cast<const void*>(&tree_top_dense<64>)})
+            CXK_TRY(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTopDenseLds));
+        }
+        if (ok) {
+          ctx->top_dense.on = true;
+          ctx->dense_level = dt;
+        }
+      }
+    }
   }
   // ---- level ranges below the top: merge consecutive levels into one launch when every
   // connected piece of the forest restricted to them fits one workgroup (<= 8 supernodes per
@@ -1341,14 +1468,39 @@ int LaunchTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
   // Bottom-up sweeps stay one launch per level: a factor step is long (thousands of cycles of
   // elimination) and a kernel boundary buys full width for ~2 us; merging levels only pays on the
   // way down, where a level step is a short back-substitution (measured: -30 % on C4).
-  for (int l = 0; l < top; l++)
+  // mode 0 with a dense range: levels below it as usual, then ONE dense factorization (+ solves)
+  // of everything from dense_level up (kernels_kkt_top.hip.h)
+  const bool dense = mode == 0 && ctx->top_dense.on;
+  const int up_end = dense ? ctx->dense_level : top;
+  for (int l = 0; l < up_end; l++)
     if (LaunchSweep(ctx, l, l + 1, mode, false, with_rhs)) return CXK_FAILURE;
-  if (top < nlev)
+  if (dense) {
+    double* rhs = with_rhs ? ctx->y.p : nullptr;
+    const int wb = with_rhs && backward;
+    const TopDenseArgs& ta = ctx->top_dense.args;
+#define CXK_TOP_DENSE(TM) \
+  tree_top_dense<TM><<<1, 256, kTopDenseLds, ctx->stream>>>(ctx->plan, ta, ctx->slab.p, rhs, ctx->d_fail.p, with_rhs, wb)
+    if (ta.T <= 32)
+      CXK_TOP_DENSE(32);
+    else if (ta.T <= 40)
+      CXK_TOP_DENSE(40);
+    else if (ta.T <= 48)
+      CXK_TOP_DENSE(48);
+    else if (ta.T <= 56)
+      CXK_TOP_DENSE(56);
+    else
+      CXK_TOP_DENSE(64);
+#undef CXK_TOP_DENSE
+    CXK_TRY(hipGetLastError());
+  } else if (top < nlev) {
     if (LaunchSweep(ctx, top, nlev, mode, backward, with_rhs)) return CXK_FAILURE;
+  }
   if (backward)
-    for (auto it = order.rbegin(); it != order.rend(); ++it)
+    for (auto it = order.rbegin(); it != order.rend(); ++it) {
+      if (dense && it->first >= ctx->dense_level) continue;  // solved inside the dense kernel
       if (it->second ? LaunchRange(ctx, *it->second, 2, true) : LaunchSweep(ctx, it->first, it->first + 1, 2, false, true))
         return CXK_FAILURE;
+    }
   return CXK_SUCCESS;
 }
 
@@ -2377,6 +2529,11 @@ int cxk_gemm_f64(int device, int ta, int tb, int M, int N, int K, int batch, con
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return CXK_SUCCESS;
+}
+
+int cxk_dense_top_columns(const cxk_context* ctx) {
+  if (!ctx || !ctx->finalized) return -1;
+  return ctx->top_dense.on ? ctx->top_dense.args.T : 0;
 }
 
 int cxk_count_sparse_lmi(const cxk_context* ctx) {

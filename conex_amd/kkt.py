@@ -87,6 +87,7 @@ _SIGNATURES = {
     "cxk_finish_assemble": (C.c_int, [C.c_void_p]),
     "cxk_assembly_work": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "cxk_count_sparse_lmi": (C.c_int, [C.c_void_p]),
+    "cxk_dense_top_columns": (C.c_int, [C.c_void_p]),
     "cxk_factor_async": (C.c_int, [C.c_void_p]),
     "cxk_factor_solve_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
     "cxk_factor_direction_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
@@ -468,6 +469,10 @@ class KktContext:
 
     def finish_assemble(self):
         self._check(self.L.cxk_finish_assemble(self.h), "cxk_finish_assemble")
+
+    def dense_top_columns(self):
+        """Columns factored by the dense top kernel (cxk_dense_top_columns); 0 when it is not used."""
+        return self.L.cxk_dense_top_columns(self.h)
 
     def count_sparse_lmi(self):
         """Constraints on the sparse-LMI evaluation path (cxk_count_sparse_lmi)."""

@@ -232,6 +232,12 @@ int cxk_gemm_f64(int device, int ta, int tb, int M, int N, int K, int batch, con
  * never/always).  Results equal the dense path's to rounding. */
 int cxk_count_sparse_lmi(const cxk_context* ctx);
 
+/* Columns of the dense range at the top of the elimination tree (0 = none): when the last levels
+ * hold a supernode of 33..64 columns and at most 64 columns in total, BlockCholeskyInPlace and
+ * the block solves (block_triangular_operations.cc:114-219) restricted to those levels run as one
+ * dense register factorization (kernels_kkt_top.hip.h) instead of supernode by supernode. */
+int cxk_dense_top_columns(const cxk_context* ctx);
+
 /* ---- timing / roofline accounting -------------------------------------- */
 /* algorithmic bytes and flops of one dense-LMI assembly launch (SURVEY 8d formulas) */
 int cxk_assembly_work(const cxk_context* ctx, double* bytes, double* flops);

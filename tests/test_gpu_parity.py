@@ -414,3 +414,15 @@ def test_c4_headline_direction_and_properties():
     # repeatability: the pull formulation has no atomics, so two runs agree bit for bit
     _, y2 = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
     assert np.array_equal(y, y2)
+
+
+@pytest.mark.parametrize("K,n,m,b_,ov,cols", [(1, 52, 40, 2, 1, 40), (1, 60, 64, 2, 1, 64), (3, 45, 50, 2, 20, 50),
+                                              (30, 20, 20, 8, 5, 0)])
+def test_dense_top_range(K, n, m, b_, ov, cols):
+    """Last levels with a 33..64-column supernode run as one dense register factorization
+    (kernels_kkt_top.hip.h); tops made of small supernodes (C4-like, cols == 0) do not."""
+    prob = syn.lmi_problem(K=K, n=n, m=m, branching=b_, overlap=ov, seed=300 + m)
+    W = syn.scaling_points(K, n, seed=3 + n)
+    o, k = make_pair(prob, "lmi", W)
+    assert k.dense_top_columns() == cols
+    check_newton_step(o, k, prob["b"], lanczos_tol=1e-7 if n > 32 else None)
