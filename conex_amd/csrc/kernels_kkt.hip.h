@@ -140,15 +140,20 @@ __global__ void build_mu_rhs(int N, double bs, double cs, const double* __restri
 
 // In-kernel stamps (diagnostic builds only: -DCXK_DEBUG_STAMPS); values go to a buffer nothing else reads.
 #ifdef CXK_DEBUG_STAMPS
-__device__ long long g_cxk_stamp[32];
-__device__ int g_cxk_sel;
-#define CXK_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_cxk_sel == 1) g_cxk_stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#define CXK_STAMPB(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_cxk_sel == 2) g_cxk_stamp[16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define CXK_STAMP_SELECT(lb, mode) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cxk_sel = ((lb) == 0) ? ((mode) == 0 ? 1 : ((mode) == 2 ? 2 : 0)) : 0; } while (0)
+// g_cxk_want (set by cxk_debug_select): 0 = single-level factor launches, 1 = merged level ranges
+// (grid > 1), 2 = the one-workgroup top.  Wave 0 of workgroup 0 records stamp i of level l of the
+// launch at g_cxk_stamp[8 l + i]; the backward stamps go to [64 + i].
+__device__ long long g_cxk_stamp[96];
+__device__ int g_cxk_sel, g_cxk_want, g_cxk_lvl;
+#define CXK_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_cxk_sel == 1) g_cxk_stamp[8 * g_cxk_lvl + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CXK_STAMPB(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && g_cxk_sel == 2) g_cxk_stamp[64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CXK_STAMP_SELECT(lb, mode) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_cxk_lvl = 0; const int kind = (lb) == 0 ? 0 : (gridDim.x > 1 ? 1 : 2); g_cxk_sel = (kind == g_cxk_want) ? ((mode) == 0 ? 1 : ((mode) == 2 ? 2 : 0)) : 0; } } while (0)
+#define CXK_STAMP_LEVEL(l) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cxk_lvl = (l); } while (0)
 #else
 #define CXK_STAMP(i) do { } while (0)
 #define CXK_STAMPB(i) do { } while (0)
 #define CXK_STAMP_SELECT(lb, mode) do { } while (0)
+#define CXK_STAMP_LEVEL(l) do { } while (0)
 #endif
 
 // Everything a wavefront needs to start on one supernode: one 128-byte record per position of
@@ -211,6 +216,7 @@ struct FactorPlan {
   const int* updb_off;       // [K] offset of the s values in `updb`
   const int* tg_ptr;         // [K+1] targets of supernode p
   const int* tg_loc;         // local offset inside [diag ns x ns | off ns x s]
+  const int* tg_reg;         // the same target in the register-shaped LDS image: 64 * column + lane
   const int* tr_ptr;         // [T+1] contributions of target t
   const int64_t* tr_src;     // index into `upd`
   const int* fs_ptr;         // [N+1] contributions of permuted row r
@@ -481,9 +487,9 @@ __device__ inline void FactorSupernodeRows(const FactorPlan& P, const SnRec& R,
   double a[NSMAX + SMAX + 1];
 #pragma unroll
   for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? base[o0 + j * st] : 0.0;
+  a[RB] = (rhs && is_row) ? rhs[R.start + lane] : 0.0;
 #pragma unroll
   for (int c = 0; c < SMAX; c++) a[NSMAX + c] = 0.0;
-  a[RB] = (rhs && is_row) ? rhs[R.start + lane] : 0.0;
   // The remaining loads are guarded by wave-uniform branches and use clamped (always valid)
   // addresses instead of per-lane predicates: a leaf skips them at the cost of a scalar branch.
   int pdst[SMAX > 0 ? SMAX : 1], pdstb = 0;
@@ -599,6 +605,145 @@ __device__ inline void FactorSupernodeRows(const FactorPlan& P, const SnRec& R,
     for (int c = 0; c < SMAX; c++)
       if (c >= sc && c < s) P.upd[pdst[c]] = -a[NSMAX + c];
     if (rhs) P.updb[pdstb] = -a[RB];
+  }
+  CXK_STAMP(5);
+}
+
+// The same step with a STRAIGHT-LINE load phase, for supernodes whose pulls fit the dense slots
+// (FastPull): a lone wavefront pays a full memory round trip (~1.2 us, nothing else to switch to)
+// for every wait it meets, and the compiler waits for ALL outstanding loads wherever a loaded
+// value is consumed inside or behind a branch that itself holds loads.  FactorSupernodeRows'
+// branch ladders (per-lane predicates, "if (i < m)") cost it three round trips in a row: panel,
+// pulled Schur values, pulled forward values.  Here every load -- panel, right-hand side, publish
+// destinations, pull locations, pulled values -- is unconditional with a clamped, always valid
+// address (the host pads the tables, kPullPad), nothing is consumed before the last one is
+// issued, and unused values are masked afterwards: ONE round trip.  The pull is applied through
+// an LDS image laid out like the registers (my[64 j + lane], P.tg_reg), written and read back
+// without predicates.  Arithmetic and its order are those of FactorSupernodeRows (masked slots
+// subtract 0.0: exact), so both give the same bits.
+constexpr int kPullPad = 64;       // spare elements behind pub_dst / pubb_dst / tg_reg / upd / updb
+constexpr int kFastTargets = 128;  // pull targets per supernode (2 per lane)
+constexpr int kFastSlots = 8;      // contributions per target / forward contributions per row
+
+__device__ __forceinline__ bool FastPull(const SnRec& R) {
+  return R.tg_end - R.tg_beg <= kFastTargets && R.m <= kFastSlots && R.mf <= kFastSlots;
+}
+
+template <int NSMAX, int SMAX, bool RHS>
+__device__ __forceinline__ void FactorSupernodeLean(const FactorPlan& P, const SnRec& R,
+                                                    double* __restrict__ slab, double* __restrict__ rhs,
+                                                    int* __restrict__ fail, double* __restrict__ my) {
+  static_assert(NSMAX + SMAX <= 64, "one lane per panel row");
+  constexpr int RB = NSMAX + SMAX, MMAX = kFastSlots, MFMAX = kFastSlots;
+  const int lane = threadIdx.x & 63;
+  const int ns = R.ns, s = R.nsep;
+  const bool is_row = lane < ns;
+  const int sc = lane - NSMAX;
+  const bool is_sep = sc >= 0 && sc < s;
+  double* base = slab + R.diag_off;
+  const unsigned rel = (unsigned)(R.offd_off - R.diag_off);
+  const unsigned o0 = is_row ? (unsigned)lane : (is_sep ? rel + (unsigned)(sc * ns) : 0u);
+  const unsigned st = is_row ? (unsigned)ns : 1u;
+  const int lim = is_row ? lane + 1 : (is_sep ? ns : 0);  // valid j < lim
+  CXK_STAMP(0);
+  // ---- load phase: no consumer before the last load
+  double a[NSMAX + SMAX + 1];
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++) a[j] = base[(j < lim) ? o0 + j * st : 0u];
+  double rb = 0.0;
+  if constexpr (RHS) rb = rhs[R.start + (is_row ? lane : 0)];
+  int pdst[SMAX > 0 ? SMAX : 1], pdstb = 0;
+  pdst[0] = 0;
+  {
+    const int k = is_sep ? sc : 0;
+    const int* dst = P.pub_dst + R.upd_off + (k * s - k * (k - 1) / 2 - k);
+#pragma unroll
+    for (int c = 0; c < SMAX; c++) {
+      int cc = c < k ? k : (c < s ? c : s - 1);
+      cc = cc < 0 ? 0 : cc;
+      pdst[c] = dst[cc];
+    }
+    if constexpr (RHS && SMAX > 0) pdstb = P.pubb_dst[R.updb_off + k];
+  }
+  const int ntg = R.tg_end - R.tg_beg;
+  const int mlast = R.m > 0 ? R.m - 1 : 0, mflast = R.mf > 0 ? R.mf - 1 : 0;
+  double pv0[MMAX], pv1[MMAX], pb[MFMAX];
+  int ploc0, ploc1 = 0;
+  {
+    const int ts = lane < ntg ? lane : 0;
+    ploc0 = P.tg_reg[R.tg_beg + ts];
+    const double* src = P.upd + R.ubase + (int64_t)ts * R.m;
+#pragma unroll
+    for (int i = 0; i < MMAX; i++) pv0[i] = src[i < R.m ? i : mlast];
+  }
+#pragma unroll
+  for (int i = 0; i < MMAX; i++) pv1[i] = 0.0;
+  if (ntg > 64) {  // wave-uniform; loads only
+    const int ts = lane + 64 < ntg ? lane + 64 : 0;
+    ploc1 = P.tg_reg[R.tg_beg + ts];
+    const double* src = P.upd + R.ubase + (int64_t)ts * R.m;
+#pragma unroll
+    for (int i = 0; i < MMAX; i++) pv1[i] = src[i < R.m ? i : mlast];
+  }
+  if constexpr (RHS) {
+    const double* src = P.updb + R.fbase + (is_row ? lane : 0) * R.mf;
+#pragma unroll
+    for (int i = 0; i < MFMAX; i++) pb[i] = src[i < R.mf ? i : mflast];
+  }
+  CXK_STAMP(1);
+  // ---- consumers
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? a[j] : 0.0;
+#pragma unroll
+  for (int c = 0; c < SMAX; c++) a[NSMAX + c] = 0.0;
+  a[RB] = (RHS && is_row) ? rb : 0.0;
+  if (ntg > 0) {
+    // descendants published Schur updates: applied in the reference's order on the LDS image
+#pragma unroll
+    for (int j = 0; j < NSMAX; j++) my[64 * j + lane] = a[j];
+    WaveSync();
+    if (lane < ntg) {
+      double acc = my[ploc0];
+#pragma unroll
+      for (int i = 0; i < MMAX; i++) acc -= (i < R.m) ? pv0[i] : 0.0;
+      my[ploc0] = acc;
+    }
+    if (lane + 64 < ntg) {
+      double acc = my[ploc1];
+#pragma unroll
+      for (int i = 0; i < MMAX; i++) acc -= (i < R.m) ? pv1[i] : 0.0;
+      my[ploc1] = acc;
+    }
+    WaveSync();
+#pragma unroll
+    for (int j = 0; j < NSMAX; j++) a[j] = my[64 * j + lane];
+  }
+  if constexpr (RHS) {
+#pragma unroll
+    for (int i = 0; i < MFMAX; i++) a[RB] -= (is_row && i < R.mf) ? pb[i] : 0.0;
+  }
+  // padding pivots: unit diagonal
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++)
+    if (j >= ns && lane == j) a[j] = 1.0;
+  CXK_STAMP(2);
+  bool bad = false;
+  ElimSteps<NSMAX, SMAX, 0>::run(a, lane, bad);
+  CXK_STAMP(3);
+  if (bad) {
+    if (lane == 0) atomicExch(fail, 1);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++)
+    if (j < lim) base[o0 + j * st] = a[j];
+  if (RHS && is_row) rhs[R.start + lane] = a[RB];
+  CXK_STAMP(4);
+  if (is_sep) {
+#pragma unroll
+    for (int c = 0; c < SMAX; c++)
+      if (c >= sc && c < s) P.upd[pdst[c]] = -a[NSMAX + c];
+    if constexpr (RHS) P.updb[pdstb] = -a[RB];
   }
   CXK_STAMP(5);
 }
@@ -870,6 +1015,7 @@ tree_sweep(FactorPlan P, const SnRec* __restrict__ recs, const int* __restrict__
     for (int l = 0; l < nl; l++) {
       const int base = TOP ? lp[l] : base0;
       const int cnt = TOP ? lp[l + 1] - base : cnt0;
+      CXK_STAMP_LEVEL(l);
       for (int idx = (TOP ? 0 : blockIdx.x * nw) + wave; idx < cnt; idx += (TOP ? 1 : gridDim.x) * nw) {
         const SnRec R = load_rec(base + idx);
         const int ns = R.ns, s = R.nsep;
@@ -921,6 +1067,26 @@ tree_sweep(FactorPlan P, const SnRec* __restrict__ recs, const int* __restrict__
   }
   CXK_STAMP(7);
   CXK_STAMPB(5);
+}
+
+// ---------------------------------------------------------------------------------------
+// One factor level whose supernodes all fit ONE register shape (NSMAX, SMAX): the same step as
+// tree_sweep<0, false>, compiled for that shape alone.  The generic kernel carries every shape's
+// elimination plus the LDS fallback and pays for it in scalar-register spills on the path of each
+// shape; a level of a regular clique tree (all of BASELINE config 4) takes this kernel instead.
+// ---------------------------------------------------------------------------------------
+template <int NSMAX, int SMAX, bool RHS>
+__global__ void __launch_bounds__(256)
+tree_factor_level(FactorPlan P, const SnRec* __restrict__ recs, int base0, int cnt0,
+                  double* __restrict__ slab, double* __restrict__ rhs, int* __restrict__ fail,
+                  int lds_per_wave) {
+  extern __shared__ double lds[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  double* my = lds + (size_t)wave * lds_per_wave;
+  const int idx = blockIdx.x * nw + wave;
+  if (idx >= cnt0) return;
+  const SnRec R = LoadRec(recs, base0 + idx);
+  FactorSupernodeLean<NSMAX, SMAX, RHS>(P, R, slab, rhs, fail, my);
 }
 
 // ---------------------------------------------------------------------------------------

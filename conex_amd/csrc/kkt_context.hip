@@ -122,7 +122,9 @@ struct cxk_context {
   std::vector<int> level_ptr, level_sn;
   size_t chol_lds = 0, solve_lds = 0;  // bytes of LDS staging one supernode needs
   int top_level = 0;                   // levels [top_level, nlev) run inside one workgroup
+  bool no_lean = false;                // CXK_NO_LEAN=1: generic kernels only (comparison runs)
   std::vector<unsigned char> level_big;  // level holds a supernode beyond the wave-per-supernode kernels
+  std::vector<int> level_shape;          // > 0: every supernode of the level has this register shape and dense pulls (tree_factor_level)
   // supernodes whose panel exceeds LDS sit at the END of their level list and are swept one by
   // one through the blocked HBM path (kernels_kkt_big.hip.h); level_nh = count of the others
   std::vector<int> level_nh;
@@ -146,7 +148,7 @@ struct cxk_context {
   // device state
   DevBuf<double> G, AWc, AQcc, sc, slab, y, b, AW, AQc, sys_sc, info2, info4, red_out, scal_out;
   DevBuf<int64_t> d_g_off, d_r_off, as_dst, as_src, rs_src;
-  DevBuf<int> as_ptr, rs_ptr, cl_ptr, cl_perm, d_level_sn, d_level_ptr, d_fail, d_pinv, tg_loc;
+  DevBuf<int> as_ptr, rs_ptr, cl_ptr, cl_perm, d_level_sn, d_level_ptr, d_fail, d_pinv, tg_loc, tg_reg;
   DevBuf<unsigned char> d_mask;
   DevBuf<int> p_ns, p_nsep, p_start, tg_ptr, tr_ptr, fs_ptr, fs_src, bs_ptr, bs_c, bs_row, updb_off;
   DevBuf<int64_t> p_diag, p_offd, tr_src, upd_off;
@@ -324,6 +326,17 @@ size_t LmiPrepareLds(int n, int m) {
 }
 size_t LmiTakeLds(int n) { return sizeof(double) * (size_t)(5 * n * n); }
 constexpr size_t kLdsLimit = 160 * 1024 - 512;
+
+// Register shape (NSMAX << 8 | SMAX) the factor kernels pick for a supernode of ns columns and s
+// separator rows (the dispatch of tree_sweep); 0 = no register kernel.
+inline int RegisterShape(int ns, int s) {
+  if (ns <= 8 && s <= 8) return 8 << 8 | 8;
+  if (ns <= 16 && s <= 8) return 16 << 8 | 8;
+  if (ns <= 24 && s == 0) return 24 << 8 | 0;
+  if (ns <= 24 && s <= 8) return 24 << 8 | 8;
+  if (ns <= 32 && s <= 16) return 32 << 8 | 16;
+  return 0;
+}
 
 // ---------------------------------------------------------------- tree structure + partition
 // Dependency levels of the supernodal elimination tree and (world > 1) the split into a
@@ -631,7 +644,7 @@ int BuildPlans(cxk_context* ctx) {
   int64_t slots = 0;
   int slotsb = 0;
   {
-    std::vector<int> tg_ptr(K + 1, 0), tr_ptr, tg_loc, pt_ptr;
+    std::vector<int> tg_ptr(K + 1, 0), tr_ptr, tg_loc, tg_reg, pt_ptr;
     std::vector<int64_t> tr_src, pt_dst, pt_src;
     tr_ptr.push_back(0);
     pt_ptr.push_back(0);
@@ -648,6 +661,13 @@ int BuildPlans(cxk_context* ctx) {
           tg_loc.push_back(off >= L.diag_off[p] && off < L.diag_off[p] + dsz
                                ? (int)(off - L.diag_off[p])
                                : (int)(dsz + off - L.offd_off[p]));
+          {
+            // the same entry in the register-shaped image of FactorSupernodeLean: 64 * column + lane
+            const int nsm = RegisterShape(ns[p], nsep[p]) >> 8, loc = tg_loc.back();
+            const int col = loc < dsz ? loc / ns[p] : (int)(loc - dsz) % ns[p];
+            const int ln = loc < dsz ? loc % ns[p] : nsm + (int)(loc - dsz) / ns[p];
+            tg_reg.push_back(nsm > 0 ? 64 * col + ln : 0);
+          }
           for (size_t i = 0; i < contrib[t].size(); i++) {
             const int64_t slot = slots + (int64_t)tl * (int64_t)m + (int64_t)i;
             pub_dst[contrib[t][i]] = (int)slot;
@@ -674,6 +694,8 @@ int BuildPlans(cxk_context* ctx) {
     CXK_TRY(ctx->tg_ptr.upload(tg_ptr));
     h_tg_ptr = tg_ptr;
     CXK_TRY(ctx->tg_loc.upload(tg_loc));
+    tg_reg.resize(tg_reg.size() + kPullPad, 0);  // FactorSupernodeLean loads unconditionally (clamped)
+    CXK_TRY(ctx->tg_reg.upload(tg_reg));
     CXK_TRY(ctx->tr_ptr.upload(tr_ptr));
     CXK_TRY(ctx->tr_src.upload(tr_src));
     CXK_TRY(ctx->pt_dst.upload(pt_dst));
@@ -715,10 +737,12 @@ int BuildPlans(cxk_context* ctx) {
     if (d < 0) d = slotsb;
   CXK_TRY(ctx->upd_off.upload(upd_off));
   CXK_TRY(ctx->updb_off.upload(updb_off));
+  pub_dst.resize(pub_dst.size() + kPullPad, (int)slots);  // padding read (never used) by clamped loads
+  pubb_dst.resize(pubb_dst.size() + kPullPad, slotsb);
   CXK_TRY(ctx->pub_dst.upload(pub_dst));
   CXK_TRY(ctx->pubb_dst.upload(pubb_dst));
-  CXK_TRY(ctx->upd.alloc((size_t)slots + 1));
-  CXK_TRY(ctx->updb.alloc((size_t)slotsb + 2));  // + dump slot + a slot that stays 0.0
+  CXK_TRY(ctx->upd.alloc((size_t)slots + 1 + kPullPad));
+  CXK_TRY(ctx->updb.alloc((size_t)slotsb + 2 + kPullPad));  // + dump slot + a slot that stays 0.0
 
   // ---- exchange layout: [T slab entries | AW_T | AQc_T | fwd_T | <w,c> <c,Qc> fail]
   if (sharded) {
@@ -796,6 +820,8 @@ int BuildPlans(cxk_context* ctx) {
         }
         ctx->level_sn.push_back(e);
         ctx->chol_lds = std::max(ctx->chol_lds, panel_bytes(e));
+        // register-shaped LDS image of FactorSupernodeLean: 64 lanes x NSMAX columns
+        ctx->chol_lds = std::max(ctx->chol_lds, sizeof(double) * 64 * (size_t)(RegisterShape(ns[e], nsep[e]) >> 8));
       }
     ctx->level_nh[l] = (int)ctx->level_sn.size() - ctx->level_ptr[l];
     for (int e : huge) ctx->level_sn.push_back(e);
@@ -841,11 +867,28 @@ int BuildPlans(cxk_context* ctx) {
     CXK_TRY(ctx->p_rec.upload(recs));
     h_recs = recs;
     ctx->h_recs = recs;
+    // levels of one register shape whose pulls all fit the dense slots: tree_factor_level
+    ctx->level_shape.assign(nlev, 0);
+    for (int l = 0; l < nlev; l++) {
+      int shape = -1;
+      if (ctx->level_nh[l] != ctx->level_ptr[l + 1] - ctx->level_ptr[l]) shape = 0;
+      for (int pos = ctx->level_ptr[l]; pos < ctx->level_ptr[l + 1] && shape != 0; pos++) {
+        const SnRec& r = recs[pos];
+        const int sh = RegisterShape(r.ns, r.nsep);
+        const bool fast = r.tg_end - r.tg_beg <= kFastTargets && r.m <= kFastSlots && r.mf <= kFastSlots;
+        if (!fast || sh == 0 || (shape > 0 && sh != shape))
+          shape = 0;
+        else
+          shape = sh;
+      }
+      ctx->level_shape[l] = shape > 0 ? shape : 0;
+    }
   }
   // narrow top of the tree: trailing levels that hold few supernodes are swept by one workgroup
   // (levels separated by a workgroup barrier instead of a kernel boundary); never below the cut
   {
     int top = nlev;
+    ctx->no_lean = getenv("CXK_NO_LEAN") != nullptr;
     while (top > 0 && ctx->level_ptr[top] - ctx->level_ptr[top - 1] <= 8 && !ctx->level_big[top - 1]) top--;
     if (sharded) top = std::max(top, ctx->cut_level);
     if (ctx->use_ldlt) top = nlev;  // LDLT sweeps run level by level, one workgroup per supernode
@@ -1066,6 +1109,7 @@ int BuildPlans(cxk_context* ctx) {
   P.updb_off = ctx->updb_off.p;
   P.tg_ptr = ctx->tg_ptr.p;
   P.tg_loc = ctx->tg_loc.p;
+  P.tg_reg = ctx->tg_reg.p;
   P.tr_ptr = ctx->tr_ptr.p;
   P.tr_src = ctx->tr_src.p;
   P.fs_ptr = ctx->fs_ptr.p;
@@ -1089,6 +1133,16 @@ hipError_t RaiseLdsLimits() {
         reinterpret_cast<const void*>(&lmi_prepare_generic<0, 0>),
         reinterpret_cast<const void*>(&lmi_prepare_generic<1, 0>),
         reinterpret_cast<const void*>(&lmi_take_step_generic<0>),
+        reinterpret_cast<const void*>(&tree_factor_level<8, 8, true>),
+        reinterpret_cast<const void*>(&tree_factor_level<8, 8, false>),
+        reinterpret_cast<const void*>(&tree_factor_level<16, 8, true>),
+        reinterpret_cast<const void*>(&tree_factor_level<16, 8, false>),
+        reinterpret_cast<const void*>(&tree_factor_level<24, 0, true>),
+        reinterpret_cast<const void*>(&tree_factor_level<24, 0, false>),
+        reinterpret_cast<const void*>(&tree_factor_level<24, 8, true>),
+        reinterpret_cast<const void*>(&tree_factor_level<24, 8, false>),
+        reinterpret_cast<const void*>(&tree_factor_level<32, 16, true>),
+        reinterpret_cast<const void*>(&tree_factor_level<32, 16, false>),
         reinterpret_cast<const void*>(&tree_sweep<0, false>),
         reinterpret_cast<const void*>(&tree_sweep<0, true>),
         reinterpret_cast<const void*>(&tree_sweep<1, false>),
@@ -1407,6 +1461,27 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
   }
   const size_t lds = (size_t)waves * ctx->chol_lds;
   double* rhs = (with_rhs || mode != 0) ? ctx->y.p : nullptr;
+  if (mode == 0 && !is_top && ctx->level_shape[lb] > 0 && !ctx->no_lean) {
+    // the whole level has one register shape: kernel compiled for that shape alone
+    const int sh = ctx->level_shape[lb];
+#define CXK_LEVEL(NS_, S_)                                                                              \
+  if (sh == ((NS_) << 8 | (S_))) {                                                                      \
+    if (rhs)                                                                                            \
+      tree_factor_level<NS_, S_, true><<<grid, waves * 64, lds, ctx->stream>>>(                         \
+          ctx->plan, ctx->p_rec.p, ctx->level_ptr[lb], maxcnt, ctx->slab.p, rhs, ctx->d_fail.p, per_wave); \
+    else                                                                                                \
+      tree_factor_level<NS_, S_, false><<<grid, waves * 64, lds, ctx->stream>>>(                        \
+          ctx->plan, ctx->p_rec.p, ctx->level_ptr[lb], maxcnt, ctx->slab.p, rhs, ctx->d_fail.p, per_wave); \
+  }
+    CXK_LEVEL(8, 8)
+    CXK_LEVEL(16, 8)
+    CXK_LEVEL(24, 0)
+    CXK_LEVEL(24, 8)
+    CXK_LEVEL(32, 16)
+#undef CXK_LEVEL
+    CXK_TRY(hipGetLastError());
+    return CXK_SUCCESS;
+  }
   // the top [lb, le) is ONE piece: its level table is the level_ptr slice itself (positions into
   // the level-ordered records)
 #define CXK_SWEEP(MODE, TOP)                                                                   \
@@ -2567,7 +2642,10 @@ int cxk_debug_sparse_stamps(long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sparse_stamp), 8 * sizeof(long long)) == hipSuccess ? 0 : 1;
 }
 int cxk_debug_stamps(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cxk_stamp), 32 * sizeof(long long)) == hipSuccess ? 0 : 1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cxk_stamp), 96 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+int cxk_debug_select(int want) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_cxk_want), &want, sizeof(int)) == hipSuccess ? 0 : 1;
 }
 #endif
 
