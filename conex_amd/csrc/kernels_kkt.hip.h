@@ -798,6 +798,51 @@ __device__ inline void BackwardSupernodeRows(const FactorPlan& P, const SnRec& R
   if (active) rhs[R.start + lane] = acc;
 }
 
+// BackwardSupernodeRows with a straight-line load phase (see FactorSupernodeLean): column of L,
+// off-block entries and the separator values y[sep] all load unconditionally from clamped
+// addresses, masks are applied afterwards.  Needs the inline separator list (R.nsep_inline == count).
+template <int NSMAX, int SMAX>
+__device__ __forceinline__ void BackwardSupernodeLean(const SnRec& R, const double* __restrict__ slab,
+                                                      double* __restrict__ rhs) {
+  const int lane = threadIdx.x & 63;
+  const int ns = R.ns;
+  const bool active = lane < ns;
+  const double* D = slab + R.diag_off + (size_t)(active ? lane : 0) * ns;  // column `lane`
+  const double* B = slab + R.offd_off + (active ? lane : 0);
+  CXK_STAMPB(1);
+  double col[NSMAX];
+#pragma unroll
+  for (int k = 0; k < NSMAX; k++) col[k] = D[(active && k > lane && k < ns) ? k : 0];
+  double dg = D[active ? lane : 0];
+  double acc = rhs[R.start + (active ? lane : 0)];
+  const int cnt = R.bs_end - R.bs_beg;
+  constexpr int QN = SMAX < 8 ? SMAX : 8;
+  double bv[QN > 0 ? QN : 1], yv[QN > 0 ? QN : 1];
+#pragma unroll
+  for (int q = 0; q < QN; q++) {
+    const unsigned w = q < cnt ? (unsigned)R.sep[q] : 0u;
+    yv[q] = rhs[w & 0x3ffffffu];
+    bv[q] = B[(size_t)(w >> 26) * ns];
+  }
+  // ---- consumers
+#pragma unroll
+  for (int k = 0; k < NSMAX; k++) col[k] = (active && k > lane && k < ns) ? col[k] : 0.0;
+  dg = active ? dg : 1.0;
+  acc = active ? acc : 0.0;
+#pragma unroll
+  for (int q = 0; q < QN; q++) acc -= ((q < cnt && active) ? bv[q] : 0.0) * (q < cnt ? yv[q] : 0.0);
+  CXK_STAMPB(2);
+  const double dinv = 1.0 / dg;
+  CXK_STAMPB(3);
+#pragma unroll
+  for (int k = NSMAX - 1; k >= 0; k--) {
+    if (lane == k) acc *= dinv;
+    acc = fma(-col[k], ReadLane(acc, k), acc);  // col[k] is zero for lanes >= k
+  }
+  CXK_STAMPB(4);
+  if (active) rhs[R.start + lane] = acc;
+}
+
 // LDS-resident fallback for supernodes that do not fit the register kernels.
 __device__ inline void CholSupernodeLds(const FactorPlan& P, int p, double* __restrict__ slab,
                                         double* __restrict__ rhs, int* __restrict__ fail,
@@ -1087,6 +1132,18 @@ tree_factor_level(FactorPlan P, const SnRec* __restrict__ recs, int base0, int c
   if (idx >= cnt0) return;
   const SnRec R = LoadRec(recs, base0 + idx);
   FactorSupernodeLean<NSMAX, SMAX, RHS>(P, R, slab, rhs, fail, my);
+}
+
+// The backward step of one level, same specialisation (no LDS).
+template <int NSMAX, int SMAX>
+__global__ void __launch_bounds__(256)
+tree_backward_level(const SnRec* __restrict__ recs, int base0, int cnt0, const double* __restrict__ slab,
+                    double* __restrict__ rhs) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int idx = blockIdx.x * nw + wave;
+  if (idx >= cnt0) return;
+  const SnRec R = LoadRec(recs, base0 + idx);
+  BackwardSupernodeLean<NSMAX, SMAX>(R, slab, rhs);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -122,8 +122,10 @@ struct cxk_context {
   std::vector<int> level_ptr, level_sn;
   size_t chol_lds = 0, solve_lds = 0;  // bytes of LDS staging one supernode needs
   int top_level = 0;                   // levels [top_level, nlev) run inside one workgroup
+  bool no_ranges = false;              // CXK_NO_RANGES=1: downward sweeps level by level (comparison runs)
   bool no_lean = false;                // CXK_NO_LEAN=1: generic kernels only (comparison runs)
   std::vector<unsigned char> level_big;  // level holds a supernode beyond the wave-per-supernode kernels
+  std::vector<unsigned char> level_inline;  // every supernode of the level carries its separator list inline (tree_backward_level)
   std::vector<int> level_shape;          // > 0: every supernode of the level has this register shape and dense pulls (tree_factor_level)
   // supernodes whose panel exceeds LDS sit at the END of their level list and are swept one by
   // one through the blocked HBM path (kernels_kkt_big.hip.h); level_nh = count of the others
@@ -326,6 +328,7 @@ size_t LmiPrepareLds(int n, int m) {
 }
 size_t LmiTakeLds(int n) { return sizeof(double) * (size_t)(5 * n * n); }
 constexpr size_t kLdsLimit = 160 * 1024 - 512;
+constexpr int kSplitTopLevels = 8;  // tops of at most this many levels may be swept level by level
 
 // Register shape (NSMAX << 8 | SMAX) the factor kernels pick for a supernode of ns columns and s
 // separator rows (the dispatch of tree_sweep); 0 = no register kernel.
@@ -869,7 +872,10 @@ int BuildPlans(cxk_context* ctx) {
     ctx->h_recs = recs;
     // levels of one register shape whose pulls all fit the dense slots: tree_factor_level
     ctx->level_shape.assign(nlev, 0);
+    ctx->level_inline.assign(nlev, 1);
     for (int l = 0; l < nlev; l++) {
+      for (int pos = ctx->level_ptr[l]; pos < ctx->level_ptr[l + 1]; pos++)
+        if (recs[pos].nsep_inline != recs[pos].bs_end - recs[pos].bs_beg) ctx->level_inline[l] = 0;
       int shape = -1;
       if (ctx->level_nh[l] != ctx->level_ptr[l + 1] - ctx->level_ptr[l]) shape = 0;
       for (int pos = ctx->level_ptr[l]; pos < ctx->level_ptr[l + 1] && shape != 0; pos++) {
@@ -889,9 +895,19 @@ int BuildPlans(cxk_context* ctx) {
   {
     int top = nlev;
     ctx->no_lean = getenv("CXK_NO_LEAN") != nullptr;
+    ctx->no_ranges = getenv("CXK_NO_RANGES") != nullptr;
     while (top > 0 && ctx->level_ptr[top] - ctx->level_ptr[top - 1] <= 8 && !ctx->level_big[top - 1]) top--;
     if (sharded) top = std::max(top, ctx->cut_level);
     if (ctx->use_ldlt) top = nlev;  // LDLT sweeps run level by level, one workgroup per supernode
+    // A short top whose levels all have a shape-specialised kernel is swept level by level as
+    // well: the lean per-level launches (one memory round trip per step) measured faster than the
+    // generic one-workgroup sweep (C4: 24 -> 2 x (6.0 + 3.6) us).  Long narrow tops (chains) keep
+    // the one-workgroup sweep: there a kernel boundary per step would dominate.
+    if (!ctx->no_lean && !getenv("CXK_KEEP_TOP") && top < nlev && nlev - top <= kSplitTopLevels) {
+      bool all = true;
+      for (int l = top; l < nlev; l++) all = all && ctx->level_shape[l] > 0 && ctx->level_inline[l];
+      if (all) top = nlev;
+    }
     ctx->top_level = top;
   }
   // ---- the top as one dense T x T factorization (single GPU, Cholesky): tables for
@@ -1070,6 +1086,12 @@ int BuildPlans(cxk_context* ctx) {
           pieces.swap(trial);
           hi++;
         }
+      bool all_lean = !ctx->no_lean;
+      for (int l = lo; l < hi; l++) all_lean = all_lean && ctx->level_shape[l] > 0 && ctx->level_inline[l];
+      if (all_lean) {  // every level has its shape-specialised backward kernel: faster than the merged sweep
+        lo = hi;
+        continue;
+      }
       if (hi - lo > 1) {
         auto rg = std::make_unique<cxk_context::SweepRange>();
         rg->lo = lo;
@@ -1459,8 +1481,30 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
     CXK_TRY(hipGetLastError());
     return CXK_SUCCESS;
   }
-  const size_t lds = (size_t)waves * ctx->chol_lds;
   double* rhs = (with_rhs || mode != 0) ? ctx->y.p : nullptr;
+  if (!is_top && waves > 4) {  // the shape-specialised level kernels are compiled for <= 256 threads
+    const bool lean = ctx->level_shape[lb] > 0 && !ctx->no_lean && (mode == 0 || (mode == 2 && ctx->level_inline[lb]));
+    if (lean) {
+      waves = 4;
+      grid = (maxcnt + waves - 1) / waves;
+    }
+  }
+  const size_t lds = (size_t)waves * ctx->chol_lds;
+  if (mode == 2 && !is_top && ctx->level_shape[lb] > 0 && ctx->level_inline[lb] && !ctx->no_lean) {
+    const int sh = ctx->level_shape[lb];
+#define CXK_LEVEL(NS_, S_)                                                                     \
+  if (sh == ((NS_) << 8 | (S_)))                                                               \
+    tree_backward_level<NS_, S_><<<grid, waves * 64, 0, ctx->stream>>>(ctx->p_rec.p, ctx->level_ptr[lb], \
+                                                                       maxcnt, ctx->slab.p, rhs);
+    CXK_LEVEL(8, 8)
+    CXK_LEVEL(16, 8)
+    CXK_LEVEL(24, 0)
+    CXK_LEVEL(24, 8)
+    CXK_LEVEL(32, 16)
+#undef CXK_LEVEL
+    CXK_TRY(hipGetLastError());
+    return CXK_SUCCESS;
+  }
   if (mode == 0 && !is_top && ctx->level_shape[lb] > 0 && !ctx->no_lean) {
     // the whole level has one register shape: kernel compiled for that shape alone
     const int sh = ctx->level_shape[lb];
@@ -1530,6 +1574,7 @@ int LaunchTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
   const int top = ctx->top_level;
   // levels below the top: merged ranges where they exist, single levels otherwise
   auto range_at = [&](int l) -> cxk_context::SweepRange* {
+    if (ctx->no_ranges) return nullptr;
     for (auto& r : ctx->ranges)
       if (r->lo == l) return r.get();
     return nullptr;
