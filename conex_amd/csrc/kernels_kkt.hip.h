@@ -22,15 +22,27 @@ namespace cxk {
 //   slab[dst[t]] = sum_k G[src[k]], k in [ptr[t], ptr[t+1]) ; src < 0 means structural zero
 //   AW/AQc in permuted order (constraint order sums), the two scalars, and -- when with_rhs --
 //   y = k (b bs + AQc cs) - 2 AW  (cone_program.cc:409-411).  Also clears the factor flag.
+// One record per slab target / per variable: the FIRST source sits in the record, so the common
+// entry (one source: everything outside the separator overlaps) costs two dependent memory hops
+// (record, value) instead of three (list bounds, list, value); further sources follow in the lists.
+struct GatherRec {
+  int64_t dst;    // slab offset
+  int64_t first;  // index into G, < 0 = structural zero
+  int beg, extra; // remaining sources: src[beg .. beg + extra)
+};
+struct ResidRec {
+  int64_t first;  // index into AWc / AQcc, < 0 = none
+  int beg, extra;
+};
+
 struct GatherArgs {
   int64_t T;
-  const int64_t* dst;
-  const int* ptr;
+  const GatherRec* rec;
   const int64_t* src;
   const double* G;
   double* slab;
   int N;
-  const int* rs_ptr;
+  const ResidRec* rrec;
   const int64_t* rs_src;
   const double* AWc;
   const double* AQcc;
@@ -49,23 +61,35 @@ struct GatherArgs {
 __global__ void __launch_bounds__(256) assemble_gather(GatherArgs a) {
   const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t t = gid; t < a.T; t += stride) {
-    double s = 0;
-    for (int k = a.ptr[t]; k < a.ptr[t + 1]; k++) {
+  const int64_t span = a.T > a.N ? a.T : (int64_t)a.N;
+  // slab entries and residual entries are gathered side by side: their loads share the round trips
+  for (int64_t t = gid; t < span; t += stride) {
+    const bool ht = t < a.T, hp = t < a.N;
+    GatherRec g = {0, -1, 0, 0};
+    ResidRec r = {-1, 0, 0};
+    if (ht) g = a.rec[t];
+    if (hp) r = a.rrec[t];
+    double s = 0, aw = 0, aq = 0, bp = 0;
+    if (g.first >= 0) s += a.G[g.first];
+    if (r.first >= 0) {
+      aw += a.AWc[r.first];
+      aq += a.AQcc[r.first];
+    }
+    if (hp && a.with_rhs) bp = a.b[t];
+    for (int k = g.beg; k < g.beg + g.extra; k++) {
       const int64_t q = a.src[k];
       if (q >= 0) s += a.G[q];
     }
-    a.slab[a.dst[t]] = s;
-  }
-  for (int64_t p = gid; p < a.N; p += stride) {
-    double aw = 0, aq = 0;
-    for (int k = a.rs_ptr[p]; k < a.rs_ptr[p + 1]; k++) {
+    for (int k = r.beg; k < r.beg + r.extra; k++) {
       aw += a.AWc[a.rs_src[k]];
       aq += a.AQcc[a.rs_src[k]];
     }
-    a.AW[p] = aw;
-    a.AQc[p] = aq;
-    if (a.with_rhs) a.y[p] = a.k * (a.b[p] * a.bs + aq * a.cs) - 2 * aw;
+    if (ht) a.slab[g.dst] = s;
+    if (hp) {
+      a.AW[t] = aw;
+      a.AQc[t] = aq;
+      if (a.with_rhs) a.y[t] = a.k * (bp * a.bs + aq * a.cs) - 2 * aw;
+    }
   }
   if (blockIdx.x == 0) {  // <w,c> and <c,Qc>: fixed-order strided partial sums + block sum
     __shared__ double red[8];
@@ -1129,9 +1153,12 @@ tree_factor_level(FactorPlan P, const SnRec* __restrict__ recs, int base0, int c
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   double* my = lds + (size_t)wave * lds_per_wave;
   const int idx = blockIdx.x * nw + wave;
+  CXK_STAMP_SELECT(0, 0);
+  CXK_STAMP(6);
   if (idx >= cnt0) return;
   const SnRec R = LoadRec(recs, base0 + idx);
   FactorSupernodeLean<NSMAX, SMAX, RHS>(P, R, slab, rhs, fail, my);
+  CXK_STAMP(7);
 }
 
 // The backward step of one level, same specialisation (no LDS).
@@ -1142,8 +1169,11 @@ tree_backward_level(const SnRec* __restrict__ recs, int base0, int cnt0, const d
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const int idx = blockIdx.x * nw + wave;
   if (idx >= cnt0) return;
+  CXK_STAMP_SELECT(0, 2);
+  CXK_STAMPB(0);
   const SnRec R = LoadRec(recs, base0 + idx);
   BackwardSupernodeLean<NSMAX, SMAX>(R, slab, rhs);
+  CXK_STAMPB(5);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -150,6 +150,8 @@ struct cxk_context {
   // device state
   DevBuf<double> G, AWc, AQcc, sc, slab, y, b, AW, AQc, sys_sc, info2, info4, red_out, scal_out;
   DevBuf<int64_t> d_g_off, d_r_off, as_dst, as_src, rs_src;
+  DevBuf<GatherRec> as_rec;
+  DevBuf<ResidRec> rs_rec;
   DevBuf<int> as_ptr, rs_ptr, cl_ptr, cl_perm, d_level_sn, d_level_ptr, d_fail, d_pinv, tg_loc, tg_reg;
   DevBuf<unsigned char> d_mask;
   DevBuf<int> p_ns, p_nsep, p_start, tg_ptr, tr_ptr, fs_ptr, fs_src, bs_ptr, bs_c, bs_row, updb_off;
@@ -559,6 +561,17 @@ int BuildPlans(cxk_context* ctx) {
   CXK_TRY(ctx->as_dst.upload(dst));
   CXK_TRY(ctx->as_ptr.upload(as_ptr));
   CXK_TRY(ctx->as_src.upload(as_src));
+  {
+    std::vector<GatherRec> recs(dst.size());
+    for (size_t t = 0; t < dst.size(); t++) {
+      const int len = as_ptr[t + 1] - as_ptr[t];
+      recs[t].dst = dst[t];
+      recs[t].first = len > 0 ? as_src[as_ptr[t]] : -1;
+      recs[t].beg = as_ptr[t] + 1;
+      recs[t].extra = len > 0 ? len - 1 : 0;
+    }
+    CXK_TRY(ctx->as_rec.upload(recs));
+  }
 
   // ---- residual gather (constraint order); variables of foreign subtrees are skipped
   {
@@ -576,6 +589,14 @@ int BuildPlans(cxk_context* ctx) {
     }
     CXK_TRY(ctx->rs_ptr.upload(ptr));
     CXK_TRY(ctx->rs_src.upload(src));
+    std::vector<ResidRec> recs(N);
+    for (int p = 0; p < N; p++) {
+      const int len = ptr[p + 1] - ptr[p];
+      recs[p].first = len > 0 ? src[ptr[p]] : -1;
+      recs[p].beg = ptr[p] + 1;
+      recs[p].extra = len > 0 ? len - 1 : 0;
+    }
+    CXK_TRY(ctx->rs_rec.upload(recs));
   }
 
   // ---- clique variables in permuted numbering
@@ -1395,13 +1416,12 @@ int LaunchSchur(cxk_context* ctx) {
 int LaunchGather(cxk_context* ctx, bool with_rhs, double k, double bs, double cs) {
   GatherArgs a;
   a.T = ctx->as_T;
-  a.dst = ctx->as_dst.p;
-  a.ptr = ctx->as_ptr.p;
+  a.rec = ctx->as_rec.p;
   a.src = ctx->as_src.p;
   a.G = ctx->G.p;
   a.slab = ctx->slab.p;
   a.N = ctx->md.N;
-  a.rs_ptr = ctx->rs_ptr.p;
+  a.rrec = ctx->rs_rec.p;
   a.rs_src = ctx->rs_src.p;
   a.AWc = ctx->AWc.p;
   a.AQcc = ctx->AQcc.p;
