@@ -125,8 +125,16 @@ struct cxk_context {
   bool no_ranges = false;              // CXK_NO_RANGES=1: downward sweeps level by level (comparison runs)
   bool no_lean = false;                // CXK_NO_LEAN=1: generic kernels only (comparison runs)
   std::vector<unsigned char> level_big;  // level holds a supernode beyond the wave-per-supernode kernels
-  std::vector<unsigned char> level_inline;  // every supernode of the level carries its separator list inline (tree_backward_level)
-  std::vector<int> level_shape;          // > 0: every supernode of the level has this register shape and dense pulls (tree_factor_level)
+  // A level's (non-huge) supernodes are sorted into SEGMENTS of one register shape; a segment
+  // whose pulls fit the dense slots takes tree_factor_level, one whose separator lists are inline
+  // takes tree_backward_level, anything else the generic tree_sweep on its sub-range.
+  struct LevelSeg {
+    int begin = 0, end = 0;  // positions into the level-ordered records
+    int shape = 0;           // NSMAX << 8 | SMAX, 0 = no register kernel
+    bool fast = false, inl = false;
+  };
+  std::vector<std::vector<LevelSeg>> level_segs;
+  std::vector<unsigned char> level_lean;  // every segment of the level has both lean kernels
   // supernodes whose panel exceeds LDS sit at the END of their level list and are swept one by
   // one through the blocked HBM path (kernels_kkt_big.hip.h); level_nh = count of the others
   std::vector<int> level_nh;
@@ -832,6 +840,12 @@ int BuildPlans(cxk_context* ctx) {
   auto panel_bytes = [&](int e) {
     return sizeof(double) * ((size_t)ns[e] * ns[e] + (size_t)ns[e] * nsep[e] + 3 * (size_t)ns[e] + 2);
   };
+  // (register shape, dense pulls, inline separator list) of a supernode: see cxk_context::LevelSeg
+  auto seg_fast = [&](int e) {
+    return h_tg_ptr[e + 1] - h_tg_ptr[e] <= kFastTargets && h_m[e] <= kFastSlots && h_mf[e] <= kFastSlots;
+  };
+  auto seg_inline = [&](int e) { return h_bs_ptr[e + 1] - h_bs_ptr[e] <= 8 && N < (1 << 26); };
+  auto seg_key = [&](int e) { return std::make_tuple(RegisterShape(ns[e], nsep[e]), seg_fast(e), seg_inline(e)); };
   for (int l = 0; l < nlev; l++) {
     std::vector<int> huge;
     for (int e = 0; e < K; e++)
@@ -848,6 +862,9 @@ int BuildPlans(cxk_context* ctx) {
         ctx->chol_lds = std::max(ctx->chol_lds, sizeof(double) * 64 * (size_t)(RegisterShape(ns[e], nsep[e]) >> 8));
       }
     ctx->level_nh[l] = (int)ctx->level_sn.size() - ctx->level_ptr[l];
+    // segments: supernodes of a level are independent, so their order inside it is free
+    std::stable_sort(ctx->level_sn.begin() + ctx->level_ptr[l], ctx->level_sn.end(),
+                     [&](int a, int b) { return seg_key(a) < seg_key(b); });
     for (int e : huge) ctx->level_sn.push_back(e);
     ctx->level_ptr[l + 1] = (int)ctx->level_sn.size();
   }
@@ -891,24 +908,34 @@ int BuildPlans(cxk_context* ctx) {
     CXK_TRY(ctx->p_rec.upload(recs));
     h_recs = recs;
     ctx->h_recs = recs;
-    // levels of one register shape whose pulls all fit the dense slots: tree_factor_level
-    ctx->level_shape.assign(nlev, 0);
-    ctx->level_inline.assign(nlev, 1);
+    ctx->level_segs.assign(nlev, {});
+    ctx->level_lean.assign(nlev, 0);
     for (int l = 0; l < nlev; l++) {
-      for (int pos = ctx->level_ptr[l]; pos < ctx->level_ptr[l + 1]; pos++)
-        if (recs[pos].nsep_inline != recs[pos].bs_end - recs[pos].bs_beg) ctx->level_inline[l] = 0;
-      int shape = -1;
-      if (ctx->level_nh[l] != ctx->level_ptr[l + 1] - ctx->level_ptr[l]) shape = 0;
-      for (int pos = ctx->level_ptr[l]; pos < ctx->level_ptr[l + 1] && shape != 0; pos++) {
-        const SnRec& r = recs[pos];
-        const int sh = RegisterShape(r.ns, r.nsep);
-        const bool fast = r.tg_end - r.tg_beg <= kFastTargets && r.m <= kFastSlots && r.mf <= kFastSlots;
-        if (!fast || sh == 0 || (shape > 0 && sh != shape))
-          shape = 0;
-        else
-          shape = sh;
+      const int first = ctx->level_ptr[l], last = first + ctx->level_nh[l];
+      bool all = ctx->level_nh[l] == ctx->level_ptr[l + 1] - ctx->level_ptr[l] && last > first;
+      for (int pos = first; pos < last; pos++) {
+        const int e = ctx->level_sn[pos];
+        auto& segs = ctx->level_segs[l];
+        const int sh = RegisterShape(ns[e], nsep[e]);
+        const bool fast = seg_fast(e), inl = seg_inline(e);
+        if (segs.empty() || segs.back().shape != sh || segs.back().fast != fast || segs.back().inl != inl) {
+          cxk_context::LevelSeg sg;
+          sg.begin = pos;
+          sg.shape = sh;
+          sg.fast = fast;
+          sg.inl = inl;
+          segs.push_back(sg);
+        }
+        segs.back().end = pos + 1;
+        all = all && sh > 0 && fast && inl;
       }
-      ctx->level_shape[l] = shape > 0 ? shape : 0;
+      ctx->level_lean[l] = all;
+      if (getenv("CXK_DEBUG_LEVELS")) {
+        fprintf(stderr, "level %d:", l);
+        for (auto& sg : ctx->level_segs[l])
+          fprintf(stderr, " [%d x <%d,%d>%s%s]", sg.end - sg.begin, sg.shape >> 8, sg.shape & 255, sg.fast ? " fast" : "", sg.inl ? " inline" : "");
+        fprintf(stderr, " + %d beyond LDS\n", ctx->level_ptr[l + 1] - ctx->level_ptr[l] - ctx->level_nh[l]);
+      }
     }
   }
   // narrow top of the tree: trailing levels that hold few supernodes are swept by one workgroup
@@ -926,7 +953,7 @@ int BuildPlans(cxk_context* ctx) {
     // the one-workgroup sweep: there a kernel boundary per step would dominate.
     if (!ctx->no_lean && !getenv("CXK_KEEP_TOP") && top < nlev && nlev - top <= kSplitTopLevels) {
       bool all = true;
-      for (int l = top; l < nlev; l++) all = all && ctx->level_shape[l] > 0 && ctx->level_inline[l];
+      for (int l = top; l < nlev; l++) all = all && ctx->level_lean[l];
       if (all) top = nlev;
     }
     ctx->top_level = top;
@@ -1108,7 +1135,7 @@ int BuildPlans(cxk_context* ctx) {
           hi++;
         }
       bool all_lean = !ctx->no_lean;
-      for (int l = lo; l < hi; l++) all_lean = all_lean && ctx->level_shape[l] > 0 && ctx->level_inline[l];
+      for (int l = lo; l < hi; l++) all_lean = all_lean && ctx->level_lean[l];
       if (all_lean) {  // every level has its shape-specialised backward kernel: faster than the merged sweep
         lo = hi;
         continue;
@@ -1502,50 +1529,55 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
     return CXK_SUCCESS;
   }
   double* rhs = (with_rhs || mode != 0) ? ctx->y.p : nullptr;
-  if (!is_top && waves > 4) {  // the shape-specialised level kernels are compiled for <= 256 threads
-    const bool lean = ctx->level_shape[lb] > 0 && !ctx->no_lean && (mode == 0 || (mode == 2 && ctx->level_inline[lb]));
-    if (lean) {
-      waves = 4;
-      grid = (maxcnt + waves - 1) / waves;
+  if (!is_top && (mode == 0 || mode == 2) && !ctx->no_lean) {
+    // segment by segment: the kernel compiled for the segment's register shape alone where its
+    // supernodes qualify, the generic kernel on the sub-range otherwise
+    auto lean = [&](const cxk_context::LevelSeg& sg) { return sg.shape > 0 && (mode == 0 ? sg.fast : sg.inl); };
+    bool any = false;
+    for (auto& sg : ctx->level_segs[lb]) any = any || lean(sg);
+    if (any) {
+      for (auto& sg : ctx->level_segs[lb]) {
+        const int cnt = sg.end - sg.begin;
+        if (!lean(sg)) {
+          const int w = std::max(1, std::min(wmax, (cnt + 255) / 256));
+          const int g = (cnt + w - 1) / w;
+          if (mode == 0)
+            tree_sweep<0, false><<<g, w * 64, (size_t)w * ctx->chol_lds, ctx->stream>>>(
+                ctx->plan, ctx->p_rec.p, nullptr, sg.begin, cnt, 1, 0, ctx->slab.p, rhs, ctx->d_fail.p, per_wave);
+          else
+            tree_sweep<2, false><<<g, w * 64, (size_t)w * ctx->chol_lds, ctx->stream>>>(
+                ctx->plan, ctx->p_rec.p, nullptr, sg.begin, cnt, 1, 0, ctx->slab.p, rhs, ctx->d_fail.p, per_wave);
+          continue;
+        }
+        // the shape-specialised level kernels are compiled for <= 256 threads
+        const int w = std::max(1, std::min(std::min(wmax, 4), (cnt + 255) / 256));
+        const int g = (cnt + w - 1) / w;
+        const size_t lds = (size_t)w * ctx->chol_lds;
+        const int sh = sg.shape;
+#define CXK_LEVEL(NS_, S_)                                                                              \
+  if (sh == ((NS_) << 8 | (S_))) {                                                                      \
+    if (mode == 2)                                                                                      \
+      tree_backward_level<NS_, S_><<<g, w * 64, 0, ctx->stream>>>(ctx->p_rec.p, sg.begin, cnt,          \
+                                                                  ctx->slab.p, rhs);                    \
+    else if (rhs)                                                                                       \
+      tree_factor_level<NS_, S_, true><<<g, w * 64, lds, ctx->stream>>>(                                \
+          ctx->plan, ctx->p_rec.p, sg.begin, cnt, ctx->slab.p, rhs, ctx->d_fail.p, per_wave);           \
+    else                                                                                                \
+      tree_factor_level<NS_, S_, false><<<g, w * 64, lds, ctx->stream>>>(                               \
+          ctx->plan, ctx->p_rec.p, sg.begin, cnt, ctx->slab.p, rhs, ctx->d_fail.p, per_wave);           \
+  }
+        CXK_LEVEL(8, 8)
+        CXK_LEVEL(16, 8)
+        CXK_LEVEL(24, 0)
+        CXK_LEVEL(24, 8)
+        CXK_LEVEL(32, 16)
+#undef CXK_LEVEL
+      }
+      CXK_TRY(hipGetLastError());
+      return CXK_SUCCESS;
     }
   }
   const size_t lds = (size_t)waves * ctx->chol_lds;
-  if (mode == 2 && !is_top && ctx->level_shape[lb] > 0 && ctx->level_inline[lb] && !ctx->no_lean) {
-    const int sh = ctx->level_shape[lb];
-#define CXK_LEVEL(NS_, S_)                                                                     \
-  if (sh == ((NS_) << 8 | (S_)))                                                               \
-    tree_backward_level<NS_, S_><<<grid, waves * 64, 0, ctx->stream>>>(ctx->p_rec.p, ctx->level_ptr[lb], \
-                                                                       maxcnt, ctx->slab.p, rhs);
-    CXK_LEVEL(8, 8)
-    CXK_LEVEL(16, 8)
-    CXK_LEVEL(24, 0)
-    CXK_LEVEL(24, 8)
-    CXK_LEVEL(32, 16)
-#undef CXK_LEVEL
-    CXK_TRY(hipGetLastError());
-    return CXK_SUCCESS;
-  }
-  if (mode == 0 && !is_top && ctx->level_shape[lb] > 0 && !ctx->no_lean) {
-    // the whole level has one register shape: kernel compiled for that shape alone
-    const int sh = ctx->level_shape[lb];
-#define CXK_LEVEL(NS_, S_)                                                                              \
-  if (sh == ((NS_) << 8 | (S_))) {                                                                      \
-    if (rhs)                                                                                            \
-      tree_factor_level<NS_, S_, true><<<grid, waves * 64, lds, ctx->stream>>>(                         \
-          ctx->plan, ctx->p_rec.p, ctx->level_ptr[lb], maxcnt, ctx->slab.p, rhs, ctx->d_fail.p, per_wave); \
-    else                                                                                                \
-      tree_factor_level<NS_, S_, false><<<grid, waves * 64, lds, ctx->stream>>>(                        \
-          ctx->plan, ctx->p_rec.p, ctx->level_ptr[lb], maxcnt, ctx->slab.p, rhs, ctx->d_fail.p, per_wave); \
-  }
-    CXK_LEVEL(8, 8)
-    CXK_LEVEL(16, 8)
-    CXK_LEVEL(24, 0)
-    CXK_LEVEL(24, 8)
-    CXK_LEVEL(32, 16)
-#undef CXK_LEVEL
-    CXK_TRY(hipGetLastError());
-    return CXK_SUCCESS;
-  }
   // the top [lb, le) is ONE piece: its level table is the level_ptr slice itself (positions into
   // the level-ordered records)
 #define CXK_SWEEP(MODE, TOP)                                                                   \
