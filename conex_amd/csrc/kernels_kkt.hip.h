@@ -1176,6 +1176,48 @@ tree_backward_level(const SnRec* __restrict__ recs, int base0, int cnt0, const d
   CXK_STAMPB(5);
 }
 
+// Two segments of one level in ONE launch (the supernodes of a level are independent): workgroups
+// [0, blocksA) run shape A, the rest shape B.  Programs that mix small cones (second-order cones:
+// shape <8,8>) with matrix cones have two shapes on every level; two launches would serialise.
+template <int NA, int SA, int NB, int SB, bool RHS>
+__global__ void __launch_bounds__(256)
+tree_factor_level2(FactorPlan P, const SnRec* __restrict__ recs, int baseA, int cntA, int blocksA,
+                   int baseB, int cntB, double* __restrict__ slab, double* __restrict__ rhs,
+                   int* __restrict__ fail, int lds_per_wave) {
+  extern __shared__ double lds[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  double* my = lds + (size_t)wave * lds_per_wave;
+  if ((int)blockIdx.x < blocksA) {
+    const int idx = blockIdx.x * nw + wave;
+    if (idx >= cntA) return;
+    const SnRec R = LoadRec(recs, baseA + idx);
+    FactorSupernodeLean<NA, SA, RHS>(P, R, slab, rhs, fail, my);
+  } else {
+    const int idx = (blockIdx.x - blocksA) * nw + wave;
+    if (idx >= cntB) return;
+    const SnRec R = LoadRec(recs, baseB + idx);
+    FactorSupernodeLean<NB, SB, RHS>(P, R, slab, rhs, fail, my);
+  }
+}
+
+template <int NA, int SA, int NB, int SB>
+__global__ void __launch_bounds__(256)
+tree_backward_level2(const SnRec* __restrict__ recs, int baseA, int cntA, int blocksA, int baseB, int cntB,
+                     const double* __restrict__ slab, double* __restrict__ rhs) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  if ((int)blockIdx.x < blocksA) {
+    const int idx = blockIdx.x * nw + wave;
+    if (idx >= cntA) return;
+    const SnRec R = LoadRec(recs, baseA + idx);
+    BackwardSupernodeLean<NA, SA>(R, slab, rhs);
+  } else {
+    const int idx = (blockIdx.x - blocksA) * nw + wave;
+    if (idx >= cntB) return;
+    const SnRec R = LoadRec(recs, baseB + idx);
+    BackwardSupernodeLean<NB, SB>(R, slab, rhs);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Mid-size supernodes (ns > 32 or s > 16, panel still LDS resident): ONE WORKGROUP per
 // supernode.  Same arithmetic as the register kernels -- right-looking elimination with

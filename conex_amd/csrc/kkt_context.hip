@@ -1203,6 +1203,13 @@ hipError_t RaiseLdsLimits() {
         reinterpret_cast<const void*>(&lmi_prepare_generic<0, 0>),
         reinterpret_cast<const void*>(&lmi_prepare_generic<1, 0>),
         reinterpret_cast<const void*>(&lmi_take_step_generic<0>),
+#define CXK_PAIR_K(NA_, SA_, NB_, SB_)                                              \
+  reinterpret_cast<const void*>(&tree_factor_level2<NA_, SA_, NB_, SB_, true>),      \
+      reinterpret_cast<const void*>(&tree_factor_level2<NA_, SA_, NB_, SB_, false>),
+        CXK_PAIR_K(8, 8, 16, 8) CXK_PAIR_K(8, 8, 24, 0) CXK_PAIR_K(8, 8, 24, 8) CXK_PAIR_K(8, 8, 32, 16)
+        CXK_PAIR_K(16, 8, 24, 0) CXK_PAIR_K(16, 8, 24, 8) CXK_PAIR_K(16, 8, 32, 16)
+        CXK_PAIR_K(24, 0, 24, 8) CXK_PAIR_K(24, 0, 32, 16) CXK_PAIR_K(24, 8, 32, 16)
+#undef CXK_PAIR_K
         reinterpret_cast<const void*>(&tree_factor_level<8, 8, true>),
         reinterpret_cast<const void*>(&tree_factor_level<8, 8, false>),
         reinterpret_cast<const void*>(&tree_factor_level<16, 8, true>),
@@ -1536,8 +1543,48 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
     bool any = false;
     for (auto& sg : ctx->level_segs[lb]) any = any || lean(sg);
     if (any) {
-      for (auto& sg : ctx->level_segs[lb]) {
+      const auto& segs = ctx->level_segs[lb];
+      for (size_t si = 0; si < segs.size(); si++) {
+        const auto& sg = segs[si];
         const int cnt = sg.end - sg.begin;
+        if (lean(sg) && si + 1 < segs.size() && lean(segs[si + 1])) {
+          // two lean segments: one launch, workgroups [0, gA) on shape A and the rest on shape B
+          const auto& sb = segs[si + 1];
+          const int cntB = sb.end - sb.begin;
+          const int w = std::max(1, std::min(std::min(wmax, 4), (std::max(cnt, cntB) + 255) / 256));
+          const int gA = (cnt + w - 1) / w, gB = (cntB + w - 1) / w;
+          const size_t lds = (size_t)w * ctx->chol_lds;
+          const int sa = sg.shape, sb2 = sb.shape;
+          bool done = false;
+#define CXK_PAIR(NA_, SA_, NB_, SB_)                                                                         \
+  if (!done && sa == ((NA_) << 8 | (SA_)) && sb2 == ((NB_) << 8 | (SB_))) {                                  \
+    done = true;                                                                                             \
+    if (mode == 2)                                                                                           \
+      tree_backward_level2<NA_, SA_, NB_, SB_><<<gA + gB, w * 64, 0, ctx->stream>>>(                         \
+          ctx->p_rec.p, sg.begin, cnt, gA, sb.begin, cntB, ctx->slab.p, rhs);                                \
+    else if (rhs)                                                                                            \
+      tree_factor_level2<NA_, SA_, NB_, SB_, true><<<gA + gB, w * 64, lds, ctx->stream>>>(                   \
+          ctx->plan, ctx->p_rec.p, sg.begin, cnt, gA, sb.begin, cntB, ctx->slab.p, rhs, ctx->d_fail.p, per_wave); \
+    else                                                                                                     \
+      tree_factor_level2<NA_, SA_, NB_, SB_, false><<<gA + gB, w * 64, lds, ctx->stream>>>(                  \
+          ctx->plan, ctx->p_rec.p, sg.begin, cnt, gA, sb.begin, cntB, ctx->slab.p, rhs, ctx->d_fail.p, per_wave); \
+  }
+          CXK_PAIR(8, 8, 16, 8)
+          CXK_PAIR(8, 8, 24, 0)
+          CXK_PAIR(8, 8, 24, 8)
+          CXK_PAIR(8, 8, 32, 16)
+          CXK_PAIR(16, 8, 24, 0)
+          CXK_PAIR(16, 8, 24, 8)
+          CXK_PAIR(16, 8, 32, 16)
+          CXK_PAIR(24, 0, 24, 8)
+          CXK_PAIR(24, 0, 32, 16)
+          CXK_PAIR(24, 8, 32, 16)
+#undef CXK_PAIR
+          if (done) {
+            si++;
+            continue;
+          }
+        }
         if (!lean(sg)) {
           const int w = std::max(1, std::min(wmax, (cnt + 255) / 256));
           const int g = (cnt + w - 1) / w;
