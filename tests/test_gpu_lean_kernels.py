@@ -1,0 +1,101 @@
+"""The shape-specialised tree kernels (tree_factor_level / tree_backward_level and their two-shape
+forms) restate the generic sweep with a straight-line load phase: same operations
+in the same order, so their results must equal the generic kernels' BIT FOR BIT.  CXK_NO_LEAN=1
+(read when a context is initialized) selects the generic kernels for the comparison; both paths
+are also held against the oracle by the other GPU tests."""
+import os
+
+import numpy as np
+import pytest
+
+from conex_amd import KktContext
+from conex_amd import synthetic as syn
+from test_gpu_random_structures import build as build_random
+from test_gpu_random_structures import random_program
+
+pytestmark = pytest.mark.gpu
+
+
+def both_paths(make):
+    """-> (lean context, generic context), same program."""
+    os.environ.pop("CXK_NO_LEAN", None)
+    lean = make()
+    os.environ["CXK_NO_LEAN"] = "1"
+    try:
+        generic = make()
+    finally:
+        os.environ.pop("CXK_NO_LEAN", None)
+    return lean, generic
+
+
+def solve_twice(k, b):
+    k.set_cost(b)
+    out = []
+    for mu in (0.7, 0.4):
+        k.kkt_solve_async(mu, 0.9, 0.8)
+        assert k.sync()
+        out.append((k.get_y().copy(), k.slab().copy()))
+        k.solve_rhs(-0.9, 0.8, 0.0)          # solve-only path on the stored factor
+        assert k.sync()
+        out.append((k.get_y().copy(), None))
+    return out
+
+
+def assert_same_bits(lean, generic, b):
+    for (y1, s1), (y2, s2) in zip(solve_twice(lean, b), solve_twice(generic, b)):
+        assert np.array_equal(y1, y2)
+        if s1 is not None:
+            assert np.array_equal(s1, s2)
+
+
+@pytest.mark.parametrize("K,branching", [(100, 8), (73, 3), (40, 1)])
+def test_lmi_tree_lean_equals_generic(K, branching):
+    prob = syn.lmi_problem(K=K, n=20, m=20, branching=branching, overlap=5, seed=11)
+    W = syn.scaling_points(K, 20, seed=12)
+
+    def make():
+        k = syn.build(KktContext, prob, "lmi", device=0)
+        for i in range(k.K):
+            k.set_W(i, W[i])
+        return k
+
+    lean, generic = both_paths(make)
+    assert_same_bits(lean, generic, prob["b"])
+
+
+def test_soc_tree_lean_equals_generic():
+    prob = syn.soc_problem(K=300, dim=10, m=10, overlap=2, tree=8)
+    W = syn.soc_scaling_points(300, 10)
+
+    def make():
+        k = syn.build(KktContext, prob, "soc", device=0)
+        for i in range(k.K):
+            k.set_W(i, W[i])
+        return k
+
+    lean, generic = both_paths(make)
+    assert_same_bits(lean, generic, prob["b"])
+
+
+def test_mixed_shapes_lean_equals_generic():
+    # Hermitian order-12 cones (shape <24,8>) and second-order cones (<8,8>) on every level:
+    # the two-shape launches
+    prob = syn.mixed_problem(K=230)
+    W = syn.mixed_scaling_points(prob)
+
+    def make():
+        k = syn.build(KktContext, prob, "mixed", device=0)
+        for i in range(k.K):
+            k.set_W(i, W[i])
+        return k
+
+    lean, generic = both_paths(make)
+    assert_same_bits(lean, generic, prob["b"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_structures_lean_equals_generic(seed):
+    # ragged cliques: levels split into several segments, some without a lean kernel
+    prob = random_program(2000 + seed)
+    lean, generic = both_paths(lambda: build_random(KktContext, prob, device=0))
+    assert_same_bits(lean, generic, prob["b"])
