@@ -822,6 +822,63 @@ __device__ inline void BackwardSupernodeRows(const FactorPlan& P, const SnRec& R
   if (active) rhs[R.start + lane] = acc;
 }
 
+// ForwardSupernodeWave (b_j <- L_j^{-1} (b_j - pulled forward updates), publish t[c] = off[:,c].b)
+// in the row-per-lane register layout with a straight-line load phase: lane r < ns holds row r of
+// L, lane NSMAX + c holds column c of the off block.  Operations and their order are those of the
+// generic kernel (reciprocal of the diagonal, multiply-then-subtract substitution, fma chain over
+// the rows for t[c]), so the results are the same bits.  Needs dense forward slots (R.mf <= 8).
+template <int NSMAX, int SMAX>
+__device__ __forceinline__ void ForwardSupernodeLean(const FactorPlan& P, const SnRec& R,
+                                                     const double* __restrict__ slab,
+                                                     double* __restrict__ rhs) {
+  constexpr int MFMAX = kFastSlots;
+  const int lane = threadIdx.x & 63;
+  const int ns = R.ns, s = R.nsep;
+  const bool is_row = lane < ns;
+  const int sc = lane - NSMAX;
+  const bool is_sep = sc >= 0 && sc < s;
+  const double* base = slab + R.diag_off;
+  const unsigned rel = (unsigned)(R.offd_off - R.diag_off);
+  const unsigned o0 = is_row ? (unsigned)lane : (is_sep ? rel + (unsigned)(sc * ns) : 0u);
+  const unsigned st = is_row ? (unsigned)ns : 1u;
+  const int lim = is_row ? lane : (is_sep ? ns : 0);  // strictly lower part of a row; a whole off column
+  // ---- load phase: no consumer before the last load
+  double a[NSMAX > 0 ? NSMAX : 1];
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++) a[j] = base[(j < lim) ? o0 + j * st : 0u];
+  double dg = base[is_row ? (unsigned)lane * (unsigned)(ns + 1) : 0u];
+  double b = rhs[R.start + (is_row ? lane : 0)];
+  int pdstb = 0;
+  if constexpr (SMAX > 0) pdstb = P.pubb_dst[R.updb_off + (is_sep ? sc : 0)];
+  const int mflast = R.mf > 0 ? R.mf - 1 : 0;
+  double pb[MFMAX];
+  {
+    const double* src = P.updb + R.fbase + (is_row ? lane : 0) * R.mf;
+#pragma unroll
+    for (int i = 0; i < MFMAX; i++) pb[i] = src[i < R.mf ? i : mflast];
+  }
+  // ---- consumers
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? a[j] : 0.0;
+  b = is_row ? b : 0.0;
+#pragma unroll
+  for (int i = 0; i < MFMAX; i++) b -= (is_row && i < R.mf) ? pb[i] : 0.0;
+  const double dinv = is_row ? 1.0 / dg : 0.0;
+  double dot = 0.0;
+#pragma unroll
+  for (int k = 0; k < NSMAX; k++) {
+    if (lane == k) b *= dinv;
+    const double bk = ReadLane(b, k);  // 0.0 for padding rows k >= ns
+    if (is_sep)
+      dot = fma(a[k], bk, dot);
+    else
+      b -= a[k] * bk;  // a[k] is zero for lanes <= k
+  }
+  if (is_row) rhs[R.start + lane] = b;
+  if constexpr (SMAX > 0)
+    if (is_sep) P.updb[pdstb] = dot;
+}
+
 // BackwardSupernodeRows with a straight-line load phase (see FactorSupernodeLean): column of L,
 // off-block entries and the separator values y[sep] all load unconditionally from clamped
 // addresses, masks are applied afterwards.  Needs the inline separator list (R.nsep_inline == count).
@@ -1174,6 +1231,35 @@ tree_backward_level(const SnRec* __restrict__ recs, int base0, int cnt0, const d
   const SnRec R = LoadRec(recs, base0 + idx);
   BackwardSupernodeLean<NSMAX, SMAX>(R, slab, rhs);
   CXK_STAMPB(5);
+}
+
+template <int NSMAX, int SMAX>
+__global__ void __launch_bounds__(256)
+tree_forward_level(FactorPlan P, const SnRec* __restrict__ recs, int base0, int cnt0,
+                   const double* __restrict__ slab, double* __restrict__ rhs) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const int idx = blockIdx.x * nw + wave;
+  if (idx >= cnt0) return;
+  const SnRec R = LoadRec(recs, base0 + idx);
+  ForwardSupernodeLean<NSMAX, SMAX>(P, R, slab, rhs);
+}
+
+template <int NA, int SA, int NB, int SB>
+__global__ void __launch_bounds__(256)
+tree_forward_level2(FactorPlan P, const SnRec* __restrict__ recs, int baseA, int cntA, int blocksA,
+                    int baseB, int cntB, const double* __restrict__ slab, double* __restrict__ rhs) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  if ((int)blockIdx.x < blocksA) {
+    const int idx = blockIdx.x * nw + wave;
+    if (idx >= cntA) return;
+    const SnRec R = LoadRec(recs, baseA + idx);
+    ForwardSupernodeLean<NA, SA>(P, R, slab, rhs);
+  } else {
+    const int idx = (blockIdx.x - blocksA) * nw + wave;
+    if (idx >= cntB) return;
+    const SnRec R = LoadRec(recs, baseB + idx);
+    ForwardSupernodeLean<NB, SB>(P, R, slab, rhs);
+  }
 }
 
 // Two segments of one level in ONE launch (the supernodes of a level are independent): workgroups

@@ -1536,10 +1536,10 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
     return CXK_SUCCESS;
   }
   double* rhs = (with_rhs || mode != 0) ? ctx->y.p : nullptr;
-  if (!is_top && (mode == 0 || mode == 2) && !ctx->no_lean) {
+  if (!is_top && !ctx->no_lean) {
     // segment by segment: the kernel compiled for the segment's register shape alone where its
     // supernodes qualify, the generic kernel on the sub-range otherwise
-    auto lean = [&](const cxk_context::LevelSeg& sg) { return sg.shape > 0 && (mode == 0 ? sg.fast : sg.inl); };
+    auto lean = [&](const cxk_context::LevelSeg& sg) { return sg.shape > 0 && (mode == 2 ? sg.inl : sg.fast); };
     bool any = false;
     for (auto& sg : ctx->level_segs[lb]) any = any || lean(sg);
     if (any) {
@@ -1562,6 +1562,9 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
     if (mode == 2)                                                                                           \
       tree_backward_level2<NA_, SA_, NB_, SB_><<<gA + gB, w * 64, 0, ctx->stream>>>(                         \
           ctx->p_rec.p, sg.begin, cnt, gA, sb.begin, cntB, ctx->slab.p, rhs);                                \
+    else if (mode == 1)                                                                                      \
+      tree_forward_level2<NA_, SA_, NB_, SB_><<<gA + gB, w * 64, 0, ctx->stream>>>(                          \
+          ctx->plan, ctx->p_rec.p, sg.begin, cnt, gA, sb.begin, cntB, ctx->slab.p, rhs);                     \
     else if (rhs)                                                                                            \
       tree_factor_level2<NA_, SA_, NB_, SB_, true><<<gA + gB, w * 64, lds, ctx->stream>>>(                   \
           ctx->plan, ctx->p_rec.p, sg.begin, cnt, gA, sb.begin, cntB, ctx->slab.p, rhs, ctx->d_fail.p, per_wave); \
@@ -1591,6 +1594,9 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
           if (mode == 0)
             tree_sweep<0, false><<<g, w * 64, (size_t)w * ctx->chol_lds, ctx->stream>>>(
                 ctx->plan, ctx->p_rec.p, nullptr, sg.begin, cnt, 1, 0, ctx->slab.p, rhs, ctx->d_fail.p, per_wave);
+          else if (mode == 1)
+            tree_sweep<1, false><<<g, w * 64, (size_t)w * ctx->chol_lds, ctx->stream>>>(
+                ctx->plan, ctx->p_rec.p, nullptr, sg.begin, cnt, 1, 0, ctx->slab.p, rhs, ctx->d_fail.p, per_wave);
           else
             tree_sweep<2, false><<<g, w * 64, (size_t)w * ctx->chol_lds, ctx->stream>>>(
                 ctx->plan, ctx->p_rec.p, nullptr, sg.begin, cnt, 1, 0, ctx->slab.p, rhs, ctx->d_fail.p, per_wave);
@@ -1606,6 +1612,9 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
     if (mode == 2)                                                                                      \
       tree_backward_level<NS_, S_><<<g, w * 64, 0, ctx->stream>>>(ctx->p_rec.p, sg.begin, cnt,          \
                                                                   ctx->slab.p, rhs);                    \
+    else if (mode == 1)                                                                                 \
+      tree_forward_level<NS_, S_><<<g, w * 64, 0, ctx->stream>>>(ctx->plan, ctx->p_rec.p, sg.begin,     \
+                                                                 cnt, ctx->slab.p, rhs);                \
     else if (rhs)                                                                                       \
       tree_factor_level<NS_, S_, true><<<g, w * 64, lds, ctx->stream>>>(                                \
           ctx->plan, ctx->p_rec.p, sg.begin, cnt, ctx->slab.p, rhs, ctx->d_fail.p, per_wave);           \
