@@ -1664,6 +1664,50 @@ tree_sweep_block_ldlt(FactorPlan P, int base0, double* __restrict__ slab, double
 }
 
 // ---------------------------------------------------------------------------------------
+// Iterative refinement (SupernodalKKTSolver::SolveInPlace, kkt_solver.cc:233-261):
+//   y <- y + K^-1 (b - K y)   with K = the assembled matrix, kept in `slab0` by the factor sweep.
+// The reference multiplies a dense N x N copy; here K y comes from the supernodal blocks:
+// kkt_matvec (one workgroup per supernode) forms  u[sn] = sym(diag) y[sn] + off y[sep]  and
+// publishes  t[c] = off[:,c] . y[sn]  into the forward-solve slots' twin `mvb`; refine_residual
+// gathers them per row in list order (deterministic) into  r = b - K y, saves y and puts r in its place.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+kkt_matvec(FactorPlan P, const double* __restrict__ slab0, const double* __restrict__ y,
+           double* __restrict__ u, double* __restrict__ mvb) {
+  const SnRec R = LoadRec(P.rec, blockIdx.x);
+  const int ns = R.ns, s = R.nsep, tid = threadIdx.x, nt = blockDim.x;
+  const double* D = slab0 + R.diag_off;
+  const double* B = slab0 + R.offd_off;
+  for (int i = tid; i < ns; i += nt) {
+    double acc = 0;
+    for (int j = 0; j < ns; j++) acc += (j <= i ? D[i + (size_t)j * ns] : D[j + (size_t)i * ns]) * y[R.start + j];
+    for (int q = R.bs_beg; q < R.bs_end; q++) acc += B[i + (size_t)P.bs_c[q] * ns] * y[P.bs_row[q]];
+    u[R.start + i] = acc;
+  }
+  for (int c = tid; c < s; c += nt) {
+    double dot = 0;
+    for (int i = 0; i < ns; i++) dot += B[i + (size_t)c * ns] * y[R.start + i];
+    mvb[P.pubb_dst[R.updb_off + c]] = dot;
+  }
+}
+
+__global__ void refine_residual(int N, const double* __restrict__ rhs0, const double* __restrict__ u,
+                                const int* __restrict__ fs_ptr, const int* __restrict__ fs_src,
+                                const double* __restrict__ mvb, double* __restrict__ y,
+                                double* __restrict__ ysave) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) {
+    double ky = u[p];
+    for (int q = fs_ptr[p]; q < fs_ptr[p + 1]; q++) ky += mvb[fs_src[q]];
+    ysave[p] = y[p];
+    y[p] = rhs0[p] - ky;
+  }
+}
+
+__global__ void refine_add(int N, const double* __restrict__ ysave, double* __restrict__ y) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x) y[p] = ysave[p] + y[p];
+}
+
+// ---------------------------------------------------------------------------------------
 // Multi-GPU exchange.  Buffer layout, all doubles:
 //   [ T slab entries (n_xs) | AW_T (n_xv) | AQc_T (n_xv) | fwd_T (n_xv) | <w,c> | <c,Qc> | fail | pad ]
 // pack:   fold this rank's subtree updates into its PARTIAL top blocks (pre-reduce pulls), then

@@ -122,6 +122,11 @@ struct cxk_context {
   std::vector<int> level_ptr, level_sn;
   size_t chol_lds = 0, solve_lds = 0;  // bytes of LDS staging one supernode needs
   int top_level = 0;                   // levels [top_level, nlev) run inside one workgroup
+  // iterative refinement (kkt_solver.cc:233-261): steps per solve, the assembled matrix kept by the
+  // factor sweep, the right-hand side of the running solve, K y pieces, the iterate
+  int refine_iters = 0;
+  bool slab0_valid = false;
+  DevBuf<double> slab0, rhs0, mv_u, mvb, ysave;
   bool no_ranges = false;              // CXK_NO_RANGES=1: downward sweeps level by level (comparison runs)
   bool no_lean = false;                // CXK_NO_LEAN=1: generic kernels only (comparison runs)
   std::vector<unsigned char> level_big;  // level holds a supernode beyond the wave-per-supernode kernels
@@ -1676,7 +1681,36 @@ int LaunchRange(cxk_context* ctx, cxk_context::SweepRange& r, int mode, bool wit
 
 // Bottom-up pass (mode 0 factor or mode 1 forward), optionally continuing straight into the
 // top-down backward pass.  The narrow top of the tree is one launch.
+int LaunchTreeCore(cxk_context* ctx, int mode, bool with_rhs, bool backward);
+
+// A sweep with the refinement steps the reference's SolveInPlace runs after every solve
+// (kkt_solver.cc:233-261); without refinement this is LaunchTreeCore.
 int LaunchTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
+  if (ctx->refine_iters <= 0) return LaunchTreeCore(ctx, mode, with_rhs, backward);
+  const int N = ctx->md.N;
+  const bool solving = backward && (mode != 0 || with_rhs);
+  if (mode == 0) {  // kkt_matrix_ = KKTMatrix() before factoring (kkt_solver.cc:177-179)
+    CXK_TRY(hipMemcpyAsync(ctx->slab0.p, ctx->slab.p, sizeof(double) * ctx->slab.n, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->slab0_valid = true;
+  }
+  if (solving)
+    CXK_TRY(hipMemcpyAsync(ctx->rhs0.p, ctx->y.p, sizeof(double) * N, hipMemcpyDeviceToDevice, ctx->stream));
+  if (LaunchTreeCore(ctx, mode, with_rhs, backward)) return CXK_FAILURE;
+  if (!solving || !ctx->slab0_valid) return CXK_SUCCESS;
+  for (int it = 0; it < ctx->refine_iters; it++) {
+    kkt_matvec<<<(int)ctx->level_sn.size(), 256, 0, ctx->stream>>>(ctx->plan, ctx->slab0.p, ctx->y.p, ctx->mv_u.p,
+                                                                   ctx->mvb.p);
+    refine_residual<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, ctx->rhs0.p, ctx->mv_u.p, ctx->fs_ptr.p,
+                                                              ctx->fs_src.p, ctx->mvb.p, ctx->y.p, ctx->ysave.p);
+    CXK_TRY(hipGetLastError());
+    if (LaunchTreeCore(ctx, 1, true, true)) return CXK_FAILURE;
+    refine_add<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, ctx->ysave.p, ctx->y.p);
+    CXK_TRY(hipGetLastError());
+  }
+  return CXK_SUCCESS;
+}
+
+int LaunchTreeCore(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
   if (ctx->use_ldlt && mode == 0) CXK_TRY(hipMemsetAsync(ctx->d_reg.p, 0, sizeof(int), ctx->stream));
   const int nlev = (int)ctx->level_ptr.size() - 1;
   const int top = ctx->top_level;
@@ -2801,6 +2835,25 @@ int cxk_debug_select(int want) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_cxk_want), &want, sizeof(int)) == hipSuccess ? 0 : 1;
 }
 #endif
+
+// SupernodalKKTSolver::SetIterativeRefinementIterations (kkt_solver.h:37): every solve after the
+// next factorization is followed by `iterations` steps  y <- y + K^-1 (b - K y).
+int cxk_set_iterative_refinement(cxk_context* ctx, int iterations) {
+  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_DEMAND(iterations >= 0, "refinement iterations must be >= 0");
+  CXK_DEMAND(ctx->world <= 1 || iterations == 0, "iterative refinement is single-GPU for now");
+  if (iterations > 0 && ctx->slab0.n == 0) {
+    const size_t N = (size_t)ctx->md.N;
+    CXK_TRY(ctx->slab0.alloc(ctx->slab.n));
+    CXK_TRY(ctx->rhs0.alloc(N));
+    CXK_TRY(ctx->mv_u.alloc(N));
+    CXK_TRY(ctx->ysave.alloc(N));
+    CXK_TRY(ctx->mvb.alloc(ctx->updb.n));
+  }
+  if (iterations != ctx->refine_iters) ctx->slab0_valid = false;
+  ctx->refine_iters = iterations;
+  return CXK_SUCCESS;
+}
 
 int cxk_enable_timing(cxk_context* ctx, int on) {
   if (!ctx) return CXK_FAILURE;

@@ -320,10 +320,10 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     for (int i = 0; i < m; i++) yout[i] = -p->linear_cost[i] * std::numeric_limits<double>::infinity();
     return 0;
   }
-  if (cfg.kkt_solver != 0 || cfg.iterative_refinement_iterations != 0) {
+  if (cfg.kkt_solver != 0) {
     fprintf(stderr,
-            "conex: kkt_solver/iterative_refinement options need the dense KKT matrix and are not "
-            "available on the device path; using LLT without refinement.\n");
+            "conex: the QR kkt_solver needs the dense KKT matrix and is not available on the device "
+            "path; using the supernodal factorization.\n");
   }
   // CONEX_PROFILE=1 in the environment: wall time of set-up, of the iteration loop and of the
   // host side of each device call on stderr
@@ -356,6 +356,9 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     p->initialized = true;
   }
   cxk_context* ctx = p->ctx;
+  // solver.SetIterativeRefinementIterations(config.iterative_refinement_iterations)
+  if (cxk_set_iterative_refinement(ctx, cfg.iterative_refinement_iterations > 0 ? cfg.iterative_refinement_iterations : 0))
+    return 0;
   if (profile) fprintf(stderr, "conex profile: set-up (symbolic analysis, plans, upload) %.2f ms\n", since(t_start));
   const auto t_loop = std::chrono::steady_clock::now();
   p->sqrt_inv_mu.assign(std::max(cfg.max_iterations, 1), 0.0);

@@ -95,6 +95,7 @@ _SIGNATURES = {
     "cxk_step_scalars_async": (C.c_int, [C.c_void_p]),
     "cxk_kernel_time": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     "cxk_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "cxk_set_iterative_refinement": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 
@@ -344,6 +345,11 @@ class KktContext:
         self._check(self.L.cxk_get_residuals(self.h, _dp(AW), _dp(AQc), _dp(sc)),
                     "cxk_get_residuals")
         return AW, AQc, sc
+
+    def set_refinement(self, iterations):
+        """SetIterativeRefinementIterations: takes effect at the next factorization."""
+        self._check(self.L.cxk_set_iterative_refinement(self.h, int(iterations)),
+                    "cxk_set_iterative_refinement")
 
     def factor(self):
         ok = C.c_int(0)

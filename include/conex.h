@@ -46,7 +46,7 @@ typedef struct {
   int initial_centering_steps_coldstart;
   double warmstart_abort_threshold;
   int max_iterations;
-  int iterative_refinement_iterations; /* dense-KKT refinement: accepted, ignored on the device */
+  int iterative_refinement_iterations; /* refinement steps per solve (device: supernodal mat-vec) */
   double infeasibility_threshold;
   double kkt_error_tolerance;
   int enable_rescaling;

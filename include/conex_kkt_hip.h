@@ -247,6 +247,12 @@ int cxk_kernel_time(cxk_context* ctx, int reset, double* avg_ms);
 /* on = 0: off; on = 1: bracket every launch of that kernel with a hipEvent pair; on = P > 1:
  * every P-th launch (an event pair costs a few us of stream time, sampling keeps the timed
  * region representative) */
+/* SupernodalKKTSolver::SetIterativeRefinementIterations (kkt_solver.h:37, loop kkt_solver.cc:233-261):
+ * the next factorization keeps the assembled matrix, and every solve after it runs `iterations`
+ * steps y <- y + K^-1 (b - K y) on the device (supernodal mat-vec; the reference multiplies a
+ * dense N x N copy).  0 switches it off.  Single GPU. */
+int cxk_set_iterative_refinement(cxk_context* ctx, int iterations);
+
 int cxk_enable_timing(cxk_context* ctx, int on);
 
 #ifdef __cplusplus

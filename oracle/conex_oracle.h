@@ -107,6 +107,9 @@ void cxo_get_residuals(const cxo_program* p, double* AW /*N*/, double* AQc /*N*/
                        double* scalars /*2: <w,c>, <c,Qc>*/);
 int cxo_factor(cxo_program* p); /* 1 = success */
 void cxo_solve_inplace(cxo_program* p, double* y /*N*/);
+/* SetIterativeRefinementIterations: the next cxo_factor keeps the dense assembled matrix and every
+ * solve then runs `iterations` refinement steps (kkt_solver.cc:177-179, 233-261) */
+void cxo_set_refinement(cxo_program* p, int iterations);
 void cxo_kkt_matrix(const cxo_program* p, double* out /*N*N, original variable order*/);
 /* PrepareStep over all constraints (cone_program.h:69-90); info = {normsqrd, norminfd} */
 void cxo_prepare_step(cxo_program* p, int affine, double c_weight, double e_weight,

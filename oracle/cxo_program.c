@@ -77,6 +77,10 @@ struct cxo_program {
   double sys_wc;
   double sys_cQc;
   double* b_permuted;
+  /* SetIterativeRefinementIterations kkt_solver.h; kkt_matrix_ = KKTMatrix() kept by Factor when
+   * iterations > 0 (kkt_solver.cc:177-179) */
+  int refinement_iterations;
+  double* kkt_matrix; /* N*N col-major, original variable order */
   int initialized;
   /* WorkspaceStats workspace.h:73-117 */
   double* sqrt_inv_mu;
@@ -169,6 +173,7 @@ void cxo_program_free(cxo_program* p) {
   free(p->sysAW);
   free(p->sysAQc);
   free(p->b_permuted);
+  free(p->kkt_matrix);
   free(p->sqrt_inv_mu);
   free(p);
 }
@@ -659,7 +664,18 @@ void cxo_get_residuals(const cxo_program* p, double* AW, double* AQc, double* sc
 /* Factor kkt_solver.cc:172-199 (LLT branch) */
 /* SupernodalKKTSolver::Factor kkt_solver.cc:172-199: Cholesky unless some constraint carries
  * multipliers, then block LDLT (which always "succeeds"; regularisation is only recorded) */
+void cxo_kkt_matrix(const cxo_program* p, double* out);
+
+/* SetIterativeRefinementIterations (kkt_solver.h): takes effect at the next Factor */
+void cxo_set_refinement(cxo_program* p, int iterations) { p->refinement_iterations = iterations; }
+
 int cxo_factor(cxo_program* p) {
+  if (p->refinement_iterations > 0) { /* kkt_solver.cc:177-179: dense copy before factoring */
+    size_t N = (size_t)p->md->N;
+    free(p->kkt_matrix);
+    p->kkt_matrix = (double*)malloc(sizeof(double) * N * N);
+    cxo_kkt_matrix(p, p->kkt_matrix);
+  }
   int use_cholesky = 1;
   for (int i = 0; i < p->K; i++)
     if (p->dual_vars[i].n > 0) {
@@ -679,7 +695,7 @@ int cxo_factor_regularized(const cxo_program* p) { return p->ws ? p->ws->regular
 
 /* SolveInPlace kkt_solver.cc:220-263 (no refinement): b_perm = Pt^T b ; solves ; b = Pt b_perm.
  * Pt.indices() = permutation_inverse, so (Pt^T b)(i) = b(permutation_inverse[i]). */
-void cxo_solve_inplace(cxo_program* p, double* y) {
+static void solve_once(cxo_program* p, double* y) {
   int N = p->md->N;
   const int* pinv = p->md->permutation_inverse;
   for (int i = 0; i < N; i++) p->b_permuted[i] = y[pinv[i]];
@@ -690,6 +706,35 @@ void cxo_solve_inplace(cxo_program* p, double* y) {
     cxo_apply_block_inverse_of_transpose(p->ws, p->b_permuted);
   }
   for (int i = 0; i < N; i++) y[pinv[i]] = p->b_permuted[i];
+}
+
+/* With refinement (kkt_solver.cc:233-261): y <- y + K^-1 (b - kkt_matrix_ y), `iterations` times,
+ * kkt_matrix_ being the dense copy Factor took of the assembled matrix. */
+void cxo_solve_inplace(cxo_program* p, double* y) {
+  int N = p->md->N;
+  int iters = p->kkt_matrix ? p->refinement_iterations : 0;
+  double* total = NULL;
+  if (iters > 0) {
+    total = (double*)malloc(sizeof(double) * (size_t)N);
+    memcpy(total, y, sizeof(double) * (size_t)N);
+  }
+  solve_once(p, y);
+  if (iters > 0) {
+    double* res = (double*)malloc(sizeof(double) * (size_t)N);
+    for (int it = 0; it < iters; it++) {
+      for (int i = 0; i < N; i++) res[i] = 0.0;
+      for (int j = 0; j < N; j++) { /* kkt_matrix_ * y, column sweep */
+        const double* col = p->kkt_matrix + (size_t)j * N;
+        double yj = y[j];
+        for (int i = 0; i < N; i++) res[i] += col[i] * yj;
+      }
+      for (int i = 0; i < N; i++) res[i] = total[i] - res[i];
+      solve_once(p, res);
+      for (int i = 0; i < N; i++) y[i] += res[i];
+    }
+    free(res);
+    free(total);
+  }
 }
 
 /* KKTMatrix kkt_solver.cc:265-269 : Pt * selfadjoint(ToDense) * Pt^T */

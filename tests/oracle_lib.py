@@ -93,6 +93,7 @@ def lib():
         "cxo_get_residuals": (None, [vp, c_double_p, c_double_p, c_double_p]),
         "cxo_factor": (C.c_int, [vp]),
         "cxo_solve_inplace": (None, [vp, c_double_p]),
+        "cxo_set_refinement": (None, [vp, C.c_int]),
         "cxo_kkt_matrix": (None, [vp, c_double_p]),
         "cxo_prepare_step": (None, [vp, C.c_int, C.c_double, C.c_double, c_double_p, c_double_p]),
         "cxo_take_step": (None, [vp, C.c_int, C.c_double, C.c_double]),
@@ -370,6 +371,9 @@ class Program:
         y = f64(y).copy()
         self.L.cxo_solve_inplace(self.h, dp(y))
         return y
+
+    def set_refinement(self, iterations):
+        self.L.cxo_set_refinement(self.h, int(iterations))
 
     def kkt_matrix(self):
         N = self.N
