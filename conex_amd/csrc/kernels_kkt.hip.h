@@ -645,6 +645,17 @@ __device__ inline void FactorSupernodeRows(const FactorPlan& P, const SnRec& R,
 // an LDS image laid out like the registers (my[64 j + lane], P.tg_reg), written and read back
 // without predicates.  Arithmetic and its order are those of FactorSupernodeRows (masked slots
 // subtract 0.0: exact), so both give the same bits.
+// Register shape (NSMAX << 8 | SMAX) the factor kernels pick for a supernode of ns columns and s
+// separator rows (the dispatch of tree_sweep); 0 = no register kernel.
+__host__ __device__ inline int RegisterShape(int ns, int s) {
+  if (ns <= 8 && s <= 8) return 8 << 8 | 8;
+  if (ns <= 16 && s <= 8) return 16 << 8 | 8;
+  if (ns <= 24 && s == 0) return 24 << 8 | 0;
+  if (ns <= 24 && s <= 8) return 24 << 8 | 8;
+  if (ns <= 32 && s <= 16) return 32 << 8 | 16;
+  return 0;
+}
+
 constexpr int kPullPad = 64;       // spare elements behind pub_dst / pubb_dst / tg_reg / upd / updb
 constexpr int kFastTargets = 128;  // pull targets per supernode (2 per lane)
 constexpr int kFastSlots = 8;      // contributions per target / forward contributions per row
@@ -1301,6 +1312,43 @@ tree_backward_level2(const SnRec* __restrict__ recs, int baseA, int cntA, int bl
     if (idx >= cntB) return;
     const SnRec R = LoadRec(recs, baseB + idx);
     BackwardSupernodeLean<NB, SB>(R, slab, rhs);
+  }
+}
+
+// The CHAIN at the top of the tree -- trailing levels of exactly one supernode each (the root and
+// what leads to it) -- as one launch of ONE wavefront: steps up (MODE 0 factor + forward, MODE 1
+// forward) and straight back down.  Consecutive steps are dependent anyway, so a launch per level
+// buys nothing here; the wavefront passes its published values to itself through memory
+// (workgroup-scope fence between steps: one CU, one L1).  Shapes A and B cover the chain's supernodes.
+template <int MODE, int NA, int SA, int NB, int SB>
+__global__ void __launch_bounds__(64)
+tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, const int* __restrict__ level_ptr, int l0,
+                int l1, double* __restrict__ slab, double* __restrict__ rhs, int* __restrict__ fail) {
+  extern __shared__ double lds[];
+  for (int l = l0; l < l1; l++) {
+    const SnRec R = LoadRec(recs, level_ptr[l]);
+    const bool isA = RegisterShape(R.ns, R.nsep) == (NA << 8 | SA);
+    if constexpr (MODE == 0) {
+      if (isA)
+        FactorSupernodeLean<NA, SA, true>(P, R, slab, rhs, fail, lds);
+      else
+        FactorSupernodeLean<NB, SB, true>(P, R, slab, rhs, fail, lds);
+    } else {
+      if (isA)
+        ForwardSupernodeLean<NA, SA>(P, R, slab, rhs);
+      else
+        ForwardSupernodeLean<NB, SB>(P, R, slab, rhs);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  }
+  for (int l = l1 - 1; l >= l0; l--) {
+    const SnRec R = LoadRec(recs, level_ptr[l]);
+    const bool isA = RegisterShape(R.ns, R.nsep) == (NA << 8 | SA);
+    if (isA)
+      BackwardSupernodeLean<NA, SA>(R, slab, rhs);
+    else
+      BackwardSupernodeLean<NB, SB>(R, slab, rhs);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   }
 }
 

@@ -140,6 +140,9 @@ struct cxk_context {
   };
   std::vector<std::vector<LevelSeg>> level_segs;
   std::vector<unsigned char> level_lean;  // every segment of the level has both lean kernels
+  // the chain at the top: levels [chain_level, nlev) hold one lean supernode each and are swept by
+  // one wavefront in one launch (tree_chain_lean); chain_a / chain_b = the (at most two) shapes
+  int chain_level = 0, chain_a = 0, chain_b = 0;
   // supernodes whose panel exceeds LDS sit at the END of their level list and are swept one by
   // one through the blocked HBM path (kernels_kkt_big.hip.h); level_nh = count of the others
   std::vector<int> level_nh;
@@ -343,18 +346,9 @@ size_t LmiPrepareLds(int n, int m) {
 }
 size_t LmiTakeLds(int n) { return sizeof(double) * (size_t)(5 * n * n); }
 constexpr size_t kLdsLimit = 160 * 1024 - 512;
+constexpr int kChainMaxLevels = 64;  // levels of one supernode each swept by one wavefront (tree_chain_lean)
 constexpr int kSplitTopLevels = 8;  // tops of at most this many levels may be swept level by level
 
-// Register shape (NSMAX << 8 | SMAX) the factor kernels pick for a supernode of ns columns and s
-// separator rows (the dispatch of tree_sweep); 0 = no register kernel.
-inline int RegisterShape(int ns, int s) {
-  if (ns <= 8 && s <= 8) return 8 << 8 | 8;
-  if (ns <= 16 && s <= 8) return 16 << 8 | 8;
-  if (ns <= 24 && s == 0) return 24 << 8 | 0;
-  if (ns <= 24 && s <= 8) return 24 << 8 | 8;
-  if (ns <= 32 && s <= 16) return 32 << 8 | 16;
-  return 0;
-}
 
 // ---------------------------------------------------------------- tree structure + partition
 // Dependency levels of the supernodal elimination tree and (world > 1) the split into a
@@ -962,6 +956,31 @@ int BuildPlans(cxk_context* ctx) {
       if (all) top = nlev;
     }
     ctx->top_level = top;
+    // chain at the top (single GPU, Cholesky, top swept level by level)
+    ctx->chain_level = nlev;
+    if (!sharded && !ctx->use_ldlt && !ctx->no_lean && top == nlev && !getenv("CXK_NO_CHAIN")) {
+      int c0 = nlev, sa = 0, sb = 0;
+      while (c0 > 0 && nlev - c0 < kChainMaxLevels) {
+        const int l = c0 - 1;
+        if (ctx->level_ptr[l + 1] - ctx->level_ptr[l] != 1 || !ctx->level_lean[l]) break;
+        const int sh = ctx->level_segs[l][0].shape;
+        if (sa == 0 || sh == sa) {
+          sa = sh;
+        } else if (sb == 0 || sh == sb) {
+          sb = sh;
+        } else {
+          break;
+        }
+        c0--;
+      }
+      if (sb != 0 && sb < sa) std::swap(sa, sb);
+      const bool pair_ok = sb == 0 || sa == (24 << 8) || sb == (24 << 8);  // compiled pairs hold <24,0>
+      if (nlev - c0 >= 2 && pair_ok) {
+        ctx->chain_level = c0;
+        ctx->chain_a = sa;
+        ctx->chain_b = sb == 0 ? sa : sb;
+      }
+    }
   }
   // ---- the top as one dense T x T factorization (single GPU, Cholesky): tables for
   // tree_top_dense.  Rows = the variables of the top supernodes in elimination order.
@@ -1215,6 +1234,8 @@ hipError_t RaiseLdsLimits() {
         CXK_PAIR_K(16, 8, 24, 0) CXK_PAIR_K(16, 8, 24, 8) CXK_PAIR_K(16, 8, 32, 16)
         CXK_PAIR_K(24, 0, 24, 8) CXK_PAIR_K(24, 0, 32, 16) CXK_PAIR_K(24, 8, 32, 16)
 #undef CXK_PAIR_K
+        reinterpret_cast<const void*>(&tree_chain_lean<0, 32, 16, 32, 16>),
+        reinterpret_cast<const void*>(&tree_chain_lean<0, 24, 0, 32, 16>),
         reinterpret_cast<const void*>(&tree_factor_level<8, 8, true>),
         reinterpret_cast<const void*>(&tree_factor_level<8, 8, false>),
         reinterpret_cast<const void*>(&tree_factor_level<16, 8, true>),
@@ -1733,9 +1754,37 @@ int LaunchTreeCore(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
   // mode 0 with a dense range: levels below it as usual, then ONE dense factorization (+ solves)
   // of everything from dense_level up (kernels_kkt_top.hip.h)
   const bool dense = mode == 0 && ctx->top_dense.on;
-  const int up_end = dense ? ctx->dense_level : top;
+  // the chain at the top: up and straight back down in one launch of one wavefront
+  const bool chain = !dense && backward && ctx->chain_level < nlev && (mode == 1 || (mode == 0 && with_rhs));
+  const int up_end = dense ? ctx->dense_level : (chain ? ctx->chain_level : top);
   for (int l = 0; l < up_end; l++)
     if (LaunchSweep(ctx, l, l + 1, mode, false, with_rhs)) return CXK_FAILURE;
+  if (chain) {
+    const int sa = ctx->chain_a, sb = ctx->chain_b;
+    bool done = false;
+#define CXK_CHAIN(NA_, SA_, NB_, SB_)                                                                       \
+  if (!done && sa == ((NA_) << 8 | (SA_)) && sb == ((NB_) << 8 | (SB_))) {                                  \
+    done = true;                                                                                            \
+    if (mode == 0)                                                                                          \
+      tree_chain_lean<0, NA_, SA_, NB_, SB_><<<1, 64, ctx->chol_lds, ctx->stream>>>(                        \
+          ctx->plan, ctx->p_rec.p, ctx->d_level_ptr.p, ctx->chain_level, nlev, ctx->slab.p, ctx->y.p, ctx->d_fail.p); \
+    else                                                                                                    \
+      tree_chain_lean<1, NA_, SA_, NB_, SB_><<<1, 64, ctx->chol_lds, ctx->stream>>>(                        \
+          ctx->plan, ctx->p_rec.p, ctx->d_level_ptr.p, ctx->chain_level, nlev, ctx->slab.p, ctx->y.p, ctx->d_fail.p); \
+  }
+    CXK_CHAIN(8, 8, 8, 8)
+    CXK_CHAIN(16, 8, 16, 8)
+    CXK_CHAIN(24, 0, 24, 0)
+    CXK_CHAIN(24, 8, 24, 8)
+    CXK_CHAIN(32, 16, 32, 16)
+    CXK_CHAIN(8, 8, 24, 0)
+    CXK_CHAIN(16, 8, 24, 0)
+    CXK_CHAIN(24, 0, 24, 8)
+    CXK_CHAIN(24, 0, 32, 16)
+#undef CXK_CHAIN
+    CXK_DEMAND(done, "internal error: no tree_chain_lean instance for the chain's shapes");
+    CXK_TRY(hipGetLastError());
+  }
   if (dense) {
     double* rhs = with_rhs ? ctx->y.p : nullptr;
     const int wb = with_rhs && backward;
@@ -1760,6 +1809,7 @@ int LaunchTreeCore(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
   if (backward)
     for (auto it = order.rbegin(); it != order.rend(); ++it) {
       if (dense && it->first >= ctx->dense_level) continue;  // solved inside the dense kernel
+      if (chain && it->first >= ctx->chain_level) continue;  // solved inside the chain kernel
       if (it->second ? LaunchRange(ctx, *it->second, 2, true) : LaunchSweep(ctx, it->first, it->first + 1, 2, false, true))
         return CXK_FAILURE;
     }
