@@ -34,6 +34,8 @@ struct GemmArgs {
   int64_t ldc, sC1, sC2;
   double* Ct;  // optional: Ct(n, m) = C(m, n), leading dimension ldct, batch strides sT1/sT2
   int64_t ldct, sT1, sT2;
+  int ctb;      // > 0: the columns of C are blocks of ctb columns; block k of Ct starts k * sTb further on
+  int64_t sTb;  // (a wide GEMM against stacked matrices whose transposes are stored one after the other)
   int inner;   // batch b -> (b / inner, b % inner)
   double alpha, beta;
   int lower_only;  // write only m >= n, skip tiles above the diagonal (SYRK-shaped updates)
@@ -166,7 +168,8 @@ __global__ void __launch_bounds__(256) gemm_f64_mfma(GemmArgs g) {
     for (int e = tid; e < 64 * 64; e += 256) {
       const int nn = e & 63, mm = e >> 6;
       const int m = m_base + mm, n = n_base + nn;
-      if (m < g.M && n < g.N) Ct[n + (int64_t)m * g.ldct] = g.alpha * lds[mm + 65 * nn];
+      if (m < g.M && n < g.N)
+        Ct[n + (int64_t)m * g.ldct + (g.ctb > 0 ? (int64_t)(n / g.ctb) * g.sTb : 0)] = g.alpha * lds[mm + 65 * nn];
     }
   }
 }

@@ -298,6 +298,13 @@ inline hipError_t LaunchLmiSchurFusedT(const LmiGroup& g, const Arena& ar, hipSt
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
     if (e != hipSuccess) return e;
     configured = true;
+    if (getenv("CXK_DEBUG_LEVELS")) {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&lmi_schur_fused<N, M>),
+                                                         Cfg::THREADS, Cfg::LDS);
+      fprintf(stderr, "lmi_schur_fused<%d,%d>: %d threads, %zu B LDS, %d workgroups per CU\n", N, M, Cfg::THREADS,
+              (size_t)Cfg::LDS, nb);
+    }
   }
   lmi_schur_fused<N, M><<<g.count, Cfg::THREADS, Cfg::LDS, stream>>>(g, ar);
   return hipGetLastError();

@@ -599,17 +599,33 @@ inline hipError_t LmiLargeSchur(const LmiGroup& g, const Arena& ar, const LmiLar
   const int n = g.n, m = g.m, m1 = m + 1;
   const int64_t nn = (int64_t)n * n;
   hipError_t e;
-  {  // P[c,i] = A[c,i] W[c], PT = transpose;  batch (c, i)
-    GemmArgs a = SquareGemm(n, g.A, m * nn, g.W, nn, ws.P, m1 * nn);
-    a.sA2 = nn;
-    a.sB2 = 0;
-    a.sC2 = nn;
-    a.Ct = ws.PT;
+  {  // PT[c,i] = W[c] A[c,i] (= P[c,i]^T, both factors symmetric), P = its transposed copy: ONE
+     // n x (n m) GEMM per constraint against the matrices side by side, [A_1 ... A_m] (contiguous,
+     // leading dimension n), instead of m GEMMs of n^3 -- at n = 200 the 64-wide tiles are 78 %
+     // full instead of 61 %.  Same products in the same k order as A_i W: same bits.
+    GemmArgs a{};
+    a.M = n;
+    a.N = n * m;
+    a.K = n;
+    a.A = g.W;
+    a.lda = n;
+    a.sA1 = nn;
+    a.B = g.A;
+    a.ldb = n;
+    a.sB1 = m * nn;
+    a.C = ws.PT;
+    a.ldc = n;
+    a.sC1 = m1 * nn;
+    a.Ct = ws.P;
     a.ldct = n;
     a.sT1 = m1 * nn;
-    a.sT2 = nn;
-    a.inner = m;
-    if (m > 0 && (e = LaunchGemm(a, false, false, g.count * m, st)) != hipSuccess) return e;
+    a.ctb = n;
+    a.sTb = nn - n;
+    a.inner = 1;
+    a.alpha = 1.0;
+    a.beta = 0.0;
+    a.splits = 1;
+    if (m > 0 && (e = LaunchGemm(a, false, false, g.count, st)) != hipSuccess) return e;
   }
   {  // P[c,m] = C[c] W[c]
     GemmArgs a = SquareGemm(n, g.C, nn, g.W, nn, ws.P + m * nn, m1 * nn);
