@@ -30,38 +30,48 @@ struct LmiLargeWs {
 };
 
 // ---- assembly ---------------------------------------------------------------------------
-// G, AQc, <c,Qc> from Gf.  One workgroup per constraint.
-__global__ void __launch_bounds__(256) lmi_large_finalize(LmiGroup g, Arena ar, LmiLargeWs ws) {
-  const int m = g.m, m1 = m + 1;
-  const int mem = blockIdx.x, id = g.ids[mem];
-  const double* Gf = ws.Gf + (size_t)mem * m1 * m1;
-  double* G = ar.G + ar.g_off[id];
-  double* AQc = ar.AQcc + ar.r_off[id];
+// Split-K reduction of Gf, its scatter into the constraint's Schur block and the traces
+// AW(i) = tr(P_i), <w,c> = tr(P_C) in ONE launch (they were three: gemm_reduce_splits,
+// lmi_large_finalize, lmi_large_traces -- each a launch and two memory hops for a 51 x 51 result at
+// C2).  One wavefront per output element, summation orders unchanged: lane l adds partials
+// l, l+64, ... then the fixed butterfly (gemm_reduce_splits); traces as in lmi_large_traces.
+__global__ void __launch_bounds__(256)
+lmi_large_reduce_finalize(LmiGroup g, Arena ar, LmiLargeWs ws, const double* __restrict__ src, int splits,
+                          int64_t sCs) {
+  const int n = g.n, m = g.m, m1 = m + 1, nn = n * n;
+  const int mem = blockIdx.y, id = g.ids[mem];
+  const int lane = threadIdx.x & 63, w = blockIdx.x * 4 + (threadIdx.x >> 6);
   const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;  // exact (power of two)
-  for (int e = threadIdx.x; e < m * m; e += blockDim.x) {
-    const int i = e % m, j = e / m;
-    if (i >= j) G[i + (size_t)j * m] = Gf[i + (size_t)j * m1] * osc;
+  if (w < m1 * m1) {
+    const int i = w % m1, j = w / m1;
+    if (i < j) return;
+    const double* P = src + (size_t)mem * m1 * m1 + i + (size_t)j * m1;
+    double acc = 0.0;
+    for (int q = lane; q < (splits > 1 ? splits : 1); q += 64) acc += P[q * sCs];
+    acc = WaveSum(acc) * osc;
+    if (lane == 0) {
+      if (i < m)
+        ar.G[ar.g_off[id] + i + (size_t)j * m] = acc;
+      else if (j < m)
+        ar.AQcc[ar.r_off[id] + j] = acc;
+      else
+        ar.sc[2 * id + 1] = acc;
+    }
+  } else if (w < m1 * m1 + m1) {
+    const int i = w - m1 * m1;
+    const double* Pi = ws.P + ((size_t)mem * m1 + i) * nn;
+    double t = 0;
+    for (int r = lane; r < n; r += 64) t += Pi[r + (size_t)r * n];
+    t = WaveSum(t) * osc;
+    if (lane == 0) {
+      if (i < m)
+        ar.AWc[ar.r_off[id] + i] = t;
+      else
+        ar.sc[2 * id] = t;
+    }
   }
-  for (int i = threadIdx.x; i < m; i += blockDim.x) AQc[i] = Gf[m + (size_t)i * m1] * osc;
-  if (threadIdx.x == 0) ar.sc[2 * id + 1] = Gf[m + (size_t)m * m1] * osc;
 }
 
-// AW(i) = tr(P_i), <w,c> = tr(P_C): one wavefront per (matrix, constraint)
-__global__ void __launch_bounds__(64) lmi_large_traces(LmiGroup g, Arena ar, LmiLargeWs ws) {
-  const int n = g.n, m = g.m, nn = n * n, m1 = m + 1;
-  const int i = blockIdx.x, mem = blockIdx.y, id = g.ids[mem];
-  const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;
-  const double* Pi = ws.P + ((size_t)mem * m1 + i) * nn;
-  double t = 0;
-  for (int r = threadIdx.x; r < n; r += 64) t += Pi[r + (size_t)r * n];
-  t = WaveSum(t) * osc;
-  if (threadIdx.x == 0) {
-    if (i < m)
-      ar.AWc[ar.r_off[id] + i] = t;
-    else
-      ar.sc[2 * id] = t;
-  }
-}
 
 // ---- step kernels -------------------------------------------------------------------------
 // S = sum_i y_i A_i - k C   (dense_lmi_constraint.cc:8-27); grid (blocks over n^2, count)
@@ -653,10 +663,13 @@ inline hipError_t LmiLargeSchur(const LmiGroup& g, const Arena& ar, const LmiLar
     a.lower_only = 1;
     a.splits = ws.splits;
     a.sCs = (int64_t)g.count * m1 * m1;
-    if ((e = LaunchGemmSplitK(a, true, false, g.count, ws.part, st)) != hipSuccess) return e;
+    const bool split = a.splits > 1;
+    if (split) a.C = ws.part;  // partials; reduced by lmi_large_reduce_finalize
+    if ((e = LaunchGemm(a, true, false, g.count, st)) != hipSuccess) return e;
+    const int waves = m1 * m1 + m1;
+    lmi_large_reduce_finalize<<<dim3((waves + 3) / 4, g.count), 256, 0, st>>>(g, ar, ws, split ? ws.part : ws.Gf,
+                                                                            a.splits, a.sCs);
   }
-  lmi_large_finalize<<<g.count, 256, 0, st>>>(g, ar, ws);
-  lmi_large_traces<<<dim3(m1, g.count), 64, 0, st>>>(g, ar, ws);
   return hipGetLastError();
 }
 
