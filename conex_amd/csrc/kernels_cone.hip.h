@@ -413,16 +413,38 @@ reduce_step_info(int K, int mode, const double* __restrict__ info, const unsigne
   __shared__ double red[8];
   __shared__ double red2[8];
   double a = 0, b = (mode == 0) ? -1.0 : 30000.0, c = -30000.0, d = 0;
-  for (int i = threadIdx.x; i < K; i += blockDim.x) {
-    if (!mask[i]) continue;
-    if (mode == 0) {
-      a += info[2 * i];
-      b = fmax(b, info[2 * i + 1]);
-    } else {
-      b = fmin(b, info[4 * i]);
-      c = fmax(c, info[4 * i + 1]);
-      a += info[4 * i + 2];
-      d += info[4 * i + 3];
+  // eight strided constraints per trip, loads issued together (a plain loop pays two dependent
+  // round trips -- mask, values -- per element); accumulation order unchanged
+  constexpr int U = 8;
+  for (int i0 = threadIdx.x; i0 < K; i0 += U * blockDim.x) {
+    bool on[U];
+    double v[U][4];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * blockDim.x;
+      const int ic = i < K ? i : 0;
+      on[u] = mask[ic] != 0 && i < K;
+      if (mode == 0) {
+        v[u][0] = info[2 * ic];
+        v[u][1] = info[2 * ic + 1];
+        v[u][2] = v[u][3] = 0.0;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[u][q] = info[4 * ic + q];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (!on[u]) continue;
+      if (mode == 0) {
+        a += v[u][0];
+        b = fmax(b, v[u][1]);
+      } else {
+        b = fmin(b, v[u][0]);
+        c = fmax(c, v[u][1]);
+        a += v[u][2];
+        d += v[u][3];
+      }
     }
   }
   a = BlockSum(a, red);
