@@ -930,7 +930,10 @@ __device__ __forceinline__ void BackwardSupernodeLean(const SnRec& R, const doub
   for (int q = 0; q < QN; q++) {
     const unsigned w = q < cnt ? (unsigned)R.sep[q] : 0u;
     yv[q] = rhs[w & 0x3ffffffu];
-    bv[q] = B[(size_t)(w >> 26) * ns];
+    // unused slots read the diagonal block instead: a supernode without separator has no off
+    // block, and the root's would start at the end of the slab
+    const double* src = q < cnt ? B + (size_t)(w >> 26) * ns : D;
+    bv[q] = src[0];
   }
   // ---- consumers
 #pragma unroll
