@@ -59,13 +59,18 @@ struct DevBuf {
     n = count;
     if (count == 0) count = 1;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    // the fill runs on the null stream, kernels on the context's stream, which may be
+    // non-blocking (no implicit ordering with the null stream): wait for it on the host
     if (e == hipSuccess) e = hipMemset(p, 0, count * sizeof(T));
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     return e;
   }
   hipError_t upload(const std::vector<T>& v) {
     hipError_t e = alloc(v.size());
     if (e != hipSuccess || v.empty()) return e;
-    return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    return e;
   }
 };
 
@@ -103,7 +108,8 @@ struct cxk_context {
   std::string err;
   std::vector<ConstraintRec> cons;
   IntLists cliques, dual_vars;
-  bool finalized = false;
+  bool finalized = false;     // symbolic analysis done (getters)
+  bool device_ready = false;  // device buffers and plans built: numeric entry points may run
   int rank = 0, world = 1;
   MatrixData md;
   Layout lay;
@@ -1821,8 +1827,30 @@ int CheckReady(cxk_context* ctx) {
   CXK_DEMAND(ctx->finalized, "context not finalized");
   CXK_DEMAND(ctx->device >= 0,
              "no HIP device bound to this context: the KKT path has no CPU fallback");
+  CXK_DEMAND(ctx->device_ready, "device state of this context was not built (cxk_finalize failed)");
   return CXK_SUCCESS;
 }
+
+// The current HIP device is per-thread state: every entry point binds the context's device for
+// its own duration and restores the caller's (another thread, a second context on another GPU,
+// or a host framework that switched devices in between would otherwise launch on the wrong one).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int want) {
+    if (want < 0) return;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != want) switched = hipSetDevice(want) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define CXK_ENTER(ctx)                          \
+  if (CheckReady(ctx)) return CXK_FAILURE;      \
+  DeviceGuard cxk_device_guard_((ctx)->device)
 
 }  // namespace
 
@@ -2002,9 +2030,25 @@ int cxk_set_shard(cxk_context* ctx, int rank, int world_size) {
   return CXK_SUCCESS;
 }
 
+static int FinalizeImpl(cxk_context* ctx);
+
 int cxk_finalize(cxk_context* ctx) {
   if (!ctx) return CXK_FAILURE;
   CXK_DEMAND(!ctx->cons.empty(), "no constraints");
+  CXK_DEMAND(!ctx->finalized, "context already finalized");
+  DeviceGuard guard(ctx->device);
+  const int rc = FinalizeImpl(ctx);
+  if (rc != CXK_SUCCESS) {
+    // a half-built context must not pass CheckReady, and the caller may change the shard or the
+    // constraints and finalize again
+    ctx->finalized = false;
+    ctx->device_ready = false;
+    ctx->groups.clear();
+  }
+  return rc;
+}
+
+static int FinalizeImpl(cxk_context* ctx) {
   try {
     ctx->md = Analyze(ctx->cliques, ctx->dual_vars);
     ctx->lay = BuildLayout(ctx->md);
@@ -2026,7 +2070,6 @@ int cxk_finalize(cxk_context* ctx) {
   ctx->finalized = true;
   if (ctx->device < 0) return CXK_SUCCESS;  // symbolic-only context
 
-  CXK_TRY(hipSetDevice(ctx->device));
   CXK_TRY(RaiseLdsLimits());
   // groups of identically shaped constraints (owned ones only carry data)
   std::map<std::tuple<int, int, int, int>, int> gmap;
@@ -2156,6 +2199,7 @@ int cxk_finalize(cxk_context* ctx) {
     CXK_TRY(ctx->d_mask.upload(ctx->owned));
   }
   if (BuildPlans(ctx) != CXK_SUCCESS) return CXK_FAILURE;
+  ctx->device_ready = true;
   return cxk_set_identity(ctx);
 }
 
@@ -2223,7 +2267,7 @@ int cxk_dual_size(const cxk_context* ctx, int i) {
 }
 
 int cxk_set_identity(cxk_context* ctx) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   for (Group& g : ctx->groups) {
     const size_t cnt = g.ids.size();
     if (cnt == 0) continue;
@@ -2238,7 +2282,7 @@ int cxk_set_identity(cxk_context* ctx) {
 }
 
 int cxk_get_W(cxk_context* ctx, int i, double* out) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_DEMAND(i >= 0 && i < (int)ctx->cons.size() && ctx->cons[i].group >= 0, "invalid constraint");
   const ConstraintRec& c = ctx->cons[i];
   const size_t sz = (size_t)cxk_dual_size(ctx, i);
@@ -2265,7 +2309,7 @@ int cxk_get_W(cxk_context* ctx, int i, double* out) {
 }
 
 int cxk_set_W(cxk_context* ctx, int i, const double* in) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_DEMAND(i >= 0 && i < (int)ctx->cons.size() && ctx->cons[i].group >= 0, "invalid constraint");
   const ConstraintRec& c = ctx->cons[i];
   const size_t sz = (size_t)cxk_dual_size(ctx, i);
@@ -2286,7 +2330,7 @@ int cxk_set_W(cxk_context* ctx, int i, const double* in) {
 
 // ------------------------------------------------------------- Newton step
 int cxk_assemble_local(cxk_context* ctx) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   if (LaunchSchur(ctx)) return CXK_FAILURE;
   return LaunchGather(ctx, false, 0, 0, 0);
 }
@@ -2341,7 +2385,7 @@ int SyncMailbox(cxk_context* ctx) {
 }
 
 int cxk_factor_async(cxk_context* ctx) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));
   if (LaunchTree(ctx, 0, false, false)) return CXK_FAILURE;
   ctx->factor_seq = ++ctx->seq;
@@ -2349,14 +2393,14 @@ int cxk_factor_async(cxk_context* ctx) {
 }
 
 int cxk_factor_status(cxk_context* ctx, int* ok) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   if (ctx->mb_seen < ctx->factor_seq && SyncMailbox(ctx)) return CXK_FAILURE;
   if (ok) *ok = ctx->mb ? (ctx->mb[10] == 0.0) : 1;
   return CXK_SUCCESS;
 }
 
 int cxk_step_scalars_async(cxk_context* ctx) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   step_scalars<<<1, 1024, 0, ctx->stream>>>(ctx->md.N, ctx->b.p, ctx->AQc.p, ctx->y.p,
                                             ctx->sys_sc.p, ctx->scal_out.p);
   CXK_TRY(hipGetLastError());
@@ -2368,7 +2412,7 @@ int cxk_step_scalars_async(cxk_context* ctx) {
 // cxk_kkt_solve_async): y <- K^-1 (cb b + cq AQc + cw AW).  With (k bs, k cs, -2) this is the Newton
 // direction, with (-bs, cs, 0) the right-hand side of ComputeMuFromDivergence (cone_program.cc:173-214).
 int cxk_factor_solve_async(cxk_context* ctx, double cb, double cq, double cw) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   const int N = ctx->md.N;
   build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, cb, cq, cw, ctx->b.p, ctx->AQc.p, ctx->AW.p,
                                                            ctx->y.p, ctx->d_fail.p);
@@ -2380,7 +2424,7 @@ int cxk_factor_solve_async(cxk_context* ctx, double cb, double cq, double cw) {
 
 // cxk_factor_async + cxk_newton_direction in one upward pass: y <- K^-1 (k (b bs + AQc cs) - 2 AW).
 int cxk_factor_direction_async(cxk_context* ctx, double k, double bs, double cs) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   const int N = ctx->md.N;
   build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p, ctx->y.p,
                                                       ctx->d_fail.p);
@@ -2396,7 +2440,7 @@ int cxk_factor(cxk_context* ctx, int* ok) {
 }
 
 int cxk_sync(cxk_context* ctx, int* factor_ok) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   if (SyncMailbox(ctx)) return CXK_FAILURE;
   CXK_TRY(hipStreamSynchronize(ctx->stream));  // the stream is idle: cheap, and later host-side copies rely on it
   if (factor_ok) *factor_ok = ctx->mb[10] == 0.0;
@@ -2413,7 +2457,7 @@ int cxk_sync(cxk_context* ctx, int* factor_ok) {
 }
 
 int cxk_set_cost(cxk_context* ctx, const double* b) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   const int N = ctx->md.N;
   std::vector<double> bp(N, 0.0);
   for (int i = 0; i < N; i++) {
@@ -2426,7 +2470,7 @@ int cxk_set_cost(cxk_context* ctx, const double* b) {
 }
 
 int cxk_newton_direction(cxk_context* ctx, double k, double bs, double cs) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   const int N = ctx->md.N;
   build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p,
                                                       ctx->y.p);
@@ -2434,7 +2478,7 @@ int cxk_newton_direction(cxk_context* ctx, double k, double bs, double cs) {
 }
 
 int cxk_solve_rhs(cxk_context* ctx, double cb, double cq, double cw) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   const int N = ctx->md.N;
   build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, cb, cq, cw, ctx->b.p, ctx->AQc.p,
                                                            ctx->AW.p, ctx->y.p);
@@ -2447,7 +2491,7 @@ int cxk_solve_rhs(cxk_context* ctx, double cb, double cq, double cw) {
 // overwrites its iterate vector).
 int cxk_line_search(cxk_context* ctx, double dinf_upper_bound, double b_scaling, double c_scaling,
                     double* result) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_DEMAND(result != nullptr, "null output");
   CXK_DEMAND(ctx->world == 1, "line search is single-GPU for now");
   const int N = ctx->md.N, K = (int)ctx->cons.size();
@@ -2492,7 +2536,7 @@ int cxk_line_search(cxk_context* ctx, double dinf_upper_bound, double b_scaling,
 }
 
 int cxk_step_scalars(cxk_context* ctx, double* out6) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   if (ctx->scal_seq < 0 && cxk_step_scalars_async(ctx)) return CXK_FAILURE;  // not enqueued yet
   if (ctx->mb_seen < ctx->scal_seq && SyncMailbox(ctx)) return CXK_FAILURE;
   for (int i = 0; i < 6; i++) out6[i] = ctx->mb[4 + i];
@@ -2501,10 +2545,12 @@ int cxk_step_scalars(cxk_context* ctx, double* out6) {
 }
 
 int cxk_kkt_solve_async(cxk_context* ctx, double k, double bs, double cs) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   if (LaunchSchur(ctx)) return CXK_FAILURE;
   if (LaunchGather(ctx, true, k, bs, cs)) return CXK_FAILURE;
-  return LaunchTree(ctx, 0, true, true);
+  if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;
+  ctx->factor_seq = ++ctx->seq;
+  return CXK_SUCCESS;
 }
 
 int cxk_solve_inplace(cxk_context* ctx, double* yh) {
@@ -2514,7 +2560,7 @@ int cxk_solve_inplace(cxk_context* ctx, double* yh) {
 }
 
 int cxk_get_y(cxk_context* ctx, double* yh) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   const int N = ctx->md.N;
   // a kernel writes y into pinned host memory: the first device-to-host hipMemcpy of a process
   // pays milliseconds of copy-engine set-up, which would dominate a whole C4 solve
@@ -2527,7 +2573,7 @@ int cxk_get_y(cxk_context* ctx, double* yh) {
 }
 
 int cxk_set_y(cxk_context* ctx, const double* yh) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   const int N = ctx->md.N;
   std::vector<double> yp(N);
   for (int i = 0; i < N; i++) yp[i] = yh[ctx->md.permutation_inverse[i]];
@@ -2537,7 +2583,7 @@ int cxk_set_y(cxk_context* ctx, const double* yh) {
 }
 
 int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_weight, double* info) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   StepArgs sa = MakeStep(ctx, ctx->info2.p, affine, c_weight, e_weight, 1.0);
   ctx->lanczos_calls++;
   for (Group& g : ctx->groups) {
@@ -2578,14 +2624,14 @@ int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_wei
 
 /* per-constraint outputs of the last cxk_prepare_step: {normsqrd, norminfd} for each constraint */
 int cxk_get_step_info(cxk_context* ctx, double* out2k) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_TRY(hipStreamSynchronize(ctx->stream));
   CXK_TRY(hipMemcpy(out2k, ctx->info2.p, sizeof(double) * 2 * ctx->cons.size(), hipMemcpyDeviceToHost));
   return CXK_SUCCESS;
 }
 
 int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_size) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   if (affine) return CXK_SUCCESS;  // the affine update is applied inside PrepareStep
   StepArgs sa = MakeStep(ctx, ctx->info2.p, affine, 0.0, e_weight, step_size);
   for (Group& g : ctx->groups) {
@@ -2624,7 +2670,7 @@ int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_siz
 }
 
 int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* out) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   StepArgs sa = MakeStep(ctx, ctx->info4.p, 0, c_weight, 0.0, 1.0);
   ctx->lanczos_calls++;
   for (Group& g : ctx->groups) {
@@ -2658,14 +2704,14 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
 
 // ------------------------------------------------------------- inspection
 int cxk_get_slab(cxk_context* ctx, double* out) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_TRY(hipStreamSynchronize(ctx->stream));
   CXK_TRY(hipMemcpy(out, ctx->slab.p, sizeof(double) * (size_t)ctx->lay.slab_size,
                     hipMemcpyDeviceToHost));
   return CXK_SUCCESS;
 }
 int cxk_set_slab(cxk_context* ctx, const double* in) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_TRY(hipStreamSynchronize(ctx->stream));
   CXK_TRY(hipMemcpy(ctx->slab.p, in, sizeof(double) * (size_t)ctx->lay.slab_size,
                     hipMemcpyHostToDevice));
@@ -2673,7 +2719,7 @@ int cxk_set_slab(cxk_context* ctx, const double* in) {
 }
 int cxk_get_constraint_schur(cxk_context* ctx, int i, double* G, double* AW, double* AQc,
                              double* scalars) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_DEMAND(i >= 0 && i < (int)ctx->cons.size(), "invalid constraint");
   const int m = ctx->cons[i].m;
   CXK_TRY(hipStreamSynchronize(ctx->stream));
@@ -2689,7 +2735,7 @@ int cxk_get_constraint_schur(cxk_context* ctx, int i, double* G, double* AW, dou
   return CXK_SUCCESS;
 }
 int cxk_get_residuals(cxk_context* ctx, double* AW, double* AQc, double* scalars) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   const int N = ctx->md.N;
   std::vector<double> t(N);
   CXK_TRY(hipStreamSynchronize(ctx->stream));
@@ -2706,7 +2752,7 @@ int cxk_get_residuals(cxk_context* ctx, double* AW, double* AQc, double* scalars
 }
 
 int cxk_exchange_buffer(cxk_context* ctx, void** dev_ptr, long* count) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_DEMAND(ctx->world > 1, "exchange buffer exists only for sharded contexts");
   *dev_ptr = ctx->xbuf.p;
   *count = (long)(ctx->n_xs + 3 * (int64_t)ctx->n_xv + 4);
@@ -2715,7 +2761,7 @@ int cxk_exchange_buffer(cxk_context* ctx, void** dev_ptr, long* count) {
 
 // host copies of the exchange buffer (tests; a real run all-reduces the device buffer in place)
 int cxk_exchange_download(cxk_context* ctx, double* out) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_DEMAND(ctx->world > 1, "exchange buffer exists only for sharded contexts");
   CXK_TRY(hipStreamSynchronize(ctx->stream));
   CXK_TRY(hipMemcpy(out, ctx->xbuf.p, sizeof(double) * (size_t)(ctx->n_xs + 3 * (int64_t)ctx->n_xv + 4),
@@ -2723,7 +2769,7 @@ int cxk_exchange_download(cxk_context* ctx, double* out) {
   return CXK_SUCCESS;
 }
 int cxk_exchange_upload(cxk_context* ctx, const double* in) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_DEMAND(ctx->world > 1, "exchange buffer exists only for sharded contexts");
   CXK_TRY(hipStreamSynchronize(ctx->stream));
   CXK_TRY(hipMemcpy(ctx->xbuf.p, in, sizeof(double) * (size_t)(ctx->n_xs + 3 * (int64_t)ctx->n_xv + 4),
@@ -2734,7 +2780,7 @@ int cxk_exchange_upload(cxk_context* ctx, const double* in) {
 // Sharded KKT solve, part 1 (no communication): assemble own constraints, factor + forward own
 // subtrees, fold their updates into the partial top blocks and pack the exchange buffer.
 int cxk_kkt_local_async(cxk_context* ctx, double k, double bs, double cs) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_DEMAND(ctx->world > 1, "cxk_kkt_local_async needs cxk_set_shard(world > 1)");
   if (LaunchSchur(ctx)) return CXK_FAILURE;
   if (LaunchGather(ctx, true, k, bs, cs)) return CXK_FAILURE;
@@ -2745,13 +2791,14 @@ int cxk_kkt_local_async(cxk_context* ctx, double k, double bs, double cs) {
   if (a.pt_T > 0) exchange_fold<<<GridFor((size_t)a.pt_T, 256), 256, 0, ctx->stream>>>(a);
   exchange_pack<<<GridFor(work, 256), 256, 0, ctx->stream>>>(a);
   CXK_TRY(hipGetLastError());
+  ctx->factor_seq = ++ctx->seq;
   return CXK_SUCCESS;
 }
 
 // Part 2, after the caller has sum-reduced the exchange buffer across ranks: unpack the
 // completed top, factor/solve it (replicated), back-substitute the own subtrees.
 int cxk_kkt_finish_async(cxk_context* ctx, double k, double bs, double cs) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_DEMAND(ctx->world > 1, "cxk_kkt_finish_async needs cxk_set_shard(world > 1)");
   ExchangeArgs a = MakeExchange(ctx, k, bs, cs);
   const size_t work = (size_t)std::max<int64_t>(ctx->n_xs, ctx->n_xv);
@@ -2764,6 +2811,7 @@ int cxk_kkt_finish_async(cxk_context* ctx, double k, double bs, double cs) {
     if (LaunchSweep(ctx, top, nlev, 0, true, true)) return CXK_FAILURE;
   for (int l = top - 1; l >= 0; l--)
     if (LaunchSweep(ctx, l, l + 1, 2, false, true)) return CXK_FAILURE;
+  ctx->factor_seq = ++ctx->seq;
   return CXK_SUCCESS;
 }
 
@@ -2792,7 +2840,7 @@ int cxk_gemm_f64(int device, int ta, int tb, int M, int N, int K, int batch, con
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || !A || !B || !C) return CXK_FAILURE;
   cxk_context scratch_ctx;  // carries the error string for CXK_TRY
   cxk_context* ctx = &scratch_ctx;
-  CXK_TRY(hipSetDevice(device));
+  DeviceGuard guard(device);
   const size_t na = (size_t)M * K, nb = (size_t)K * N, nc = (size_t)M * N;
   DevBuf<double> dA, dB, dC, dP;
   CXK_TRY(dA.alloc(na * batch));
@@ -2889,7 +2937,7 @@ int cxk_debug_select(int want) {
 // SupernodalKKTSolver::SetIterativeRefinementIterations (kkt_solver.h:37): every solve after the
 // next factorization is followed by `iterations` steps  y <- y + K^-1 (b - K y).
 int cxk_set_iterative_refinement(cxk_context* ctx, int iterations) {
-  if (CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER(ctx);
   CXK_DEMAND(iterations >= 0, "refinement iterations must be >= 0");
   CXK_DEMAND(ctx->world <= 1 || iterations == 0, "iterative refinement is single-GPU for now");
   if (iterations > 0 && ctx->slab0.n == 0) {

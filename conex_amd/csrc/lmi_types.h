@@ -1,0 +1,56 @@
+// Argument structs shared by the LMI kernel files and their host launchers (plain data, no
+// device code: safe to include from several translation units).
+#pragma once
+#include <cstdint>
+
+namespace cxk {
+
+struct LmiGroup {
+  int n;
+  int m;
+  int count;
+  const double* A;  // count x m x (n*n)
+  const double* C;  // count x (n*n)
+  double* W;        // count x (n*n)
+  double* T1;       // count x (n*n)   temp_1 of WorkspaceDensePSD (WS between Prepare/TakeStep)
+  const int* ids;   // member -> constraint id
+  // 0: DenseLMIConstraint semantics.  d in {1,2,4}: HermitianPsdConstraint over R / C / H stored
+  // through its real representation (order n = d * hyper-complex order): outputs carry the
+  // factor 1/d (tr over the representation = d * Re tr), TakeStep uses the reference's
+  // Taylor-squaring exponential and the eigenvalue estimates its random-start Lanczos
+  // (hermitian_psd.cc:10-91, exponential_map.cc:15-43, jordan_matrix_algebra.cc:386-452).
+  int herm_d;
+  // Sparse groups (kernels_lmi_sparse.hip.h): A is not stored densely.  Nonzeros (both triangles)
+  // matrix-major -- entries of (member, i) at [sp_eptr[mem*m+i], sp_eptr[mem*m+i+1]), sp_erc =
+  // row | col << 16 -- and position-major for the slack: entries of (member, position q) at
+  // [sp_pptr[mem*n*n+q], ...), variable index ascending.  All null for dense groups.
+  const int* sp_eptr;
+  const int* sp_erc;
+  const double* sp_eval;
+  const int* sp_pptr;
+  const int* sp_pvar;
+  const double* sp_pval;
+};
+
+struct Arena {
+  double* G;              // per-constraint m x m Schur blocks (lower triangle meaningful)
+  const int64_t* g_off;   // [K]
+  double* AWc;            // per-constraint AW / AQc
+  double* AQcc;
+  const int64_t* r_off;   // [K]
+  double* sc;             // [2K] <w,c>, <c,Qc>
+};
+
+struct StepArgs {
+  const double* y;        // permuted Newton direction (device)
+  const int* cl_ptr;      // [K+1] clique pointer
+  const int* cl_perm;     // permuted index of each clique variable
+  double* info;           // per-constraint outputs (2 or 4 doubles each)
+  int affine;
+  double c_weight;
+  double e_weight;
+  double step_size;
+  unsigned long long call;  // index of this PrepareStep / eigenvalue query (Hermitian start vectors)
+};
+
+}  // namespace cxk

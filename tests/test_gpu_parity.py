@@ -350,6 +350,33 @@ def test_c3_soc_newton_step():
     check_newton_step(o, k, prob["b"], inv_sqrt_mu=0.9)
 
 
+# --------------------------------------------------------------------- BASELINE configs 3 and 5 at FULL size
+@pytest.mark.parametrize("tree", [0, 8])
+def test_c3_full_size_5000_soc(tree):
+    """BASELINE config 3 as named: 5000 second-order cones of dimension 10.  tree = 0 is the
+    reference-style chain (clique k = {8k .. 8k+9}: 5000 elimination levels, N = 40002), tree = 8
+    SURVEY 8d's clique-tree variant.  Schur blocks / slab <= 1e-13, direction <= 1e-10, updates
+    <= 1e-11 against the oracle, stage by stage."""
+    K = 5000
+    prob = syn.soc_problem(K=K, dim=10, m=10, overlap=2, tree=tree)
+    assert prob["num_vars"] == 40002
+    W = syn.soc_scaling_points(K, 10)
+    o, k = make_pair(prob, "soc", W)
+    assert k.N == 40002
+    check_newton_step(o, k, prob["b"])
+
+
+def test_c5_full_size_mixed_hermitian_soc():
+    """BASELINE config 5 at full size: 4600 constraints (1600 complex Hermitian cones of order 12
+    over 24 variables + 3000 second-order cones of dimension 10), N = 50004."""
+    prob = syn.mixed_problem()
+    assert prob["num_vars"] == 50004 and prob["kinds"].count("herm") == 1600
+    W = syn.mixed_scaling_points(prob)
+    o, k = make_pair(prob, "mixed", W)
+    assert k.N == 50004
+    check_newton_step(o, k, prob["b"], inv_sqrt_mu=0.5)
+
+
 # --------------------------------------------------------------------- mixed cones
 def test_mixed_cones_with_fill_in():
     """LMI + SOC + linear + constant block on the 4-cycle clique pattern (needs fill-in;
