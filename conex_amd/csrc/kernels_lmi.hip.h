@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) lmi_schur_generic(LmiGroup g, Arena ar) {
   double* sX = sP + nn;
   const int mem = blockIdx.x;
   const int id = g.ids[mem];
-  const double* A = g.A + (size_t)mem * m * nn;
+  const double* A = g.A + (size_t)mem * g.a_stride;
   const double* Cm = g.C + (size_t)mem * nn;
   const double* Wg = g.W + (size_t)mem * nn;
   double* G = ar.G + ar.g_off[id];
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(256) lmi_prepare_generic(LmiGroup g, StepArgs 
   double* red = sy + m;             // 8
   const int mem = blockIdx.x;
   const int id = g.ids[mem];
-  const double* A = g.A + (size_t)mem * m * nn;
+  const double* A = g.A + (size_t)mem * g.a_stride;
   const double* Cm = g.C + (size_t)mem * nn;
   double* Wg = g.W + (size_t)mem * nn;
   double* T1 = g.T1 + (size_t)mem * nn;

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__((FusedCfg<N, M>::THREADS)) lmi_schur_fused(Lmi
   const int r = lane - gsub * N;
   const int i = wave * MPW + gsub;
   const bool active = (gsub < MPW) && (i < M1);
-  const double* A = g.A + (size_t)mem * M * NN;
+  const double* A = g.A + (size_t)mem * g.a_stride;
   const double* Cm = g.C + (size_t)mem * NN;
   const double* Wg = g.W + (size_t)mem * NN;
   FSTAMP(0);

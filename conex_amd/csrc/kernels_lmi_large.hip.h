@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) lmi_large_slack(LmiGroup g, StepArgs sa, 
   extern __shared__ double sy[];
   for (int q = threadIdx.x; q < m; q += blockDim.x) sy[q] = sa.y[sa.cl_perm[sa.cl_ptr[id] + q]];
   __syncthreads();
-  const double* A = g.A + (size_t)mem * m * nn;
+  const double* A = g.A + (size_t)mem * g.a_stride;
   const double* Cm = g.C + (size_t)mem * nn;
   if (g.sp_pptr) {  // sparse group: nonzeros of each position, variable index ascending
     const int* pp = g.sp_pptr + (size_t)mem * nn;

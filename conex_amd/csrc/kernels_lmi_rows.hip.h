@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa)
   double2 acc[CH];
 #pragma unroll
   for (int u = 0; u < CH; u++) acc[u] = make_double2(0.0, 0.0);
-  const double2* base = reinterpret_cast<const double2*>(g.A + (size_t)mem * m * NN);
+  const double2* base = reinterpret_cast<const double2*>(g.A + (size_t)mem * g.a_stride);
 #pragma unroll 5
   for (int i = 0; i < m; i++) {
     const double yi = ReadLaneUniform(yv, i);

@@ -25,6 +25,7 @@
 #include "kernels_kkt_big.hip.h"
 #include "kernels_lmi.hip.h"
 #include "kernels_lmi_fused.hip.h"
+#include "lmi_fused_mfma.h"
 #include "kernels_lmi_sparse.hip.h"
 #include "kernels_lmi_rows.hip.h"
 #include "kernels_kkt_top.hip.h"
@@ -42,6 +43,9 @@ struct ConstraintRec {
   std::vector<double> A, C;
   int group = -1, member = -1;
   bool sparse = false;  // LMI evaluated from its nonzeros (kernels_lmi_sparse.hip.h)
+  // every A_i and C equals its transpose.  The fast kernels use tr(W A_i W A_j) = tr(P_i P_j),
+  // P = A W, which needs that; anything else takes the literal kernels (dense_lmi_constraint.cc:72-88)
+  bool symmetric = true;
 };
 
 template <typename T>
@@ -81,6 +85,8 @@ struct Group {
   DevBuf<int> dids;
   int herm_d = 0;
   bool fused = false;
+  bool mfma = false;     // lmi_schur_mfma (lmi_fused_mfma.hip) instead of lmi_schur_fused
+  bool literal = false;  // non-symmetric data: literal kernels only
   // orders beyond the LDS-resident kernels: HBM-resident matrices + MFMA GEMM pipeline
   bool large = false;
   // assembly through the batched MFMA GEMM pipeline (always when `large`; also for LDS-resident
@@ -104,6 +110,7 @@ struct Group {
 struct cxk_context {
   int num_vars = 0;
   int device = -1;
+  int cus = 256;  // multiprocessors of the device
   hipStream_t stream = nullptr;
   std::string err;
   std::vector<ConstraintRec> cons;
@@ -274,6 +281,7 @@ LmiGroup MakeLmi(Group& g) {
   d.m = g.m;
   d.count = static_cast<int>(g.ids.size());
   d.A = g.A.p;
+  d.a_stride = (long long)(g.mfma ? g.m + 1 : g.m) * g.n * g.n;
   d.C = g.C.p;
   d.W = g.W.p;
   d.T1 = g.T1.p;
@@ -1455,6 +1463,8 @@ int LaunchSchur(cxk_context* ctx) {
           CXK_TRY(LaunchLmiSchurSparse(g, ar, ctx->stream));
         } else if (g.schur_gemm) {
           CXK_TRY(LmiLargeSchur(MakeLmi(g), ar, MakeLargeWs(g), ctx->stream));
+        } else if (g.mfma) {
+          CXK_TRY(LaunchLmiSchurMfma(MakeLmi(g), ar, ctx->cus, ctx->stream));
         } else if (g.fused) {
           CXK_TRY(LaunchLmiSchurFused(MakeLmi(g), ar, ctx->stream));
         } else {
@@ -1902,6 +1912,14 @@ int cxk_add_lmi(cxk_context* ctx, int n, int m, const double* A, const double* C
   r.m = m;
   r.A.assign(A, A + (size_t)m * n * n);
   r.C.assign(C, C + (size_t)n * n);
+  auto symmetric = [n](const double* X) {
+    for (int c = 0; c < n; c++)
+      for (int q = c + 1; q < n; q++)
+        if (X[q + (size_t)c * n] != X[c + (size_t)q * n]) return false;
+    return true;
+  };
+  r.symmetric = symmetric(C);
+  for (int i = 0; i < m && r.symmetric; i++) r.symmetric = symmetric(A + (size_t)i * n * n);
   return AddConstraint(ctx, std::move(r), vars);
 }
 
@@ -2071,6 +2089,7 @@ static int FinalizeImpl(cxk_context* ctx) {
   if (ctx->device < 0) return CXK_SUCCESS;  // symbolic-only context
 
   CXK_TRY(RaiseLdsLimits());
+  CXK_TRY(hipDeviceGetAttribute(&ctx->cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
   // groups of identically shaped constraints (owned ones only carry data)
   std::map<std::tuple<int, int, int, int>, int> gmap;
   ctx->groups.clear();
@@ -2084,10 +2103,17 @@ static int FinalizeImpl(cxk_context* ctx) {
       const char* force = getenv("CXK_SPARSE_LMI");
       const bool lds_resident = LmiTakeLds(c.n) <= kLdsLimit && LmiPrepareLds(c.n, c.m) <= kLdsLimit;
       c.sparse = force ? (atoi(force) != 0)
-                       : LmiSparsePays(c.n, c.m, nnz, lds_resident, LmiFusedSupports(c.n, c.m));
+                       : LmiSparsePays(c.n, c.m, nnz, lds_resident, LmiFusedSupports(c.n, c.m) || LmiMfmaSupports(c.n, c.m));
       if (c.n > 65535) c.sparse = false;  // packed row | col << 16
+      if (!c.symmetric) {
+        // The reference accepts non-symmetric matrices and evaluates <W A_i W, A_j> as written;
+        // only the literal LDS kernels do the same.
+        c.sparse = false;
+        CXK_DEMAND(lds_resident, "non-symmetric LMI data beyond the LDS-resident orders is not supported: "
+                                 "the large-order kernels use tr(W A_i W A_j) = tr(P_i P_j), which needs A_i = A_i^T");
+      }
     }
-    auto key = std::make_tuple(c.type, c.n, c.m, c.herm_d + (c.sparse ? 16 : 0));
+    auto key = std::make_tuple(c.type, c.n, c.m, c.herm_d + (c.sparse ? 16 : 0) + (c.type == CXK_LMI && !c.symmetric ? 32 : 0));
     auto it = gmap.find(key);
     if (it == gmap.end()) {
       it = gmap.emplace(key, (int)ctx->groups.size()).first;
@@ -2097,6 +2123,7 @@ static int FinalizeImpl(cxk_context* ctx) {
       ctx->groups.back().m = c.m;
       ctx->groups.back().herm_d = c.herm_d;
       ctx->groups.back().sparse = c.sparse;
+      ctx->groups.back().literal = c.type == CXK_LMI && !c.symmetric;
     }
     c.group = it->second;
     c.member = (int)ctx->groups[it->second].ids.size();
@@ -2110,8 +2137,14 @@ static int FinalizeImpl(cxk_context* ctx) {
         a_sz = (size_t)g.m * g.n * g.n;
         c_sz = w_sz = (size_t)g.n * g.n;
         g.large = !(LmiTakeLds(g.n) <= kLdsLimit && LmiPrepareLds(g.n, g.m) <= kLdsLimit);
-        g.fused = !g.sparse && !g.large && LmiFusedSupports(g.n, g.m);
-        g.schur_gemm = !g.sparse && (g.large || (!g.fused && g.n >= 32 &&
+        {
+          // CXK_LMI_SCHUR = dpp | generic selects the older kernels (comparison runs, tests)
+          const char* pick = getenv("CXK_LMI_SCHUR");
+          const bool want_dpp = pick && !strcmp(pick, "dpp"), want_generic = pick && !strcmp(pick, "generic");
+          g.mfma = !g.sparse && !g.large && !g.literal && !want_dpp && !want_generic && LmiMfmaSupports(g.n, g.m);
+          g.fused = !g.sparse && !g.large && !g.literal && !g.mfma && !want_generic && LmiFusedSupports(g.n, g.m);
+        }
+        g.schur_gemm = !g.sparse && !g.literal && (g.large || (!g.fused && !g.mfma && g.n >= 32 &&
                                    cnt * 2 * ((size_t)g.m + 1) * g.n * g.n * sizeof(double) <= ((size_t)8 << 30)));
         break;
       case CXK_LINEAR:
@@ -2131,10 +2164,14 @@ static int FinalizeImpl(cxk_context* ctx) {
       if (UploadSparseLmi(ctx, g)) return CXK_FAILURE;
       a_sz = 0;  // no dense copy of A on the device
     }
-    std::vector<double> hA(a_sz * cnt), hC(c_sz * cnt);
+    // lmi_schur_mfma reads [A_1 .. A_m | C] of a constraint as one contiguous array of stacked
+    // rows: such groups keep a copy of C right behind the A_i (LmiGroup::a_stride)
+    const size_t a_blk = a_sz + (g.type == CXK_LMI && g.mfma ? c_sz : 0);
+    std::vector<double> hA(a_blk * cnt), hC(c_sz * cnt);
     for (size_t k = 0; k < cnt; k++) {
       const ConstraintRec& c = ctx->cons[g.ids[k]];
-      if (a_sz) std::copy(c.A.begin(), c.A.end(), hA.begin() + k * a_sz);
+      if (a_sz) std::copy(c.A.begin(), c.A.end(), hA.begin() + k * a_blk);
+      if (a_blk > a_sz) std::copy(c.C.begin(), c.C.end(), hA.begin() + k * a_blk + a_sz);
       std::copy(c.C.begin(), c.C.end(), hC.begin() + k * c_sz);
     }
     CXK_TRY(g.A.upload(hA));
@@ -2593,7 +2630,7 @@ int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_wei
       CXK_TRY(LmiLargePrepare(MakeLmi(g), sa, MakeLargeWs(g), 0, ctx->stream));
     else if (g.type == CXK_LMI) {
       static const bool lds_kernel = getenv("CXK_PREPARE_LDS") != nullptr;  // A/B switch (tests, timing)
-      if (!affine && !lds_kernel && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse))
+      if (!affine && !lds_kernel && !g.literal && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse))
         lmi_prepare_rows<0, 20><<<(cnt + 3) / 4, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
       else if (g.n == 20)
         lmi_prepare_generic<0, 20><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
@@ -2641,7 +2678,7 @@ int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_siz
       CXK_TRY(LmiLargeTakeStep(MakeLmi(g), sa, MakeLargeWs(g), ctx->stream));
     else if (g.type == CXK_LMI) {
       static const bool lds_kernel = getenv("CXK_TAKE_STEP_LDS") != nullptr;  // A/B switch (tests, timing)
-      if (LmiTakeStepRowsSupports(g.n) && !lds_kernel) {
+      if (LmiTakeStepRowsSupports(g.n) && !lds_kernel && !g.literal) {
         const int blocks = (cnt + 3) / 4;
         if (g.herm_d == 0) {
           if (g.n <= 20)
@@ -2680,7 +2717,7 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
       CXK_TRY(LmiLargePrepare(MakeLmi(g), sa, MakeLargeWs(g), 1, ctx->stream));
     else if (g.type == CXK_LMI) {
       static const bool lds_kernel = getenv("CXK_PREPARE_LDS") != nullptr;
-      if (!lds_kernel && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse))
+      if (!lds_kernel && !g.literal && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse))
         lmi_prepare_rows<1, 20><<<(cnt + 3) / 4, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
       else if (g.n == 20)
         lmi_prepare_generic<1, 20><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
@@ -2900,6 +2937,17 @@ int cxk_count_sparse_lmi(const cxk_context* ctx) {
   if (!ctx || !ctx->finalized) return -1;
   int k = 0;
   for (size_t i = 0; i < ctx->cons.size(); i++) k += ctx->cons[i].type == CXK_LMI && ctx->owned[i] && ctx->cons[i].sparse;
+  return k;
+}
+
+int cxk_count_lmi_kernel(const cxk_context* ctx, int which) {
+  if (!ctx || !ctx->device_ready) return -1;
+  int k = 0;
+  for (const Group& g : ctx->groups) {
+    if (g.type != CXK_LMI) continue;
+    const int kind = g.sparse ? 4 : g.schur_gemm ? 3 : g.mfma ? 2 : g.fused ? 1 : 0;
+    if (kind == which) k += (int)g.ids.size();
+  }
   return k;
 }
 

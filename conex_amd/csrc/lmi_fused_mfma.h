@@ -1,0 +1,18 @@
+// Host interface of the MFMA dense-LMI Schur kernel (lmi_fused_mfma.hip): its own translation
+// unit, so the kernel rebuilds in seconds and this header stays free of device code.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lmi_types.h"
+
+namespace cxk {
+
+// Shapes the persistent producer / consumer kernel covers: order n in {20, 24} (a multiple of 4
+// above 16), any number of variables m with m + 1 <= 24 matrices whose two P images fit LDS.
+bool LmiMfmaSupports(int n, int m);
+
+// ConstructSchurComplementSystem(DenseLMIConstraint*) for every member of the group
+// (dense_lmi_constraint.cc:72-103); `cus` = multiprocessors of the device the stream runs on.
+hipError_t LaunchLmiSchurMfma(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stream);
+
+}  // namespace cxk

@@ -1,0 +1,526 @@
+// lmi_schur_mfma<N>: dense-LMI Schur assembly on the fp64 matrix pipe, persistent producer /
+// consumer workgroups.  Reference semantics: ConstructSchurComplementSystem(DenseLMIConstraint*),
+// dense_lmi_constraint.cc:72-103 (G(i,j) = <W A_i W, A_j>, AW(i) = tr(A_i W), AQc(i) = <C, W A_i W>,
+// <w,c> = <C, W>, <c,Qc> = <C, W C W>), A_i and C symmetric (the host routes anything else to the
+// literal kernel).
+//
+// Why this shape.  On gfx950 fp64 FMAs and fp64 MFMAs drain the SAME pipe (measured,
+// profiles/r02/mfma_f64_peak.jsonl: 16 multiply-adds per clock per SIMD either way, no overlap
+// between the two), so the kernel is priced by multiply-adds executed, and at the benchmark shape
+// (n = m = 20) the 72 KB of A per constraint need as long to arrive (6.3 TB/s) as the pipe needs for
+// them: the design goal is "both busy all the time".
+//
+//   stage 1  P = S W,  S = [A_1; ..; A_m; C] stacked (M1 N rows x N).  A 16-row tile is ONE MFMA
+//            A-operand per k-step in both shapes used: v_mfma_f64_16x16x4 against W[:, 0..15] and
+//            v_mfma_f64_4x4x4 (4 blocks) against W[:, 16..] -- the two instructions share the
+//            A-operand layout (lane = 16 k + row; layout of the 4x4x4 form measured,
+//            profiles/r02/mfma_f64_4x4x4_layout.txt), so N = 20 costs 5 x (64 + 16) cycles per tile
+//            with no padded columns.  Operands come STRAIGHT from HBM in that layout: lane (row, q)
+//            loads the N/4 consecutive doubles q N/4 .. of its row (the k-steps take k = q N/4 + e,
+//            W's operand rows are permuted to match); a tile is 16 N contiguous doubles and this
+//            gather streams as fast as a coalesced copy (tools/load_pattern_bench.hip: 6.3 TB/s).
+//            No LDS staging of A, no VALU work on the data.
+//   stage 2  G(i,j) = tr(P_i P_j) (A symmetric: the second product W (A_i W) is never formed):
+//            a (M1 x N^2)(N^2 x M1) product over the P image in LDS, v_mfma_f64_16x16x4; for
+//            17 <= M1 <= 24 the lower triangle is covered by TWO 16 x 16 tiles (rows R..M1-1 x
+//            columns 0..15, and the symmetric block over matrices {0..R-1} u {16..M1-1}, R = M1-16).
+//
+// Roles.  One 512-thread workgroup per CU, persistent over its constraints.  Waves 0-3 (one per
+// SIMD) are PRODUCERS: they own the tiles t = wave (mod 4), keep the NEXT constraint's tiles in
+// flight in registers (a tile's registers are reloaded as soon as its MFMAs have issued: a whole
+// constraint of prefetch distance) and write P into one of two LDS images.  Waves 4-7 are
+// CONSUMERS: contraction of the previous constraint from the other image (k-steps dealt to the
+// four waves, partial tiles summed in a fixed order through LDS), then the epilogue.  Each SIMD
+// thus always has a wave with MFMAs to issue; two workgroup barriers per constraint:
+//
+//   iteration it    producers                         consumers
+//     phase X       tiles 0 .. TPW-2 of c_it          contraction of c_{it-1} -> partial tiles
+//     barrier 1
+//     phase Y       last tile of c_it                 reduce partials, traces, write G / AW / AQc / scalars
+//     barrier 2
+//
+// All sums run in a fixed order: results are bit-reproducible run to run.  Differences to the
+// reference's summation order are rounding-level (tests: <= 1e-13 on every Schur block).
+#include "lmi_fused_mfma.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "device_utils.h"
+
+namespace cxk {
+namespace {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kDestSlots = 64;  // per-workgroup table of output offsets (LDS)
+
+#ifdef CXK_MFMA_STAMPS
+// diagnostic build only (make dbg): s_memtime stamps of workgroups 0 and 200, per wave
+__device__ long long g_mfma_stamp[2 * 16 * 64];
+#define MSTAMP(slot)                                                                               \
+  do {                                                                                             \
+    if ((blockIdx.x == 0 || blockIdx.x == 200) && (threadIdx.x & 63) == 0 && (slot) < 64)          \
+      g_mfma_stamp[((blockIdx.x ? 1 : 0) * 16 + (threadIdx.x >> 6)) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define MSTAMP(slot) \
+  do {               \
+  } while (0)
+#endif
+
+template <int N>
+struct MfmaCfg {
+  static_assert(N % 4 == 0 && N > 16 && N < 32, "one 16-column tile plus 4-column blocks");
+  static constexpr int NK = N / 4;            // stage-1 k-steps = doubles of its row a lane holds
+  static constexpr int NC4 = (N - 16) / 4;    // 4-column blocks beside the 16-column tile
+  static constexpr int LD = N + 1;            // odd row stride of the P image
+  static constexpr int MS = N * LD + (6 - (N * LD) % 4) % 4;  // matrix stride = 2 (mod 4) doubles
+  static constexpr int KSTEPS = N * N / 4;    // stage-2 k-steps
+  static constexpr int PROD = 8, CONS = 4;    // producer / consumer wavefronts (two / one per SIMD)
+  static constexpr int TPW = 4;               // tiles per producer wave (<= 32 tiles of 16 rows)
+  static constexpr int YSLOTS = 1;            // tile slots a producer keeps for phase Y
+  static constexpr int THREADS = 64 * (PROD + CONS);
+  static constexpr int RPW = N / CONS;        // stage-2 rows (of N/4 k-steps each) per consumer wave
+  static_assert(N % CONS == 0, "stage-2 rows are dealt evenly");
+  static_assert(MS % 4 == 2, "both stage-2 operand reads are bank-conflict free only then");
+};
+
+// LDS traffic of this wave has landed, then the workgroup barrier.  Not __syncthreads(): its
+// release fence would also wait for the producers' prefetch loads (vmcnt).
+__device__ __forceinline__ void LdsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int N>
+__device__ __forceinline__ int PAddr(int rho) {  // stacked row -> offset of its row in the P image
+  using Cfg = MfmaCfg<N>;
+  const int mat = rho / N;
+  return mat * Cfg::MS + (rho - mat * N) * Cfg::LD;
+}
+
+// Per-lane geometry of the producer's tiles: the same for every constraint, computed once.
+// The host stores C behind the m matrices A_i of its constraint (LmiGroup::a_stride = (m+1) n^2),
+// so the stacked rows [A_1; ..; A_m; C] are ONE contiguous (M1 N) x N row-major array.
+template <int N>
+struct TileGeom {
+  unsigned src[MfmaCfg<N>::TPW];  // byte offset of the lane's NK operands inside the constraint's block
+  int p16[MfmaCfg<N>::TPW][4];    // P-image offsets (doubles) of the four 16x16x4 result elements
+  int p4[MfmaCfg<N>::TPW];        // P-image offset of the 4x4x4 result (first 4-column block)
+  unsigned keep;                  // bit 8 tt + e (e < 4): 16x16x4 element e is a real row; bit 8 tt + 4: the 4x4x4 row is
+};
+
+template <int N>
+__device__ __forceinline__ void MakeGeom(TileGeom<N>& gm, int wave, int lane, int rows, int nt1) {
+  using Cfg = MfmaCfg<N>;
+  const int s = lane & 15, q = lane >> 4;
+  gm.keep = 0;
+#pragma unroll
+  for (int tt = 0; tt < Cfg::TPW; tt++) {
+    int t = wave + Cfg::PROD * tt;
+    const bool real = t < nt1;
+    t = real ? t : nt1 - 1;             // a slot past the last tile re-reads the last tile (results unused)
+#pragma unroll
+    for (int e = 0; e < 4; e++) gm.keep |= (real && 16 * t + q + 4 * e < rows ? 1u : 0u) << (8 * tt + e);
+    gm.keep |= (real && 16 * t + 4 * ((lane >> 2) & 3) + q < rows ? 1u : 0u) << (8 * tt + 4);
+    int rho = 16 * t + s;
+    rho = rho < rows ? rho : rows - 1;  // rows past the last matrix: any valid address, results unused
+    gm.src[tt] = (unsigned)(rho * N + q * Cfg::NK) * 8u;
+    // 16x16x4 result: element e of lane l is (row (l >> 4) + 4 e, column l & 15)
+#pragma unroll
+    for (int e = 0; e < 4; e++) gm.p16[tt][e] = PAddr<N>(16 * t + q + 4 * e) + s;
+    // 4x4x4 result: lane l holds (row 4 ((l >> 2) & 3) + (l >> 4), column l & 3) of each block
+    gm.p4[tt] = PAddr<N>(16 * t + 4 * ((lane >> 2) & 3) + q) + 16 + (lane & 3);
+  }
+}
+
+// Lane (row s, k-group q) fetches its NK doubles of the stacked row it owns in tile slot tt:
+// uniform base + per-lane 32-bit offset (no address arithmetic on the vector ALU, which the
+// fp64 matrix instructions keep busy: measured, every VALU instruction costs pipe time).
+template <int N>
+__device__ __forceinline__ void LoadTile(double (&a)[MfmaCfg<N>::NK], const TileGeom<N>& gm, int tt,
+                                         const double* __restrict__ block) {
+  constexpr int NK = MfmaCfg<N>::NK;
+  const double* src = reinterpret_cast<const double*>(reinterpret_cast<const char*>(block) + gm.src[tt]);
+#pragma unroll
+  for (int e = 0; e < NK; e++) a[e] = src[e];
+}
+
+template <int N>
+struct WOps {  // stage-1 B operands of one constraint: k-step e uses W row q NK + e
+  double w16[MfmaCfg<N>::NK];
+  double w4[MfmaCfg<N>::NC4][MfmaCfg<N>::NK];
+};
+
+template <int N>
+__device__ __forceinline__ void LoadW(WOps<N>& w, const double* __restrict__ Wg, int lane) {
+  using Cfg = MfmaCfg<N>;
+  const int s = lane & 15, q = lane >> 4, j = lane & 3;
+#pragma unroll
+  for (int e = 0; e < Cfg::NK; e++) {
+    const double* row = Wg + (size_t)(q * Cfg::NK + e) * N;
+    w.w16[e] = row[s];
+#pragma unroll
+    for (int cb = 0; cb < Cfg::NC4; cb++) w.w4[cb][e] = row[16 + 4 * cb + j];
+  }
+}
+
+template <int N>
+struct TileAcc {  // results of one tile: the 16-column MFMA tile and the 4-column blocks
+  d4_t a16;
+  double a4[MfmaCfg<N>::NC4];
+};
+
+// Piece e of a finished tile: pieces 0..3 are the 16x16x4 elements (rows (l >> 4) + 4 e, column
+// l & 15), pieces 4.. the 4x4x4 blocks.
+template <int N, bool MASKED>
+__device__ __forceinline__ void StorePiece(const TileAcc<N>& r, int e, double* __restrict__ Pb, const TileGeom<N>& gm, int tp) {
+  if (e < 4) {
+    if (!MASKED || ((gm.keep >> (8 * tp + e)) & 1)) Pb[gm.p16[tp][e]] = r.a16[e];
+  } else {
+    if (!MASKED || ((gm.keep >> (8 * tp + 4)) & 1)) Pb[gm.p4[tp] + 4 * (e - 4)] = r.a4[e - 4];
+  }
+}
+
+// Tile slot tt's MFMAs issue back to back; the stores of the PREVIOUS slot's results are dealt
+// into the gaps between them (an MFMA occupies the pipe for 64 / 16 cycles during which the wave
+// may issue LDS work), pinned there by the scheduling barriers.  A slot that still has MFMAs to
+// issue is never preceded by the ragged last tile, so these stores need no lane mask.
+template <int N, bool HAS_PREV>
+__device__ __forceinline__ void FullStep(TileAcc<N>& cur, const double (&a)[MfmaCfg<N>::NK], const WOps<N>& w,
+                                         const TileAcc<N>& prev, double* __restrict__ Pb, const TileGeom<N>& gm, int tt) {
+  using Cfg = MfmaCfg<N>;
+  const d4_t zero4 = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int e = 0; e < Cfg::NK; e++) {
+    cur.a16 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], w.w16[e], e == 0 ? zero4 : cur.a16, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (HAS_PREV) StorePiece<N, false>(prev, e, Pb, gm, tt - 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int cb = 0; cb < Cfg::NC4; cb++)
+      cur.a4[cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[e], w.w4[cb][e], e == 0 ? 0.0 : cur.a4[cb], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+struct ConstraintPtrs {
+  const double* block;  // [A_1 .. A_m | C] of the constraint
+  const double* Wg;
+};
+__device__ __forceinline__ ConstraintPtrs Member(const LmiGroup& g, int mem, int nn) {
+  ConstraintPtrs p;
+  p.block = g.A + (size_t)mem * g.a_stride;
+  p.Wg = g.W + (size_t)mem * nn;
+  return p;
+}
+
+template <int N>
+__global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g, Arena ar) {
+  using Cfg = MfmaCfg<N>;
+  constexpr int NK = Cfg::NK, LD = Cfg::LD, MS = Cfg::MS, TPW = Cfg::TPW, NN = N * N;
+  extern __shared__ double lds[];
+  const int M = g.m, M1 = M + 1, rows = M1 * N;
+  const int nt1 = (rows + 15) >> 4;
+  const int pbuf = M1 * MS;
+  const bool two = M1 > 16;
+  const int ntl = two ? 2 : 1;
+  double* P0 = lds;
+  double* scratch = lds + 2 * (size_t)pbuf;  // CONS x ntl x 256 partial-tile entries
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int first = blockIdx.x, stride = gridDim.x;
+  const int cnt = (g.count - first + stride - 1) / stride;  // constraints of this workgroup (>= 1)
+
+  if (wave < Cfg::PROD) {
+    // ------------------------------------------------------------------ producers
+    double a[TPW][NK];
+    WOps<N> w, wn;
+    TileGeom<N> gm;
+    MakeGeom<N>(gm, wave, lane, rows, nt1);
+    MSTAMP(0);
+    {
+      const ConstraintPtrs c0 = Member(g, first, NN);
+      // Issue order matters: waits count loads in flight in issue order, and the loop below
+      // reloads the slots in the order 0, 1, ...; the scheduling barriers keep the compiler from
+      // permuting these independent loads (it emitted them last-slot-first, which made every
+      // iteration wait for ALL of its operands before its first MFMA).
+      LoadW<N>(wn, c0.Wg, lane);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tt = 0; tt < TPW; tt++) {
+        LoadTile<N>(a[tt], gm, tt, c0.block);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    for (int it = 0; it < cnt; it++) {
+      // Every load below is unconditional (a tile slot past the last tile re-reads the last tile,
+      // the last iteration re-reads its own constraint: cache hits that nothing waits for), so the
+      // count of loads in flight is the same on every path and each wait can be exact.
+      MSTAMP(1 + 4 * it);
+      const int itn = it + 1 < cnt ? it + 1 : it;
+      const ConstraintPtrs nx = Member(g, first + itn * stride, NN);
+      w = wn;
+      LoadW<N>(wn, nx.Wg, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      double* Pb = P0 + (it & 1) * pbuf;
+      TileAcc<N> res[2];
+#pragma unroll
+      for (int tt = 0; tt <= TPW; tt++) {
+        if (tt == TPW - Cfg::YSLOTS) {
+          MSTAMP(2 + 4 * it);
+          LdsBarrier();  // barrier 1
+          MSTAMP(3 + 4 * it);
+        }
+        const bool cur_ok = tt < TPW && wave + Cfg::PROD * tt < nt1;
+        const bool prev_ok = tt > 0 && wave + Cfg::PROD * (tt - 1) < nt1;
+        if (cur_ok) {
+          if (tt == 0)
+            FullStep<N, false>(res[0], a[0], w, res[1], Pb, gm, 0);
+          else
+            FullStep<N, true>(res[tt & 1], a[tt < TPW ? tt : 0], w, res[(tt & 1) ^ 1], Pb, gm, tt);
+        } else if (prev_ok) {
+          // the wave's last tile (possibly the ragged last tile of the constraint: masked stores)
+#pragma unroll
+          for (int e = 0; e < NK; e++) StorePiece<N, true>(res[(tt & 1) ^ 1], e, Pb, gm, tt - 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef CXK_EXPERIMENT_NO_RELOAD  // diagnostic: operands of the first constraint are reused (wrong results, compute-only timing)
+        if (tt > 0) LoadTile<N>(a[tt - 1], gm, tt - 1, nx.block);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      MSTAMP(4 + 4 * it);
+      LdsBarrier();  // barrier 2
+    }
+    MSTAMP(1 + 4 * cnt);
+    LdsBarrier();  // drain iteration: the consumers finish the last constraint
+    LdsBarrier();
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  // The consumers are the longer dependency chain of an iteration: their instructions win the
+  // SIMD's issue arbitration, the two producer waves beside each of them fill what is left.
+  __builtin_amdgcn_s_setprio(2);
+  const int cw = wave - Cfg::PROD;
+  const int ct = threadIdx.x - 64 * Cfg::PROD;  // 0 .. 255
+  const int il = lane & 15, kq = lane >> 4;
+  const int R = M1 - 16;
+  const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;  // Hermitian cones: tr over the real representation
+  // operand rows of the two tiles (or of the single tile when M1 <= 16; rows past M1 alias M1 - 1)
+  const int rowA = two ? (R + il) * MS : (il < M1 ? il : M1 - 1) * MS;
+  const int colA = two ? il * MS : rowA;
+  const int setB = two ? (il < R ? il : (il < 2 * R ? 16 + il - R : M1 - 1)) * MS : 0;
+  // Iteration 0 has nothing to consume: look up where this workgroup's constraints write (two
+  // dependent loads each) and park the answers in LDS, off every later critical path.
+  int64_t* dest = reinterpret_cast<int64_t*>(scratch + (size_t)Cfg::CONS * ntl * 256);  // kDestSlots x {id, g_off, r_off}
+  if (ct < kDestSlots && ct < cnt) {
+    const int id = g.ids[first + ct * stride];
+    dest[3 * ct] = id;
+    dest[3 * ct + 1] = ar.g_off[id];
+    dest[3 * ct + 2] = ar.r_off[id];
+  }
+  // ... and tabulate the epilogue: entry e = (ii, jj <= ii) of the lower triangle of the M1 x M1
+  // result -> where its four partial sums sit in the tiles and where the total goes
+  // (kind 0: G[dst], 1: AQc[dst], 2: <c,Qc>), packed  tile offset | kind << 10 | dst << 12.
+  int* etab = reinterpret_cast<int*>(dest + 3 * kDestSlots);
+  const int nout = M1 * (M1 + 1) / 2;
+  for (int idx = ct; idx < M1 * M1; idx += 64 * Cfg::CONS) {
+    const int ii = idx / M1, jj = idx - ii * M1;
+    if (jj > ii) continue;
+    int off;
+    if (two) {
+      if (ii >= R && jj < 16)
+        off = (ii - R) * 16 + jj;                        // tile 0
+      else if (ii < R)
+        off = 256 + ii * 16 + jj;                        // tile 1, both among the first R
+      else
+        off = 256 + (R + ii - 16) * 16 + (R + jj - 16);  // tile 1, both >= 16
+    } else {
+      off = ii * 16 + jj;
+    }
+    const int kind = ii < M ? 0 : (jj < M ? 1 : 2);
+    const int dst = ii < M ? ii + jj * M : (jj < M ? jj : 0);
+    etab[ii * (ii + 1) / 2 + jj] = off | kind << 10 | dst << 12;
+  }
+  LdsBarrier();
+  LdsBarrier();
+  MSTAMP(0);
+  for (int it = 1; it <= cnt; it++) {
+    MSTAMP(1 + 4 * it);
+    const double* Pb = P0 + ((it - 1) & 1) * pbuf;
+    // k-steps: this wave takes the RPW rows rr = cw RPW .. of the N x N index space, NK steps
+    // each; the operands of the next row are in flight while the current row's MFMAs issue
+    d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0}, acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
+    const int rr0 = cw * Cfg::RPW;
+    if (two) {
+      double a0[2][NK], b0[2][NK], a1[2][NK], b1[2][NK];
+      auto fetch = [&](int buf, int rr) {
+#pragma unroll
+        for (int bi = 0; bi < NK; bi++) {
+          const int ao = rr * LD + 4 * bi + kq, bo = (4 * bi + kq) * LD + rr;
+          a0[buf][bi] = Pb[rowA + ao];
+          b0[buf][bi] = Pb[colA + bo];
+          a1[buf][bi] = Pb[setB + ao];
+          b1[buf][bi] = Pb[setB + bo];
+        }
+      };
+      fetch(0, rr0);
+      // the next row's operands are read in the gaps between this row's MFMAs (a lone wavefront
+      // issues a ds_read_b64 every ~17 cycles: 20 reads up front would idle the pipe for ~300)
+#pragma unroll
+      for (int r = 0; r < Cfg::RPW; r++) {
+        const int cb_ = r & 1, nb_ = cb_ ^ 1, rn = rr0 + r + 1;
+        if (it == cnt) MSTAMP(48 + r);
+#pragma unroll
+        for (int bi = 0; bi < NK; bi++) {
+          const int ao = rn * LD + 4 * bi + kq, bo = (4 * bi + kq) * LD + rn;
+          __builtin_amdgcn_sched_barrier(0);
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[cb_][bi], b0[cb_][bi], acc0, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#ifndef CXK_EXPERIMENT_NO_READS  // diagnostic: operands of the first row are reused (wrong results, MFMA-only timing)
+          if (r + 1 < Cfg::RPW) {
+            a0[nb_][bi] = Pb[rowA + ao];
+            b0[nb_][bi] = Pb[colA + bo];
+          }
+#else
+          a0[nb_][bi] = a0[cb_][bi]; b0[nb_][bi] = b0[cb_][bi];
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[cb_][bi], b1[cb_][bi], acc1, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#ifndef CXK_EXPERIMENT_NO_READS
+          if (r + 1 < Cfg::RPW) {
+            a1[nb_][bi] = Pb[setB + ao];
+            b1[nb_][bi] = Pb[setB + bo];
+          }
+#else
+          a1[nb_][bi] = a1[cb_][bi]; b1[nb_][bi] = b1[cb_][bi];
+#endif
+        }
+      }
+    } else {
+      double a0[2][NK], b0[2][NK];
+      auto fetch = [&](int buf, int rr) {
+#pragma unroll
+        for (int bi = 0; bi < NK; bi++) {
+          a0[buf][bi] = Pb[rowA + rr * LD + 4 * bi + kq];
+          b0[buf][bi] = Pb[rowA + (4 * bi + kq) * LD + rr];
+        }
+      };
+      fetch(0, rr0);
+#pragma unroll
+      for (int r = 0; r < Cfg::RPW; r++) {
+        const int cb_ = r & 1, nb_ = cb_ ^ 1, rn = rr0 + r + 1;
+#pragma unroll
+        for (int bi = 0; bi < NK; bi++) {
+          __builtin_amdgcn_sched_barrier(0);
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[cb_][bi], b0[cb_][bi], acc0, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (r + 1 < Cfg::RPW) {
+            a0[nb_][bi] = Pb[rowA + rn * LD + 4 * bi + kq];
+            b0[nb_][bi] = Pb[rowA + (4 * bi + kq) * LD + rn];
+          }
+        }
+      }
+    }
+    if (it == cnt) MSTAMP(48 + Cfg::RPW);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {  // C/D layout: column = lane & 15, row = (lane >> 4) + 4 e
+      scratch[(cw * ntl) * 256 + (kq + 4 * e) * 16 + il] = acc0[e];
+      if (two) scratch[(cw * ntl + 1) * 256 + (kq + 4 * e) * 16 + il] = acc1[e];
+    }
+    // where the results go (the host sizes the grid so that a workgroup never has more than
+    // kDestSlots constraints)
+    const int id = (int)dest[3 * (it - 1)];
+    const int64_t goff = dest[3 * (it - 1) + 1], roff = dest[3 * (it - 1) + 2];
+    double* G = ar.G + goff;
+    MSTAMP(2 + 4 * it);
+    LdsBarrier();  // barrier 1
+    MSTAMP(3 + 4 * it);
+    {
+      double* AW = ar.AWc + roff;
+      double* AQc = ar.AQcc + roff;
+      for (int e = ct; e < nout; e += 64 * Cfg::CONS) {
+        const int code = etab[e];
+        const int off = code & 1023, kind = (code >> 10) & 3, dst = code >> 12;
+        double sum = 0;
+#pragma unroll
+        for (int wv = 0; wv < Cfg::CONS; wv++) sum += scratch[wv * ntl * 256 + off];
+        sum *= osc;
+        if (kind == 0)
+          G[dst] = sum;
+        else if (kind == 1)
+          AQc[dst] = sum;
+        else
+          ar.sc[2 * id + 1] = sum;
+      }
+      for (int ii = ct; ii < M1; ii += 64 * Cfg::CONS) {  // AW(i) = tr(P_i), <w,c> = tr(P_C)
+        double sum = 0;
+#pragma unroll
+        for (int r = 0; r < N; r++) sum += Pb[ii * MS + r * LD + r];
+        sum *= osc;
+        if (ii < M)
+          AW[ii] = sum;
+        else
+          ar.sc[2 * id] = sum;
+      }
+    }
+    MSTAMP(4 + 4 * it);
+    LdsBarrier();  // barrier 2
+  }
+  MSTAMP(1 + 4 * (cnt + 1));
+}
+
+template <int N>
+size_t MfmaLds(int m) {
+  using Cfg = MfmaCfg<N>;
+  const int m1 = m + 1;
+  return sizeof(double) * (2 * (size_t)m1 * Cfg::MS + (size_t)Cfg::CONS * (m1 > 16 ? 2 : 1) * 256 + 3 * kDestSlots) +
+         sizeof(int) * (size_t)(m1 * (m1 + 1) / 2);
+}
+
+constexpr size_t kLdsPerCu = 160 * 1024;
+
+template <int N>
+bool SupportsT(int m) {
+  const int m1 = m + 1;
+  return m >= 1 && m1 <= 24 && (m1 * N + 15) / 16 <= MfmaCfg<N>::TPW * MfmaCfg<N>::PROD && MfmaLds<N>(m) <= kLdsPerCu;
+}
+
+template <int N>
+hipError_t LaunchT(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stream) {
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lmi_schur_mfma<N>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  int grid = g.count < cus ? g.count : cus;
+  const int need = (g.count + kDestSlots - 1) / kDestSlots;  // at most kDestSlots constraints per workgroup
+  if (grid < need) grid = need;
+  lmi_schur_mfma<N><<<grid, MfmaCfg<N>::THREADS, MfmaLds<N>(g.m), stream>>>(g, ar);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool LmiMfmaSupports(int n, int m) {
+  if (n == 20) return SupportsT<20>(m);
+  if (n == 24) return SupportsT<24>(m);
+  return false;
+}
+
+hipError_t LaunchLmiSchurMfma(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stream) {
+  if (g.count <= 0) return hipSuccess;
+  if (g.n == 20) return LaunchT<20>(g, ar, cus, stream);
+  if (g.n == 24) return LaunchT<24>(g, ar, cus, stream);
+  return hipErrorNotSupported;
+}
+
+}  // namespace cxk
+
+#ifdef CXK_MFMA_STAMPS
+extern "C" __attribute__((visibility("default"))) int cxk_debug_mfma_stamps(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(cxk::g_mfma_stamp), sizeof(long long) * 2 * 16 * 64) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -9,7 +9,10 @@ struct LmiGroup {
   int n;
   int m;
   int count;
-  const double* A;  // count x m x (n*n)
+  const double* A;  // count x a_stride: the m matrices (n*n each) of a member, col-major
+  // doubles between the A blocks of consecutive members: m n^2, or (m+1) n^2 for groups whose
+  // kernel wants C stored right behind the A_i (lmi_schur_mfma); C itself always also lives in `C`
+  long long a_stride;
   const double* C;  // count x (n*n)
   double* W;        // count x (n*n)
   double* T1;       // count x (n*n)   temp_1 of WorkspaceDensePSD (WS between Prepare/TakeStep)

@@ -87,6 +87,7 @@ _SIGNATURES = {
     "cxk_finish_assemble": (C.c_int, [C.c_void_p]),
     "cxk_assembly_work": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "cxk_count_sparse_lmi": (C.c_int, [C.c_void_p]),
+    "cxk_count_lmi_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_dense_top_columns": (C.c_int, [C.c_void_p]),
     "cxk_factor_async": (C.c_int, [C.c_void_p]),
     "cxk_factor_solve_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
@@ -483,6 +484,11 @@ class KktContext:
     def count_sparse_lmi(self):
         """Constraints on the sparse-LMI evaluation path (cxk_count_sparse_lmi)."""
         return self.L.cxk_count_sparse_lmi(self.h)
+
+    def count_lmi_kernel(self, which):
+        """Constraints whose Schur block comes from kernel `which` (cxk_count_lmi_kernel): 0 literal,
+        1 DPP + MFMA rows, 2 persistent MFMA, 3 GEMM pipeline, 4 sparse."""
+        return self.L.cxk_count_lmi_kernel(self.h, which)
 
     def assembly_work(self):
         b = C.c_double()

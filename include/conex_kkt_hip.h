@@ -232,6 +232,14 @@ int cxk_gemm_f64(int device, int ta, int tb, int M, int N, int K, int batch, con
  * never/always).  Results equal the dense path's to rounding. */
 int cxk_count_sparse_lmi(const cxk_context* ctx);
 
+/* Number of (owned) LMI / Hermitian constraints whose Schur complement
+ * (ConstructSchurComplementSystem, dense_lmi_constraint.cc:72-103) is evaluated by kernel `which`:
+ * 0 literal LDS kernel (lmi_schur_generic; also every constraint with non-symmetric data, which
+ * the reference accepts and evaluates as written), 1 row-per-lane DPP + MFMA kernel
+ * (lmi_schur_fused), 2 persistent MFMA producer/consumer kernel (lmi_schur_mfma), 3 batched GEMM
+ * pipeline (orders beyond LDS and mid-size orders), 4 sparse evaluation. */
+int cxk_count_lmi_kernel(const cxk_context* ctx, int which);
+
 /* Columns of the dense range at the top of the elimination tree (0 = none): when the last levels
  * hold a supernode of 33..64 columns and at most 64 columns in total, BlockCholeskyInPlace and
  * the block solves (block_triangular_operations.cc:114-219) restricted to those levels run as one

@@ -119,6 +119,74 @@ def test_lmi_newton_step(K, n, m, b_, ov):
     check_newton_step(o, k, prob["b"])
 
 
+@pytest.mark.parametrize("K,n,m,b_,ov", [(1, 20, 1, 2, 1), (7, 20, 9, 3, 2), (300, 20, 15, 4, 3), (5, 20, 16, 2, 4),
+                                          (70, 20, 20, 8, 5), (3, 24, 10, 2, 2), (9, 24, 14, 2, 5)])
+def test_lmi_mfma_kernel_shapes(K, n, m, b_, ov):
+    """The persistent MFMA Schur kernel (lmi_fused_mfma.hip) takes the number of variables at run
+    time: one 16 x 16 contraction tile up to 16 matrices (m + 1), the two-tile cover from 17 to 24;
+    K = 300 gives the 256 workgroups two constraints each (both P images in use), K < 256 one."""
+    prob = syn.lmi_problem(K=K, n=n, m=m, branching=b_, overlap=ov, seed=700 + K + m)
+    W = syn.scaling_points(K, n, seed=17 + K)
+    o, k = make_pair(prob, "lmi", W)
+    assert k.count_lmi_kernel(2) == K
+    check_newton_step(o, k, prob["b"])
+    # bit-reproducible: all sums run in a fixed order
+    k.assemble()
+    G1 = [k.constraint_schur(i)[0].copy() for i in range(0, K, max(1, K // 5))]
+    k.assemble()
+    G2 = [k.constraint_schur(i)[0] for i in range(0, K, max(1, K // 5))]
+    assert all(np.array_equal(a, b) for a, b in zip(G1, G2))
+
+
+def test_lmi_mfma_kernel_many_constraints_per_workgroup():
+    """More constraints than 4 x CUs: every workgroup walks a long list (P images alternate)."""
+    K = 1500
+    prob = syn.lmi_problem(K=K, n=20, m=4, branching=8, overlap=1, seed=3)
+    W = syn.scaling_points(K, 20, seed=4)
+    o, k = make_pair(prob, "lmi", W)
+    assert k.count_lmi_kernel(2) == K
+    o.assemble()
+    k.assemble()
+    for i in list(range(0, K, 97)) + [K - 1, K - 2, 255, 256, 257, 511, 512, 1023, 1024, 1279, 1280]:
+        Go, AWo, AQo, sco = o.constraint_schur(i)
+        Gk, AWk, AQk, sck = k.constraint_schur(i)
+        assert rel(np.tril(Gk), np.tril(Go)) <= TOL_SCHUR
+        assert rel(AWk, AWo) <= TOL_SCHUR and rel(AQk, AQo) <= TOL_SCHUR and rel(sck, sco) <= TOL_SCHUR
+    assert rel(blocks(k, k.slab()), blocks(o, o.slab())) <= TOL_SCHUR
+
+
+@pytest.mark.parametrize("n,m", [(20, 20), (7, 5), (24, 24), (40, 6)])
+def test_lmi_non_symmetric_data_matches_the_reference_formula(n, m):
+    """The reference accepts non-symmetric A_i / C and evaluates G(i,j) = <W A_i W, A_j>,
+    AW(i) = tr(A_i W), AQc(i) = <C, W A_i W> as written (dense_lmi_constraint.cc:72-88; the oracle
+    restates exactly that).  The fast kernels use tr(W A_i W A_j) = tr(P_i P_j), P = A W, which
+    holds for symmetric data only, so such a constraint is routed to the literal kernels."""
+    rng = np.random.default_rng(n + m)
+    prob = syn.lmi_problem(K=6, n=n, m=m, branching=2, overlap=min(2, m - 1), seed=55)
+    prob["A"] = rng.uniform(-1, 1, prob["A"].shape)               # no symmetrisation
+    prob["A"][0] = 0.5 * (prob["A"][0] + np.transpose(prob["A"][0], (0, 2, 1)))  # constraint 0 stays symmetric
+    W = syn.scaling_points(6, n, seed=8)
+    o, k = make_pair(prob, "lmi", W)
+    assert k.count_lmi_kernel(0) >= 5
+    o.assemble()
+    k.assemble()
+    for i in range(6):
+        Go, AWo, AQo, sco = o.constraint_schur(i)
+        Gk, AWk, AQk, sck = k.constraint_schur(i)
+        assert rel(np.tril(Gk), np.tril(Go)) <= TOL_SCHUR
+        assert rel(AWk, AWo) <= TOL_SCHUR and rel(AQk, AQo) <= TOL_SCHUR and rel(sck, sco) <= TOL_SCHUR
+    assert rel(blocks(k, k.slab()), blocks(o, o.slab())) <= TOL_SCHUR
+
+
+def test_lmi_non_symmetric_data_beyond_lds_orders_is_refused():
+    prob = syn.lmi_problem(K=1, n=90, m=3, branching=2, overlap=1, seed=5)
+    prob["A"] = np.random.default_rng(1).uniform(-1, 1, prob["A"].shape)
+    k = KktContext(prob["num_vars"], device=0)
+    k.add_lmi(prob["A"][0], prob["C"][0], prob["cliques"][0])
+    with pytest.raises(RuntimeError, match="non-symmetric"):
+        k.initialize()
+
+
 @pytest.mark.parametrize("K,n,m,b_,ov", [(1, 70, 6, 2, 1), (3, 96, 9, 2, 3), (1, 200, 50, 2, 1)])
 def test_lmi_large_order_newton_step(K, n, m, b_, ov):
     """Orders beyond the LDS-resident kernels: HBM-resident matrices, every product on the fp64

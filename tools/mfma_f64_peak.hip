@@ -24,7 +24,14 @@ constexpr int kIters = 2048;   // loop trips; each trip issues kUnroll instructi
 
 template <int MODE>
 __global__ void __launch_bounds__(1024) rate_kernel(double* out, long long* cyc, double seed) {
+  __shared__ double lds_buf[4096];
   const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds_buf[i] = seed * i;
+  const double* lp = lds_buf + lane + 64 * (threadIdx.x >> 6);
+  double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+  double2 rr = make_double2(0, 0);
+  int iv[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+  int sv = 0;
   double a = seed + lane * 1e-3, b = seed * 0.5 - lane * 1e-3;
   d4_t acc[8];
 #pragma unroll
@@ -65,6 +72,56 @@ __global__ void __launch_bounds__(1024) rate_kernel(double* out, long long* cyc,
         for (int j = 0; j < 4; j++)
           asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(s[4 * i + j]) : "v"(a), "v"(b));
       }
+    } else if constexpr (MODE == 9) {   // MFMA 16x16x4 + 2 ds_read_b64 in its shadow (results unused until the end)
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        acc[i & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i & 1], 0, 0, 0);
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:512" : "=v"(r0), "=v"(r1) : "v"((unsigned)(size_t)lp + 64 * i));
+      }
+    } else if constexpr (MODE == 10) {  // MFMA 16x16x4 + 4 ds_read_b64
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        acc[i & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i & 1], 0, 0, 0);
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:512\n\tds_read_b64 %2, %4 offset:1024\n\tds_read_b64 %3, %4 offset:1536"
+                     : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3) : "v"((unsigned)(size_t)lp + 64 * i));
+      }
+    } else if constexpr (MODE == 11) {  // MFMA 16x16x4 + 1 ds_read_b128
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        acc[i & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i & 1], 0, 0, 0);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(rr) : "v"((unsigned)(size_t)(lds_buf + 2 * lane) + 128 * i));
+      }
+    } else if constexpr (MODE == 12) {  // 2 ds_read_b64 alone (no MFMA): the wave's own LDS issue rate
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:512" : "=v"(r0), "=v"(r1) : "v"((unsigned)(size_t)lp + 64 * i));
+    } else if constexpr (MODE == 13) {  // MFMA 16x16x4 + 2 ds_write_b64
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        acc[i & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i & 1], 0, 0, 0);
+        asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %1 offset:512" : : "v"((unsigned)(size_t)lp + 64 * i), "v"(a) : "memory");
+      }
+    } else if constexpr (MODE == 14) {  // MFMA 16x16x4 + 8 integer VALU ops
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        acc[i & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i & 1], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; j++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(iv[j]) : "v"(lane));
+      }
+    } else if constexpr (MODE == 15) {  // MFMA 16x16x4 + 16 integer VALU ops
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        acc[i & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i & 1], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 16; j++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(iv[j & 7]) : "v"(lane));
+      }
+    } else if constexpr (MODE == 16) {  // MFMA 16x16x4 + 8 scalar ALU ops
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        acc[i & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i & 1], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; j++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sv));
+      }
     } else if constexpr (MODE == 8) {   // MFMA 16x16x4 interleaved with 8 plain FMAs each
 #pragma unroll
       for (int i = 0; i < 2; i++) {
@@ -74,8 +131,11 @@ __global__ void __launch_bounds__(1024) rate_kernel(double* out, long long* cyc,
       }
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const long long t1 = __builtin_amdgcn_s_memtime();
-  double r = 0;
+  double r = r0 + r1 + r2 + r3 + rr.x + rr.y + sv;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r += iv[j];
 #pragma unroll
   for (int i = 0; i < 8; i++) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
 #pragma unroll
@@ -141,6 +201,14 @@ int main() {
       {"v_fmac_f64 dependent", 6, 16, 128.0},
       {"mfma16 + 4 dpp fma interleaved (per group of 5)", 7, 20, (2048.0 + 4 * 128.0) / 5},
       {"mfma16 + 8 fma interleaved (per group of 9)", 8, 18, (2048.0 + 8 * 128.0) / 9},
+      {"mfma16 + 2 ds_read_b64 each (per mfma)", 9, 8, 2048.0},
+      {"mfma16 + 4 ds_read_b64 each (per mfma)", 10, 8, 2048.0},
+      {"mfma16 + 1 ds_read_b128 each (per mfma)", 11, 8, 2048.0},
+      {"2 ds_read_b64 alone (per pair)", 12, 8, 0.0},
+      {"mfma16 + 2 ds_write_b64 each (per mfma)", 13, 8, 2048.0},
+      {"mfma16 + 8 v_add_u32 each (per mfma)", 14, 8, 2048.0},
+      {"mfma16 + 16 v_add_u32 each (per mfma)", 15, 8, 2048.0},
+      {"mfma16 + 8 s_add_u32 each (per mfma)", 16, 8, 2048.0},
   };
   for (int w : {1, 2, 4}) {
     run<0>(vs[0], w, out, cyc, ncu);
@@ -152,6 +220,14 @@ int main() {
     run<6>(vs[6], w, out, cyc, ncu);
     run<7>(vs[7], w, out, cyc, ncu);
     run<8>(vs[8], w, out, cyc, ncu);
+    run<9>(vs[9], w, out, cyc, ncu);
+    run<10>(vs[10], w, out, cyc, ncu);
+    run<11>(vs[11], w, out, cyc, ncu);
+    run<12>(vs[12], w, out, cyc, ncu);
+    run<13>(vs[13], w, out, cyc, ncu);
+    run<14>(vs[14], w, out, cyc, ncu);
+    run<15>(vs[15], w, out, cyc, ncu);
+    run<16>(vs[16], w, out, cyc, ncu);
   }
   return 0;
 }
