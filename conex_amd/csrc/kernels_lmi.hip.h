@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256) lmi_prepare_generic(LmiGroup g, StepArgs 
   __syncthreads();
   if (threadIdx.x == 0) {
     double mn = red[4], mx = red[5];
-    ClampToSpectrumBound(n, t1, t2, &mn, &mx);
+    if (!sa.no_clamp) ClampToSpectrumBound(n, t1, t2, &mn, &mx);
     if (g.herm_d > 1) {  // traces over the real representation are d x the reference's
       t2 /= g.herm_d;
       t1 /= g.herm_d;

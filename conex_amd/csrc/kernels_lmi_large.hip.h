@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(512) lmi_large_spectrum(LmiGroup g, StepArgs s
   __syncthreads();
   if (tid == 0) {
     double mn = red[8], mx = red[9];
-    ClampToSpectrumBound(n, t1, t2, &mn, &mx);
+    if (!sa.no_clamp) ClampToSpectrumBound(n, t1, t2, &mn, &mx);
     if (g.herm_d > 1) {
       t2 /= g.herm_d;
       t1 /= g.herm_d;

@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa)
   WaveSync();
   if (lane == 0) {
     double mn = sOut[wave][0], mx = sOut[wave][1];
-    ClampToSpectrumBound(N, t1, t2, &mn, &mx);
+    if (!sa.no_clamp) ClampToSpectrumBound(N, t1, t2, &mn, &mx);
     if (MODE == 0) {
       const double l1 = fabs(sa.e_weight + mn), l2 = fabs(sa.e_weight + mx);
       sa.info[2 * id] = t2 + 2 * t1 + N;

@@ -58,14 +58,22 @@ struct DevBuf {
     p = nullptr;
     n = 0;
   }
-  hipError_t alloc(size_t count) {
+  // `zeroed`: the code relies on the initial zeros (slots that are never written but read).
+  // Everything else is scratch that must be written before it is read: with CXK_DEBUG_FILL_NAN=1
+  // in the environment such buffers start as NaN (all-ones bytes), so that a read of unwritten
+  // memory shows up in the results instead of passing by luck (diagnostic runs of the test suite).
+  hipError_t alloc(size_t count, bool zeroed = false) {
     release();
     n = count;
     if (count == 0) count = 1;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    static const bool nan_fill = [] {
+      const char* v = getenv("CXK_DEBUG_FILL_NAN");
+      return v && atoi(v) != 0;
+    }();
     // the fill runs on the null stream, kernels on the context's stream, which may be
     // non-blocking (no implicit ordering with the null stream): wait for it on the host
-    if (e == hipSuccess) e = hipMemset(p, 0, count * sizeof(T));
+    if (e == hipSuccess) e = hipMemset(p, (nan_fill && !zeroed) ? 0xFF : 0, count * sizeof(T));
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     return e;
   }
@@ -115,6 +123,12 @@ struct cxk_context {
   std::string err;
   std::vector<ConstraintRec> cons;
   IntLists cliques, dual_vars;
+  // Reference identity: reproduce the reference AS WRITTEN where this library deliberately departs
+  // from it -- (i) BindDiagonalBlock's unchecked direct_update placement on fill-in supernodes
+  // (supernodal_assembler.cc:72-91) instead of scatter-by-position, (ii) raw Lanczos Ritz values
+  // (approximate_eigenvalues.cc:178-239) instead of the Samuelson-clamped ones.  Set by
+  // cxk_set_reference_identity() or CXK_REFERENCE_QUIRKS=1 in the environment, before cxk_finalize.
+  int reference_identity = -1;  // -1: take the environment's word at finalize
   bool finalized = false;     // symbolic analysis done (getters)
   bool device_ready = false;  // device buffers and plans built: numeric entry points may run
   int rank = 0, world = 1;
@@ -338,6 +352,7 @@ StepArgs MakeStep(cxk_context* ctx, double* info, int affine, double cw, double 
   s.e_weight = ew;
   s.step_size = ss;
   s.call = ctx->lanczos_calls;
+  s.no_clamp = ctx->reference_identity > 0;
   return s;
 }
 
@@ -524,8 +539,7 @@ int BuildPlans(cxk_context* ctx) {
     }
     return srcs[entry_of[off]];
   };
-  const char* quirks_env = getenv("CXK_REFERENCE_QUIRKS");
-  const bool quirks = quirks_env && atoi(quirks_env) != 0;
+  const bool quirks = ctx->reference_identity > 0;
   for (int e = K - 1; e >= 0; e--) {
     const int i = md.clique_order[e];
     const int m = ctx->cons[i].m;
@@ -786,8 +800,8 @@ int BuildPlans(cxk_context* ctx) {
   pubb_dst.resize(pubb_dst.size() + kPullPad, slotsb);
   CXK_TRY(ctx->pub_dst.upload(pub_dst));
   CXK_TRY(ctx->pubb_dst.upload(pubb_dst));
-  CXK_TRY(ctx->upd.alloc((size_t)slots + 1 + kPullPad));
-  CXK_TRY(ctx->updb.alloc((size_t)slotsb + 2 + kPullPad));  // + dump slot + a slot that stays 0.0
+  CXK_TRY(ctx->upd.alloc((size_t)slots + 1 + kPullPad, true));   // unused slots subtract 0.0
+  CXK_TRY(ctx->updb.alloc((size_t)slotsb + 2 + kPullPad, true));  // + dump slot + a slot that stays 0.0
 
   // ---- exchange layout: [T slab entries | AW_T | AQc_T | fwd_T | <w,c> <c,Qc> fail]
   if (sharded) {
@@ -2050,6 +2064,12 @@ int cxk_set_shard(cxk_context* ctx, int rank, int world_size) {
 
 static int FinalizeImpl(cxk_context* ctx);
 
+int cxk_set_reference_identity(cxk_context* ctx, int on) {
+  if (!ctx || ctx->finalized) return CXK_FAILURE;
+  ctx->reference_identity = on != 0;
+  return CXK_SUCCESS;
+}
+
 int cxk_finalize(cxk_context* ctx) {
   if (!ctx) return CXK_FAILURE;
   CXK_DEMAND(!ctx->cons.empty(), "no constraints");
@@ -2067,6 +2087,10 @@ int cxk_finalize(cxk_context* ctx) {
 }
 
 static int FinalizeImpl(cxk_context* ctx) {
+  if (ctx->reference_identity < 0) {
+    const char* quirks_env = getenv("CXK_REFERENCE_QUIRKS");
+    ctx->reference_identity = quirks_env && atoi(quirks_env) != 0;
+  }
   try {
     ctx->md = Analyze(ctx->cliques, ctx->dual_vars);
     ctx->lay = BuildLayout(ctx->md);
@@ -2213,14 +2237,14 @@ static int FinalizeImpl(cxk_context* ctx) {
   CXK_TRY(ctx->sys_sc.alloc(2));
   CXK_TRY(ctx->red_out.alloc(4));
   CXK_TRY(ctx->scal_out.alloc(8));
-  CXK_TRY(ctx->d_fail.alloc(1));
+  CXK_TRY(ctx->d_fail.alloc(1, true));
   ctx->use_ldlt = false;
   for (const IntList& dv : ctx->dual_vars)
     if (!dv.empty()) ctx->use_ldlt = true;  // kkt_solver.cc:180-186
   if (ctx->use_ldlt) {
     CXK_DEMAND(ctx->world == 1, "equality constraints (LDLT path) are single-GPU for now");
     CXK_TRY(ctx->d_tr.alloc(N));
-    CXK_TRY(ctx->d_reg.alloc(1));
+    CXK_TRY(ctx->d_reg.alloc(1, true));
   }
   {
     // per-constraint step outputs; constraints without a cone (constant blocks) keep the
@@ -2232,7 +2256,7 @@ static int FinalizeImpl(cxk_context* ctx) {
         info[4 * i + 1] = -DBL_MAX;
       }
     CXK_TRY(ctx->info4.upload(info));
-    CXK_TRY(ctx->info2.alloc((size_t)2 * K));
+    CXK_TRY(ctx->info2.alloc((size_t)2 * K, true));  // cone-less constraints keep StepInfo {0, 0}
     CXK_TRY(ctx->d_mask.upload(ctx->owned));
   }
   if (BuildPlans(ctx) != CXK_SUCCESS) return CXK_FAILURE;
@@ -2994,7 +3018,7 @@ int cxk_set_iterative_refinement(cxk_context* ctx, int iterations) {
     CXK_TRY(ctx->rhs0.alloc(N));
     CXK_TRY(ctx->mv_u.alloc(N));
     CXK_TRY(ctx->ysave.alloc(N));
-    CXK_TRY(ctx->mvb.alloc(ctx->updb.n));
+    CXK_TRY(ctx->mvb.alloc(ctx->updb.n, true));
   }
   if (iterations != ctx->refine_iters) ctx->slab0_valid = false;
   ctx->refine_iters = iterations;

@@ -54,6 +54,9 @@ struct StepArgs {
   double e_weight;
   double step_size;
   unsigned long long call;  // index of this PrepareStep / eigenvalue query (Hermitian start vectors)
+  // reference identity (cxk_set_reference_identity / CXK_REFERENCE_QUIRKS=1): the Ritz values go
+  // out exactly as approximate_eigenvalues.cc:178-239 produces them, without the Samuelson clamp
+  int no_clamp;
 };
 
 }  // namespace cxk

@@ -73,6 +73,7 @@ struct Program {
   bool initialized = false;
   bool dirty = true;
   int device = 0;
+  int reference_identity = -1;  // -1: environment (CXK_REFERENCE_QUIRKS); see CONEX_HIP_SetReferenceIdentity
   double b_scaling = 1, c_scaling = 1;
   std::vector<double> sqrt_inv_mu;
   int num_iter = 0;
@@ -162,6 +163,7 @@ int BuildContext(Program* p) {
     fprintf(stderr, "conex: no HIP device available; this library has no CPU fallback.\n");
     return 1;
   }
+  if (p->reference_identity >= 0) cxk_set_reference_identity(p->ctx, p->reference_identity);
   for (const Cone& c : p->cones) {
     int id = -1;
     const int m = static_cast<int>(c.vars.size());
@@ -1012,6 +1014,16 @@ int CONEX_HIP_SetDevice(void* x, int device) {
   Program* p = static_cast<Program*>(x);
   if (!p) return CONEX_FAILURE;
   p->device = device;
+  p->dirty = true;
+  return CONEX_SUCCESS;
+}
+
+/* not part of conex.h: 1 = reproduce the reference as written where this library deliberately
+ * departs from it (conex_kkt_hip.h, cxk_set_reference_identity); default: CXK_REFERENCE_QUIRKS */
+int CONEX_HIP_SetReferenceIdentity(void* x, int on) {
+  Program* p = static_cast<Program*>(x);
+  if (!p) return CONEX_FAILURE;
+  p->reference_identity = on != 0;
   p->dirty = true;
   return CONEX_SUCCESS;
 }

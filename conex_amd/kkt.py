@@ -88,6 +88,7 @@ _SIGNATURES = {
     "cxk_assembly_work": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "cxk_count_sparse_lmi": (C.c_int, [C.c_void_p]),
     "cxk_count_lmi_kernel": (C.c_int, [C.c_void_p, C.c_int]),
+    "cxk_set_reference_identity": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_dense_top_columns": (C.c_int, [C.c_void_p]),
     "cxk_factor_async": (C.c_int, [C.c_void_p]),
     "cxk_factor_solve_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),

@@ -83,13 +83,25 @@ int cxk_num_constraints(const cxk_context* ctx);
  * exchange slab that the caller sum-reduces across ranks (RCCL all-reduce). */
 int cxk_set_shard(cxk_context* ctx, int rank, int world_size);
 
+/* Reference identity (one switch for every place where this library deliberately departs from the
+ * reference as written; must precede cxk_finalize; default off, or CXK_REFERENCE_QUIRKS=1 in the
+ * environment):
+ *   (i)  a constraint's Schur block lands where BindDiagonalBlock's unchecked direct_update test
+ *        puts it on fill-in supernodes (supernodal_assembler.cc:72-91) instead of being scattered
+ *        by position (a defect of the reference on rare structures);
+ *   (ii) PrepareStep / GetWeightedSlackEigenvalues return the Lanczos Ritz values exactly as
+ *        approximate_eigenvalues.cc:178-239 produces them; by default they are clamped to
+ *        Samuelson's bound on the spectrum of W S (a noise-dominated Lanczos run near convergence
+ *        otherwise yields an eigenvalue far outside the spectrum and a needlessly small step).
+ * With the switch on, CONEX_Maximize reproduces the iteration count and mu sequence of the
+ * reference algorithm (tests/test_gpu_solver.py::test_reference_identity_reproduces_the_oracle_trajectory). */
+int cxk_set_reference_identity(cxk_context* ctx, int on);
+
 /* Initialize(): symbolic analysis (SupernodalKKTSolver ctor kkt_solver.cc:104-116),
  * Bind (kkt_solver.h:26-33), workspace carve + SetIdentity (cone_program.cc:78-112),
  * upload of constant data, construction of device index tables and level schedule.
  * Environment read here: CXK_SPARSE_LMI=0/1 (force the dense / sparse LMI evaluation),
- * CXK_REFERENCE_QUIRKS=1 (place a constraint's block where BindDiagonalBlock's unchecked
- * direct_update test puts it on fill-in supernodes, supernodal_assembler.cc:72-91, instead of
- * scattering it by position). */
+ * CXK_REFERENCE_QUIRKS=1 (= cxk_set_reference_identity(ctx, 1) unless that was called). */
 int cxk_finalize(cxk_context* ctx);
 
 /* ---- symbolic results (MatrixData supernodal_solver.h:18-29; bit-exact vs reference) */

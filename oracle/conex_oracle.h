@@ -125,6 +125,7 @@ int cxo_kkt_solve(cxo_program* p, const double* b, double inv_sqrt_mu, double b_
 /* conex::Solve(b, prog, config, y) cone_program.cc:235-552; returns solved flag */
 int cxo_solve(cxo_program* p, const double* b, const cxo_config* cfg, double* y);
 int cxo_num_iterations(const cxo_program* p);
+double cxo_iteration_mu(const cxo_program* p, int iter); /* CONEX_GetIterationStats conex.cc:259-285 */
 void cxo_get_dual_variable(cxo_program* p, int i, double* out);
 void cxo_set_verbose(int v);
 /* 1: direct_update only when the supernode's positions are exactly 0..m-1 (fixes a reference defect
@@ -159,6 +160,8 @@ int cxo_ws_cholesky(cxo_ws_handle* h);
 void cxo_ws_forward(cxo_ws_handle* h, double* y);
 void cxo_ws_backward(cxo_ws_handle* h, double* y);
 void cxo_ws_to_dense(const cxo_ws_handle* h, double* out);
+int cxo_ws_ldlt(cxo_ws_handle* h);                  /* BlockLDLTInPlace :315-349 */
+void cxo_ws_solve_ldlt(cxo_ws_handle* h, double* y); /* inv(M D) then inv(M^T) :222-299 */
 
 #ifdef __cplusplus
 }

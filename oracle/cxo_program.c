@@ -1616,6 +1616,12 @@ int cxo_solve(cxo_program* p, const double* bin, const cxo_config* cfg, double* 
 }
 
 int cxo_num_iterations(const cxo_program* p) { return p->num_iter; }
+/* CONEX_GetIterationStats (interfaces/conex.cc:259-285): mu of iteration i (negative: from the end) */
+double cxo_iteration_mu(const cxo_program* p, int iter) {
+  if (iter < 0) iter = p->num_iter + iter;
+  if (iter < 0 || iter >= p->num_iter) return -1.0;
+  return 1.0 / (p->sqrt_inv_mu[iter] * p->sqrt_inv_mu[iter]);
+}
 
 /* Program::GetDualVariable cone_program.h:120-134 */
 void cxo_get_dual_variable(cxo_program* p, int i, double* out) {
@@ -1711,3 +1717,7 @@ int cxo_ws_cholesky(cxo_ws_handle* h) { return cxo_block_cholesky(h->w); }
 void cxo_ws_forward(cxo_ws_handle* h, double* y) { cxo_apply_block_inverse(h->w, y); }
 void cxo_ws_backward(cxo_ws_handle* h, double* y) { cxo_apply_block_inverse_of_transpose(h->w, y); }
 void cxo_ws_to_dense(const cxo_ws_handle* h, double* out) { cxo_workspace_to_dense(h->w, out); }
+/* BlockLDLTInPlace + ApplyBlockInverseOfMD + ApplyBlockInverseOfMTranspose on a raw workspace
+ * (block_triangular_operations.cc:315-349, 222-299), as block_triangular_operations_test.cc:183-212 uses them */
+int cxo_ws_ldlt(cxo_ws_handle* h) { return cxo_block_ldlt(h->w); }
+void cxo_ws_solve_ldlt(cxo_ws_handle* h, double* y) { cxo_solve_ldlt(h->w, y); }

@@ -102,6 +102,7 @@ def lib():
                                     c_double_p]),
         "cxo_solve": (C.c_int, [vp, c_double_p, C.POINTER(Config), c_double_p]),
         "cxo_num_iterations": (C.c_int, [vp]),
+        "cxo_iteration_mu": (C.c_double, [vp, C.c_int]),
         "cxo_get_dual_variable": (None, [vp, C.c_int, c_double_p]),
         "cxo_set_verbose": (None, [C.c_int]),
         "cxo_set_strict_direct_update": (None, [C.c_int]),
@@ -129,6 +130,8 @@ def lib():
         "cxo_ws_forward": (None, [vp, c_double_p]),
         "cxo_ws_backward": (None, [vp, c_double_p]),
         "cxo_ws_to_dense": (None, [vp, c_double_p]),
+        "cxo_ws_ldlt": (C.c_int, [vp]),
+        "cxo_ws_solve_ldlt": (None, [vp, c_double_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -416,6 +419,9 @@ class Program:
         self.L.cxo_get_dual_variable(self.h, i, dp(w))
         return w[:n]
 
+    def iteration_mu(self, i):
+        return self.L.cxo_iteration_mu(self.h, int(i))
+
     def num_iterations(self):
         return self.L.cxo_num_iterations(self.h)
 
@@ -493,6 +499,14 @@ class Workspace:
     def backward(self, y):
         y = f64(y).copy()
         self.L.cxo_ws_backward(self.h, dp(y))
+        return y
+
+    def ldlt(self):
+        return self.L.cxo_ws_ldlt(self.h)
+
+    def solve_ldlt(self, y):
+        y = f64(y).copy()
+        self.L.cxo_ws_solve_ldlt(self.h, dp(y))
         return y
 
     def to_dense(self):

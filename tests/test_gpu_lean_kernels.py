@@ -45,7 +45,7 @@ def assert_same_bits(lean, generic, b):
     for (y1, s1), (y2, s2) in zip(solve_twice(lean, b), solve_twice(generic, b)):
         assert np.array_equal(y1, y2)
         if s1 is not None:
-            assert np.array_equal(s1, s2)
+            assert np.array_equal(s1, s2, equal_nan=True)  # never-written padding may hold NaN under CXK_DEBUG_FILL_NAN
 
 
 @pytest.mark.parametrize("K,branching", [(100, 8), (73, 3), (40, 1)])

@@ -254,6 +254,57 @@ def test_c4_full_ipm_solve_through_conex_h():
     L.CONEX_DeleteConeProgram(p)
 
 
+def test_reference_identity_reproduces_the_oracle_trajectory():
+    """One switch (CXK_REFERENCE_QUIRKS=1 / CONEX_HIP_SetReferenceIdentity) turns off both deliberate
+    departures from the reference as written (block placement on fill-in supernodes, Samuelson
+    clamp on the Ritz values; psd_constraint.cc:45-84, approximate_eigenvalues.cc:178-239,
+    supernodal_assembler.cc:72-91).  Under it the headline program solved through conex.h follows
+    the oracle's trajectory: the same mu (CONEX_GetIterationStats) at every iteration for as long as
+    that trajectory is reproducible at all.  The horizon is measured, not assumed: the oracle is run
+    twice, the second time with ONE cost entry moved by one ulp; from the iteration where those two
+    runs part (the unreorthogonalised Lanczos breaks down near convergence, beta^2 at the 1e-6
+    threshold, and amplifies rounding noise into O(1) changes of the step length) no implementation
+    -- including the reference on another compiler -- repeats the sequence."""
+    from conex_amd import synthetic as syn
+    prob = syn.lmi_problem()
+    L = ca.api()
+    p = L.CONEX_CreateConeProgram()
+    L.CONEX_HIP_SetReferenceIdentity.argtypes = [C.c_void_p, C.c_int]
+    assert L.CONEX_HIP_SetReferenceIdentity(p, 1) == 0
+    assert L.CONEX_SetNumberOfVariables(p, prob["num_vars"]) == 0
+    for c, cl in enumerate(prob["cliques"]):
+        a, cm = ca.colmajor(prob["A"][c]), ca.colmajor(prob["C"][c])
+        v = np.ascontiguousarray(cl, dtype=np.int64)
+        assert L.CONEX_AddSparseLMIConstraint(p, ca.dp(a), 20, 20, 20, ca.dp(cm), 20, 20,
+                                              v.ctypes.data_as(C.POINTER(C.c_long)), 20) == c
+    ok, y = _maximize(L, p, prob["b"])
+    o = syn.build(ol.Program, prob, "lmi")
+    oko, yo = o.solve(prob["b"])
+    assert ok == 1 and oko == 1
+    mu_o = [o.iteration_mu(i) for i in range(o.num_iterations())]
+    b2 = prob["b"].copy()
+    b2[7] = np.nextafter(b2[7], np.inf)
+    o2 = syn.build(ol.Program, prob, "lmi")
+    assert o2.solve(b2)[0] == 1
+    mu_o2 = [o2.iteration_mu(i) for i in range(o2.num_iterations())]
+    horizon = 0
+    while (horizon < min(len(mu_o), len(mu_o2)) and
+           abs(mu_o[horizon] - mu_o2[horizon]) <= 1e-9 * mu_o[horizon]):
+        horizon += 1
+    assert horizon >= 8                     # mu has dropped by more than two orders of magnitude by then
+    st = ca.IterationStats()
+    L.CONEX_GetIterationStats(p, C.byref(st), -1)
+    assert st.iteration_number + 1 >= horizon
+    for i in range(horizon):
+        L.CONEX_GetIterationStats(p, C.byref(st), i)
+        assert abs(st.mu - mu_o[i]) <= 1e-9 * mu_o[i], (i, st.mu, mu_o[i])
+    # beyond the horizon only the optimum is comparable -- and only loosely: without the clamp this
+    # run took noise-dominated eigenvalue estimates three times and ends at mu ~ 1e-9 instead of
+    # 1.5e-11 (which is what the clamp is for; the default mode meets 1e-6 here, test above)
+    assert abs(prob["b"] @ y - prob["b"] @ yo) <= 1e-3 * abs(prob["b"] @ yo)
+    L.CONEX_DeleteConeProgram(p)
+
+
 def test_sdp_mixed_literal():
     """test_sdp.cc:13-59: S == ones(2,2) to 1e-6."""
     L = ca.api()

@@ -292,6 +292,114 @@ def test_block_inverse_of_transpose(oracle, cliques):  # :148-167
 
 
 # --------------------------------------------------------------------------
+# block_triangular_operations_test.cc:183-235  (block LDLT literal: diagonals -101 + 100 i)
+# --------------------------------------------------------------------------
+LDLT_SETS_DIAGONAL = [
+    [[0, 1]],
+    [[0, 1, 2], [2]],
+    [[0, 1, 2, 4, 7], [3, 4], [5, 6, 7]],
+    [[0, 1, 5], [1, 2, 5], [3, 4, 5]],
+    [[0, 1, 2], [1, 2, 3], [3, 4, 2]],
+    [[0, 1], [2, 4], [3, 4], [5, 6, 7], [7, 8, 9, 10]],
+]
+
+
+@pytest.mark.parametrize("diagonal,cliques",
+                         [(True, c) for c in LDLT_SETS_DIAGONAL] + [(False, c) for c in LDLT_SETS_DIAGONAL[1:]])
+def test_block_ldlt_literal(oracle, diagonal, cliques):  # DoLDLTTest :183-212, cases :214-233
+    w = fill_in_pattern(cliques)
+    for j in range(w.K):
+        ns = w.supernode_size[j]
+        s = len(w.path[j]) - ns
+        if diagonal:
+            w.slab[w.diag_off[j]:w.diag_off[j] + ns * ns] = 0
+            w.slab[w.offd_off[j]:w.offd_off[j] + ns * s] = 0
+        for i in range(ns):
+            w.slab[w.diag_off[j] + i * ns + i] = -101 + i * 100
+    X = np.tril(w.to_dense())
+    X = X + np.tril(X, -1).T
+    assert w.ldlt() == 1
+    z = np.zeros(w.N)
+    z[1] = 1
+    y = w.solve_ldlt(X @ z)   # X = M D M^T:  z = inv(M^T) inv(M D) (X z)
+    assert np.linalg.norm(z - y) <= 1e-12
+
+
+# --------------------------------------------------------------------------
+# assembly_test.cc:67-106 (BuildLQRProblem), :108-169 (LDLT.TestAssembly), :171-194 (LDLT.Benchmark2)
+# --------------------------------------------------------------------------
+def build_lqr_problem(cls, N, **kw):
+    """BuildLQRProblem: equality blocks first (their multipliers are numbered in that order), then
+    the constant 2 I cost blocks.  Returns the built program."""
+    A0 = np.array([[1., 1, 0], [1, 0, 1]])
+    Ai = np.array([[1., 1, 1, 1, 0], [1, 1, 1, 0, 1]])
+    bi = np.array([1., 2])
+    Qi = 2.0 * np.eye(3)
+    p = cls((N + 1) * 3, **kw)
+    p.add_equality(A0, bi, [0, 1, 2])
+    o = 0
+    for i in range(N):
+        p.add_equality(Ai * (i + 2), bi * (i + 2), [1 + o, 2 + o, 3 + o, 4 + o, 5 + o])
+        o += 3
+    p.add_static(Qi, [0, 1, 2])
+    o = 3
+    for i in range(N):
+        p.add_static(Qi, [o, 1 + o, 2 + o])
+        o += 3
+    p.initialize()
+    return p
+
+
+LQR_A = np.array([[1., 1, 0, 0, 0, 0, 0, 0, 0],
+                  [1, 0, 1, 0, 0, 0, 0, 0, 0],
+                  [0, 2, 2, 2, 2, 0, 0, 0, 0],
+                  [0, 2, 2, 2, 0, 2, 0, 0, 0],
+                  [0, 0, 0, 0, 3, 3, 3, 3, 0],
+                  [0, 0, 0, 0, 3, 3, 3, 0, 3]])
+LQR_B = np.concatenate([np.zeros(9), [1., 2, 2, 4, 3, 6]])
+
+
+def lqr_kkt_literal():
+    n, m = 9, 6
+    T = np.zeros((n + m, n + m))
+    T[:n, :n] = 2.0 * np.eye(n)
+    T[:n, n:] = LQR_A.T
+    T[n:, :n] = LQR_A
+    return T
+
+
+def test_lqr_assembly_literal(oracle):  # LDLT.TestAssembly :108-169
+    p = build_lqr_problem(ol.Program, 2)
+    assert p.N == 15
+    p.assemble()
+    T = lqr_kkt_literal()
+    M = p.kkt_matrix()
+    M = np.tril(M) + np.tril(M, -1).T
+    assert np.array_equal(M, T)                      # EXPECT_EQ(error.norm(), 0)
+    _, AQc, _ = p.residuals()
+    assert np.array_equal(AQc, LQR_B)                # AQc == b exactly
+    assert p.factor() == 1
+    b = LQR_B.copy()
+    for _ in range(3):                               # three chained solves against a dense LDLT
+        yref = np.linalg.solve(T, b)
+        y = p.solve_inplace(b)
+        assert np.linalg.norm(y - yref) <= 1e-9
+        b = y
+
+
+def test_lqr_benchmark2(oracle):  # LDLT.Benchmark2 :171-194
+    p = build_lqr_problem(ol.Program, 40)
+    p.assemble()
+    T = p.kkt_matrix()
+    T = np.tril(T) + np.tril(T, -1).T
+    b = np.ones(p.N)
+    assert p.factor() == 1
+    for _ in range(3):
+        y = p.solve_inplace(b)
+        assert np.linalg.norm(T @ y - b) <= 1e-9
+
+
+# --------------------------------------------------------------------------
 # assembly_test.cc:196-219  (out-of-order clique variables, exact equality)
 # --------------------------------------------------------------------------
 def test_assemble_variables_out_of_order(oracle):
