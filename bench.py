@@ -142,27 +142,32 @@ def main():
             ctx.add_hermitian(prob["A"][c], prob["C"][c], cl)
         else:
             ctx.add_soc(prob["A"][c], prob["C"][c], cl)
-    if sharded:
-        # --shard-path on one GPU: rank 0 of a virtual 2-rank world (half the tree is missing from
-        # the exchange, so only timing and the plumbing are meaningful, not the direction)
-        ctx.set_shard(rank, world if world > 1 else 2)
+    if world > 1:
+        # the library's own RCCL communicator: rank 0 makes the unique id, torch.distributed only
+        # carries the 128 bytes (and the timing barrier below); every collective of the step --
+        # the all-reduce of the packed top of the tree -- is issued by libconex.so on its stream
+        uid = [KktContext.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init_rccl(uid[0], rank, world)
+    elif sharded:
+        # --shard-path on one GPU: rank 0 of a virtual 2-rank world with a do-nothing all-reduce
+        # (half the tree is missing from the exchange, so only timing and the plumbing are
+        # meaningful, not the direction)
+        ctx.set_shard(0, 2)
     ctx.initialize()
+    if sharded and world == 1:
+        ctx.comm_set_allreduce(lambda arr, op: arr)
     for i in range(ctx.K):
         if not sharded or ctx.owns(i):
             ctx.set_W(i, W[i])
     ctx.set_cost(prob["b"])
 
-    exch = None
-    if sharded:
-        exch = ctx.exchange_tensor(torch)   # zero-copy view of the device exchange buffer
+    exch_bytes = 8 * ctx.shard_info()[2] if sharded else 0
 
     def step():
-        if not sharded:
-            ctx.kkt_solve_async(0.7, 0.9, 0.8)
-        else:
-            ctx.kkt_local_async(0.7, 0.9, 0.8)      # own constraints + own subtrees
-            dist.all_reduce(exch)                    # RCCL sum of the packed top (a few KB)
-            ctx.kkt_finish_async(0.7, 0.9, 0.8)     # replicated top + own back-substitution
+        # sharded contexts: own constraints + own subtrees, ONE ncclAllReduce(sum) of the packed top
+        # (a few KB) issued by the library, replicated top, own back-substitution
+        ctx.kkt_solve_async(0.7, 0.9, 0.8)
 
     def fence():
         if sharded:
@@ -225,7 +230,7 @@ def main():
                                           "dim 10, 8-ary clique tree overlap 4, N=50004"}[args.workload],
                        "K": args.K, "n": n_order, "m": m_vars, "N": ctx.N,
                        "parallelism": (f"elimination-subtree sharding x{world}, one RCCL all-reduce "
-                                       f"of {exch.numel() * 8} B per solve") if sharded
+                                       f"of {exch_bytes} B per solve, issued by libconex.so") if sharded
                        else "single GPU",
                        "factor_ok": bool(ok)},
         }

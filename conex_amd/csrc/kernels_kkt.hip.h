@@ -1859,6 +1859,84 @@ __global__ void __launch_bounds__(256) exchange_unpack(ExchangeArgs a) {
   }
 }
 
+// Solve-only exchange (right-hand sides after the factorization: mu selection, line search,
+// cxk_solve_inplace): only the forward-solve contributions of this rank's subtrees to the top
+// variables travel, x[j] = sum of its published t values; after the sum all-reduce every rank
+// subtracts the total from its (replicated, complete) right-hand side of the top.
+__global__ void __launch_bounds__(256) exchange_pack_solve(ExchangeArgs a) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < a.n_xv; j += (int64_t)gridDim.x * blockDim.x) {
+    double f = 0;
+    for (int q = a.pf_ptr[j]; q < a.pf_ptr[j + 1]; q++) f += a.updb[a.pf_src[q]];
+    a.x[j] = f;
+  }
+}
+__global__ void __launch_bounds__(256) exchange_unpack_solve(ExchangeArgs a) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < a.n_xv; j += (int64_t)gridDim.x * blockDim.x)
+    a.y[a.xv_idx[j]] -= a.x[j];
+}
+// Factor-only exchange (cxk_factor_async on a sharded context): the forward slots hold nothing
+// meaningful, the right-hand side of the top is left alone.
+__global__ void __launch_bounds__(256) exchange_unpack_matrix(ExchangeArgs a) {
+  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = gid; i < a.n_xs; i += stride) a.slab[a.xs_off[i]] = a.x[i];
+  for (int64_t j = gid; j < a.n_xv; j += stride) {
+    const int p = a.xv_idx[j];
+    a.AW[p] = a.x[a.n_xs + j];
+    a.AQc[p] = a.x[a.n_xs + a.n_xv + j];
+  }
+  if (gid == 0) {
+    const int64_t o = a.n_xs + 3 * (int64_t)a.n_xv;
+    a.sys_sc[0] = a.x[o];
+    a.sys_sc[1] = a.x[o + 1];
+    if (a.x[o + 2] > 0.0) *a.fail = 1;
+  }
+}
+
+// out[i] = count[i] ? in[i] : 0 -- a rank's share of a vector whose entries are spread over the
+// ranks (own subtrees; the replicated top counts on rank 0 only): the sum all-reduce of these
+// shares is the whole vector.
+__global__ void masked_copy(int n, const unsigned char* __restrict__ count, const double* __restrict__ in,
+                            double* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = count[i] ? in[i] : 0.0;
+}
+// per-constraint pairs (2 doubles each) of the constraints this rank owns, zero elsewhere
+__global__ void masked_copy_pairs(int K, const unsigned char* __restrict__ owned, const double* __restrict__ in,
+                                  double* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * K; i += gridDim.x * blockDim.x)
+    out[i] = owned[i >> 1] ? in[i] : 0.0;
+}
+
+// step_scalars over this rank's share of the variables (see masked_copy); out[4], out[5] are the
+// already complete <w,c>, <c,Qc>.  The caller sum-reduces out[0..3] across ranks.
+__global__ void __launch_bounds__(1024)
+step_scalars_masked(int N, const unsigned char* __restrict__ count, const double* __restrict__ b,
+                    const double* __restrict__ AQc, const double* __restrict__ y,
+                    const double* __restrict__ sys_sc, double* __restrict__ out) {
+  __shared__ double red[16];
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int p = threadIdx.x; p < N; p += blockDim.x) {
+    if (!count[p]) continue;
+    const double vb = b[p], vq = AQc[p], vy = y[p];
+    s0 = fma(vb, vy, s0);
+    s1 = fma(vq, vy, s1);
+    s2 = fma(vb, vb, s2);
+    s3 = fma(vq, vq, s3);
+  }
+  s0 = BlockSum(s0, red);
+  s1 = BlockSum(s1, red);
+  s2 = BlockSum(s2, red);
+  s3 = BlockSum(s3, red);
+  if (threadIdx.x == 0) {
+    out[0] = s0;
+    out[1] = s1;
+    out[2] = s2;
+    out[3] = s3;
+    out[4] = sys_sc[0];
+    out[5] = sys_sc[1];
+  }
+}
+
 // permuted <-> original order copies
 __global__ void permute_gather(int N, const int* __restrict__ idx, const double* __restrict__ in,
                                double* __restrict__ out) {

@@ -4,6 +4,8 @@
 // supernodal slab, right-hand sides) lives in HBM for the lifetime of the context; per
 // Newton step only scalars cross PCIe.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library itself is loaded on demand (cxk_comm_init_rccl)
 
 #include <algorithm>
 #include <atomic>
@@ -214,6 +216,23 @@ struct cxk_context {
   DevBuf<int> d_tr, d_reg;
   DevBuf<double> y2;  // second solve vector of the line search
   std::vector<double> y_at_prepare;  // lambda_ = y.tail(rows) is latched by PrepareStep
+  // Collectives of a sharded context (world > 1): RCCL over xGMI (cxk_comm_init_rccl: librccl.so is
+  // loaded on demand, all-reduces run on the context's stream), or a caller-supplied all-reduce
+  // (cxk_comm_set_allreduce: other transports, tests).  count_mask[p] = 1 where this rank's value
+  // of permuted variable p counts in a cross-rank sum (own subtrees; the replicated top on rank 0).
+  struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclComm_t comm = nullptr;
+  } rccl;
+  cxk_allreduce_fn coll_fn = nullptr;
+  void* coll_user = nullptr;
+  DevBuf<unsigned char> d_count_mask;
+  DevBuf<double> shard_tmp;        // N doubles: this rank's share of a vector / of the per-constraint pairs
+  double rhs_c[3] = {0, 0, 0};     // right-hand side of the running factor-and-solve: cb b + cq AQc + cw AW
   // timing of the dominant (dense-LMI Schur) kernel
   bool timing = false;
   int timing_period = 1, timing_tick = 0;  // hipEvents bracket every timing_period-th launch
@@ -827,6 +846,13 @@ int BuildPlans(cxk_context* ctx) {
     CXK_TRY(ctx->pf_ptr.upload(pf_ptr));
     CXK_TRY(ctx->pf_src.upload(pf_src));
     CXK_TRY(ctx->xbuf.alloc((size_t)ctx->n_xs + 3 * (size_t)ctx->n_xv + 4));
+    std::vector<unsigned char> count(N, 0);
+    for (int p = 0; p < N; p++) {
+      const int e = L.var_to_sn[p];
+      count[p] = ctx->sn_top[e] ? (ctx->rank == 0) : (ctx->sn_mine[e] != 0);
+    }
+    CXK_TRY(ctx->d_count_mask.upload(count));
+    CXK_TRY(ctx->shard_tmp.alloc(std::max<size_t>((size_t)N, 2 * ctx->cons.size())));
   }
 
   {
@@ -986,9 +1012,10 @@ int BuildPlans(cxk_context* ctx) {
     ctx->top_level = top;
     // chain at the top (single GPU, Cholesky, top swept level by level)
     ctx->chain_level = nlev;
-    if (!sharded && !ctx->use_ldlt && !ctx->no_lean && top == nlev && !getenv("CXK_NO_CHAIN")) {
+    if (!ctx->use_ldlt && !ctx->no_lean && top == nlev && !getenv("CXK_NO_CHAIN")) {
       int c0 = nlev, sa = 0, sb = 0;
-      while (c0 > 0 && nlev - c0 < kChainMaxLevels) {
+      const int floor_level = sharded ? ctx->cut_level : 0;  // the chain stays inside the replicated top
+      while (c0 > floor_level && nlev - c0 < kChainMaxLevels) {
         const int l = c0 - 1;
         if (ctx->level_ptr[l + 1] - ctx->level_ptr[l] != 1 || !ctx->level_lean[l]) break;
         const int sh = ctx->level_segs[l][0].shape;
@@ -1736,7 +1763,10 @@ int LaunchTreeCore(cxk_context* ctx, int mode, bool with_rhs, bool backward);
 
 // A sweep with the refinement steps the reference's SolveInPlace runs after every solve
 // (kkt_solver.cc:233-261); without refinement this is LaunchTreeCore.
+int ShardedTree(cxk_context* ctx, int mode, bool with_rhs, bool backward);
+
 int LaunchTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
+  if (ctx->world > 1) return ShardedTree(ctx, mode, with_rhs, backward);  // (refinement is single-GPU)
   if (ctx->refine_iters <= 0) return LaunchTreeCore(ctx, mode, with_rhs, backward);
   const int N = ctx->md.N;
   const bool solving = backward && (mode != 0 || with_rhs);
@@ -1758,6 +1788,37 @@ int LaunchTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
     refine_add<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, ctx->ysave.p, ctx->y.p);
     CXK_TRY(hipGetLastError());
   }
+  return CXK_SUCCESS;
+}
+
+// The chain at the top of the tree (levels [chain_level, nlev), one supernode each): up and
+// straight back down in one launch of one wavefront.  mode 0 factor + forward, mode 1 forward.
+int LaunchChain(cxk_context* ctx, int mode) {
+  const int nlev = (int)ctx->level_ptr.size() - 1;
+    const int sa = ctx->chain_a, sb = ctx->chain_b;
+    bool done = false;
+#define CXK_CHAIN(NA_, SA_, NB_, SB_)                                                                       \
+  if (!done && sa == ((NA_) << 8 | (SA_)) && sb == ((NB_) << 8 | (SB_))) {                                  \
+    done = true;                                                                                            \
+    if (mode == 0)                                                                                          \
+      tree_chain_lean<0, NA_, SA_, NB_, SB_><<<1, 64, ctx->chol_lds, ctx->stream>>>(                        \
+          ctx->plan, ctx->p_rec.p, ctx->d_level_ptr.p, ctx->chain_level, nlev, ctx->slab.p, ctx->y.p, ctx->d_fail.p); \
+    else                                                                                                    \
+      tree_chain_lean<1, NA_, SA_, NB_, SB_><<<1, 64, ctx->chol_lds, ctx->stream>>>(                        \
+          ctx->plan, ctx->p_rec.p, ctx->d_level_ptr.p, ctx->chain_level, nlev, ctx->slab.p, ctx->y.p, ctx->d_fail.p); \
+  }
+    CXK_CHAIN(8, 8, 8, 8)
+    CXK_CHAIN(16, 8, 16, 8)
+    CXK_CHAIN(24, 0, 24, 0)
+    CXK_CHAIN(24, 8, 24, 8)
+    CXK_CHAIN(32, 16, 32, 16)
+    CXK_CHAIN(8, 8, 24, 0)
+    CXK_CHAIN(16, 8, 24, 0)
+    CXK_CHAIN(24, 0, 24, 8)
+    CXK_CHAIN(24, 0, 32, 16)
+#undef CXK_CHAIN
+    CXK_DEMAND(done, "internal error: no tree_chain_lean instance for the chain's shapes");
+    CXK_TRY(hipGetLastError());
   return CXK_SUCCESS;
 }
 
@@ -1789,32 +1850,7 @@ int LaunchTreeCore(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
   const int up_end = dense ? ctx->dense_level : (chain ? ctx->chain_level : top);
   for (int l = 0; l < up_end; l++)
     if (LaunchSweep(ctx, l, l + 1, mode, false, with_rhs)) return CXK_FAILURE;
-  if (chain) {
-    const int sa = ctx->chain_a, sb = ctx->chain_b;
-    bool done = false;
-#define CXK_CHAIN(NA_, SA_, NB_, SB_)                                                                       \
-  if (!done && sa == ((NA_) << 8 | (SA_)) && sb == ((NB_) << 8 | (SB_))) {                                  \
-    done = true;                                                                                            \
-    if (mode == 0)                                                                                          \
-      tree_chain_lean<0, NA_, SA_, NB_, SB_><<<1, 64, ctx->chol_lds, ctx->stream>>>(                        \
-          ctx->plan, ctx->p_rec.p, ctx->d_level_ptr.p, ctx->chain_level, nlev, ctx->slab.p, ctx->y.p, ctx->d_fail.p); \
-    else                                                                                                    \
-      tree_chain_lean<1, NA_, SA_, NB_, SB_><<<1, 64, ctx->chol_lds, ctx->stream>>>(                        \
-          ctx->plan, ctx->p_rec.p, ctx->d_level_ptr.p, ctx->chain_level, nlev, ctx->slab.p, ctx->y.p, ctx->d_fail.p); \
-  }
-    CXK_CHAIN(8, 8, 8, 8)
-    CXK_CHAIN(16, 8, 16, 8)
-    CXK_CHAIN(24, 0, 24, 0)
-    CXK_CHAIN(24, 8, 24, 8)
-    CXK_CHAIN(32, 16, 32, 16)
-    CXK_CHAIN(8, 8, 24, 0)
-    CXK_CHAIN(16, 8, 24, 0)
-    CXK_CHAIN(24, 0, 24, 8)
-    CXK_CHAIN(24, 0, 32, 16)
-#undef CXK_CHAIN
-    CXK_DEMAND(done, "internal error: no tree_chain_lean instance for the chain's shapes");
-    CXK_TRY(hipGetLastError());
-  }
+  if (chain && LaunchChain(ctx, mode)) return CXK_FAILURE;
   if (dense) {
     double* rhs = with_rhs ? ctx->y.p : nullptr;
     const int wb = with_rhs && backward;
@@ -1843,6 +1879,84 @@ int LaunchTreeCore(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
       if (it->second ? LaunchRange(ctx, *it->second, 2, true) : LaunchSweep(ctx, it->first, it->first + 1, 2, false, true))
         return CXK_FAILURE;
     }
+  return CXK_SUCCESS;
+}
+
+// ---------------------------------------------------------------- sharded contexts
+enum { kOpSum = 0, kOpMax = 1, kOpMin = 2 };
+
+// In-place all-reduce of `count` doubles of device memory across the ranks, ordered on the
+// context's stream (RCCL) or complete on return (caller-supplied function).
+int ShardAllReduce(cxk_context* ctx, double* buf, size_t count, int op) {
+  if (ctx->world <= 1 || count == 0) return CXK_SUCCESS;
+  if (ctx->coll_fn) {
+    CXK_DEMAND(ctx->coll_fn(ctx->coll_user, buf, (long)count, op, ctx->stream) == 0,
+               "the caller-supplied all-reduce reported a failure");
+    return CXK_SUCCESS;
+  }
+  CXK_DEMAND(ctx->rccl.comm != nullptr,
+             "sharded context without a communicator: call cxk_comm_init_rccl or cxk_comm_set_allreduce first");
+  const ncclRedOp_t rop = op == kOpSum ? ncclSum : (op == kOpMax ? ncclMax : ncclMin);
+  const ncclResult_t r = ctx->rccl.AllReduce(buf, buf, count, ncclDouble, rop, ctx->rccl.comm, ctx->stream);
+  if (r != ncclSuccess) {
+    ctx->err = std::string("ncclAllReduce: ") + (ctx->rccl.GetErrorString ? ctx->rccl.GetErrorString(r) : "error");
+    fprintf(stderr, "conex_kkt_hip: %s\n", ctx->err.c_str());
+    return CXK_FAILURE;
+  }
+  return CXK_SUCCESS;
+}
+
+long ExchangeCount(const cxk_context* ctx) { return (long)(ctx->n_xs + 3 * (int64_t)ctx->n_xv + 4); }
+
+// One sweep of a sharded context.  Bottom-up over this rank's subtrees (mode 0 factor [+ forward
+// substitution when with_rhs], mode 1 forward substitution), ONE sum all-reduce of what the
+// subtrees contribute to the replicated top of the tree --
+//   mode 0: [top slab entries | AW_T | AQc_T | forward values | <w,c> <c,Qc> | failure flag]
+//           (supernodal_assembler.cc:103-111,162-164 and block_triangular_operations.cc:209-215 are
+//            the sums that cross ranks here),
+//   mode 1: [forward values]  --
+// then the top on every rank (bit-identical: same data, same kernels) and, when `backward`, the
+// back-substitution down this rank's subtrees.
+int ShardedTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
+  if (ctx->use_ldlt && mode == 0) CXK_TRY(hipMemsetAsync(ctx->d_reg.p, 0, sizeof(int), ctx->stream));
+  const int nlev = ctx->nlev, cut = ctx->cut_level, top = ctx->top_level;
+  const bool rhs = with_rhs || mode != 0;
+  for (int l = 0; l < cut; l++)
+    if (LaunchSweep(ctx, l, l + 1, mode, false, rhs)) return CXK_FAILURE;
+  ExchangeArgs a = MakeExchange(ctx, 0, 0, 0);
+  a.cb = ctx->rhs_c[0];
+  a.cq = ctx->rhs_c[1];
+  a.cw = ctx->rhs_c[2];
+  const size_t work = (size_t)std::max<int64_t>(std::max<int64_t>(ctx->n_xs, ctx->n_xv), 1);
+  if (mode == 0) {
+    if (a.pt_T > 0) exchange_fold<<<GridFor((size_t)a.pt_T, 256), 256, 0, ctx->stream>>>(a);
+    exchange_pack<<<GridFor(work, 256), 256, 0, ctx->stream>>>(a);
+    CXK_TRY(hipGetLastError());
+    if (ShardAllReduce(ctx, ctx->xbuf.p, (size_t)ExchangeCount(ctx), kOpSum)) return CXK_FAILURE;
+    if (with_rhs)
+      exchange_unpack<<<GridFor(work, 256), 256, 0, ctx->stream>>>(a);
+    else
+      exchange_unpack_matrix<<<GridFor(work, 256), 256, 0, ctx->stream>>>(a);
+  } else if (ctx->n_xv > 0) {
+    exchange_pack_solve<<<GridFor((size_t)ctx->n_xv, 256), 256, 0, ctx->stream>>>(a);
+    CXK_TRY(hipGetLastError());
+    if (ShardAllReduce(ctx, ctx->xbuf.p, (size_t)ctx->n_xv, kOpSum)) return CXK_FAILURE;
+    exchange_unpack_solve<<<GridFor((size_t)ctx->n_xv, 256), 256, 0, ctx->stream>>>(a);
+  }
+  CXK_TRY(hipGetLastError());
+  // the replicated top: levels [cut, nlev)
+  const bool chain = backward && rhs && ctx->chain_level < nlev && ctx->chain_level >= cut;
+  const int up_end = chain ? ctx->chain_level : top;
+  for (int l = cut; l < up_end; l++)
+    if (LaunchSweep(ctx, l, l + 1, mode, false, rhs)) return CXK_FAILURE;
+  if (chain) {
+    if (LaunchChain(ctx, mode)) return CXK_FAILURE;
+  } else if (top < nlev) {
+    if (LaunchSweep(ctx, top, nlev, mode, backward, rhs)) return CXK_FAILURE;
+  }
+  if (backward)
+    for (int l = std::min(top, up_end) - 1; l >= 0; l--)
+      if (LaunchSweep(ctx, l, l + 1, 2, false, true)) return CXK_FAILURE;
   return CXK_SUCCESS;
 }
 
@@ -1911,6 +2025,7 @@ void cxk_destroy(cxk_context* ctx) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
   }
+  if (ctx->rccl.comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->rccl.comm);
   if (ctx->mb) (void)hipHostFree(ctx->mb);
   if (ctx->pin_y) (void)hipHostFree(ctx->pin_y);
   delete ctx;
@@ -2063,6 +2178,95 @@ int cxk_set_shard(cxk_context* ctx, int rank, int world_size) {
 }
 
 static int FinalizeImpl(cxk_context* ctx);
+
+int cxk_comm_unique_id(void* out128) {
+  if (!out128) return CXK_FAILURE;
+  void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) {
+    fprintf(stderr, "conex_kkt_hip: librccl.so not found (%s)\n", dlerror());
+    return CXK_FAILURE;
+  }
+  auto get = reinterpret_cast<ncclResult_t (*)(ncclUniqueId*)>(dlsym(lib, "ncclGetUniqueId"));
+  if (!get) return CXK_FAILURE;
+  static_assert(sizeof(ncclUniqueId) == 128, "cxk_comm_unique_id hands out 128 bytes");
+  return get(static_cast<ncclUniqueId*>(out128)) == ncclSuccess ? CXK_SUCCESS : CXK_FAILURE;
+}
+
+int cxk_comm_init_rccl(cxk_context* ctx, const void* unique_id128, int rank, int world_size) {
+  if (!ctx || !unique_id128 || world_size < 1 || rank < 0 || rank >= world_size) return CXK_FAILURE;
+  CXK_DEMAND(ctx->device >= 0, "a communicator needs a HIP device");
+  if (!ctx->finalized) {
+    ctx->rank = rank;
+    ctx->world = world_size;
+  }
+  CXK_DEMAND(ctx->rank == rank && ctx->world == world_size, "communicator rank / size differ from cxk_set_shard");
+  DeviceGuard guard(ctx->device);
+  auto& R = ctx->rccl;
+  if (!R.lib) {
+    R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!R.lib) R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    CXK_DEMAND(R.lib != nullptr, "librccl.so not found");
+    R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(dlsym(R.lib, "ncclCommInitRank"));
+    R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(dlsym(R.lib, "ncclCommDestroy"));
+    R.AllReduce = reinterpret_cast<decltype(R.AllReduce)>(dlsym(R.lib, "ncclAllReduce"));
+    R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(dlsym(R.lib, "ncclGetErrorString"));
+    CXK_DEMAND(R.CommInitRank && R.CommDestroy && R.AllReduce, "librccl.so lacks ncclCommInitRank / ncclAllReduce");
+  }
+  if (R.comm) {
+    R.CommDestroy(R.comm);
+    R.comm = nullptr;
+  }
+  ncclUniqueId id;
+  memcpy(&id, unique_id128, sizeof(id));
+  const ncclResult_t r = R.CommInitRank(&R.comm, world_size, id, rank);
+  if (r != ncclSuccess) {
+    ctx->err = std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(r) : "error");
+    fprintf(stderr, "conex_kkt_hip: %s\n", ctx->err.c_str());
+    R.comm = nullptr;
+    return CXK_FAILURE;
+  }
+  return CXK_SUCCESS;
+}
+
+__global__ void comm_selftest_fill(int n, double* x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] = 0.5 * i - 3.0;
+}
+
+// Runs sum, max and min all-reduces of `count` doubles through the attached RCCL communicator on
+// the context's stream and checks the result against world_size copies of the same input (every
+// rank fills the same values): the RCCL call path, exercised also by a one-rank communicator.
+int cxk_comm_selftest(cxk_context* ctx, int count) {
+  if (!ctx || count < 1) return CXK_FAILURE;
+  CXK_DEMAND(ctx->rccl.comm != nullptr, "no RCCL communicator attached");
+  DeviceGuard guard(ctx->device);
+  DevBuf<double> buf;
+  CXK_TRY(buf.alloc((size_t)count));
+  std::vector<double> h((size_t)count);
+  const int saved_world = ctx->world;
+  for (int op = 0; op < 3; op++) {
+    comm_selftest_fill<<<GridFor((size_t)count, 256), 256, 0, ctx->stream>>>(count, buf.p);
+    CXK_TRY(hipGetLastError());
+    ctx->world = 2;  // ShardAllReduce skips single-rank contexts; the communicator decides the real size
+    const int rc = ShardAllReduce(ctx, buf.p, (size_t)count, op);
+    ctx->world = saved_world;
+    if (rc) return CXK_FAILURE;
+    CXK_TRY(hipStreamSynchronize(ctx->stream));
+    CXK_TRY(hipMemcpy(h.data(), buf.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; i++) {
+      const double v = 0.5 * i - 3.0, want = op == kOpSum ? v * saved_world : v;
+      CXK_DEMAND(h[i] == want, "RCCL all-reduce returned a wrong value");
+    }
+  }
+  return CXK_SUCCESS;
+}
+
+int cxk_comm_set_allreduce(cxk_context* ctx, cxk_allreduce_fn fn, void* user) {
+  if (!ctx) return CXK_FAILURE;
+  ctx->coll_fn = fn;
+  ctx->coll_user = user;
+  return CXK_SUCCESS;
+}
 
 int cxk_set_reference_identity(cxk_context* ctx, int on) {
   if (!ctx || ctx->finalized) return CXK_FAILURE;
@@ -2242,7 +2446,6 @@ static int FinalizeImpl(cxk_context* ctx) {
   for (const IntList& dv : ctx->dual_vars)
     if (!dv.empty()) ctx->use_ldlt = true;  // kkt_solver.cc:180-186
   if (ctx->use_ldlt) {
-    CXK_DEMAND(ctx->world == 1, "equality constraints (LDLT path) are single-GPU for now");
     CXK_TRY(ctx->d_tr.alloc(N));
     CXK_TRY(ctx->d_reg.alloc(1, true));
   }
@@ -2462,8 +2665,16 @@ int cxk_factor_status(cxk_context* ctx, int* ok) {
 
 int cxk_step_scalars_async(cxk_context* ctx) {
   CXK_ENTER(ctx);
-  step_scalars<<<1, 1024, 0, ctx->stream>>>(ctx->md.N, ctx->b.p, ctx->AQc.p, ctx->y.p,
-                                            ctx->sys_sc.p, ctx->scal_out.p);
+  if (ctx->world > 1) {
+    // every rank sums over its own share of the variables, the four dot products are then summed
+    step_scalars_masked<<<1, 1024, 0, ctx->stream>>>(ctx->md.N, ctx->d_count_mask.p, ctx->b.p, ctx->AQc.p, ctx->y.p,
+                                                     ctx->sys_sc.p, ctx->scal_out.p);
+    CXK_TRY(hipGetLastError());
+    if (ShardAllReduce(ctx, ctx->scal_out.p, 4, kOpSum)) return CXK_FAILURE;
+  } else {
+    step_scalars<<<1, 1024, 0, ctx->stream>>>(ctx->md.N, ctx->b.p, ctx->AQc.p, ctx->y.p,
+                                              ctx->sys_sc.p, ctx->scal_out.p);
+  }
   CXK_TRY(hipGetLastError());
   ctx->scal_seq = ++ctx->seq;
   return CXK_SUCCESS;
@@ -2478,6 +2689,9 @@ int cxk_factor_solve_async(cxk_context* ctx, double cb, double cq, double cw) {
   build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, cb, cq, cw, ctx->b.p, ctx->AQc.p, ctx->AW.p,
                                                            ctx->y.p, ctx->d_fail.p);
   CXK_TRY(hipGetLastError());
+  ctx->rhs_c[0] = cb;
+  ctx->rhs_c[1] = cq;
+  ctx->rhs_c[2] = cw;
   if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;
   ctx->factor_seq = ++ctx->seq;
   return CXK_SUCCESS;
@@ -2490,6 +2704,9 @@ int cxk_factor_direction_async(cxk_context* ctx, double k, double bs, double cs)
   build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p, ctx->y.p,
                                                       ctx->d_fail.p);
   CXK_TRY(hipGetLastError());
+  ctx->rhs_c[0] = k * bs;
+  ctx->rhs_c[1] = k * cs;
+  ctx->rhs_c[2] = -2.0;
   if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;
   ctx->factor_seq = ++ctx->seq;
   return CXK_SUCCESS;
@@ -2554,7 +2771,6 @@ int cxk_line_search(cxk_context* ctx, double dinf_upper_bound, double b_scaling,
                     double* result) {
   CXK_ENTER(ctx);
   CXK_DEMAND(result != nullptr, "null output");
-  CXK_DEMAND(ctx->world == 1, "line search is single-GPU for now");
   const int N = ctx->md.N, K = (int)ctx->cons.size();
   if (ctx->y2.n != (size_t)N) CXK_TRY(ctx->y2.alloc(N));
   build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, 0.0, 0.0, -2.0, ctx->b.p, ctx->AQc.p,
@@ -2580,8 +2796,16 @@ int cxk_line_search(cxk_context* ctx, double dinf_upper_bound, double b_scaling,
   }
   CXK_TRY(hipGetLastError());
   std::vector<double> out((size_t)2 * K);
+  const double* pairs = ctx->info2.p;
+  if (ctx->world > 1) {  // every rank evaluated its own linear constraints: gather the bounds
+    CXK_DEMAND((size_t)2 * K <= ctx->shard_tmp.n, "internal error: shard scratch too small");
+    masked_copy_pairs<<<GridFor((size_t)2 * K, 256), 256, 0, ctx->stream>>>(K, ctx->d_mask.p, ctx->info2.p, ctx->shard_tmp.p);
+    CXK_TRY(hipGetLastError());
+    if (ShardAllReduce(ctx, ctx->shard_tmp.p, (size_t)2 * K, kOpSum)) return CXK_FAILURE;
+    pairs = ctx->shard_tmp.p;
+  }
   CXK_TRY(hipStreamSynchronize(ctx->stream));
-  CXK_TRY(hipMemcpy(out.data(), ctx->info2.p, sizeof(double) * 2 * K, hipMemcpyDeviceToHost));
+  CXK_TRY(hipMemcpy(out.data(), pairs, sizeof(double) * 2 * K, hipMemcpyDeviceToHost));
   double lb = -DBL_MAX, ub = DBL_MAX;
   *result = -1;
   for (int i = 0; i < K; i++) {
@@ -2609,7 +2833,10 @@ int cxk_kkt_solve_async(cxk_context* ctx, double k, double bs, double cs) {
   CXK_ENTER(ctx);
   if (LaunchSchur(ctx)) return CXK_FAILURE;
   if (LaunchGather(ctx, true, k, bs, cs)) return CXK_FAILURE;
-  if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;
+  ctx->rhs_c[0] = k * bs;
+  ctx->rhs_c[1] = k * cs;
+  ctx->rhs_c[2] = -2.0;
+  if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;  // sharded contexts: local sweep, all-reduce, top, back
   ctx->factor_seq = ++ctx->seq;
   return CXK_SUCCESS;
 }
@@ -2626,7 +2853,16 @@ int cxk_get_y(cxk_context* ctx, double* yh) {
   // a kernel writes y into pinned host memory: the first device-to-host hipMemcpy of a process
   // pays milliseconds of copy-engine set-up, which would dominate a whole C4 solve
   if (!ctx->pin_y) CXK_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->pin_y), sizeof(double) * (size_t)N, hipHostMallocDefault));
-  copy_doubles<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, ctx->y.p, ctx->pin_y);
+  const double* ysrc = ctx->y.p;
+  // a rank holds y for its own subtrees and the top: assemble the whole vector (callers that run
+  // the exchange themselves, without a communicator, get the local vector: cxk_get_valid_variables)
+  if (ctx->world > 1 && (ctx->coll_fn || ctx->rccl.comm)) {
+    masked_copy<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, ctx->d_count_mask.p, ctx->y.p, ctx->shard_tmp.p);
+    CXK_TRY(hipGetLastError());
+    if (ShardAllReduce(ctx, ctx->shard_tmp.p, (size_t)N, kOpSum)) return CXK_FAILURE;
+    ysrc = ctx->shard_tmp.p;
+  }
+  copy_doubles<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, ysrc, ctx->pin_y);
   CXK_TRY(hipGetLastError());
   CXK_TRY(hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < N; i++) yh[ctx->md.permutation_inverse[i]] = ctx->pin_y[i];
@@ -2676,6 +2912,9 @@ int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_wei
   if (affine) return CXK_SUCCESS;
   reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), 0, ctx->info2.p, ctx->d_mask.p,
                                                ctx->red_out.p);
+  // sharded: sum of normsqrd, max of norminfd over the ranks (each reduced its own constraints)
+  if (ShardAllReduce(ctx, ctx->red_out.p, 1, kOpSum) || ShardAllReduce(ctx, ctx->red_out.p + 1, 1, kOpMax))
+    return CXK_FAILURE;
   ctx->seq++;
   if (SyncMailbox(ctx)) return CXK_FAILURE;
   info[0] = ctx->mb[0];
@@ -2757,6 +2996,10 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
   reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), 1, ctx->info4.p, ctx->d_mask.p,
                                                ctx->red_out.p);
   CXK_TRY(hipGetLastError());
+  // sharded: {min lambda_min, max lambda_max, sum frob, sum trace} over the ranks
+  if (ShardAllReduce(ctx, ctx->red_out.p, 1, kOpMin) || ShardAllReduce(ctx, ctx->red_out.p + 1, 1, kOpMax) ||
+      ShardAllReduce(ctx, ctx->red_out.p + 2, 2, kOpSum))
+    return CXK_FAILURE;
   ctx->seq++;
   if (SyncMailbox(ctx)) return CXK_FAILURE;
   for (int i = 0; i < 4; i++) out[i] = ctx->mb[i];

@@ -74,6 +74,12 @@ struct Program {
   bool dirty = true;
   int device = 0;
   int reference_identity = -1;  // -1: environment (CXK_REFERENCE_QUIRKS); see CONEX_HIP_SetReferenceIdentity
+  // multi-GPU (one process per GPU, every rank builds the same program): see CONEX_HIP_SetCommunicator
+  int shard_rank = 0, shard_world = 1;
+  bool have_unique_id = false;
+  unsigned char unique_id[128] = {0};
+  cxk_allreduce_fn allreduce_fn = nullptr;
+  void* allreduce_user = nullptr;
   double b_scaling = 1, c_scaling = 1;
   std::vector<double> sqrt_inv_mu;
   int num_iter = 0;
@@ -164,6 +170,17 @@ int BuildContext(Program* p) {
     return 1;
   }
   if (p->reference_identity >= 0) cxk_set_reference_identity(p->ctx, p->reference_identity);
+  if (p->shard_world > 1) {
+    if (cxk_set_shard(p->ctx, p->shard_rank, p->shard_world)) return 1;
+    if (p->allreduce_fn) {
+      if (cxk_comm_set_allreduce(p->ctx, p->allreduce_fn, p->allreduce_user)) return 1;
+    } else if (p->have_unique_id) {
+      if (cxk_comm_init_rccl(p->ctx, p->unique_id, p->shard_rank, p->shard_world)) return 1;
+    } else {
+      fprintf(stderr, "conex: a sharded program needs CONEX_HIP_SetCommunicator or CONEX_HIP_SetAllReduce\n");
+      return 1;
+    }
+  }
   for (const Cone& c : p->cones) {
     int id = -1;
     const int m = static_cast<int>(c.vars.size());
@@ -1024,6 +1041,40 @@ int CONEX_HIP_SetReferenceIdentity(void* x, int on) {
   Program* p = static_cast<Program*>(x);
   if (!p) return CONEX_FAILURE;
   p->reference_identity = on != 0;
+  p->dirty = true;
+  return CONEX_SUCCESS;
+}
+
+/* Multi-GPU, not part of conex.h (the reference is single process).  One process per GPU; every
+ * rank builds the SAME program and calls CONEX_Maximize / CONEX_Solve with the same arguments;
+ * constraints are dealt to the ranks by elimination subtree, the Schur sums that cross ranks go
+ * through one RCCL all-reduce per factorization / solve, the step scalars through small ones
+ * (conex_kkt_hip.h, "Collectives").  Every rank returns the same y; a dual variable
+ * (CONEX_GetDualVariable) is current on the rank that owns its constraint.
+ *   CONEX_HIP_GetUniqueId      128 bytes (ncclGetUniqueId) made by one rank, shipped to all
+ *   CONEX_HIP_SetCommunicator  rank / world and the unique id: RCCL over xGMI
+ *   CONEX_HIP_SetAllReduce     rank / world and a caller-supplied all-reduce (other transports, tests) */
+int CONEX_HIP_GetUniqueId(void* out128) { return cxk_comm_unique_id(out128) == CXK_SUCCESS ? CONEX_SUCCESS : CONEX_FAILURE; }
+
+int CONEX_HIP_SetCommunicator(void* x, const void* unique_id128, int rank, int world_size) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || !unique_id128 || world_size < 1 || rank < 0 || rank >= world_size) return CONEX_FAILURE;
+  p->shard_rank = rank;
+  p->shard_world = world_size;
+  memcpy(p->unique_id, unique_id128, 128);
+  p->have_unique_id = true;
+  p->allreduce_fn = nullptr;
+  p->dirty = true;
+  return CONEX_SUCCESS;
+}
+
+int CONEX_HIP_SetAllReduce(void* x, int rank, int world_size, cxk_allreduce_fn fn, void* user) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || !fn || world_size < 1 || rank < 0 || rank >= world_size) return CONEX_FAILURE;
+  p->shard_rank = rank;
+  p->shard_world = world_size;
+  p->allreduce_fn = fn;
+  p->allreduce_user = user;
   p->dirty = true;
   return CONEX_SUCCESS;
 }

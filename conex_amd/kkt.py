@@ -89,6 +89,10 @@ _SIGNATURES = {
     "cxk_count_sparse_lmi": (C.c_int, [C.c_void_p]),
     "cxk_count_lmi_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_set_reference_identity": (C.c_int, [C.c_void_p, C.c_int]),
+    "cxk_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "cxk_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "cxk_comm_set_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cxk_comm_selftest": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_dense_top_columns": (C.c_int, [C.c_void_p]),
     "cxk_factor_async": (C.c_int, [C.c_void_p]),
     "cxk_factor_solve_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
@@ -437,6 +441,48 @@ class KktContext:
     def kkt_finish_async(self, inv_sqrt_mu, b_scaling=1.0, c_scaling=1.0):
         self._check(self.L.cxk_kkt_finish_async(self.h, inv_sqrt_mu, b_scaling, c_scaling),
                     "cxk_kkt_finish_async")
+
+    # ---- collectives of a sharded context (cxk_comm_*)
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId: 128 bytes made by ONE rank and handed to all (cxk_comm_unique_id)."""
+        buf = C.create_string_buffer(128)
+        if load_library().cxk_comm_unique_id(buf) != 0:
+            raise KktError("cxk_comm_unique_id failed (librccl.so missing?)")
+        return buf.raw
+
+    def comm_init_rccl(self, unique_id, rank, world):
+        """RCCL communicator for this context's device; before initialize() it also sets the shard."""
+        assert len(unique_id) == 128
+        self._check(self.L.cxk_comm_init_rccl(self.h, C.c_char_p(unique_id), rank, world), "cxk_comm_init_rccl")
+
+    def comm_selftest(self, count=1000):
+        self._check(self.L.cxk_comm_selftest(self.h, count), "cxk_comm_selftest")
+
+    def comm_set_allreduce(self, host_allreduce):
+        """Another transport / tests: host_allreduce(array, op) -> array reduces HOST copies across the
+        ranks (op 0 sum, 1 max, 2 min); the wrapper moves the device buffer to the host and back."""
+        hip = C.CDLL("libamdhip64.so")
+        fn_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p)
+
+        def _cb(user, dev, count, op, stream):
+            try:
+                buf = np.empty(count)
+                if hip.hipStreamSynchronize(C.c_void_p(stream)) != 0:
+                    return 1
+                if hip.hipMemcpy(buf.ctypes.data_as(C.c_void_p), C.c_void_p(dev), C.c_size_t(8 * count), 2) != 0:
+                    return 1
+                out = np.ascontiguousarray(host_allreduce(buf, op), dtype=np.float64)
+                if hip.hipMemcpy(C.c_void_p(dev), out.ctypes.data_as(C.c_void_p), C.c_size_t(8 * count), 1) != 0:
+                    return 1
+                return 0
+            except Exception:  # an exception must not cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._coll_cb = fn_t(_cb)  # keeps the trampoline alive as long as the context
+        self._check(self.L.cxk_comm_set_allreduce(self.h, C.cast(self._coll_cb, C.c_void_p), None),
+                    "cxk_comm_set_allreduce")
 
     def owns(self, i):
         return bool(self.L.cxk_owns_constraint(self.h, i))

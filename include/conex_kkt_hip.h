@@ -199,6 +199,30 @@ int cxk_get_residuals(cxk_context* ctx, double* AW /* N */, double* AQc /* N */,
  *     cxk_kkt_finish_async  unpack, factor/solve the top (replicated), back-substitute own
  *                           subtrees
  * after which a rank holds y for its own and for the top variables (cxk_get_valid_variables). */
+/* Collectives.  With a communicator attached EVERY entry point of this header works on a sharded
+ * context exactly as on a single-GPU one -- cxk_kkt_solve_async, cxk_factor*_async, cxk_solve_rhs,
+ * cxk_newton_direction, cxk_solve_inplace (local sweep, ONE sum all-reduce of the top's share,
+ * top, back-substitution), cxk_prepare_step / cxk_weighted_slack_eigenvalues / cxk_step_scalars /
+ * cxk_line_search (scalar sum / max / min all-reduces), cxk_get_y (the whole vector) -- so the host
+ * IPM loop (CONEX_Maximize) runs unchanged, every rank taking the same decisions from the same
+ * reduced scalars.  The sums that cross ranks are those of supernodal_assembler.cc:103-111,162-164
+ * (separator overlaps into the Schur system) and block_triangular_operations.cc:209-215 (Schur
+ * updates of eliminated subtrees).
+ *   cxk_comm_unique_id      ncclGetUniqueId on one rank; ship the 128 bytes to the others
+ *   cxk_comm_init_rccl      ncclCommInitRank for this context's device (one process per GPU);
+ *                           implies cxk_set_shard(rank, world) when called before cxk_finalize.
+ *                           librccl.so is loaded on demand: single-GPU users need no RCCL
+ *   cxk_comm_set_allreduce  any other transport / tests: in-place all-reduce of `count` doubles of
+ *                           DEVICE memory, op 0 sum, 1 max, 2 min; work enqueued on `stream` before
+ *                           the call must be seen and the result must be in place on return */
+typedef int (*cxk_allreduce_fn)(void* user, double* device_buffer, long count, int op, void* stream);
+int cxk_comm_unique_id(void* out128);
+int cxk_comm_init_rccl(cxk_context* ctx, const void* unique_id128, int rank, int world_size);
+int cxk_comm_set_allreduce(cxk_context* ctx, cxk_allreduce_fn fn, void* user);
+/* sum / max / min all-reduces of `count` doubles through the RCCL communicator, checked */
+int cxk_comm_selftest(cxk_context* ctx, int count);
+
+/* The two halves of a sharded KKT solve, for callers that run the all-reduce themselves: */
 int cxk_exchange_buffer(cxk_context* ctx, void** dev_ptr, long* count /* doubles */);
 int cxk_exchange_download(cxk_context* ctx, double* out);   /* host copy, tests */
 int cxk_exchange_upload(cxk_context* ctx, const double* in);

@@ -1,9 +1,17 @@
 """Multi-GPU sharding.
 
-CPU part: the deterministic partition every rank computes for itself (host-only contexts), and
-a world_size-2 gloo exchange of a buffer of the real exchange size.
-GPU part: G ranks emulated on one device -- local phases, a manual sum of the exchange buffers
-(what RCCL all-reduce does), finish phases -- must reproduce the single-context Newton direction.
+CPU part: the deterministic partition every rank computes for itself (host-only contexts), and a
+world_size-2 gloo run over that partition.
+GPU part, all through the library's own collective path (ShardAllReduce inside the cxk_* entry
+points; the transport is a caller-supplied all-reduce here because one box has one GPU, RCCL in
+production):
+  * G ranks as G threads on one device, reductions through a barrier -- a whole Newton iteration
+    (KKT solve, solve-only right-hand sides, PrepareStep, eigenvalue query, step scalars, TakeStep)
+    and whole CONEX_Maximize runs must reproduce the single-context results;
+  * TWO PROCESSES (torch.distributed, gloo) sharing GPU 0: the real exchange buffers travel through
+    gloo and the direction matches the single-context one;
+  * the RCCL call path itself (librccl.so loaded on demand, ncclAllReduce on the context's stream)
+    through a one-rank communicator.
 """
 import os
 import subprocess
@@ -105,6 +113,266 @@ def test_world_size_2_gloo_exchange(tmp_path):
         capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "GLOO_OK" in out.stdout
+
+
+class ThreadRanks:
+    """G ranks as G threads of one process: the all-reduce every rank calls deposits its array,
+    waits for the others and reduces the deposits in rank order (deterministic)."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.slots = [None] * world
+        self.barrier = threading.Barrier(world)
+        self.errors = []
+
+    def allreduce(self, rank):
+        def fn(arr, op):
+            self.slots[rank] = arr.copy()
+            self.barrier.wait(timeout=120)
+            stack = np.stack(self.slots)
+            out = stack.sum(axis=0) if op == 0 else (stack.max(axis=0) if op == 1 else stack.min(axis=0))
+            self.barrier.wait(timeout=120)
+            return out
+        return fn
+
+    def run(self, body):
+        import threading
+        results = [None] * self.world
+
+        def work(r):
+            try:
+                results[r] = body(r, self.allreduce(r))
+            except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+                self.errors.append((r, repr(e)))
+                self.barrier.abort()
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=600)
+        assert not self.errors, self.errors
+        return results
+
+
+def _program(kind, seed):
+    if kind == "lmi":
+        prob = syn.lmi_problem(K=120, n=6, m=20, branching=8, overlap=5, seed=seed)
+        W = syn.scaling_points(120, 6, seed=4)
+    elif kind == "c4":
+        prob = syn.lmi_problem(K=300, n=20, m=20, branching=8, overlap=5, seed=seed)   # MFMA Schur kernel, chain at the top
+        W = syn.scaling_points(300, 20, seed=4)
+    elif kind == "mixed":
+        prob = syn.mixed_problem(K=230, seed=seed)
+        W = syn.mixed_scaling_points(prob, seed=32)
+    else:
+        raise ValueError(kind)
+    return prob, W
+
+
+def _newton_iteration(k, prob, W, owned_only):
+    """One full Newton iteration through the ordinary entry points; returns everything comparable."""
+    for i in range(k.K):
+        if not owned_only or k.owns(i):
+            k.set_W(i, W[i])
+    out = {}
+    ok, out["y"] = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    assert ok == 1
+    out["eig"] = k.weighted_slack_eigenvalues(None, 0.7 * 0.8)
+    out["info"] = k.prepare_step(None, 0.7 * 0.8, 1.0)
+    out["scal"] = k.step_scalars()
+    k.take_step(min(1.0, 2.0 / out["info"][1] ** 2))
+    # a second, separately assembled factorization and two solve-only right-hand sides
+    k.assemble()
+    assert k.factor() == 1
+    k.newton_direction(0.9, 0.8, 0.7)
+    out["y2"] = k.get_y()
+    rhs = np.random.default_rng(5).uniform(-1, 1, k.N)
+    out["y3"] = k.solve_inplace(rhs)
+    out["W"] = {i: k.get_W(i) for i in range(k.K) if not owned_only or k.owns(i)}
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,world", [("lmi", 2), ("lmi", 3), ("c4", 4), ("mixed", 2), ("mixed", 5)])
+def test_sharded_newton_iteration_through_the_library_collectives(kind, world):
+    prob, W = _program(kind, 11)
+    build_kind = "mixed" if kind == "mixed" else "lmi"
+    ref = _newton_iteration(syn.build(KktContext, prob, build_kind, device=0), prob, W, False)
+
+    def body(rank, allreduce):
+        k = KktContext(prob["num_vars"], device=0)
+        for c, cl in enumerate(prob["cliques"]):
+            if build_kind == "lmi":
+                k.add_lmi(prob["A"][c], prob["C"][c], cl)
+            elif prob["kinds"][c] == "herm":
+                k.add_hermitian(prob["A"][c], prob["C"][c], cl)
+            else:
+                k.add_soc(prob["A"][c], prob["C"][c], cl)
+        k.set_shard(rank, world)
+        k.initialize()
+        k.comm_set_allreduce(allreduce)
+        k.set_cost(prob["b"])
+        return _newton_iteration(k, prob, W, True)
+
+    for out in ThreadRanks(world).run(body):
+        for key in ("y", "y2", "y3"):
+            assert np.linalg.norm(out[key] - ref[key]) <= 1e-10 * np.linalg.norm(ref[key]), key
+        assert np.allclose(out["eig"], ref["eig"], rtol=1e-9, atol=0)
+        assert np.allclose(out["info"], ref["info"], rtol=1e-9, atol=0)
+        assert np.allclose(out["scal"], ref["scal"], rtol=1e-10, atol=1e-12)
+        for i, w in out["W"].items():
+            assert np.linalg.norm(w - ref["W"][i]) <= 1e-10 * np.linalg.norm(ref["W"][i])
+
+
+@pytest.mark.gpu
+def test_sharded_equality_constraints_take_the_ldlt_path():
+    """Multipliers make the KKT matrix indefinite: block LDLT under sharding (the LQR program of
+    assembly_test.cc:67-106 with 40 stages) against the single-context solve."""
+    from test_oracle_kat import build_lqr_problem
+    ref = build_lqr_problem(KktContext, 40, device=0)
+    ref.assemble()
+    assert ref.factor() == 1
+    rhs = np.random.default_rng(2).uniform(-1, 1, ref.N)
+    y_ref = ref.solve_inplace(rhs)
+    world = 3
+
+    def body(rank, allreduce):
+        k = build_lqr_problem(lambda nv, **kw: _sharded(nv, rank, world), 40)
+        k.comm_set_allreduce(allreduce)
+        k.assemble()
+        assert k.factor() == 1
+        return k.solve_inplace(rhs)
+
+    def _sharded(nv, rank, world):
+        k = KktContext(nv, device=0)
+        k.set_shard(rank, world)
+        return k
+
+    for y in ThreadRanks(world).run(body):
+        assert np.linalg.norm(y - y_ref) <= 1e-10 * np.linalg.norm(y_ref)
+
+
+@pytest.mark.gpu
+def test_sharded_conex_maximize_matches_single_gpu():
+    """CONEX_Maximize with a communicator set runs the sharded IPM loop: every rank builds the same
+    program, returns the same y, and that y is the single-GPU optimum."""
+    import ctypes as C
+    import conex_api as ca
+    prob = syn.lmi_problem(K=100, n=20, m=20, branching=8, overlap=5, seed=21)
+    L = ca.api()
+    L.CONEX_HIP_SetAllReduce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    fn_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p)
+    hip = C.CDLL("libamdhip64.so")
+
+    def solve(rank, world, allreduce):
+        p = L.CONEX_CreateConeProgram()
+        keep = None
+        if world > 1:
+            def cb(user, dev, count, op, stream):
+                buf = np.empty(count)
+                hip.hipStreamSynchronize(C.c_void_p(stream))
+                hip.hipMemcpy(buf.ctypes.data_as(C.c_void_p), C.c_void_p(dev), C.c_size_t(8 * count), 2)
+                out = np.ascontiguousarray(allreduce(buf, op))
+                hip.hipMemcpy(C.c_void_p(dev), out.ctypes.data_as(C.c_void_p), C.c_size_t(8 * count), 1)
+                return 0
+            keep = fn_t(cb)
+            assert L.CONEX_HIP_SetAllReduce(p, rank, world, C.cast(keep, C.c_void_p), None) == 0
+        assert L.CONEX_SetNumberOfVariables(p, prob["num_vars"]) == 0
+        for c, cl in enumerate(prob["cliques"]):
+            a, cm = ca.colmajor(prob["A"][c]), ca.colmajor(prob["C"][c])
+            v = np.ascontiguousarray(cl, dtype=np.int64)
+            assert L.CONEX_AddSparseLMIConstraint(p, ca.dp(a), 20, 20, 20, ca.dp(cm), 20, 20,
+                                                  v.ctypes.data_as(C.POINTER(C.c_long)), 20) == c
+        cfg = ca.default_config()
+        y = np.zeros(prob["num_vars"])
+        b = np.ascontiguousarray(prob["b"])
+        ok = L.CONEX_Maximize(p, ca.dp(b), len(b), C.byref(cfg), ca.dp(y), len(y))
+        st = ca.IterationStats()
+        L.CONEX_GetIterationStats(p, C.byref(st), -1)
+        L.CONEX_DeleteConeProgram(p)
+        return ok, y, st.iteration_number + 1
+
+    ok0, y0, it0 = solve(0, 1, None)
+    assert ok0 == 1
+    world = 4
+    results = ThreadRanks(world).run(lambda r, ar: solve(r, world, ar))
+    for ok, y, it in results:
+        assert ok == 1 and abs(it - it0) <= 3
+        assert np.array_equal(y, results[0][1])           # every rank returns the same vector
+        assert abs(prob["b"] @ y - prob["b"] @ y0) <= 1e-6 * abs(prob["b"] @ y0)
+
+
+@pytest.mark.gpu
+def test_rccl_call_path_with_a_one_rank_communicator():
+    """librccl.so loaded on demand, ncclCommInitRank, ncclAllReduce (sum, max, min) of device
+    memory on the context's stream.  (Two ranks cannot share the one GPU of this box; the driver's
+    multi-GPU bench runs the same code with world > 1.)"""
+    prob = syn.lmi_problem(K=5, n=4, m=4, branching=2, overlap=2, seed=3)
+    k = KktContext(prob["num_vars"], device=0)
+    for c, cl in enumerate(prob["cliques"]):
+        k.add_lmi(prob["A"][c], prob["C"][c], cl)
+    k.comm_init_rccl(KktContext.comm_unique_id(), 0, 1)
+    k.initialize()
+    k.comm_selftest(5000)
+    ok, y = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    assert ok == 1 and np.all(np.isfinite(y))
+
+
+TWO_PROCESS_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from conex_amd import KktContext
+from conex_amd import synthetic as syn
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+prob = syn.lmi_problem(K=120, n=20, m=20, branching=8, overlap=5, seed=3)
+W = syn.scaling_points(120, 20, seed=4)
+k = KktContext(prob["num_vars"], device=0)            # both processes share GPU 0
+for c, cl in enumerate(prob["cliques"]):
+    k.add_lmi(prob["A"][c], prob["C"][c], cl)
+k.set_shard(rank, world)
+k.initialize()
+def allreduce(arr, op):                                 # the REAL exchange buffers travel through gloo
+    t = torch.from_numpy(arr.copy())
+    dist.all_reduce(t, op={0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}[op])
+    return t.numpy()
+k.comm_set_allreduce(allreduce)
+for i in range(k.K):
+    if k.owns(i):
+        k.set_W(i, W[i])
+ok, y = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+assert ok == 1
+info = k.prepare_step(None, 0.56, 1.0)
+if rank == 0:
+    ref = syn.build(KktContext, prob, "lmi", device=0)
+    for i in range(ref.K):
+        ref.set_W(i, W[i])
+    okr, yr = ref.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    ir = ref.prepare_step(None, 0.56, 1.0)
+    err = np.linalg.norm(y - yr) / np.linalg.norm(yr)
+    assert okr == 1 and err <= 1e-10, err
+    assert np.allclose(info, ir, rtol=1e-9, atol=0)
+    print("TWO_PROCESS_OK", err)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_two_processes_exchange_the_real_buffers_through_gloo(tmp_path):
+    script = tmp_path / "worker2.py"
+    script.write_text(TWO_PROCESS_WORKER)
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    port = 29600 + (os.getpid() % 1000)
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT],
+        capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "TWO_PROCESS_OK" in out.stdout
 
 
 @pytest.mark.gpu
