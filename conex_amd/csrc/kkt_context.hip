@@ -240,6 +240,26 @@ struct cxk_context {
   size_t ev_used = 0;
   double time_acc_ms = 0;
   int time_samples = 0;
+  // kkt_solver = CONEX_QR_FACTORIZATION (kkt_solver.cc:172-231): the reference factors the DENSE
+  // N x N KKT matrix with a column-pivoted Householder QR (Eigen::ColPivHouseholderQR) and solves
+  // with it -- a debugging mode for rank-deficient systems, O(N^2) memory and O(N^3) work on one
+  // host core there.  Same here: Factor brings the assembled slab to the host, solves go through
+  // the host; everything else of the iteration stays on the device.  Orders beyond kQrMaxOrder are
+  // refused.
+  int solver_mode = 0;               // 0 LLT / LDLT by structure (the reference's modes 0 and 1), 2 QR
+  struct DenseQr {
+    int n = 0, rank = 0;
+    std::vector<double> qr, tau;     // Householder vectors below the diagonal, R on and above
+    std::vector<int> piv;
+    bool valid = false;
+  } qr;
+  // Per-phase device timers (the reference's START_TIMER / END_TIMER of debug_macros.h:18-52 around
+  // Assemble / Factor / Solve / Update, cone_program.cc:338-437): hipEvents recorded on the stream
+  // at every phase mark; the time between two consecutive marks belongs to the earlier phase.
+  bool phase_on = false;
+  std::vector<std::pair<hipEvent_t, int>> phase_marks;  // (event, phase that starts there)
+  std::vector<hipEvent_t> phase_pool;
+  double phase_us[CXK_PHASE_COUNT] = {0, 0, 0, 0, 0};
   // Host mailbox (pinned, device-visible): the scalars the IPM loop reads every iteration --
   // reduced step info / eigenvalue bounds [0..3], step scalars [4..9], factor-failure flag [10],
   // sequence number [11] -- are written by one tiny kernel at the end of the enqueued work and
@@ -1765,7 +1785,15 @@ int LaunchTreeCore(cxk_context* ctx, int mode, bool with_rhs, bool backward);
 // (kkt_solver.cc:233-261); without refinement this is LaunchTreeCore.
 int ShardedTree(cxk_context* ctx, int mode, bool with_rhs, bool backward);
 
+int QrFactor(cxk_context* ctx);
+int QrSolve(cxk_context* ctx);
+
 int LaunchTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
+  if (ctx->solver_mode == 2) {  // CONEX_QR_FACTORIZATION
+    if (mode == 0 && QrFactor(ctx)) return CXK_FAILURE;
+    if ((mode != 0 || with_rhs) && backward) return QrSolve(ctx);
+    return CXK_SUCCESS;
+  }
   if (ctx->world > 1) return ShardedTree(ctx, mode, with_rhs, backward);  // (refinement is single-GPU)
   if (ctx->refine_iters <= 0) return LaunchTreeCore(ctx, mode, with_rhs, backward);
   const int N = ctx->md.N;
@@ -1879,6 +1907,137 @@ int LaunchTreeCore(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
       if (it->second ? LaunchRange(ctx, *it->second, 2, true) : LaunchSweep(ctx, it->first, it->first + 1, 2, false, true))
         return CXK_FAILURE;
     }
+  return CXK_SUCCESS;
+}
+
+// ---------------------------------------------------------------- QR solver mode (B10)
+constexpr int kQrMaxOrder = 1500;
+
+// Column-pivoted Householder QR, A P = Q R, of the n x n column-major matrix `a` (overwritten:
+// R on and above the diagonal, the essential parts of the reflectors below).  Pivot rule, rank
+// threshold and the solve are those of Eigen::ColPivHouseholderQR (largest remaining column norm
+// first; rank = number of pivots above epsilon * n * largest pivot; solve() applies Q^T, solves
+// with the leading rank x rank triangle and leaves the remaining unknowns zero).
+void DenseQrFactor(int n, std::vector<double>& a, std::vector<double>& tau, std::vector<int>& piv, int* rank) {
+  tau.assign(n, 0.0);
+  piv.resize(n);
+  std::vector<double> norm2(n);
+  for (int j = 0; j < n; j++) {
+    piv[j] = j;
+    double t = 0;
+    for (int i = 0; i < n; i++) t += a[i + (size_t)j * n] * a[i + (size_t)j * n];
+    norm2[j] = t;
+  }
+  double maxpivot = 0;
+  int r = 0;
+  for (int k = 0; k < n; k++) {
+    int best = k;
+    for (int j = k; j < n; j++) {  // column norms of the trailing block, recomputed (n is small)
+      double t = 0;
+      for (int i = k; i < n; i++) t += a[i + (size_t)j * n] * a[i + (size_t)j * n];
+      norm2[j] = t;
+      if (t > norm2[best]) best = j;
+    }
+    if (best != k) {
+      for (int i = 0; i < n; i++) std::swap(a[i + (size_t)k * n], a[i + (size_t)best * n]);
+      std::swap(piv[k], piv[best]);
+      std::swap(norm2[k], norm2[best]);
+    }
+    double* col = &a[(size_t)k * n];
+    const double alpha = col[k];
+    double tail = 0;
+    for (int i = k + 1; i < n; i++) tail += col[i] * col[i];
+    double beta = alpha;
+    if (tail > 0) {
+      beta = std::sqrt(alpha * alpha + tail);
+      if (alpha >= 0) beta = -beta;
+      tau[k] = (beta - alpha) / beta;
+      const double scale = 1.0 / (alpha - beta);
+      for (int i = k + 1; i < n; i++) col[i] *= scale;
+      col[k] = beta;
+      for (int j = k + 1; j < n; j++) {  // apply H_k = I - tau v v^T, v = [1; col[k+1:]]
+        double* cj = &a[(size_t)j * n];
+        double w = cj[k];
+        for (int i = k + 1; i < n; i++) w += col[i] * cj[i];
+        w *= tau[k];
+        cj[k] -= w;
+        for (int i = k + 1; i < n; i++) cj[i] -= w * col[i];
+      }
+    }
+    maxpivot = std::max(maxpivot, std::fabs(beta));
+  }
+  const double thresh = DBL_EPSILON * n * maxpivot;
+  for (int k = 0; k < n; k++)
+    if (std::fabs(a[k + (size_t)k * n]) > thresh) r++;
+  *rank = r;
+}
+
+void DenseQrSolve(const cxk_context::DenseQr& Q, std::vector<double>& b) {
+  const int n = Q.n;
+  const std::vector<double>& a = Q.qr;
+  for (int k = 0; k < n; k++) {  // c = Q^T b
+    if (Q.tau[k] == 0.0) continue;
+    double w = b[k];
+    for (int i = k + 1; i < n; i++) w += a[i + (size_t)k * n] * b[i];
+    w *= Q.tau[k];
+    b[k] -= w;
+    for (int i = k + 1; i < n; i++) b[i] -= w * a[i + (size_t)k * n];
+  }
+  std::vector<double> z(n, 0.0);
+  for (int k = Q.rank - 1; k >= 0; k--) {
+    double t = b[k];
+    for (int j = k + 1; j < Q.rank; j++) t -= a[k + (size_t)j * n] * z[j];
+    z[k] = t / a[k + (size_t)k * n];
+  }
+  for (int k = 0; k < n; k++) b[Q.piv[k]] = z[k];
+}
+
+// Factor(): kkt_matrix_ = KKTMatrix() = Pt G Pt^T from the assembled slab (kkt_solver.cc:175-178,
+// 265-269; supernodal_solver.cc:117-137 ToDense), qr_decomp_.compute(kkt_matrix_) (:196).
+int QrFactor(cxk_context* ctx) {
+  const Layout& L = ctx->lay;
+  const int N = ctx->md.N;
+  CXK_DEMAND(N <= kQrMaxOrder, "kkt_solver = QR factors the dense N x N KKT matrix on one host core: N exceeds the limit (1500)");
+  CXK_DEMAND(ctx->world == 1, "the QR solver mode is single-GPU");
+  std::vector<double> slab((size_t)L.slab_size);
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(slab.data(), ctx->slab.p, sizeof(double) * slab.size(), hipMemcpyDeviceToHost));
+  std::vector<double> G((size_t)N * N, 0.0);  // permuted order, then both triangles
+  for (int e = 0; e < L.K; e++) {
+    const int ns = L.supernode_size[e], st = L.supernode_start[e];
+    for (int j = 0; j < ns; j++)
+      for (int i = j; i < ns; i++) G[(size_t)(st + i) + (size_t)(st + j) * N] = slab[L.diag_off[e] + i + (int64_t)j * ns];
+    for (size_t c = 0; c < L.separators[e].size(); c++)
+      for (int i = 0; i < ns; i++) G[(size_t)L.separators[e][c] + (size_t)(st + i) * N] = slab[L.offd_off[e] + i + (int64_t)c * ns];
+  }
+  auto& Q = ctx->qr;
+  Q.n = N;
+  Q.qr.assign((size_t)N * N, 0.0);
+  const std::vector<int>& pinv = ctx->md.permutation_inverse;  // permuted position -> original variable
+  for (int j = 0; j < N; j++)
+    for (int i = j; i < N; i++) {
+      const double v = G[(size_t)i + (size_t)j * N];
+      Q.qr[(size_t)pinv[i] + (size_t)pinv[j] * N] = v;
+      Q.qr[(size_t)pinv[j] + (size_t)pinv[i] * N] = v;
+    }
+  DenseQrFactor(N, Q.qr, Q.tau, Q.piv, &Q.rank);
+  Q.valid = true;
+  CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));  // Factor() returns true (:197)
+  return CXK_SUCCESS;
+}
+
+// SolveInPlace with the QR (kkt_solver.cc:227-231): the device's right-hand side is in permuted
+// order, the factorization in the original one.
+int QrSolve(cxk_context* ctx) {
+  CXK_DEMAND(ctx->qr.valid, "QR solve before a QR factorization");
+  const int N = ctx->md.N;
+  std::vector<double> yp(N), y(N);
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  CXK_TRY(hipMemcpy(yp.data(), ctx->y.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+  for (int i = 0; i < N; i++) y[ctx->md.permutation_inverse[i]] = yp[i];
+  DenseQrSolve(ctx->qr, y);
+  for (int i = 0; i < N; i++) yp[i] = y[ctx->md.permutation_inverse[i]];
+  CXK_TRY(hipMemcpy(ctx->y.p, yp.data(), sizeof(double) * N, hipMemcpyHostToDevice));
   return CXK_SUCCESS;
 }
 
@@ -2025,6 +2184,8 @@ void cxk_destroy(cxk_context* ctx) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
   }
+  for (auto& m : ctx->phase_marks) (void)hipEventDestroy(m.first);
+  for (hipEvent_t e : ctx->phase_pool) (void)hipEventDestroy(e);
   if (ctx->rccl.comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->rccl.comm);
   if (ctx->mb) (void)hipHostFree(ctx->mb);
   if (ctx->pin_y) (void)hipHostFree(ctx->pin_y);
@@ -3265,6 +3426,55 @@ int cxk_set_iterative_refinement(cxk_context* ctx, int iterations) {
   }
   if (iterations != ctx->refine_iters) ctx->slab0_valid = false;
   ctx->refine_iters = iterations;
+  return CXK_SUCCESS;
+}
+
+int cxk_set_solver_mode(cxk_context* ctx, int mode) {
+  if (!ctx) return CXK_FAILURE;
+  CXK_DEMAND(mode == 0 || mode == 1 || mode == 2, "solver mode must be 0 (LLT), 1 (LDLT) or 2 (QR)");
+  ctx->solver_mode = mode == 2 ? 2 : 0;  // LLT vs LDLT follows the structure (kkt_solver.cc:180-193)
+  ctx->qr.valid = false;
+  return CXK_SUCCESS;
+}
+
+int cxk_phase_timers(cxk_context* ctx, int on) {
+  if (!ctx) return CXK_FAILURE;
+  ctx->phase_on = on != 0;
+  return CXK_SUCCESS;
+}
+
+int cxk_phase_mark(cxk_context* ctx, int phase) {
+  if (!ctx || !ctx->phase_on) return CXK_SUCCESS;
+  CXK_ENTER(ctx);
+  CXK_DEMAND(phase >= 0 && phase < CXK_PHASE_COUNT, "unknown phase");
+  hipEvent_t ev;
+  if (!ctx->phase_pool.empty()) {
+    ev = ctx->phase_pool.back();
+    ctx->phase_pool.pop_back();
+  } else {
+    CXK_TRY(hipEventCreate(&ev));
+  }
+  CXK_TRY(hipEventRecord(ev, ctx->stream));
+  ctx->phase_marks.emplace_back(ev, phase);
+  return CXK_SUCCESS;
+}
+
+int cxk_phase_read(cxk_context* ctx, double* us, int reset) {
+  if (!ctx || !us) return CXK_FAILURE;
+  CXK_ENTER(ctx);
+  if (!ctx->phase_marks.empty()) {
+    CXK_TRY(hipEventSynchronize(ctx->phase_marks.back().first));
+    for (size_t k = 0; k + 1 < ctx->phase_marks.size(); k++) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ctx->phase_marks[k].first, ctx->phase_marks[k + 1].first) == hipSuccess)
+        ctx->phase_us[ctx->phase_marks[k].second] += 1e3 * ms;
+    }
+    for (auto& m : ctx->phase_marks) ctx->phase_pool.push_back(m.first);
+    ctx->phase_marks.clear();
+  }
+  for (int k = 0; k < CXK_PHASE_COUNT; k++) us[k] = ctx->phase_us[k];
+  if (reset)
+    for (int k = 0; k < CXK_PHASE_COUNT; k++) ctx->phase_us[k] = 0;
   return CXK_SUCCESS;
 }
 

@@ -339,11 +339,6 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     for (int i = 0; i < m; i++) yout[i] = -p->linear_cost[i] * std::numeric_limits<double>::infinity();
     return 0;
   }
-  if (cfg.kkt_solver != 0) {
-    fprintf(stderr,
-            "conex: the QR kkt_solver needs the dense KKT matrix and is not available on the device "
-            "path; using the supernodal factorization.\n");
-  }
   // CONEX_PROFILE=1 in the environment: wall time of set-up, of the iteration loop and of the
   // host side of each device call on stderr
   const bool profile = getenv("CONEX_PROFILE") != nullptr;
@@ -365,7 +360,12 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
   // Initialize :78-112
   if (!p->initialized || p->dirty || cfg.initialization_mode == 0) {
     if (p->dirty || !p->ctx) {
+      // "Sparsity Analysis(us)" of cone_program.cc:95-109: symbolic analysis + upload, host wall time
+      const auto t_sp = std::chrono::steady_clock::now();
       if (BuildContext(p)) return 0;
+      if (getenv("CONEX_ENABLE_TIMER") && atoi(getenv("CONEX_ENABLE_TIMER")) != 0)
+        printf("Sparsity Analysis(us): %.0f, \n",
+               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_sp).count());
     }
     if (cfg.initialization_mode == 0) {
       p->b_scaling = 1;
@@ -375,6 +375,13 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     p->initialized = true;
   }
   cxk_context* ctx = p->ctx;
+  // CONEX_ENABLE_TIMER=1 (the reference's compile-time macro of debug_macros.h:18-52 as an
+  // environment switch): device time of the four phases the reference brackets, per iteration
+  const bool timers = getenv("CONEX_ENABLE_TIMER") != nullptr && atoi(getenv("CONEX_ENABLE_TIMER")) != 0;
+  cxk_phase_timers(ctx, timers ? 1 : 0);
+  if (cxk_set_solver_mode(ctx, cfg.kkt_solver)) return 0;  // solver->SetSolverMode(config.kkt_solver) :305
+  double phase_prev[CXK_PHASE_COUNT] = {0, 0, 0, 0, 0};
+  if (timers) cxk_phase_read(ctx, phase_prev, 1);
   // solver.SetIterativeRefinementIterations(config.iterative_refinement_iterations)
   if (cxk_set_iterative_refinement(ctx, cfg.iterative_refinement_iterations > 0 ? cfg.iterative_refinement_iterations : 0))
     return 0;
@@ -420,6 +427,7 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
         break;
       }
     }
+    cxk_phase_mark(ctx, CXK_PHASE_ASSEMBLE);
     if (TIMED(0, cxk_assemble(ctx))) return 0;
     if (i < 1 && cfg.enable_rescaling) {
       if (cfg.initialization_mode == 0) {
@@ -440,6 +448,7 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     // line search, the Newton direction itself when mu stays (its value is final before Factor()).
     const bool fuse_mu_solve = update_mu && !cfg.enable_line_search;
     const bool fuse_direction = !update_mu;
+    cxk_phase_mark(ctx, CXK_PHASE_FACTOR);  // (a fused first solve of the iteration rides in the factor sweep)
     if (fuse_direction) {
       if (initial_centering == 0) centering_steps++;
       ApplyLimits(&inv_sqrt_mu, std::sqrt(1.0 / (1e-15 + cfg.maximum_mu)), inv_sqrt_mu_max);
@@ -467,6 +476,7 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
       return kFailed;
     };
     if (update_mu) {
+      cxk_phase_mark(ctx, CXK_PHASE_OTHER);  // mu selection: untimed in the reference
       double temp = -1;
       if (cfg.enable_line_search) {  // cone_program.cc:376-384
         if (cxk_line_search(ctx, cfg.dinf_upper_bound, b_scaling, c_scaling, &temp)) return 0;
@@ -492,11 +502,13 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     }
     ApplyLimits(&inv_sqrt_mu, std::sqrt(1.0 / (1e-15 + cfg.maximum_mu)), inv_sqrt_mu_max);
 
+    cxk_phase_mark(ctx, CXK_PHASE_SOLVE);
     if (!fuse_direction && TIMED(4, cxk_newton_direction(ctx, inv_sqrt_mu, b_scaling, c_scaling))) return 0;
     if (TIMED(6, cxk_step_scalars_async(ctx))) return 0;  // by / cx of :439-446 need y only: same round trip
     e_weight = 1;
     c_weight = inv_sqrt_mu * c_scaling;
     double info[2];
+    cxk_phase_mark(ctx, CXK_PHASE_UPDATE);
     if (TIMED(5, cxk_prepare_step(ctx, 0, c_weight, e_weight, info))) return 0;
     if (!update_mu) {
       const int fo = factor_outcome();
@@ -513,6 +525,15 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
       warmstart_aborted = true;
     } else {
       if (TIMED(7, cxk_take_step(ctx, 0, e_weight, step_size))) return 0;
+    }
+    cxk_phase_mark(ctx, CXK_PHASE_OTHER);
+    if (timers) {  // "Assemble(us): 12, Factor(us): 40, ..." as the reference's END_TIMER prints them
+      double us[CXK_PHASE_COUNT];
+      if (cxk_phase_read(ctx, us, 0) == CXK_SUCCESS) {
+        static const char* const names[4] = {"Assemble", "Factor", "Solve", "Update"};
+        for (int k = 0; k < 4; k++) printf("%s(us): %.0f, ", names[k], us[k] - phase_prev[k]);
+        for (int k = 0; k < CXK_PHASE_COUNT; k++) phase_prev[k] = us[k];
+      }
     }
     const double d_2 = std::sqrt(std::fabs(info[0]));
     const double d_inf = std::fabs(info[1]);
@@ -1033,6 +1054,14 @@ int CONEX_HIP_SetDevice(void* x, int device) {
   p->device = device;
   p->dirty = true;
   return CONEX_SUCCESS;
+}
+
+/* not part of conex.h: device microseconds per phase {Assemble, Factor, Solve, Update, other}
+ * accumulated by the solves of this program while CONEX_ENABLE_TIMER=1 */
+int CONEX_HIP_GetPhaseTimes(void* x, double* us5) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || !p->ctx || !us5) return CONEX_FAILURE;
+  return cxk_phase_read(p->ctx, us5, 0) == CXK_SUCCESS ? CONEX_SUCCESS : CONEX_FAILURE;
 }
 
 /* not part of conex.h: 1 = reproduce the reference as written where this library deliberately

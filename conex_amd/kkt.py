@@ -89,6 +89,10 @@ _SIGNATURES = {
     "cxk_count_sparse_lmi": (C.c_int, [C.c_void_p]),
     "cxk_count_lmi_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_set_reference_identity": (C.c_int, [C.c_void_p, C.c_int]),
+    "cxk_set_solver_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "cxk_phase_timers": (C.c_int, [C.c_void_p, C.c_int]),
+    "cxk_phase_mark": (C.c_int, [C.c_void_p, C.c_int]),
+    "cxk_phase_read": (C.c_int, [C.c_void_p, c_double_p, C.c_int]),
     "cxk_comm_unique_id": (C.c_int, [C.c_void_p]),
     "cxk_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "cxk_comm_set_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -441,6 +445,21 @@ class KktContext:
     def kkt_finish_async(self, inv_sqrt_mu, b_scaling=1.0, c_scaling=1.0):
         self._check(self.L.cxk_kkt_finish_async(self.h, inv_sqrt_mu, b_scaling, c_scaling),
                     "cxk_kkt_finish_async")
+
+    def set_solver_mode(self, mode):
+        """0 / 1 supernodal LLT / LDLT (by structure), 2 dense column-pivoted QR (cxk_set_solver_mode)."""
+        self._check(self.L.cxk_set_solver_mode(self.h, mode), "cxk_set_solver_mode")
+
+    def phase_timers(self, on=True):
+        self._check(self.L.cxk_phase_timers(self.h, int(bool(on))), "cxk_phase_timers")
+
+    def phase_mark(self, phase):
+        self._check(self.L.cxk_phase_mark(self.h, phase), "cxk_phase_mark")
+
+    def phase_read(self, reset=False):
+        out = np.zeros(5)
+        self._check(self.L.cxk_phase_read(self.h, _dp(out), int(bool(reset))), "cxk_phase_read")
+        return out
 
     # ---- collectives of a sharded context (cxk_comm_*)
     @staticmethod

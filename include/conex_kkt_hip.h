@@ -222,6 +222,30 @@ int cxk_comm_set_allreduce(cxk_context* ctx, cxk_allreduce_fn fn, void* user);
 /* sum / max / min all-reduces of `count` doubles through the RCCL communicator, checked */
 int cxk_comm_selftest(cxk_context* ctx, int count);
 
+/* SupernodalKKTSolver::SetSolverMode (kkt_solver.h:41; SolverConfiguration::kkt_solver): 0 / 1 the
+ * supernodal LLT / LDLT (chosen by the structure, as kkt_solver.cc:180-193 does), 2
+ * CONEX_QR_FACTORIZATION -- the reference's debugging mode for rank-deficient systems: Factor()
+ * forms the dense N x N KKT matrix and takes its column-pivoted Householder QR, every solve goes
+ * through it (kkt_solver.cc:175-178, 196-198, 227-231).  As there, this is dense host arithmetic on
+ * one core (the assembled slab travels to the host at Factor, right-hand sides at every solve);
+ * N is limited to 1500, single GPU. */
+int cxk_set_solver_mode(cxk_context* ctx, int mode);
+
+/* ---- per-phase device timers ------------------------------------------------------------
+ * The reference brackets Assemble / Factor / Solve / Update of every iteration with START_TIMER /
+ * END_TIMER (debug_macros.h:18-52; cone_program.cc:338-341, 359-372, 412-414, 421-437) when built
+ * with CONEX_ENABLE_TIMER.  Here the caller marks the START of a phase; a hipEvent is recorded on
+ * the context's stream (nothing waits), the device time up to the next mark is charged to that
+ * phase, CXK_PHASE_OTHER collects what the reference leaves untimed (mu selection).
+ * cxk_phase_read waits for the last mark, folds finished intervals and returns microseconds per
+ * phase accumulated since the last reset.  CONEX_Maximize uses them when CONEX_ENABLE_TIMER=1 is
+ * in the environment and prints the reference's "Assemble(us): .., Factor(us): .., ..." fields. */
+enum { CXK_PHASE_ASSEMBLE = 0, CXK_PHASE_FACTOR = 1, CXK_PHASE_SOLVE = 2, CXK_PHASE_UPDATE = 3,
+       CXK_PHASE_OTHER = 4, CXK_PHASE_COUNT = 5 };
+int cxk_phase_timers(cxk_context* ctx, int on);
+int cxk_phase_mark(cxk_context* ctx, int phase);
+int cxk_phase_read(cxk_context* ctx, double* us /* CXK_PHASE_COUNT */, int reset);
+
 /* The two halves of a sharded KKT solve, for callers that run the all-reduce themselves: */
 int cxk_exchange_buffer(cxk_context* ctx, void** dev_ptr, long* count /* doubles */);
 int cxk_exchange_download(cxk_context* ctx, double* out);   /* host copy, tests */

@@ -305,6 +305,99 @@ def test_reference_identity_reproduces_the_oracle_trajectory():
     L.CONEX_DeleteConeProgram(p)
 
 
+def _small_lmi_program(L, prob):
+    p = L.CONEX_CreateConeProgram()
+    n = prob["n"]
+    assert L.CONEX_SetNumberOfVariables(p, prob["num_vars"]) == 0
+    for c, cl in enumerate(prob["cliques"]):
+        a, cm = ca.colmajor(prob["A"][c]), ca.colmajor(prob["C"][c])
+        v = np.ascontiguousarray(cl, dtype=np.int64)
+        assert L.CONEX_AddSparseLMIConstraint(p, ca.dp(a), n, n, len(cl), ca.dp(cm), n, n,
+                                              v.ctypes.data_as(C.POINTER(C.c_long)), len(cl)) == c
+    return p
+
+
+def test_qr_solver_mode_matches_the_supernodal_solve():
+    """SolverConfiguration::kkt_solver = 2 (CONEX_QR_FACTORIZATION, kkt_solver.cc:172-231): Factor
+    takes a column-pivoted Householder QR of the dense KKT matrix, solves go through it.  On a
+    full-rank program the optimum equals the LLT mode's; at the cxk level every solve matches the
+    supernodal one, also on an indefinite (equality-constrained) system."""
+    from conex_amd import KktContext, synthetic as syn
+    prob = syn.lmi_problem(K=9, n=6, m=6, branching=3, overlap=2, seed=41)
+    L = ca.api()
+    ys = []
+    for mode in (0, 2):
+        p = _small_lmi_program(L, prob)
+        cfg = ca.default_config()
+        cfg.kkt_solver = mode
+        ok, y = _maximize(L, p, prob["b"], cfg)
+        assert ok == 1
+        ys.append(y)
+        L.CONEX_DeleteConeProgram(p)
+    assert np.linalg.norm(ys[1] - ys[0]) <= 1e-7 * np.linalg.norm(ys[0])
+    # cxk level: the same right-hand sides through both factorizations
+    W = syn.scaling_points(9, 6, seed=2)
+    k = syn.build(KktContext, prob, "lmi", device=0)
+    for i in range(k.K):
+        k.set_W(i, W[i])
+    ok, y_llt = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    k.set_solver_mode(2)
+    ok2, y_qr = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    assert ok == 1 and ok2 == 1
+    assert np.linalg.norm(y_qr - y_llt) <= 1e-10 * np.linalg.norm(y_llt)
+    rhs = np.random.default_rng(0).uniform(-1, 1, k.N)
+    y1 = k.solve_inplace(rhs)
+    k.set_solver_mode(0)
+    k.assemble()
+    assert k.factor() == 1
+    assert np.linalg.norm(y1 - k.solve_inplace(rhs)) <= 1e-10 * np.linalg.norm(y1)
+    # indefinite system (multipliers): QR against block LDLT
+    from test_oracle_kat import build_lqr_problem
+    q = build_lqr_problem(KktContext, 6, device=0)
+    q.assemble()
+    assert q.factor() == 1
+    r2 = np.random.default_rng(1).uniform(-1, 1, q.N)
+    y_ldlt = q.solve_inplace(r2)
+    q.set_solver_mode(2)
+    q.assemble()
+    assert q.factor() == 1
+    assert np.linalg.norm(q.solve_inplace(r2) - y_ldlt) <= 1e-9 * np.linalg.norm(y_ldlt)
+
+
+def test_qr_solver_mode_refuses_large_systems():
+    from conex_amd import KktContext, synthetic as syn
+    prob = syn.lmi_problem(K=120, n=4, m=20, branching=8, overlap=5, seed=4)   # N = 1805
+    k = syn.build(KktContext, prob, "lmi", device=0)
+    k.set_solver_mode(2)
+    k.assemble()
+    with pytest.raises(RuntimeError, match="QR"):
+        k.factor()
+
+
+def test_phase_timers_report_the_reference_phases(monkeypatch, capfd):
+    """CONEX_ENABLE_TIMER=1: device time of Assemble / Factor / Solve / Update per iteration
+    (debug_macros.h:18-52, cone_program.cc:338-437), printed with the reference's field names."""
+    from conex_amd import synthetic as syn
+    monkeypatch.setenv("CONEX_ENABLE_TIMER", "1")
+    prob = syn.lmi_problem(K=60, n=20, m=20, branching=4, overlap=5, seed=8)
+    L = ca.api()
+    p = _small_lmi_program(L, prob)
+    ok, y = _maximize(L, p, prob["b"])
+    assert ok == 1
+    L.CONEX_HIP_GetPhaseTimes.argtypes = [C.c_void_p, ca.c_double_p]
+    us = np.zeros(5)
+    assert L.CONEX_HIP_GetPhaseTimes(p, ca.dp(us)) == 0
+    st = ca.IterationStats()
+    L.CONEX_GetIterationStats(p, C.byref(st), -1)
+    iters = st.iteration_number + 1
+    assert us[0] > 5 * iters and us[1] > 5 * iters and us[3] > 5 * iters     # every phase took microseconds per iteration
+    assert us.sum() < 1e6 * 60
+    out = capfd.readouterr().out
+    for name in ("Sparsity Analysis(us):", "Assemble(us):", "Factor(us):", "Solve(us):", "Update(us):"):
+        assert name in out
+    L.CONEX_DeleteConeProgram(p)
+
+
 def test_sdp_mixed_literal():
     """test_sdp.cc:13-59: S == ones(2,2) to 1e-6."""
     L = ca.api()
