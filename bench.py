@@ -35,7 +35,11 @@ def pmc_traffic():
         return None
     try:
         with open(files[-1]) as f:
-            return float(json.load(f)["lmi_schur_fused"]["hbm_traffic_bytes_per_launch"])
+            d = json.load(f)
+            for key in ("lmi_schur_mfma", "lmi_schur_fused"):
+                if key in d:
+                    return float(d[key]["hbm_traffic_bytes_per_launch"])
+            return None
     except Exception:
         return None
 
@@ -56,8 +60,9 @@ def cpu_baseline(prob, W, budget_s=12.0, kind="lmi"):
         if el >= budget_s or n >= 200:
             break
     return {"value": n / el, "unit": "KKT-solves/s", "cores": 1, "kind": "port",
-            "sample": f"{n} full KKT-solves of the same workload ({o.K} LMI blocks), 1 thread, "
-                      f"{el:.1f} s"}, y
+            "host_cores": os.cpu_count(),
+            "sample": f"{n} full KKT-solves of the same workload ({o.K} constraints), 1 thread of "
+                      f"{os.cpu_count()} host cores, {el:.1f} s"}, y
 
 
 def main():
@@ -82,6 +87,9 @@ def main():
                          "world size 1: exercises the multi-GPU code path on a single-GPU box")
     ap.add_argument("--soc-tree", type=int, default=0,
                     help="with --workload c3: arrange the cones in a b-ary clique tree instead of a chain")
+    ap.add_argument("--cold-copies", type=int, default=5,
+                    help="c4, one GPU: also time the step cycling this many copies of the program "
+                         "(5 x 64 MB of A > the 256 MiB Infinity Cache), reported as \"cold_cache\"; 0/1 = off")
     ap.add_argument("--event-period", type=int, default=8,
                     help="hipEvent-bracket every P-th launch of the dominant kernel in the timed region")
     args = ap.parse_args()
@@ -256,7 +264,11 @@ def main():
                                    "algorithmic_bytes": sbytes,
                                    "note": "bytes = nonzeros (12 B each) + W, C, outputs; the kernel is "
                                            "latency-bound at this size, the dense path streams 72.4 MB"}
-            elif args.workload in ("c3", "c5"):
+            elif args.workload == "c3":
+                # second-order cones only: no LMI kernel is timed; the step is bound by the depth of
+                # the elimination tree (latency), reported as achieved bytes of the whole step
+                pass
+            elif args.workload == "c5":
                 out["roofline"] = {"bound": "hbm", "kernel": "Hermitian assembly (lmi_schur_fused<24,24>)",
                                    "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
@@ -280,7 +292,48 @@ def main():
                                "traffic_source": "rocprofv3 PMC passes committed under profiles/",
                                "kernel_ms": kern_ms, "kernel_samples": nsamp,
                                "algorithmic_bytes": abytes, "algorithmic_gflop": aflops / 1e9,
-                               "achieved_tflops": aflops / (kern_ms * 1e-3) / 1e12}
+                               "achieved_tflops": aflops / (kern_ms * 1e-3) / 1e12,
+                               "fp64_mfma_peak_measured_tflops": 77.5,
+                               "note": "the kernel sits at the fp64 ridge: 72.4 MB need 11.5 us at the "
+                                       "6.3 TB/s this chip streams (9 us at the 8 TB/s spec priced here), its "
+                                       "multiply-adds 10 us of the fp64 pipe (MFMA and VALU share it: "
+                                       "profiles/r02/mfma_f64_peak.jsonl)"}
+        if args.workload == "c4" and not sharded and args.cold_copies > 1:
+            # The same step with the operands coming from HBM: COPIES contexts of the same program
+            # are cycled, so a context's 64 MB of A matrices are evicted from the 256 MiB Infinity
+            # Cache (and from L2) before their next use.
+            copies = [ctx]
+            for _ in range(args.cold_copies - 1):
+                c2 = syn.build(KktContext, prob, "lmi", device=local_rank, stream=stream)
+                for i in range(c2.K):
+                    c2.set_W(i, W[i])
+                c2.set_cost(prob["b"])
+                copies.append(c2)
+            for c2 in copies:
+                c2.kkt_solve_async(0.7, 0.9, 0.8)
+            for c2 in copies:
+                c2.sync()
+            ctx.enable_timing(1)
+            ctx.kernel_time(reset=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = max(1, args.steps // 4)
+            for r in range(reps):
+                for c2 in copies:
+                    c2.kkt_solve_async(0.7, 0.9, 0.8)
+            for c2 in copies:
+                c2.sync()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            ctx.enable_timing(False)
+            ns2, km2 = ctx.kernel_time(reset=True)
+            out["cold_cache"] = {"copies": args.cold_copies,
+                                 "resident_bytes_cycled": args.cold_copies * abytes,
+                                 "value": reps * len(copies) / el, "unit": "KKT-solves/s",
+                                 "ms_per_step": 1e3 * el / (reps * len(copies)),
+                                 "kernel_ms": km2, "kernel_samples": ns2,
+                                 "achieved_GBps": (abytes / (km2 * 1e-3) / 1e9) if km2 > 0 else None}
+            del copies
         if not args.no_cpu and not sharded:
             cb, yo = cpu_baseline(prob, W, kind=kind)
             out["cpu_baseline"] = cb
