@@ -1,0 +1,472 @@
+// Batched fp64 GEMM on the matrix pipe: kernels and launchers (interface: kernels_gemm.hip.h).
+//
+// Two kernels share the 64 x 64 workgroup tile (four wavefronts, 2 x 2 MFMA tiles each):
+//
+//  gemm_f64_dma   the fast path.  Measured on gfx950 (profiles/r02/mfma_f64_peak.jsonl): while an
+//                 fp64 MFMA executes, NO vector-ALU instruction of that SIMD issues, and an LDS
+//                 store costs ~10 cycles of the same pipe -- address arithmetic, predicates and
+//                 register-staged ds_writes come straight out of the MFMA rate.  So the operand
+//                 tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR, no VALU,
+//                 no ds_write), 32 k-values per stage, two stages in LDS, ONE raw barrier per stage
+//                 with the next stage's DMA in flight across it (counted s_waitcnt, never a fence).
+//                 A DMA instruction writes 1 KiB of LDS contiguously in lane order but takes its
+//                 SOURCE address per lane: the images are made bank-conflict free for the MFMA
+//                 operand reads by rotating which 16-byte chunk a lane fetches (odd k-rows by 8
+//                 chunks in the m-major image, row m by m mod 16 chunks in the k-major image), and
+//                 k-rows past K are fetched from a page of zeros.  The main loop has no vector-ALU
+//                 instruction besides the MFMAs.  Needs even leading dimensions and 16-byte
+//                 aligned operands (a chunk is two doubles).
+//  gemm_f64_mfma  the general kernel (any alignment / odd sizes): register-staged, predicated loads.
+#include "kernels_gemm.hip.h"
+
+#include <algorithm>
+
+#include "device_utils.h"
+
+namespace cxk {
+
+constexpr int kGemmBM = 64, kGemmBN = 64;
+constexpr int kGemmLdM = 80;  // [k][m] image: 64 + 16 -> rows k, k+1 fall in disjoint bank halves
+constexpr int kGemmLdK = 17;  // [m][k] image: odd stride
+constexpr int kGemmLdsDoubles = 64 * 65;  // result staging (>= the two operand images)
+static_assert(2 * kGemmBK * kGemmLdM <= kGemmLdsDoubles && 2 * 64 * kGemmLdK <= kGemmLdsDoubles, "");
+
+typedef double gemm_d4 __attribute__((ext_vector_type(4)));
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) gemm_f64_mfma(GemmArgs g) {
+  __shared__ double lds[kGemmLdsDoubles];
+  double* sA = lds;
+  double* sB = lds + (TA ? 64 * kGemmLdK : kGemmBK * kGemmLdM);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_m = (g.M + kGemmBM - 1) / kGemmBM;
+  const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+  const int m_base = tm * kGemmBM, n_base = tn * kGemmBN;
+  if (g.lower_only && m_base + kGemmBM - 1 < n_base) return;  // uniform per workgroup
+  const int b1 = blockIdx.z / g.inner, b2 = blockIdx.z % g.inner;
+  const double* A = g.A + b1 * g.sA1 + b2 * g.sA2;
+  const double* B = g.B + b1 * g.sB1 + b2 * g.sB2;
+  // K range of this split, in whole BK steps
+  const int ksteps = (g.K + kGemmBK - 1) / kGemmBK;
+  const int per = (ksteps + g.splits - 1) / g.splits;
+  const int ks0 = blockIdx.y * per, ks1 = min(ksteps, ks0 + per);
+
+  // staging maps: element e = tid + 256 u, u < 4, of a 64 x 16 operand tile
+  double ra[4], rb[4];
+  auto load_tiles = [&](int k_base) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = tid + 256 * u;
+      {
+        const int mm = TA ? (e >> 4) : (e & 63), kk = TA ? (e & 15) : (e >> 6);
+        const int m = m_base + mm, k = k_base + kk;
+        const bool ok = m < g.M && k < g.K;
+        ra[u] = ok ? (TA ? A[k + (int64_t)m * g.lda] : A[m + (int64_t)k * g.lda]) : 0.0;
+      }
+      {
+        const int nn = TB ? (e & 63) : (e >> 4), kk = TB ? (e >> 6) : (e & 15);
+        const int n = n_base + nn, k = k_base + kk;
+        const bool ok = n < g.N && k < g.K;
+        rb[u] = ok ? (TB ? B[n + (int64_t)k * g.ldb] : B[k + (int64_t)n * g.ldb]) : 0.0;
+      }
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = tid + 256 * u;
+      if (TA)
+        sA[(e >> 4) * kGemmLdK + (e & 15)] = ra[u];
+      else
+        sA[(e >> 6) * kGemmLdM + (e & 63)] = ra[u];
+      if (TB)
+        sB[(e >> 6) * kGemmLdM + (e & 63)] = rb[u];
+      else
+        sB[(e >> 4) * kGemmLdK + (e & 15)] = rb[u];
+    }
+  };
+
+  gemm_d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = gemm_d4{0.0, 0.0, 0.0, 0.0};
+  const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+  const int l15 = lane & 15, kq = lane >> 4;
+
+  if (ks0 < ks1) load_tiles(ks0 * kGemmBK);
+  for (int ks = ks0; ks < ks1; ks++) {
+    __syncthreads();  // previous step's MFMA operand reads are done
+    store_tiles();
+    __syncthreads();
+    if (ks + 1 < ks1) load_tiles((ks + 1) * kGemmBK);
+#pragma unroll
+    for (int sub = 0; sub < kGemmBK / 4; sub++) {
+      const int k = sub * 4 + kq;
+      double a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int m = wm + 16 * i + l15;
+        a[i] = TA ? sA[m * kGemmLdK + k] : sA[k * kGemmLdM + m];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int n = wn + 16 * j + l15;
+        b[j] = TB ? sB[k * kGemmLdM + n] : sB[n * kGemmLdK + k];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // result tile -> LDS (row m, column n at m + 65 n), then coalesced global writes
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        lds[(wm + 16 * i + kq + 4 * e) + 65 * (wn + 16 * j + l15)] = acc[i][j][e];
+  __syncthreads();
+  double* C = g.C + b1 * g.sC1 + b2 * g.sC2 + (g.splits > 1 ? blockIdx.y * g.sCs : 0);
+  const bool partial = g.splits > 1;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int mm = e & 63, nn = e >> 6;
+    const int m = m_base + mm, n = n_base + nn;
+    if (m < g.M && n < g.N && (!g.lower_only || m >= n)) {
+      double v = lds[mm + 65 * nn];
+      double* dst = C + m + (int64_t)n * g.ldc;
+      if (partial)
+        *dst = v;
+      else
+        *dst = (g.beta == 0.0) ? g.alpha * v : g.alpha * v + g.beta * *dst;
+    }
+  }
+  if (g.Ct && !partial) {
+    double* Ct = g.Ct + b1 * g.sT1 + b2 * g.sT2;
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int nn = e & 63, mm = e >> 6;
+      const int m = m_base + mm, n = n_base + nn;
+      if (m < g.M && n < g.N)
+        Ct[n + (int64_t)m * g.ldct + (g.ctb > 0 ? (int64_t)(n / g.ctb) * g.sTb : 0)] = g.alpha * lds[mm + 65 * nn];
+    }
+  }
+}
+
+// C = alpha * sum_s partial[s] + beta * C over the split partials.  One wavefront per output
+// element: lane l adds partials l, l+64, ... in order, then a fixed butterfly -- the summation
+// order depends only on `splits`, so results are reproducible run to run.
+__global__ void __launch_bounds__(256) gemm_reduce_splits(GemmArgs g, const double* __restrict__ part) {
+  const int b1 = blockIdx.z / g.inner, b2 = blockIdx.z % g.inner;
+  const double* P = part + b1 * g.sC1 + b2 * g.sC2;
+  double* C = g.C + b1 * g.sC1 + b2 * g.sC2;
+  const int64_t total = (int64_t)g.M * g.N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t e = (int64_t)blockIdx.x * 4 + wave; e < total; e += (int64_t)gridDim.x * 4) {
+    const int m = (int)(e % g.M), n = (int)(e / g.M);
+    if (g.lower_only && m < n) continue;
+    double acc = 0.0;
+    for (int s = lane; s < g.splits; s += 64) acc += P[s * g.sCs + m + (int64_t)n * g.ldc];
+    acc = WaveSum(acc);
+    if (lane == 0) {
+      double* dst = C + m + (int64_t)n * g.ldc;
+      *dst = (g.beta == 0.0) ? g.alpha * acc : g.alpha * acc + g.beta * *dst;
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA kernel
+// ------------------------------------------------------------------------------------------
+// k-values per stage: BK = 32 (two stages of two 16 KB tiles = 64 KB of LDS, two workgroups per
+// CU) for long K, BK = 16 (32 KB, four workgroups per CU: more tiles in flight to hide a short
+// tile's start-up and epilogue) otherwise.  The epilogue stages 64 x 65 doubles in the same array.
+constexpr int kDmaLdsDoubles = 4 * 64 * 32;
+static_assert(kDmaLdsDoubles >= 64 * 65, "result staging fits the operand stages");
+__device__ double g_gemm_zero_page[128];         // k-rows past K are fetched from here (zeros)
+
+// LDS traffic of this wave has landed / is visible, then the workgroup barrier; no vmcnt wait
+// (the next stage's DMA stays in flight across it).
+__device__ __forceinline__ void GemmBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Which 16-byte chunk lane `c` of DMA instruction `i` (0..15) of an operand tile fetches, and where
+// an element sits in the image.
+//   m-major image (source contiguous along the tile's 64 rows r): instruction i = k-rows 2i, 2i+1;
+//     chunk position p < 32: (k = 2i, rows 2p, 2p+1); p >= 32: (k = 2i+1, rows 2q, 2q+1), q = (p - 8) & 31
+//     element (r, k) at  (k >> 1) * 128 + ((k & 1) ? 64 + ((r + 16) & 63) : r)
+//   k-major image (source contiguous along k): instruction i = rows 4i .. 4i+3;
+//     chunk position p: row r = 4i + (p >> 4), k-pair kp = ((p & 15) - r) & 15
+//     element (r, k) at  (r >> 2) * 128 + (r & 3) * 32 + 2 * (((k >> 1) + r) & 15) + (k & 1)
+//   (KP = BK / 2 chunks per k-major row, RPI = 64 / KP rows per instruction)
+template <bool KMAJOR, int BK>
+__device__ __forceinline__ int ImageOffset(int r, int k) {
+  constexpr int KP = BK / 2, RPI = 64 / KP;
+  if (KMAJOR) return (r / RPI) * 128 + (r % RPI) * BK + 2 * (((k >> 1) + r) % KP) + (k & 1);
+  return (k >> 1) * 128 + ((k & 1) ? 64 + ((r + 16) & 63) : r);
+}
+
+// Per-lane source geometry of the four DMA instructions a wave issues for one operand per stage.
+struct DmaLane {
+  unsigned off[4];   // byte offset of the lane's chunk from the operand's tile origin at stage 0 (k = k_base)
+  int krel[4];       // m-major: the chunk's k relative to the stage start (to test against K); k-major: first k of the pair
+};
+
+// rows = valid rows of the operand in this tile (clamped fetch beyond), ld in doubles
+template <bool KMAJOR, int BK>
+__device__ __forceinline__ void MakeDmaLane(DmaLane& d, int wave, int lane, int rows, int64_t ld) {
+  constexpr int KP = BK / 2, RPI = 64 / KP, NI = BK / 8;  // NI DMA instructions per wave, operand and stage
+#pragma unroll
+  for (int u = 0; u < NI; u++) {
+    const int i = wave + 4 * u;
+    int r, k;
+    if (KMAJOR) {
+      r = RPI * i + lane / KP;
+      k = 2 * ((lane % KP - r) & (KP - 1));
+    } else {
+      k = 2 * i + (lane >> 5);
+      const int p = lane & 31;
+      r = 2 * ((lane >> 5) ? ((p - 8) & 31) : p);
+    }
+    int rc = r < rows ? r : (rows - 1) & ~(KMAJOR ? 0 : 1);   // rows past the edge re-read a valid row (results unused)
+    if (rc < 0) rc = 0;
+    d.krel[u] = k;
+    d.off[u] = (unsigned)((KMAJOR ? (int64_t)rc * ld + k : (int64_t)k * ld + rc) * 8);
+  }
+}
+
+template <bool TA, bool TB, int BK>
+__global__ void __launch_bounds__(256) gemm_f64_dma(GemmArgs g) {
+  constexpr int kDmaBK = BK, kDmaTile = 64 * BK, NI = BK / 8;
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_m = (g.M + kGemmBM - 1) / kGemmBM;
+  const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+  const int m_base = tm * kGemmBM, n_base = tn * kGemmBN;
+  if (g.lower_only && m_base + kGemmBM - 1 < n_base) return;  // uniform per workgroup
+  const int b1 = blockIdx.z / g.inner, b2 = blockIdx.z % g.inner;
+  const double* A = g.A + b1 * g.sA1 + b2 * g.sA2;
+  const double* B = g.B + b1 * g.sB1 + b2 * g.sB2;
+  // K range of this split, in whole kGemmBK steps (as the general kernel deals them)
+  const int ksteps = (g.K + kGemmBK - 1) / kGemmBK;
+  const int per = (ksteps + g.splits - 1) / g.splits;
+  const int k_lo = min(g.K, (int)blockIdx.y * per * kGemmBK), k_hi = min(g.K, k_lo + per * kGemmBK);
+  const int nstage = (k_hi - k_lo + kDmaBK - 1) / kDmaBK;
+
+  // A tile: rows = m; stored m-major when !TA (A(m,k) at m + k lda), k-major when TA (k + m lda)
+  // B tile: rows = n; stored m-major when TB (B(k,n) at n + k ldb), k-major when !TB (k + n ldb)
+  constexpr bool AK = TA, BKM = !TB;
+  DmaLane da, db;
+  MakeDmaLane<AK, BK>(da, wave, lane, g.M - m_base, g.lda);
+  MakeDmaLane<BKM, BK>(db, wave, lane, g.N - n_base, g.ldb);
+  const char* a0 = reinterpret_cast<const char*>(A + (AK ? (int64_t)m_base * g.lda + k_lo : (int64_t)k_lo * g.lda + m_base));
+  const char* b0 = reinterpret_cast<const char*>(B + (BKM ? (int64_t)n_base * g.ldb + k_lo : (int64_t)k_lo * g.ldb + n_base));
+  const int64_t a_step = (AK ? (int64_t)kDmaBK : (int64_t)kDmaBK * g.lda) * 8;
+  const int64_t b_step = (BKM ? (int64_t)kDmaBK : (int64_t)kDmaBK * g.ldb) * 8;
+  const char* zero = reinterpret_cast<const char*>(g_gemm_zero_page) + 16 * lane;
+
+  auto issue = [&](int s) {
+    double* sa = lds + (s & 1) * 2 * kDmaTile;
+    double* sb = sa + kDmaTile;
+    const int krem = k_hi - k_lo - s * kDmaBK;  // k-values of this stage that exist
+    const char* as = a0 + (int64_t)s * a_step;
+    const char* bs = b0 + (int64_t)s * b_step;
+#pragma unroll
+    for (int u = 0; u < NI; u++) {
+      const int i = wave + 4 * u;
+      const char* src = da.krel[u] < krem ? as + da.off[u] : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                       (__attribute__((address_space(3))) void*)(sa + i * 128), 16, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < NI; u++) {
+      const int i = wave + 4 * u;
+      const char* src = db.krel[u] < krem ? bs + db.off[u] : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                       (__attribute__((address_space(3))) void*)(sb + i * 128), 16, 0, 0);
+    }
+  };
+
+  gemm_d4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = gemm_d4{0.0, 0.0, 0.0, 0.0};
+  const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+  const int l15 = lane & 15, kq = lane >> 4;
+  // operand read offsets of this lane at k-sub-step 0 (the k-step offsets are compile-time constants)
+  int ao[2], bo[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    ao[i] = ImageOffset<AK, BK>(wm + 16 * i + l15, kq);
+    bo[i] = ImageOffset<BKM, BK>(wn + 16 * i + l15, kq);
+  }
+
+  if (nstage > 0) issue(0);
+  for (int s = 0; s < nstage; s++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage s has landed
+    GemmBarrier();                                     // ... everybody's; and stage s-1 is no longer read
+    if (s + 1 < nstage) issue(s + 1);                  // in flight during the MFMAs below
+    const double* sa = lds + (s & 1) * 2 * kDmaTile;
+    const double* sb = sa + kDmaTile;
+    // element (r, 4 sub + kq): m-major images advance 2 row pairs (256 doubles) per sub-step;
+    // k-major images rotate by two chunks inside the row.  The operands of sub-step sub + 1 are
+    // read while the MFMAs of sub-step sub issue (a lone ds_read waits ~100 cycles for its data).
+    double a[2][2], b[2][2];
+    auto fetch = [&](int buf, int sub) {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        if (AK) {
+          const int r = wm + 16 * i + l15;
+          a[buf][i] = sa[ImageOffset<true, BK>(r, 4 * sub + kq)];
+        } else {
+          a[buf][i] = sa[ao[i] + 256 * sub];
+        }
+        if (BKM) {
+          const int r = wn + 16 * i + l15;
+          b[buf][i] = sb[ImageOffset<true, BK>(r, 4 * sub + kq)];
+        } else {
+          b[buf][i] = sb[bo[i] + 256 * sub];
+        }
+      }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int sub = 0; sub < kDmaBK / 4; sub++) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (sub + 1 < kDmaBK / 4) fetch((sub + 1) & 1, sub + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sub & 1][i], b[sub & 1][j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // result tile -> LDS (row m, column n at m + 65 n), then coalesced global writes
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        lds[(wm + 16 * i + kq + 4 * e) + 65 * (wn + 16 * j + l15)] = acc[i][j][e];
+  __syncthreads();
+  double* C = g.C + b1 * g.sC1 + b2 * g.sC2 + (g.splits > 1 ? blockIdx.y * g.sCs : 0);
+  const bool partial = g.splits > 1;
+  {
+    // 16 elements per thread, loads of the old C values issued together (beta != 0)
+    const int mm = tid & 63, m = m_base + mm;
+    double v[16], c0[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int nn = (tid >> 6) + 4 * u, n = n_base + nn;
+      v[u] = lds[mm + 65 * nn];
+      const bool on = m < g.M && n < g.N && (!g.lower_only || m >= n);
+      c0[u] = (on && !partial && g.beta != 0.0) ? C[m + (int64_t)n * g.ldc] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int nn = (tid >> 6) + 4 * u, n = n_base + nn;
+      if (m < g.M && n < g.N && (!g.lower_only || m >= n)) {
+        double* dst = C + m + (int64_t)n * g.ldc;
+        if (partial)
+          *dst = v[u];
+        else
+          *dst = (g.beta == 0.0) ? g.alpha * v[u] : g.alpha * v[u] + g.beta * c0[u];
+      }
+    }
+  }
+  if (g.Ct && !partial) {
+    double* Ct = g.Ct + b1 * g.sT1 + b2 * g.sT2;
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int nn = e & 63, mm = e >> 6;
+      const int m = m_base + mm, n = n_base + nn;
+      if (m < g.M && n < g.N)
+        Ct[n + (int64_t)m * g.ldct + (g.ctb > 0 ? (int64_t)(n / g.ctb) * g.sTb : 0)] = g.alpha * lds[mm + 65 * nn];
+    }
+  }
+}
+
+namespace {
+
+bool Aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// The DMA path fetches 16-byte chunks (two doubles): every chunk must be aligned and inside its
+// matrix.  m-major operands: even leading dimension (a pair of rows of one column).  k-major
+// operands: even leading dimension and even K (a pair of k of one row).
+bool DmaEligible(const GemmArgs& g, bool ta, bool tb) {
+  if (getenv("CXK_GEMM_GENERAL")) return false;  // comparison runs
+  if (g.M < 2 || g.N < 2 || g.K < 2) return false;
+  if ((g.lda & 1) || (g.ldb & 1) || (g.sA1 & 1) || (g.sA2 & 1) || (g.sB1 & 1) || (g.sB2 & 1)) return false;
+  if (!Aligned16(g.A) || !Aligned16(g.B)) return false;
+  if ((ta || !tb) && (g.K & 1)) return false;
+  // byte offsets inside a tile are kept in 32 bits
+  if ((ta ? 64 * g.lda : (int64_t)g.K * g.lda) * 8 >= (1ll << 31)) return false;
+  if ((!tb ? 64 * g.ldb : (int64_t)g.K * g.ldb) * 8 >= (1ll << 31)) return false;
+  return true;
+}
+
+template <bool TA, bool TB, int BK>
+hipError_t LaunchDmaBK(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+  constexpr size_t lds = sizeof(double) * (4 * 64 * BK > 64 * 65 ? 4 * 64 * BK : 64 * 65);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_dma<TA, TB, BK>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  gemm_f64_dma<TA, TB, BK><<<grid, 256, lds, stream>>>(g);
+  return hipGetLastError();
+}
+
+template <bool TA, bool TB>
+hipError_t LaunchDma(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+  const int ksteps = (g.K + kGemmBK - 1) / kGemmBK;
+  const int per_split = (ksteps + std::max(g.splits, 1) - 1) / std::max(g.splits, 1) * kGemmBK;
+  if (per_split >= 512) return LaunchDmaBK<TA, TB, 32>(g, grid, stream);
+  return LaunchDmaBK<TA, TB, 16>(g, grid, stream);
+}
+
+}  // namespace
+
+hipError_t LaunchGemm(const GemmArgs& g, bool ta, bool tb, int batch, hipStream_t stream) {
+  if (g.M <= 0 || g.N <= 0 || batch <= 0) return hipSuccess;
+  const int tiles = ((g.M + kGemmBM - 1) / kGemmBM) * ((g.N + kGemmBN - 1) / kGemmBN);
+  dim3 grid(tiles, g.splits > 1 ? g.splits : 1, batch);
+  if (DmaEligible(g, ta, tb)) {
+    if (!ta && !tb) return LaunchDma<false, false>(g, grid, stream);
+    if (ta && !tb) return LaunchDma<true, false>(g, grid, stream);
+    if (!ta && tb) return LaunchDma<false, true>(g, grid, stream);
+    return LaunchDma<true, true>(g, grid, stream);
+  }
+  if (!ta && !tb)
+    gemm_f64_mfma<false, false><<<grid, 256, 0, stream>>>(g);
+  else if (ta && !tb)
+    gemm_f64_mfma<true, false><<<grid, 256, 0, stream>>>(g);
+  else if (!ta && tb)
+    gemm_f64_mfma<false, true><<<grid, 256, 0, stream>>>(g);
+  else
+    gemm_f64_mfma<true, true><<<grid, 256, 0, stream>>>(g);
+  return hipGetLastError();
+}
+
+hipError_t LaunchGemmSplitK(GemmArgs g, bool ta, bool tb, int batch, double* part, hipStream_t stream) {
+  if (g.splits <= 1) return LaunchGemm(g, ta, tb, batch, stream);
+  GemmArgs p = g;
+  p.C = part;
+  p.Ct = nullptr;
+  hipError_t e = LaunchGemm(p, ta, tb, batch, stream);
+  if (e != hipSuccess) return e;
+  const int64_t total = (int64_t)g.M * g.N;
+  dim3 grid((unsigned)std::min<int64_t>((total + 3) / 4, 4096), 1, batch);
+  gemm_reduce_splits<<<grid, 256, 0, stream>>>(g, part);
+  return hipGetLastError();
+}
+
+}  // namespace cxk

@@ -58,6 +58,7 @@ struct GatherArgs {
   int* fail;
 };
 
+#ifndef CXK_DEVICE_FUNCTIONS_ONLY  // plain (non-template) kernels: one translation unit only
 __global__ void __launch_bounds__(256) assemble_gather(GatherArgs a) {
   const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -177,6 +178,8 @@ __global__ void build_mu_rhs(int N, double bs, double cs, const double* __restri
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x)
     y[p] = AQc[p] * cs - b[p] * bs;
 }
+
+#endif  // CXK_DEVICE_FUNCTIONS_ONLY
 
 // In-kernel stamps (diagnostic builds only: -DCXK_DEBUG_STAMPS); values go to a buffer nothing else reads.
 #ifdef CXK_DEBUG_STAMPS
@@ -1730,6 +1733,7 @@ tree_sweep_block_ldlt(FactorPlan P, int base0, double* __restrict__ slab, double
   }
 }
 
+#ifndef CXK_DEVICE_FUNCTIONS_ONLY
 // ---------------------------------------------------------------------------------------
 // Iterative refinement (SupernodalKKTSolver::SolveInPlace, kkt_solver.cc:233-261):
 //   y <- y + K^-1 (b - K y)   with K = the assembled matrix, kept in `slab0` by the factor sweep.
@@ -1943,5 +1947,7 @@ __global__ void permute_gather(int N, const int* __restrict__ idx, const double*
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
     out[i] = in[idx[i]];
 }
+
+#endif  // CXK_DEVICE_FUNCTIONS_ONLY
 
 }  // namespace cxk

@@ -20,7 +20,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
     }                                                                              \
   } while (0)
 
-constexpr int kIters = 2048;   // loop trips; each trip issues kUnroll instructions
+constexpr int kIters = 16384;   // loop trips; each trip issues kUnroll instructions
 
 template <int MODE>
 __global__ void __launch_bounds__(1024) rate_kernel(double* out, long long* cyc, double seed) {
@@ -31,6 +31,17 @@ __global__ void __launch_bounds__(1024) rate_kernel(double* out, long long* cyc,
   double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
   double2 rr = make_double2(0, 0);
   int iv[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+  double ra[8], rb[8];
+  {
+    unsigned long long z = 0x9E3779B97F4A7C15ull * (blockIdx.x * 1024 + threadIdx.x + 1);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      ra[i] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      rb[i] = ((double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0) * 1e-3;
+    }
+  }
   int sv = 0;
   double a = seed + lane * 1e-3, b = seed * 0.5 - lane * 1e-3;
   d4_t acc[8];
@@ -122,6 +133,9 @@ __global__ void __launch_bounds__(1024) rate_kernel(double* out, long long* cyc,
 #pragma unroll
         for (int j = 0; j < 8; j++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sv));
       }
+    } else if constexpr (MODE == 17) {  // 8 independent 16x16x4 accumulators, RANDOM operands (power / clock under load)
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[i], rb[(i + it) & 7], acc[i], 0, 0, 0);
     } else if constexpr (MODE == 8) {   // MFMA 16x16x4 interleaved with 8 plain FMAs each
 #pragma unroll
       for (int i = 0; i < 2; i++) {
@@ -209,6 +223,7 @@ int main() {
       {"mfma16 + 8 v_add_u32 each (per mfma)", 14, 8, 2048.0},
       {"mfma16 + 16 v_add_u32 each (per mfma)", 15, 8, 2048.0},
       {"mfma16 + 8 s_add_u32 each (per mfma)", 16, 8, 2048.0},
+      {"mfma_f64_16x16x4 independent, random operands", 17, 8, 2.0 * 16 * 16 * 4},
   };
   for (int w : {1, 2, 4}) {
     run<0>(vs[0], w, out, cyc, ncu);
@@ -228,6 +243,7 @@ int main() {
     run<14>(vs[14], w, out, cyc, ncu);
     run<15>(vs[15], w, out, cyc, ncu);
     run<16>(vs[16], w, out, cyc, ncu);
+    run<17>(vs[17], w, out, cyc, ncu);
   }
   return 0;
 }
