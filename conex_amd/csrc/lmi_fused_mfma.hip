@@ -21,23 +21,27 @@
 //            gather streams as fast as a coalesced copy (tools/load_pattern_bench.hip: 6.3 TB/s).
 //            No LDS staging of A, no VALU work on the data.
 //   stage 2  G(i,j) = tr(P_i P_j) (A symmetric: the second product W (A_i W) is never formed):
-//            a (M1 x N^2)(N^2 x M1) product over the P image in LDS, v_mfma_f64_16x16x4; for
-//            17 <= M1 <= 24 the lower triangle is covered by TWO 16 x 16 tiles (rows R..M1-1 x
-//            columns 0..15, and the symmetric block over matrices {0..R-1} u {16..M1-1}, R = M1-16).
+//            a (M1 x N^2)(N^2 x M1) product over the P image in LDS.  For 17 <= M1 <= 24 the lower
+//            triangle is covered by ONE 16 x 16 v_mfma_f64_16x16x4 tile (rows R..M1-1 x columns
+//            0..15, R = M1 - 16) plus the two R x R triangles it leaves out, on v_mfma_f64_4x4x4
+//            blocks (Triangles below); for M1 <= 16 by one tile.
 //
-// Roles.  One 512-thread workgroup per CU, persistent over its constraints.  Waves 0-3 (one per
-// SIMD) are PRODUCERS: they own the tiles t = wave (mod 4), keep the NEXT constraint's tiles in
+// Roles.  One 768-thread workgroup per CU, persistent over its constraints.  Waves 0-7 (two per
+// SIMD) are PRODUCERS: wave w owns the tiles t = w (mod 8), keeps the NEXT constraint's tiles in
 // flight in registers (a tile's registers are reloaded as soon as its MFMAs have issued: a whole
-// constraint of prefetch distance) and write P into one of two LDS images.  Waves 4-7 are
-// CONSUMERS: contraction of the previous constraint from the other image (k-steps dealt to the
-// four waves, partial tiles summed in a fixed order through LDS), then the epilogue.  Each SIMD
-// thus always has a wave with MFMAs to issue; two workgroup barriers per constraint:
+// constraint of prefetch distance) and writes P into one of two LDS images.  Waves 8-11 (one per
+// SIMD) are CONSUMERS, three iterations deep in all:
 //
-//   iteration it    producers                         consumers
-//     phase X       tiles 0 .. TPW-2 of c_it          contraction of c_{it-1} -> partial tiles
-//     barrier 1
-//     phase Y       last tile of c_it                 reduce partials, traces, write G / AW / AQc / scalars
-//     barrier 2
+//   iteration it    producers            consumers
+//                   stage 1 of c_it      contraction of c_{it-1} (K split over the waves -> partial
+//                                        tiles in LDS buffer (it-1) & 1), traces of c_{it-1}, then the
+//                                        epilogue of c_{it-2}: partial tiles of buffer it & 1 summed
+//                                        in a fixed order -> G / AQc / <c,Qc>
+//                   --------------------- one workgroup barrier ---------------------
+//
+// The pipe is the bound: with real operands a 16x16x4 instruction holds a SIMD for 64-80 cycles
+// (profiles/r02/mfma_f64_peak.jsonl, random operands), an iteration at n = m = 20 issues ~6.3 k
+// cycles of them per SIMD and takes ~8.5 k (in-kernel timeline: profiles/r02/lmi_schur_mfma_stamps.txt).
 //
 // All sums run in a fixed order: results are bit-reproducible run to run.  Differences to the
 // reference's summation order are rounding-level (tests: <= 1e-13 on every Schur block).
@@ -81,8 +85,7 @@ struct MfmaCfg {
   static constexpr int TPW = 4;               // tiles per producer wave (<= 32 tiles of 16 rows)
   static constexpr int YSLOTS = 1;            // tile slots a producer keeps for phase Y
   static constexpr int THREADS = 64 * (PROD + CONS);
-  static constexpr int RPW = N / CONS;        // stage-2 rows (of N/4 k-steps each) per consumer wave
-  static_assert(N % CONS == 0, "stage-2 rows are dealt evenly");
+  static_assert(N % CONS == 0, "stage-2 rows (N/4 k-steps each) are dealt evenly to the consumer waves");
   static_assert(MS % 4 == 2, "both stage-2 operand reads are bank-conflict free only then");
 };
 
@@ -213,6 +216,140 @@ __device__ __forceinline__ ConstraintPtrs Member(const LmiGroup& g, int mem, int
   return p;
 }
 
+// One consumer wave's share of the stage-2 contraction: ROWS rows rr0 .. of the N x N index space
+// (NK k-steps each) of the tile whose A-operand rows are the matrices at ra(lane) and whose
+// B-operand columns are the matrices at ca(lane).  The operands of the next row are read in the
+// gaps between this row's MFMAs (a lone wavefront issues a ds_read_b64 every ~17 cycles: a row's
+// reads up front would idle the pipe).
+template <int N, int ROWS>
+__device__ __forceinline__ d4_t Contract(const double* __restrict__ Pb, int ra, int ca, int rr0, int kq, int nrows = ROWS) {
+  using Cfg = MfmaCfg<N>;
+  constexpr int NK = Cfg::NK, LD = Cfg::LD;
+  d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+  double a0[2][NK], b0[2][NK];
+  const double* pa = Pb + ra + rr0 * LD + kq;   // A side: P_x[r][4 bi + kq]
+  const double* pb = Pb + ca + kq * LD + rr0;   // B side: P_y[4 bi + kq][r]
+#pragma unroll
+  for (int bi = 0; bi < NK; bi++) {
+    a0[0][bi] = pa[4 * bi];
+    b0[0][bi] = pb[4 * bi * LD];
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    if (r >= nrows) break;  // wave-uniform (N rows do not always divide evenly)
+    const int cb_ = r & 1, nb_ = cb_ ^ 1;
+    const bool more = r + 1 < ROWS && r + 1 < nrows;
+#pragma unroll
+    for (int bi = 0; bi < NK; bi++) {
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[cb_][bi], b0[cb_][bi], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef CXK_EXPERIMENT_NO_READS  // diagnostic: operands of the first row are reused (wrong results, MFMA-only timing)
+      // next row's operands, two per LDS instruction (ds_read2_b64: neighbours share a base
+      // register): the A-side pair after an even k-step, the B-side pair after an odd one
+      if (more) {
+        if ((bi & 1) == 0) {
+          a0[nb_][bi] = pa[(r + 1) * LD + 4 * bi];
+          if (bi + 1 < NK) a0[nb_][bi + 1] = pa[(r + 1) * LD + 4 * (bi + 1)];
+          if (bi + 1 == NK) b0[nb_][bi] = pb[4 * bi * LD + r + 1];
+        } else {
+          b0[nb_][bi - 1] = pb[4 * (bi - 1) * LD + r + 1];
+          b0[nb_][bi] = pb[4 * bi * LD + r + 1];
+        }
+      }
+#else
+      a0[nb_][bi] = a0[cb_][bi];
+      b0[nb_][bi] = b0[cb_][bi];
+#endif
+    }
+  }
+  return acc;
+}
+
+// The two R x R triangles (R = M1 - 16 <= 8) the 16 x 16 tile leaves out -- G over the matrices
+// {0..R-1} and over {16..M1-1} -- on v_mfma_f64_4x4x4 (four independent 4 x 4 x 4 blocks per
+// instruction, a quarter of the 16 x 16 x 4 instruction's pipe time).  Block of a lane
+// ((lane >> 2) & 3) = 2 t + h: triangle t, K parity h (row r = 2 p + h of the N x N index space);
+// instruction u covers the 4 x 4 sub-block (brow, bcol) = (0,0), (1,0), (1,1) of both triangles
+// (u = 0 alone when R <= 4; slots past R alias R - 1).  A second 16 x 16 tile for these 2 x 15
+// entries would double the contraction's pipe time for 12 % of its results.
+// Layouts (measured, profiles/r02/mfma_f64_4x4x4_layout.txt): A[blk][i][k] and B[blk][k][j] sit in
+// lane 16 k + 4 blk + (i or j), D[blk][i][j] in lane 16 i + 4 blk + j.
+template <int N, bool BIG>  // BIG: R > 4
+__device__ __forceinline__ void Triangles(const double* __restrict__ Pb, double* __restrict__ out, int lane, int M1) {
+  using Cfg = MfmaCfg<N>;
+  constexpr int NK = Cfg::NK, LD = Cfg::LD, MS = Cfg::MS;
+  const int R = M1 - 16;
+  const int kq = lane >> 4, blk = (lane >> 2) & 3, i = lane & 3, t = blk >> 1, h = blk & 1;
+  const int lo = (t ? 16 : 0) + (i < R ? i : R - 1), hi = (t ? 16 : 0) + (4 + i < R ? 4 + i : R - 1);
+  // operand offsets: A-side P_x[r][4 bi + kq], B-side P_y[4 bi + kq][r], r = 2 p + h
+  const int a_lo = lo * MS + h * LD + kq, a_hi = hi * MS + h * LD + kq;
+  const int b_lo = lo * MS + kq * LD + h, b_hi = hi * MS + kq * LD + h;
+  constexpr bool big = BIG;
+  double acc0 = 0, acc1 = 0, acc2 = 0;
+  constexpr int STEPS = (N / 2) * NK;  // step st: rows 2 (st / NK) + h, columns 4 (st % NK) + kq
+  static_assert(STEPS % 2 == 0, "operands are fetched two steps at a time");
+  auto aoff = [](int st) { return 2 * (st / NK) * LD + 4 * (st % NK); };
+  auto boff = [](int st) { return 4 * (st % NK) * LD + 2 * (st / NK); };
+  const double *pal = Pb + a_lo, *pbl = Pb + b_lo, *pah = Pb + a_hi, *pbh = Pb + b_hi;
+  double al[2][2], ah[2][2], bl[2][2], bh[2][2];  // [buffer][step of the pair]
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    al[0][q] = pal[aoff(q)];
+    bl[0][q] = pbl[boff(q)];
+    ah[0][q] = big ? pah[aoff(q)] : 0.0;
+    bh[0][q] = big ? pbh[boff(q)] : 0.0;
+  }
+#pragma unroll
+  for (int st = 0; st < STEPS; st += 2) {
+    const int cb_ = (st >> 1) & 1, nb_ = cb_ ^ 1;
+    const bool more = st + 2 < STEPS;
+    // six instructions per pair of steps; the next pair's operands arrive as four ds_read2_b64
+    // dealt into the gaps
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(al[cb_][0], bl[cb_][0], acc0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) {
+      al[nb_][0] = pal[aoff(st + 2)];
+      al[nb_][1] = pal[aoff(st + 3)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (big) {
+      acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(ah[cb_][0], bl[cb_][0], acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc2 = __builtin_amdgcn_mfma_f64_4x4x4f64(ah[cb_][0], bh[cb_][0], acc2, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) {
+      bl[nb_][0] = pbl[boff(st + 2)];
+      bl[nb_][1] = pbl[boff(st + 3)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(al[cb_][1], bl[cb_][1], acc0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (big) {
+      if (more) {
+        ah[nb_][0] = pah[aoff(st + 2)];
+        ah[nb_][1] = pah[aoff(st + 3)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(ah[cb_][1], bl[cb_][1], acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        bh[nb_][0] = pbh[boff(st + 2)];
+        bh[nb_][1] = pbh[boff(st + 3)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc2 = __builtin_amdgcn_mfma_f64_4x4x4f64(ah[cb_][1], bh[cb_][1], acc2, 0, 0, 0);
+    }
+  }
+  out[lane] = acc0;
+  if (big) {
+    out[64 + lane] = acc1;
+    out[128 + lane] = acc2;
+  }
+}
+
 template <int N>
 __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g, Arena ar) {
   using Cfg = MfmaCfg<N>;
@@ -222,9 +359,15 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
   const int nt1 = (rows + 15) >> 4;
   const int pbuf = M1 * MS;
   const bool two = M1 > 16;
-  const int ntl = two ? 2 : 1;
   double* P0 = lds;
-  double* scratch = lds + 2 * (size_t)pbuf;  // CONS x ntl x 256 partial-tile entries
+  double* scratch = lds + 2 * (size_t)pbuf;  // 2 buffers x CONS partial tiles of 256 entries
+  constexpr int SB = Cfg::CONS * 256;
+  // where this workgroup's constraints write (kDestSlots x {id, g_off, r_off}) and the epilogue
+  // table, both filled by the consumers in iteration 0
+  int64_t* dest = reinterpret_cast<int64_t*>(scratch + 2 * SB);
+  int* etab = reinterpret_cast<int*>(dest + 3 * kDestSlots);
+  const int nout = M1 * (M1 + 1) / 2;
+  const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;  // Hermitian cones: tr over the real representation
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int first = blockIdx.x, stride = gridDim.x;
   const int cnt = (g.count - first + stride - 1) / stride;  // constraints of this workgroup (>= 1)
@@ -264,13 +407,9 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
       TileAcc<N> res[2];
 #pragma unroll
       for (int tt = 0; tt <= TPW; tt++) {
-        if (tt == TPW - Cfg::YSLOTS) {
-          MSTAMP(2 + 4 * it);
-          LdsBarrier();  // barrier 1
-          MSTAMP(3 + 4 * it);
-        }
         const bool cur_ok = tt < TPW && wave + Cfg::PROD * tt < nt1;
         const bool prev_ok = tt > 0 && wave + Cfg::PROD * (tt - 1) < nt1;
+        if (it == 2) MSTAMP(48 + 2 * tt);
         if (cur_ok) {
           if (tt == 0)
             FullStep<N, false>(res[0], a[0], w, res[1], Pb, gm, 0);
@@ -282,36 +421,39 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
           for (int e = 0; e < NK; e++) StorePiece<N, true>(res[(tt & 1) ^ 1], e, Pb, gm, tt - 1);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (it == 2) MSTAMP(49 + 2 * tt);
 #ifndef CXK_EXPERIMENT_NO_RELOAD  // diagnostic: operands of the first constraint are reused (wrong results, compute-only timing)
         if (tt > 0) LoadTile<N>(a[tt - 1], gm, tt - 1, nx.block);
 #endif
         __builtin_amdgcn_sched_barrier(0);
       }
-      MSTAMP(4 + 4 * it);
-      LdsBarrier();  // barrier 2
+      MSTAMP(2 + 4 * it);
+      LdsBarrier();
     }
     MSTAMP(1 + 4 * cnt);
-    LdsBarrier();  // drain iteration: the consumers finish the last constraint
-    LdsBarrier();
+    LdsBarrier();  // the consumers contract the last constraint (and then write its results out)
     return;
   }
 
   // -------------------------------------------------------------------- consumers
-  // The consumers are the longer dependency chain of an iteration: their instructions win the
-  // SIMD's issue arbitration, the two producer waves beside each of them fill what is left.
-  __builtin_amdgcn_s_setprio(2);
+  // The consumers' instructions win the SIMD's issue arbitration (measured: priority 1 and 2 alike
+  // shorten an iteration by ~6 % against equal priorities).
+  __builtin_amdgcn_s_setprio(1);
   const int cw = wave - Cfg::PROD;
   const int ct = threadIdx.x - 64 * Cfg::PROD;  // 0 .. 255
   const int il = lane & 15, kq = lane >> 4;
   const int R = M1 - 16;
-  const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;  // Hermitian cones: tr over the real representation
-  // operand rows of the two tiles (or of the single tile when M1 <= 16; rows past M1 alias M1 - 1)
-  const int rowA = two ? (R + il) * MS : (il < M1 ? il : M1 - 1) * MS;
-  const int colA = two ? il * MS : rowA;
-  const int setB = two ? (il < R ? il : (il < 2 * R ? 16 + il - R : M1 - 1)) * MS : 0;
+  // Work split.  17 <= M1: waves 0-2 take a third of the K range each of the 16 x 16 tile
+  // (rows = matrices R .., columns = matrices 0 .. 15), wave 3 the two R x R triangles that tile
+  // leaves out.  M1 <= 16: the four waves take the K quarters of the single tile (rows past M1
+  // alias M1 - 1).
+  const int parts = two ? Cfg::CONS - 1 : Cfg::CONS;
+  const int part = cw < parts ? cw : 0;
+  const int rr0 = part * N / parts, nrows = (part + 1) * N / parts - rr0;
+  const int ra = two ? (R + il) * MS : (il < M1 ? il : M1 - 1) * MS;
+  const int ca = two ? il * MS : ra;
   // Iteration 0 has nothing to consume: look up where this workgroup's constraints write (two
   // dependent loads each) and park the answers in LDS, off every later critical path.
-  int64_t* dest = reinterpret_cast<int64_t*>(scratch + (size_t)Cfg::CONS * ntl * 256);  // kDestSlots x {id, g_off, r_off}
   if (ct < kDestSlots && ct < cnt) {
     const int id = g.ids[first + ct * stride];
     dest[3 * ct] = id;
@@ -319,21 +461,21 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
     dest[3 * ct + 2] = ar.r_off[id];
   }
   // ... and tabulate the epilogue: entry e = (ii, jj <= ii) of the lower triangle of the M1 x M1
-  // result -> where its four partial sums sit in the tiles and where the total goes
-  // (kind 0: G[dst], 1: AQc[dst], 2: <c,Qc>), packed  tile offset | kind << 10 | dst << 12.
-  int* etab = reinterpret_cast<int*>(dest + 3 * kDestSlots);
-  const int nout = M1 * (M1 + 1) / 2;
+  // result -> where the first of its partial sums sits in a buffer of partial tiles (tile: the
+  // others follow at multiples of 256; triangle: the other K parity 4 further) and where the total goes (kind 0: G[dst], 1: AQc[dst],
+  // 2: <c,Qc>), packed  offset | kind << 10 | dst << 12.
   for (int idx = ct; idx < M1 * M1; idx += 64 * Cfg::CONS) {
     const int ii = idx / M1, jj = idx - ii * M1;
     if (jj > ii) continue;
     int off;
     if (two) {
-      if (ii >= R && jj < 16)
-        off = (ii - R) * 16 + jj;                        // tile 0
-      else if (ii < R)
-        off = 256 + ii * 16 + jj;                        // tile 1, both among the first R
-      else
-        off = 256 + (R + ii - 16) * 16 + (R + jj - 16);  // tile 1, both >= 16
+      if (ii >= R && jj < 16) {
+        off = (ii - R) * 16 + jj;  // the tile: waves 0 - 2
+      } else {                     // a triangle: wave 3, instruction u, lane 16 i + 4 (2 t + h) + j
+        const int t = ii < R ? 0 : 1, a = ii - 16 * t, b = jj - 16 * t;
+        const int u = a < 4 ? 0 : (b < 4 ? 1 : 2);
+        off = 768 + 64 * u + 16 * (a & 3) + 8 * t + (b & 3);
+      }
     } else {
       off = ii * 16 + jj;
     }
@@ -341,132 +483,74 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
     const int dst = ii < M ? ii + jj * M : (jj < M ? jj : 0);
     etab[ii * (ii + 1) / 2 + jj] = off | kind << 10 | dst << 12;
   }
-  LdsBarrier();
+  // AW(i) = tr(P_i), <w,c> = tr(P_C) from the image being contracted: one lane per matrix.
+  auto traces = [&](int c) {
+    if (ct >= M1) return;
+    const double* Pc = P0 + (c & 1) * pbuf + ct * MS;
+    double s0 = 0, s1 = 0;
+#pragma unroll
+    for (int r = 0; r < N; r += 2) {
+      s0 += Pc[r * LD + r];
+      s1 += Pc[(r + 1) * LD + r + 1];
+    }
+    const double sum = (s0 + s1) * osc;
+    if (ct < M)
+      ar.AWc[dest[3 * c + 2] + ct] = sum;
+    else
+      ar.sc[2 * dest[3 * c]] = sum;
+  };
+  // Epilogue of constraint c, one iteration after its contraction: the K-split partial tiles are
+  // summed in a fixed order and written out.
+  auto epilogue = [&](int c) {
+    const double* sb = scratch + (c & 1) * SB;
+    const int id = (int)dest[3 * c];
+    double* G = ar.G + dest[3 * c + 1];
+    double* AQc = ar.AQcc + dest[3 * c + 2];
+    for (int e = ct; e < nout; e += 64 * Cfg::CONS) {
+      const int code = etab[e];
+      const int off = code & 1023, kind = (code >> 10) & 3, dst = code >> 12;
+      double sum;
+      if (two && off >= 768)
+        sum = sb[off] + sb[off + 4];
+      else
+        sum = (sb[off] + sb[off + 256]) + sb[off + 512];
+      if (!two) sum += sb[off + 768];
+      sum *= osc;
+      if (kind == 0)
+        G[dst] = sum;
+      else if (kind == 1)
+        AQc[dst] = sum;
+      else
+        ar.sc[2 * id + 1] = sum;
+    }
+  };
   LdsBarrier();
   MSTAMP(0);
+  constexpr int MAXROWS = (N + Cfg::CONS - 2) / (Cfg::CONS - 1);
   for (int it = 1; it <= cnt; it++) {
     MSTAMP(1 + 4 * it);
     const double* Pb = P0 + ((it - 1) & 1) * pbuf;
-    // k-steps: this wave takes the RPW rows rr = cw RPW .. of the N x N index space, NK steps
-    // each; the operands of the next row are in flight while the current row's MFMAs issue
-    d4_t acc0 = (d4_t){0.0, 0.0, 0.0, 0.0}, acc1 = (d4_t){0.0, 0.0, 0.0, 0.0};
-    const int rr0 = cw * Cfg::RPW;
-    if (two) {
-      double a0[2][NK], b0[2][NK], a1[2][NK], b1[2][NK];
-      auto fetch = [&](int buf, int rr) {
-#pragma unroll
-        for (int bi = 0; bi < NK; bi++) {
-          const int ao = rr * LD + 4 * bi + kq, bo = (4 * bi + kq) * LD + rr;
-          a0[buf][bi] = Pb[rowA + ao];
-          b0[buf][bi] = Pb[colA + bo];
-          a1[buf][bi] = Pb[setB + ao];
-          b1[buf][bi] = Pb[setB + bo];
-        }
-      };
-      fetch(0, rr0);
-      // the next row's operands are read in the gaps between this row's MFMAs (a lone wavefront
-      // issues a ds_read_b64 every ~17 cycles: 20 reads up front would idle the pipe for ~300)
-#pragma unroll
-      for (int r = 0; r < Cfg::RPW; r++) {
-        const int cb_ = r & 1, nb_ = cb_ ^ 1, rn = rr0 + r + 1;
-        if (it == cnt) MSTAMP(48 + r);
-#pragma unroll
-        for (int bi = 0; bi < NK; bi++) {
-          const int ao = rn * LD + 4 * bi + kq, bo = (4 * bi + kq) * LD + rn;
-          __builtin_amdgcn_sched_barrier(0);
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[cb_][bi], b0[cb_][bi], acc0, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-#ifndef CXK_EXPERIMENT_NO_READS  // diagnostic: operands of the first row are reused (wrong results, MFMA-only timing)
-          if (r + 1 < Cfg::RPW) {
-            a0[nb_][bi] = Pb[rowA + ao];
-            b0[nb_][bi] = Pb[colA + bo];
-          }
-#else
-          a0[nb_][bi] = a0[cb_][bi]; b0[nb_][bi] = b0[cb_][bi];
-#endif
-          __builtin_amdgcn_sched_barrier(0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[cb_][bi], b1[cb_][bi], acc1, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-#ifndef CXK_EXPERIMENT_NO_READS
-          if (r + 1 < Cfg::RPW) {
-            a1[nb_][bi] = Pb[setB + ao];
-            b1[nb_][bi] = Pb[setB + bo];
-          }
-#else
-          a1[nb_][bi] = a1[cb_][bi]; b1[nb_][bi] = b1[cb_][bi];
-#endif
-        }
-      }
+    double* sb = scratch + ((it - 1) & 1) * SB;
+    if (two && cw == Cfg::CONS - 1) {
+      if (R > 4)
+        Triangles<N, true>(Pb, sb + 256 * (Cfg::CONS - 1), lane, M1);
+      else
+        Triangles<N, false>(Pb, sb + 256 * (Cfg::CONS - 1), lane, M1);
     } else {
-      double a0[2][NK], b0[2][NK];
-      auto fetch = [&](int buf, int rr) {
+      const d4_t acc = Contract<N, MAXROWS>(Pb, ra, ca, rr0, kq, nrows);
 #pragma unroll
-        for (int bi = 0; bi < NK; bi++) {
-          a0[buf][bi] = Pb[rowA + rr * LD + 4 * bi + kq];
-          b0[buf][bi] = Pb[rowA + (4 * bi + kq) * LD + rr];
-        }
-      };
-      fetch(0, rr0);
-#pragma unroll
-      for (int r = 0; r < Cfg::RPW; r++) {
-        const int cb_ = r & 1, nb_ = cb_ ^ 1, rn = rr0 + r + 1;
-#pragma unroll
-        for (int bi = 0; bi < NK; bi++) {
-          __builtin_amdgcn_sched_barrier(0);
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[cb_][bi], b0[cb_][bi], acc0, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (r + 1 < Cfg::RPW) {
-            a0[nb_][bi] = Pb[rowA + rn * LD + 4 * bi + kq];
-            b0[nb_][bi] = Pb[rowA + (4 * bi + kq) * LD + rn];
-          }
-        }
-      }
+      for (int e = 0; e < 4; e++)  // C/D layout: column = lane & 15, row = (lane >> 4) + 4 e
+        sb[cw * 256 + (kq + 4 * e) * 16 + il] = acc[e];
     }
-    if (it == cnt) MSTAMP(48 + Cfg::RPW);
-#pragma unroll
-    for (int e = 0; e < 4; e++) {  // C/D layout: column = lane & 15, row = (lane >> 4) + 4 e
-      scratch[(cw * ntl) * 256 + (kq + 4 * e) * 16 + il] = acc0[e];
-      if (two) scratch[(cw * ntl + 1) * 256 + (kq + 4 * e) * 16 + il] = acc1[e];
-    }
-    // where the results go (the host sizes the grid so that a workgroup never has more than
-    // kDestSlots constraints)
-    const int id = (int)dest[3 * (it - 1)];
-    const int64_t goff = dest[3 * (it - 1) + 1], roff = dest[3 * (it - 1) + 2];
-    double* G = ar.G + goff;
     MSTAMP(2 + 4 * it);
-    LdsBarrier();  // barrier 1
-    MSTAMP(3 + 4 * it);
-    {
-      double* AW = ar.AWc + roff;
-      double* AQc = ar.AQcc + roff;
-      for (int e = ct; e < nout; e += 64 * Cfg::CONS) {
-        const int code = etab[e];
-        const int off = code & 1023, kind = (code >> 10) & 3, dst = code >> 12;
-        double sum = 0;
-#pragma unroll
-        for (int wv = 0; wv < Cfg::CONS; wv++) sum += scratch[wv * ntl * 256 + off];
-        sum *= osc;
-        if (kind == 0)
-          G[dst] = sum;
-        else if (kind == 1)
-          AQc[dst] = sum;
-        else
-          ar.sc[2 * id + 1] = sum;
-      }
-      for (int ii = ct; ii < M1; ii += 64 * Cfg::CONS) {  // AW(i) = tr(P_i), <w,c> = tr(P_C)
-        double sum = 0;
-#pragma unroll
-        for (int r = 0; r < N; r++) sum += Pb[ii * MS + r * LD + r];
-        sum *= osc;
-        if (ii < M)
-          AW[ii] = sum;
-        else
-          ar.sc[2 * id] = sum;
-      }
-    }
+    // The consumers finish their contraction well before the producers their tiles: the results
+    // leave in that slack.
+    traces(it - 1);
+    if (it >= 2) epilogue(it - 2);
     MSTAMP(4 + 4 * it);
-    LdsBarrier();  // barrier 2
+    LdsBarrier();
   }
+  epilogue(cnt - 1);
   MSTAMP(1 + 4 * (cnt + 1));
 }
 
@@ -474,7 +558,7 @@ template <int N>
 size_t MfmaLds(int m) {
   using Cfg = MfmaCfg<N>;
   const int m1 = m + 1;
-  return sizeof(double) * (2 * (size_t)m1 * Cfg::MS + (size_t)Cfg::CONS * (m1 > 16 ? 2 : 1) * 256 + 3 * kDestSlots) +
+  return sizeof(double) * (2 * (size_t)m1 * Cfg::MS + 2 * (size_t)Cfg::CONS * 256 + 3 * kDestSlots) +
          sizeof(int) * (size_t)(m1 * (m1 + 1) / 2);
 }
 

@@ -13,7 +13,7 @@ import numpy as np
 
 import conex_amd.kkt as kk
 
-kk.LIB_PATH = os.path.join(os.path.dirname(kk.LIB_PATH), "libconex_dbg.so")
+kk.LIB_PATH = os.path.join(os.path.dirname(kk.LIB_PATH), os.environ.get("CXK_DBG_LIB", "libconex_dbg.so"))
 from conex_amd import KktContext, synthetic as syn
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
@@ -34,7 +34,7 @@ assert L.cxk_debug_mfma_stamps(buf) == 0
 s = np.array(buf[:], dtype=np.int64).reshape(2, 16, 64)
 for b, name in enumerate(("workgroup 0", "workgroup 200")):
     t0 = s[b][s[b] > 0].min()
-    print(name, "(cycles since the workgroup's first stamp)")
+    print(name, "(cycles since the workgroup's first stamp; per iteration: start / tiles or contraction done / results written)")
     for w in range(12):
         row = s[b, w]
         role = "producer" if w < 8 else "consumer"
@@ -43,7 +43,7 @@ for b, name in enumerate(("workgroup 0", "workgroup 200")):
             q = row[1 + 4 * it:5 + 4 * it]
             if q[0] <= 0:
                 continue
-            its.append("it%d[start %d, before b1 %s, after b1 %s, before b2 %s]" % (
-                it, q[0] - t0, q[1] - t0 if q[1] > 0 else "-", q[2] - t0 if q[2] > 0 else "-", q[3] - t0 if q[3] > 0 else "-"))
-        rows = [int(v - t0) for v in row[48:60] if v > 0]
-        print("  wave %d %s: first %d | %s | last contraction rows %s" % (w, role, row[0] - t0, " ".join(its), rows))
+            its.append("it%d[%s]" % (it, " ".join(str(int(v - t0)) if v > 0 else "-" for v in (q[0], q[1], q[3]))))
+        fine = [int(v - t0) for v in row[48:60] if v > 0]
+        print("  wave %2d %s: first %5d | %s%s" % (w, role, row[0] - t0, " ".join(its), (" | iteration 2, per tile slot (start, MFMAs issued): %s" % fine) if fine else ""))
+    print("  span %d cycles" % (s[b].max() - t0))
