@@ -43,6 +43,7 @@ struct GatherArgs {
   double* slab;
   int N;
   const ResidRec* rrec;
+  const int* var_idx;  // residual record t describes variable var_idx[t] (nullptr: variable t)
   const int64_t* rs_src;
   const double* AWc;
   const double* AQcc;
@@ -58,25 +59,28 @@ struct GatherArgs {
   int* fail;
 };
 
-#ifndef CXK_DEVICE_FUNCTIONS_ONLY  // plain (non-template) kernels: one translation unit only
-__global__ void __launch_bounds__(256) assemble_gather(GatherArgs a) {
-  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+// The gather of workgroup `block` of `nblocks` (assemble_gather, and the gather workgroups that
+// ride in the first factor level's launch: tree_factor_level_asm).
+__device__ __forceinline__ void GatherBody(const GatherArgs& a, int block, int nblocks) {
+  const int64_t gid = block * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)nblocks * blockDim.x;
   const int64_t span = a.T > a.N ? a.T : (int64_t)a.N;
   // slab entries and residual entries are gathered side by side: their loads share the round trips
   for (int64_t t = gid; t < span; t += stride) {
     const bool ht = t < a.T, hp = t < a.N;
     GatherRec g = {0, -1, 0, 0};
     ResidRec r = {-1, 0, 0};
+    int var = (int)t;
     if (ht) g = a.rec[t];
     if (hp) r = a.rrec[t];
+    if (hp && a.var_idx) var = a.var_idx[t];
     double s = 0, aw = 0, aq = 0, bp = 0;
     if (g.first >= 0) s += a.G[g.first];
     if (r.first >= 0) {
       aw += a.AWc[r.first];
       aq += a.AQcc[r.first];
     }
-    if (hp && a.with_rhs) bp = a.b[t];
+    if (hp && a.with_rhs) bp = a.b[var];
     for (int k = g.beg; k < g.beg + g.extra; k++) {
       const int64_t q = a.src[k];
       if (q >= 0) s += a.G[q];
@@ -87,12 +91,12 @@ __global__ void __launch_bounds__(256) assemble_gather(GatherArgs a) {
     }
     if (ht) a.slab[g.dst] = s;
     if (hp) {
-      a.AW[t] = aw;
-      a.AQc[t] = aq;
-      if (a.with_rhs) a.y[t] = a.k * (bp * a.bs + aq * a.cs) - 2 * aw;
+      a.AW[var] = aw;
+      a.AQc[var] = aq;
+      if (a.with_rhs) a.y[var] = a.k * (bp * a.bs + aq * a.cs) - 2 * aw;
     }
   }
-  if (blockIdx.x == 0) {  // <w,c> and <c,Qc>: fixed-order strided partial sums + block sum
+  if (block == 0) {  // <w,c> and <c,Qc>: fixed-order strided partial sums + block sum
     __shared__ double red[8];
     double s0 = 0, s1 = 0;
     for (int i = threadIdx.x; i < a.K; i += blockDim.x) {
@@ -108,6 +112,9 @@ __global__ void __launch_bounds__(256) assemble_gather(GatherArgs a) {
     }
   }
 }
+
+#ifndef CXK_DEVICE_FUNCTIONS_ONLY  // plain (non-template) kernels: one translation unit only
+__global__ void __launch_bounds__(256) assemble_gather(GatherArgs a) { GatherBody(a, blockIdx.x, gridDim.x); }
 
 // y = k (b bs + AQc cs) - 2 AW   (cone_program.cc:409-411), all in permuted order
 // (reset: when not null, the factorization-failure flag cleared here instead of by a memset launch)
@@ -243,6 +250,27 @@ __device__ __forceinline__ SnRec LoadRec(const SnRec* __restrict__ rec, int pos)
   for (int q = 0; q < 8; q++) R.sep[q] = f(24 + q);
   return R;
 }
+
+// A supernode without descendants whose panel is a permuted block of ONE constraint's Schur block
+// (the leaves of a clique tree: BuildPlans checks every gather list): the first factor level
+// loads it straight from the Schur kernels' output -- G(pos[r], pos[c]) -- together with its
+// right-hand side, and the separate assembly launch disappears (the rest of the gather rides in
+// the same launch as extra workgroups: tree_factor_level_asm).
+struct AsmRec {
+  int64_t g_off;          // the constraint's m x m block in G (column-major, lower triangle written)
+  int64_t r_off;          // its entries of AWc / AQcc
+  int m;
+  int pad_;
+  unsigned char pos[72];  // panel row q (the ns rows, then the separator rows) -> position in the constraint
+};
+static_assert(sizeof(AsmRec) == 96, "AsmRec is read as 24 lanes x 4 bytes");
+struct AsmIn {
+  const AsmRec* rec;  // [level-0 position]
+  const double *G, *AWc, *AQcc, *b;
+  double *AW, *AQc;
+  double k, bs, cs;   // y = k (b bs + AQc cs) - 2 AW  (cone_program.cc:409-411)
+  int tag;            // a failed pivot writes fail[1] = tag (fail[0] is being reset by the gather beside it)
+};
 
 struct FactorPlan {
   const SnRec* rec;          // [level positions]
@@ -683,10 +711,11 @@ __device__ __forceinline__ bool FastPull(const SnRec& R) {
   return R.tg_end - R.tg_beg <= kFastTargets && R.m <= kFastSlots && R.mf <= kFastSlots;
 }
 
-template <int NSMAX, int SMAX, bool RHS>
+template <int NSMAX, int SMAX, bool RHS, bool ASM = false>
 __device__ __forceinline__ void FactorSupernodeLean(const FactorPlan& P, const SnRec& R,
                                                     double* __restrict__ slab, double* __restrict__ rhs,
-                                                    int* __restrict__ fail, double* __restrict__ my) {
+                                                    int* __restrict__ fail, double* __restrict__ my,
+                                                    const AsmIn* ai = nullptr, int aw2 = 0) {
   static_assert(NSMAX + SMAX <= 64, "one lane per panel row");
   constexpr int RB = NSMAX + SMAX, MMAX = kFastSlots, MFMAX = kFastSlots;
   const int lane = threadIdx.x & 63;
@@ -702,10 +731,31 @@ __device__ __forceinline__ void FactorSupernodeLean(const FactorPlan& P, const S
   CXK_STAMP(0);
   // ---- load phase: no consumer before the last load
   double a[NSMAX + SMAX + 1];
+  double rb = 0.0, awv = 0.0, aqv = 0.0;
+  if constexpr (ASM) {
+    // aw2 = this lane's word of the AsmRec (loaded beside the SnRec): block offsets, then the
+    // positions, one byte per panel row
+    auto f = [&](int i) { return __builtin_amdgcn_readlane(aw2, i); };
+    const double* Gk = ai->G + (((int64_t)f(1) << 32) | (uint32_t)f(0));
+    const int64_t roff = ((int64_t)f(3) << 32) | (uint32_t)f(2);
+    const int M = f(4);
+    const int q = is_row ? lane : (is_sep ? ns + sc : 0);
+    const int myp = (__builtin_amdgcn_ds_bpermute(4 * (6 + (q >> 2)), aw2) >> (8 * (q & 3))) & 255;
 #pragma unroll
-  for (int j = 0; j < NSMAX; j++) a[j] = base[(j < lim) ? o0 + j * st : 0u];
-  double rb = 0.0;
-  if constexpr (RHS) rb = rhs[R.start + (is_row ? lane : 0)];
+    for (int j = 0; j < NSMAX; j++) {
+      const int pj = (f(6 + (j >> 2)) >> (8 * (j & 3))) & 255;  // wave-uniform
+      const int hi = myp > pj ? myp : pj, lo = myp > pj ? pj : myp;
+      a[j] = Gk[(j < lim) ? hi + lo * M : 0];
+    }
+    const int pr = is_row ? myp : (f(6) & 255);
+    awv = ai->AWc[roff + pr];
+    aqv = ai->AQcc[roff + pr];
+    if constexpr (RHS) rb = ai->b[R.start + (is_row ? lane : 0)];
+  } else {
+#pragma unroll
+    for (int j = 0; j < NSMAX; j++) a[j] = base[(j < lim) ? o0 + j * st : 0u];
+    if constexpr (RHS) rb = rhs[R.start + (is_row ? lane : 0)];
+  }
   int pdst[SMAX > 0 ? SMAX : 1], pdstb = 0;
   pdst[0] = 0;
   {
@@ -746,6 +796,19 @@ __device__ __forceinline__ void FactorSupernodeLean(const FactorPlan& P, const S
   }
   CXK_STAMP(1);
   // ---- consumers
+  if constexpr (ASM) {
+    // what assemble_gather would have produced: sums that start from +0.0 (a -0.0 source ends up
+    // +0.0), AW / AQc of the own variables for the kernels that follow, and the right-hand side
+#pragma unroll
+    for (int j = 0; j < NSMAX; j++) a[j] = 0.0 + a[j];
+    awv = 0.0 + awv;
+    aqv = 0.0 + aqv;
+    if (is_row) {
+      ai->AW[R.start + lane] = awv;
+      ai->AQc[R.start + lane] = aqv;
+    }
+    if constexpr (RHS) rb = ai->k * (rb * ai->bs + aqv * ai->cs) - 2 * awv;
+  }
 #pragma unroll
   for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? a[j] : 0.0;
 #pragma unroll
@@ -785,7 +848,12 @@ __device__ __forceinline__ void FactorSupernodeLean(const FactorPlan& P, const S
   ElimSteps<NSMAX, SMAX, 0>::run(a, lane, bad);
   CXK_STAMP(3);
   if (bad) {
-    if (lane == 0) atomicExch(fail, 1);
+    if (lane == 0) {
+      if constexpr (ASM)
+        atomicExch(fail + 1, ai->tag);
+      else
+        atomicExch(fail, 1);
+    }
     return;
   }
 #pragma unroll
@@ -1249,6 +1317,30 @@ tree_factor_level(FactorPlan P, const SnRec* __restrict__ recs, int base0, int c
   const SnRec R = LoadRec(recs, base0 + idx);
   FactorSupernodeLean<NSMAX, SMAX, RHS>(P, R, slab, rhs, fail, my);
   CXK_STAMP(7);
+}
+
+// The first factor level with the assembly folded in: workgroups [0, fwgs) factor supernodes
+// whose panels come straight from the Schur blocks (AsmRec), the others run the gather of
+// everything else (slab entries of the levels above, their right-hand side, <w,c>, <c,Qc>) --
+// needed by the NEXT level's launch only.
+template <int NSMAX, int SMAX, bool RHS>
+__global__ void __launch_bounds__(256)
+tree_factor_level_asm(FactorPlan P, const SnRec* __restrict__ recs, int base0, int cnt0,
+                      double* __restrict__ slab, double* __restrict__ rhs, int* __restrict__ fail,
+                      int lds_per_wave, AsmIn ai, GatherArgs ga, int fwgs) {
+  extern __shared__ double lds[];
+  if ((int)blockIdx.x >= fwgs) {
+    GatherBody(ga, blockIdx.x - fwgs, gridDim.x - fwgs);
+    return;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  double* my = lds + (size_t)wave * lds_per_wave;
+  const int idx = blockIdx.x * nw + wave;
+  if (idx >= cnt0) return;
+  const int lane = threadIdx.x & 63;
+  const int aw2 = reinterpret_cast<const int*>(ai.rec + idx)[lane < 24 ? lane : 0];  // same trip as the record
+  const SnRec R = LoadRec(recs, base0 + idx);
+  FactorSupernodeLean<NSMAX, SMAX, RHS, true>(P, R, slab, rhs, fail, my, &ai, aw2);
 }
 
 // The backward step of one level, same specialisation (no LDS).

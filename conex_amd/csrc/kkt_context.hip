@@ -207,6 +207,21 @@ struct cxk_context {
   DevBuf<int64_t> xs_off, pt_dst, pt_src;
   DevBuf<int> xv_idx, pt_ptr, pf_ptr, pf_src;
   int64_t as_T = 0;
+  // the assembly folded into the first factor level (tree_factor_level_asm): records of the level's
+  // supernodes, and the gather lists without what those supernodes load themselves
+  bool fused_asm = false;
+  DevBuf<AsmRec> asm_rec;
+  DevBuf<GatherRec> as_rec2;
+  DevBuf<ResidRec> rs_rec2;
+  DevBuf<int> rs_var2;
+  int64_t as_T2 = 0;
+  int rs_N2 = 0;
+  struct AsmPending {
+    bool on = false, with_rhs = false;
+    double k = 0, bs = 0, cs = 0;
+  } asm_pending;
+  int asm_tag = 0;    // tag of the latest fused launch (a failed pivot there writes d_fail[1] = tag)
+  int fail_tag = 0;   // what mailbox_pack compares d_fail[1] with: asm_tag, or 0 after any other factorization
   FactorPlan plan{};
   // index of the next PrepareStep / eigenvalue query (keys the Hermitian start vectors)
   unsigned long long lanczos_calls = 0;
@@ -631,6 +646,7 @@ int BuildPlans(cxk_context* ctx) {
     for (int64_t q : srcs[t]) as_src.push_back(q);
     as_ptr[t + 1] = (int)as_src.size();
   }
+  std::vector<GatherRec> h_as_rec;
   ctx->as_T = (int64_t)dst.size();
   CXK_TRY(ctx->as_dst.upload(dst));
   CXK_TRY(ctx->as_ptr.upload(as_ptr));
@@ -645,11 +661,13 @@ int BuildPlans(cxk_context* ctx) {
       recs[t].extra = len > 0 ? len - 1 : 0;
     }
     CXK_TRY(ctx->as_rec.upload(recs));
+    h_as_rec = recs;
   }
 
   // ---- residual gather (constraint order); variables of foreign subtrees are skipped
+  std::vector<std::vector<int64_t>> per(N);
+  std::vector<ResidRec> h_rs_rec;
   {
-    std::vector<std::vector<int64_t>> per(N);
     for (int i = 0; i < (int)ctx->cons.size(); i++) {
       if (!ctx->owned[i]) continue;
       for (int q = 0; q < (int)ctx->cliques[i].size(); q++)
@@ -671,6 +689,7 @@ int BuildPlans(cxk_context* ctx) {
       recs[p].extra = len > 0 ? len - 1 : 0;
     }
     CXK_TRY(ctx->rs_rec.upload(recs));
+    h_rs_rec = recs;
   }
 
   // ---- clique variables in permuted numbering
@@ -1055,6 +1074,86 @@ int BuildPlans(cxk_context* ctx) {
         ctx->chain_a = sa;
         ctx->chain_b = sb == 0 ? sa : sb;
       }
+    }
+  }
+  // ---- assembly folded into the first factor level.  Taken when level 0 is ONE segment of a
+  // register shape with dense pulls, launched on its own (not part of a chain / dense top), and
+  // every supernode in it is a leaf whose panel entries and right-hand-side rows have exactly one
+  // source each, all in the Schur block of its own constraint, at positions pos[row] -- the
+  // leaves of a clique tree.  Those supernodes then read G(max(pos_r, pos_c), min(..)) themselves
+  // and the gather lists shrink to what the levels above need.
+  ctx->fused_asm = false;
+  if (!sharded && !ctx->use_ldlt && !ctx->no_lean && !getenv("CXK_NO_FUSED_ASM") && nlev >= 2 &&
+      ctx->level_segs[0].size() == 1 && ctx->level_lean[0] && ctx->top_level >= 1 && ctx->chain_level >= 1 &&
+      ctx->level_segs[0][0].shape != 0 && 4 * ctx->chol_lds <= kLdsLimit) {
+    const int first = ctx->level_ptr[0], cnt0 = ctx->level_nh[0];
+    std::vector<AsmRec> arecs(cnt0);
+    std::vector<char> slab_own(h_as_rec.size(), 0), var_own(N, 0);
+    bool ok = cnt0 > 0 && cnt0 == ctx->level_ptr[1] - first;
+    for (int q = 0; q < cnt0 && ok; q++) {
+      const int e = ctx->level_sn[first + q];
+      const int i = md.clique_order[e];
+      const int m = ctx->cons[i].m;
+      const IntList& r = md.supernodes_pos[e];
+      const IntList& sp = md.separators_pos[e];
+      const int nse = (int)r.size(), nsp = (int)sp.size();
+      ok = nse == ns[e] && nsp == nsep[e] && nse + nsp <= 72 && m <= 255 && ctx->owned[i] &&
+           h_tg_ptr[e + 1] == h_tg_ptr[e] && h_mf[e] == 0;
+      AsmRec& ar = arecs[q];
+      memset(&ar, 0, sizeof(ar));
+      ar.g_off = ctx->g_off[i];
+      ar.r_off = ctx->r_off[i];
+      ar.m = m;
+      for (int a = 0; a < nse && ok; a++) {
+        ok = r[a] >= 0 && r[a] < m;
+        ar.pos[a] = (unsigned char)r[a];
+      }
+      for (int a = 0; a < nsp && ok; a++) {
+        ok = sp[a] >= 0 && sp[a] < m;
+        ar.pos[nse + a] = (unsigned char)sp[a];
+      }
+      auto single = [&](int64_t off, int pa, int pb) {  // the slab entry has the one source G(pa, pb)
+        const int t = entry_of[off];
+        if (t < 0) return false;
+        const GatherRec& g = h_as_rec[t];
+        const int hi = std::max(pa, pb), lo = std::min(pa, pb);
+        if (g.extra != 0 || g.first != ar.g_off + hi + (int64_t)lo * m) return false;
+        slab_own[t] = 1;
+        return true;
+      };
+      for (int j = 0; j < nse && ok; j++)
+        for (int i2 = j; i2 < nse && ok; i2++) ok = single(L.diag_off[e] + (int64_t)j * nse + i2, r[i2], r[j]);
+      for (int j = 0; j < nsp && ok; j++)
+        for (int i2 = 0; i2 < nse && ok; i2++) ok = single(L.offd_off[e] + (int64_t)j * nse + i2, r[i2], sp[j]);
+      for (int a = 0; a < nse && ok; a++) {
+        const int pvar = start[e] + a;
+        ok = per[pvar].size() == 1 && per[pvar][0] == ar.r_off + r[a];
+        var_own[pvar] = 1;
+      }
+    }
+    if (ok) {
+      std::vector<GatherRec> g2;
+      for (size_t t = 0; t < h_as_rec.size(); t++)
+        if (!slab_own[t]) g2.push_back(h_as_rec[t]);
+      std::vector<ResidRec> r2;
+      std::vector<int> v2;
+      for (int pvar = 0; pvar < N; pvar++)
+        if (!var_own[pvar]) {
+          r2.push_back(h_rs_rec[pvar]);
+          v2.push_back(pvar);
+        }
+      ctx->as_T2 = (int64_t)g2.size();
+      ctx->rs_N2 = (int)v2.size();
+      if (g2.empty()) g2.push_back(GatherRec{0, -1, 0, 0});
+      if (v2.empty()) {
+        r2.push_back(ResidRec{-1, 0, 0});
+        v2.push_back(0);
+      }
+      CXK_TRY(ctx->asm_rec.upload(arecs));
+      CXK_TRY(ctx->as_rec2.upload(g2));
+      CXK_TRY(ctx->rs_rec2.upload(r2));
+      CXK_TRY(ctx->rs_var2.upload(v2));
+      ctx->fused_asm = true;
     }
   }
   // ---- the top as one dense T x T factorization (single GPU, Cholesky): tables for
@@ -1550,7 +1649,7 @@ int LaunchSchur(cxk_context* ctx) {
   return CXK_SUCCESS;
 }
 
-int LaunchGather(cxk_context* ctx, bool with_rhs, double k, double bs, double cs) {
+GatherArgs MakeGather(cxk_context* ctx, bool with_rhs, double k, double bs, double cs) {
   GatherArgs a;
   a.T = ctx->as_T;
   a.rec = ctx->as_rec.p;
@@ -1559,6 +1658,7 @@ int LaunchGather(cxk_context* ctx, bool with_rhs, double k, double bs, double cs
   a.slab = ctx->slab.p;
   a.N = ctx->md.N;
   a.rrec = ctx->rs_rec.p;
+  a.var_idx = nullptr;
   a.rs_src = ctx->rs_src.p;
   a.AWc = ctx->AWc.p;
   a.AQcc = ctx->AQcc.p;
@@ -1574,9 +1674,15 @@ int LaunchGather(cxk_context* ctx, bool with_rhs, double k, double bs, double cs
   a.b = ctx->b.p;
   a.y = ctx->y.p;
   a.fail = ctx->d_fail.p;
+  return a;
+}
+
+int LaunchGather(cxk_context* ctx, bool with_rhs, double k, double bs, double cs) {
+  const GatherArgs a = MakeGather(ctx, with_rhs, k, bs, cs);
   assemble_gather<<<GridFor((size_t)std::max<int64_t>(ctx->as_T, ctx->md.N), 256), 256, 0,
                     ctx->stream>>>(a);
   CXK_TRY(hipGetLastError());
+  ctx->fail_tag = 0;
   return CXK_SUCCESS;
 }
 
@@ -1725,6 +1831,55 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
       tree_factor_level<NS_, S_, false><<<g, w * 64, lds, ctx->stream>>>(                               \
           ctx->plan, ctx->p_rec.p, sg.begin, cnt, ctx->slab.p, rhs, ctx->d_fail.p, per_wave);           \
   }
+        if (mode == 0 && lb == 0 && ctx->asm_pending.on) {
+          // the assembly rides in this launch: factor workgroups [0, g) read their panels from
+          // the Schur blocks, the others gather what the levels above need
+          const cxk_context::AsmPending ap = ctx->asm_pending;
+          ctx->asm_pending.on = false;
+          GatherArgs ga = MakeGather(ctx, ap.with_rhs, ap.k, ap.bs, ap.cs);
+          ga.T = ctx->as_T2;
+          ga.rec = ctx->as_rec2.p;
+          ga.N = ctx->rs_N2;
+          ga.rrec = ctx->rs_rec2.p;
+          ga.var_idx = ctx->rs_var2.p;
+          AsmIn ai;
+          ai.rec = ctx->asm_rec.p;
+          ai.G = ctx->G.p;
+          ai.AWc = ctx->AWc.p;
+          ai.AQcc = ctx->AQcc.p;
+          ai.b = ctx->b.p;
+          ai.AW = ctx->AW.p;
+          ai.AQc = ctx->AQc.p;
+          ai.k = ap.k;
+          ai.bs = ap.bs;
+          ai.cs = ap.cs;
+          ctx->asm_tag = ctx->asm_tag >= (1 << 30) ? 1 : ctx->asm_tag + 1;
+          ai.tag = ctx->fail_tag = ctx->asm_tag;
+          // 256 threads per workgroup whatever the level's size: the gather's fixed-order sums
+          // (<w,c>, <c,Qc>) are dealt by thread index, and must come out as in assemble_gather
+          const int w = 4, g = (cnt + w - 1) / w;
+          const size_t lds = (size_t)w * ctx->chol_lds;
+          const int gg = GridFor((size_t)std::max<int64_t>(std::max<int64_t>(ga.T, ga.N), 1), 256);
+          bool done = false;
+#define CXK_LEVEL_ASM(NS_, S_)                                                                          \
+  if (sh == ((NS_) << 8 | (S_))) {                                                                      \
+    done = true;                                                                                        \
+    if (ap.with_rhs)                                                                                    \
+      tree_factor_level_asm<NS_, S_, true><<<g + gg, w * 64, lds, ctx->stream>>>(                       \
+          ctx->plan, ctx->p_rec.p, sg.begin, cnt, ctx->slab.p, rhs, ctx->d_fail.p, per_wave, ai, ga, g); \
+    else                                                                                                \
+      tree_factor_level_asm<NS_, S_, false><<<g + gg, w * 64, lds, ctx->stream>>>(                      \
+          ctx->plan, ctx->p_rec.p, sg.begin, cnt, ctx->slab.p, rhs, ctx->d_fail.p, per_wave, ai, ga, g); \
+  }
+          CXK_LEVEL_ASM(8, 8)
+          CXK_LEVEL_ASM(16, 8)
+          CXK_LEVEL_ASM(24, 0)
+          CXK_LEVEL_ASM(24, 8)
+          CXK_LEVEL_ASM(32, 16)
+#undef CXK_LEVEL_ASM
+          CXK_DEMAND(done, "internal error: no tree_factor_level_asm instance for the first level's shape");
+          continue;
+        }
         CXK_LEVEL(8, 8)
         CXK_LEVEL(16, 8)
         CXK_LEVEL(24, 0)
@@ -2023,6 +2178,7 @@ int QrFactor(cxk_context* ctx) {
   DenseQrFactor(N, Q.qr, Q.tau, Q.piv, &Q.rank);
   Q.valid = true;
   CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));  // Factor() returns true (:197)
+  ctx->fail_tag = 0;
   return CXK_SUCCESS;
 }
 
@@ -2602,7 +2758,7 @@ static int FinalizeImpl(cxk_context* ctx) {
   CXK_TRY(ctx->sys_sc.alloc(2));
   CXK_TRY(ctx->red_out.alloc(4));
   CXK_TRY(ctx->scal_out.alloc(8));
-  CXK_TRY(ctx->d_fail.alloc(1, true));
+  CXK_TRY(ctx->d_fail.alloc(2, true));
   ctx->use_ldlt = false;
   for (const IntList& dv : ctx->dual_vars)
     if (!dv.empty()) ctx->use_ldlt = true;  // kkt_solver.cc:180-186
@@ -2772,11 +2928,12 @@ __global__ void copy_doubles(int n, const double* __restrict__ src, double* __re
 }
 
 __global__ void mailbox_pack(const double* __restrict__ red, const double* __restrict__ scal,
-                             const int* __restrict__ fail, double seq, double* __restrict__ mb) {
+                             const int* __restrict__ fail, int tag, double seq, double* __restrict__ mb) {
   const int t = threadIdx.x;
   if (t < 4) mb[t] = red[t];
   if (t >= 4 && t < 10) mb[t] = scal[t - 4];
-  if (t == 10) mb[10] = (double)*fail;
+  // fail[1] == tag: a pivot failed in the first factor level of the latest fused launch
+  if (t == 10) mb[10] = (fail[0] != 0 || (tag != 0 && fail[1] == tag)) ? 1.0 : 0.0;
   __threadfence_system();
   __syncthreads();
   if (t == 0) mb[11] = seq;
@@ -2790,7 +2947,7 @@ int SyncMailbox(cxk_context* ctx) {
     ctx->mb[11] = -1.0;
   }
   const long long want = ++ctx->seq;
-  mailbox_pack<<<1, 64, 0, ctx->stream>>>(ctx->red_out.p, ctx->scal_out.p, ctx->d_fail.p, (double)want, ctx->mb);
+  mailbox_pack<<<1, 64, 0, ctx->stream>>>(ctx->red_out.p, ctx->scal_out.p, ctx->d_fail.p, ctx->fail_tag, (double)want, ctx->mb);
   CXK_TRY(hipGetLastError());
   // spin on the sequence number (a stream synchronisation costs tens of microseconds of driver
   // wake-up); the stream is polled now and then so that a failed launch cannot hang the host
@@ -2812,6 +2969,7 @@ int SyncMailbox(cxk_context* ctx) {
 int cxk_factor_async(cxk_context* ctx) {
   CXK_ENTER(ctx);
   CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));
+  ctx->fail_tag = 0;
   if (LaunchTree(ctx, 0, false, false)) return CXK_FAILURE;
   ctx->factor_seq = ++ctx->seq;
   return CXK_SUCCESS;
@@ -2850,6 +3008,7 @@ int cxk_factor_solve_async(cxk_context* ctx, double cb, double cq, double cw) {
   build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, cb, cq, cw, ctx->b.p, ctx->AQc.p, ctx->AW.p,
                                                            ctx->y.p, ctx->d_fail.p);
   CXK_TRY(hipGetLastError());
+  ctx->fail_tag = 0;
   ctx->rhs_c[0] = cb;
   ctx->rhs_c[1] = cq;
   ctx->rhs_c[2] = cw;
@@ -2865,6 +3024,7 @@ int cxk_factor_direction_async(cxk_context* ctx, double k, double bs, double cs)
   build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p, ctx->y.p,
                                                       ctx->d_fail.p);
   CXK_TRY(hipGetLastError());
+  ctx->fail_tag = 0;
   ctx->rhs_c[0] = k * bs;
   ctx->rhs_c[1] = k * cs;
   ctx->rhs_c[2] = -2.0;
@@ -2993,11 +3153,23 @@ int cxk_step_scalars(cxk_context* ctx, double* out6) {
 int cxk_kkt_solve_async(cxk_context* ctx, double k, double bs, double cs) {
   CXK_ENTER(ctx);
   if (LaunchSchur(ctx)) return CXK_FAILURE;
-  if (LaunchGather(ctx, true, k, bs, cs)) return CXK_FAILURE;
+  // single GPU, Cholesky, no refinement copies of the assembled system: the assembly rides in
+  // the first factor level's launch (BuildPlans decides whether the tree allows it)
+  const bool fused = ctx->fused_asm && ctx->world == 1 && ctx->solver_mode != 2 && ctx->refine_iters <= 0 && !ctx->no_lean;
+  if (fused) {
+    ctx->asm_pending.on = true;
+    ctx->asm_pending.with_rhs = true;
+    ctx->asm_pending.k = k;
+    ctx->asm_pending.bs = bs;
+    ctx->asm_pending.cs = cs;
+  } else if (LaunchGather(ctx, true, k, bs, cs)) {
+    return CXK_FAILURE;
+  }
   ctx->rhs_c[0] = k * bs;
   ctx->rhs_c[1] = k * cs;
   ctx->rhs_c[2] = -2.0;
   if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;  // sharded contexts: local sweep, all-reduce, top, back
+  CXK_DEMAND(!ctx->asm_pending.on, "internal error: the folded assembly was not launched");
   ctx->factor_seq = ++ctx->seq;
   return CXK_SUCCESS;
 }
@@ -3367,6 +3539,8 @@ int cxk_count_sparse_lmi(const cxk_context* ctx) {
   for (size_t i = 0; i < ctx->cons.size(); i++) k += ctx->cons[i].type == CXK_LMI && ctx->owned[i] && ctx->cons[i].sparse;
   return k;
 }
+
+int cxk_fused_assembly(const cxk_context* ctx) { return ctx && ctx->fused_asm ? 1 : 0; }
 
 int cxk_count_lmi_kernel(const cxk_context* ctx, int which) {
   if (!ctx || !ctx->device_ready) return -1;

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "cxk_assembly_work": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "cxk_count_sparse_lmi": (C.c_int, [C.c_void_p]),
     "cxk_count_lmi_kernel": (C.c_int, [C.c_void_p, C.c_int]),
+    "cxk_fused_assembly": (C.c_int, [C.c_void_p]),
     "cxk_set_reference_identity": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_set_solver_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_phase_timers": (C.c_int, [C.c_void_p, C.c_int]),
@@ -550,6 +551,10 @@ class KktContext:
     def count_sparse_lmi(self):
         """Constraints on the sparse-LMI evaluation path (cxk_count_sparse_lmi)."""
         return self.L.cxk_count_sparse_lmi(self.h)
+
+    def fused_assembly(self):
+        """True when the assembly rides in the first factor level's launch (cxk_fused_assembly)."""
+        return bool(self.L.cxk_fused_assembly(self.h))
 
     def count_lmi_kernel(self, which):
         """Constraints whose Schur block comes from kernel `which` (cxk_count_lmi_kernel): 0 literal,

@@ -60,7 +60,51 @@ def test_lmi_tree_lean_equals_generic(K, branching):
         return k
 
     lean, generic = both_paths(make)
+    # a clique tree's leaves take their panels straight from the Schur blocks (the assembly rides in
+    # the first factor level's launch); the generic path assembles in a launch of its own
+    assert lean.fused_assembly() == (branching > 1) and not generic.fused_assembly()
     assert_same_bits(lean, generic, prob["b"])
+
+
+def test_fused_assembly_equals_separate_assembly_launch():
+    """tree_factor_level_asm against the same lean kernels behind assemble_gather
+    (CXK_NO_FUSED_ASM=1): direction, factor, AW / AQc (through the step scalars) bit for bit, and a
+    failed pivot in the first level is reported."""
+    prob = syn.lmi_problem(K=230, n=20, m=20, branching=8, overlap=5, seed=21)
+    W = syn.scaling_points(230, 20, seed=22)
+
+    def make():
+        k = syn.build(KktContext, prob, "lmi", device=0)
+        for i in range(k.K):
+            k.set_W(i, W[i])
+        return k
+
+    fused = make()
+    os.environ["CXK_NO_FUSED_ASM"] = "1"
+    try:
+        plain = make()
+    finally:
+        os.environ.pop("CXK_NO_FUSED_ASM", None)
+    assert fused.fused_assembly() and not plain.fused_assembly()
+    assert_same_bits(fused, plain, prob["b"])
+    for k in (fused, plain):
+        k.kkt_solve_async(0.7, 0.9, 0.8)
+    assert np.array_equal(fused.step_scalars(), plain.step_scalars())
+    # an indefinite scaling point on a leaf: the factorization must report failure on both paths
+    bad = W[prob_leaf(fused)].copy()
+    bad[0, 0] = -1e3
+    for k in (fused, plain):
+        k.set_W(prob_leaf(fused), bad)
+        ok, _ = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+        assert ok == 0
+        k.set_W(prob_leaf(fused), W[prob_leaf(fused)])
+        ok, _ = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+        assert ok == 1
+
+
+def prob_leaf(k):
+    """A constraint eliminated at a leaf of the tree: the last one of an 8-ary tree in BFS order."""
+    return k.K - 1
 
 
 def test_soc_tree_lean_equals_generic():
