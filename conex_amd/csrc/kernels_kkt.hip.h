@@ -223,9 +223,10 @@ struct SnRec {
 };
 static_assert(sizeof(SnRec) == 128, "SnRec is read as 32 lanes x 4 bytes");
 
-__device__ __forceinline__ SnRec LoadRec(const SnRec* __restrict__ rec, int pos) {
-  const int lane = threadIdx.x & 63;
-  const int w = reinterpret_cast<const int*>(rec + pos)[lane & 31];
+__device__ __forceinline__ int LoadRecWord(const SnRec* __restrict__ rec, int pos) {
+  return reinterpret_cast<const int*>(rec + pos)[threadIdx.x & 31];
+}
+__device__ __forceinline__ SnRec DecodeRec(int w) {
   auto f = [&](int i) { return __builtin_amdgcn_readlane(w, i); };
   auto f64 = [&](int i) { return ((int64_t)f(i + 1) << 32) | (uint32_t)f(i); };
   SnRec R;
@@ -249,6 +250,35 @@ __device__ __forceinline__ SnRec LoadRec(const SnRec* __restrict__ rec, int pos)
 #pragma unroll
   for (int q = 0; q < 8; q++) R.sep[q] = f(24 + q);
   return R;
+}
+__device__ __forceinline__ SnRec LoadRec(const SnRec* __restrict__ rec, int pos) { return DecodeRec(LoadRecWord(rec, pos)); }
+
+// The root of the tree (no separator) solved backward straight from the registers of its upward
+// step: the rows of L go through an LDS image with an odd stride (my[65 j + row]) and come back
+// as columns; arithmetic and order are BackwardSupernodeLean's, so are the bits.  `y` is the
+// forward-solved right-hand side of lane's row.  Needs 65 NSMAX doubles at `my`.
+template <int NSMAX, bool DIAG_IN_ROWS, int LEN>
+__device__ __forceinline__ double RootBackward(const double (&a)[LEN], double dg, double y, int ns, double* __restrict__ my) {
+  const int lane = threadIdx.x & 63;
+  const bool active = lane < ns;
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++) my[65 * j + lane] = a[j];
+  WaveSync();
+  double col[NSMAX];
+#pragma unroll
+  for (int k = 0; k < NSMAX; k++) col[k] = my[65 * (active ? lane : 0) + k];
+  if constexpr (DIAG_IN_ROWS) dg = my[66 * (active ? lane : 0)];  // a[lane] of the own row
+#pragma unroll
+  for (int k = 0; k < NSMAX; k++) col[k] = (active && k > lane && k < ns) ? col[k] : 0.0;
+  dg = active ? dg : 1.0;
+  double acc = active ? y : 0.0;
+  const double dinv = 1.0 / dg;
+#pragma unroll
+  for (int k = NSMAX - 1; k >= 0; k--) {
+    if (lane == k) acc *= dinv;
+    acc = fma(-col[k], ReadLane(acc, k), acc);  // col[k] is zero for lanes >= k
+  }
+  return acc;
 }
 
 // A supernode without descendants whose panel is a permuted block of ONE constraint's Schur block
@@ -711,7 +741,7 @@ __device__ __forceinline__ bool FastPull(const SnRec& R) {
   return R.tg_end - R.tg_beg <= kFastTargets && R.m <= kFastSlots && R.mf <= kFastSlots;
 }
 
-template <int NSMAX, int SMAX, bool RHS, bool ASM = false>
+template <int NSMAX, int SMAX, bool RHS, bool ASM = false, bool ROOTBACK = false>
 __device__ __forceinline__ void FactorSupernodeLean(const FactorPlan& P, const SnRec& R,
                                                     double* __restrict__ slab, double* __restrict__ rhs,
                                                     int* __restrict__ fail, double* __restrict__ my,
@@ -859,6 +889,13 @@ __device__ __forceinline__ void FactorSupernodeLean(const FactorPlan& P, const S
 #pragma unroll
   for (int j = 0; j < NSMAX; j++)
     if (j < lim) base[o0 + j * st] = a[j];
+  if constexpr (ROOTBACK) {
+    // the chain's last step: the root is solved backward from these registers (tree_chain_lean)
+    static_assert(RHS, "the root is solved backward only with a right-hand side");
+    const double yv = RootBackward<NSMAX, true>(a, 0.0, a[RB], ns, my);
+    if (is_row) rhs[R.start + lane] = yv;
+    return;
+  }
   if (RHS && is_row) rhs[R.start + lane] = a[RB];
   CXK_STAMP(4);
   if (is_sep) {
@@ -925,10 +962,10 @@ __device__ inline void BackwardSupernodeRows(const FactorPlan& P, const SnRec& R
 // L, lane NSMAX + c holds column c of the off block.  Operations and their order are those of the
 // generic kernel (reciprocal of the diagonal, multiply-then-subtract substitution, fma chain over
 // the rows for t[c]), so the results are the same bits.  Needs dense forward slots (R.mf <= 8).
-template <int NSMAX, int SMAX>
+template <int NSMAX, int SMAX, bool ROOTBACK = false>
 __device__ __forceinline__ void ForwardSupernodeLean(const FactorPlan& P, const SnRec& R,
                                                      const double* __restrict__ slab,
-                                                     double* __restrict__ rhs) {
+                                                     double* __restrict__ rhs, double* __restrict__ my = nullptr) {
   constexpr int MFMAX = kFastSlots;
   const int lane = threadIdx.x & 63;
   const int ns = R.ns, s = R.nsep;
@@ -971,6 +1008,11 @@ __device__ __forceinline__ void ForwardSupernodeLean(const FactorPlan& P, const 
       dot = fma(a[k], bk, dot);
     else
       b -= a[k] * bk;  // a[k] is zero for lanes <= k
+  }
+  if constexpr (ROOTBACK) {  // the chain's last step (no separator): straight back down from these registers
+    const double yv = RootBackward<NSMAX, false>(a, dg, b, ns, my);
+    if (is_row) rhs[R.start + lane] = yv;
+    return;
   }
   if (is_row) rhs[R.start + lane] = b;
   if constexpr (SMAX > 0)
@@ -1433,36 +1475,77 @@ tree_backward_level2(const SnRec* __restrict__ recs, int baseA, int cntA, int bl
 // what leads to it) -- as one launch of ONE wavefront: steps up (MODE 0 factor + forward, MODE 1
 // forward) and straight back down.  Consecutive steps are dependent anyway, so a launch per level
 // buys nothing here; the wavefront passes its published values to itself through memory
-// (workgroup-scope fence between steps: one CU, one L1).  Shapes A and B cover the chain's supernodes.
+// (workgroup-scope fence between steps: one CU, one L1).  Shapes A and B cover the chain's
+// supernodes.  Dependent memory round trips are what a step costs (~1.2 us each), so: the
+// records come from consecutive positions (no table look-up), each is fetched while the step
+// before it runs and kept in LDS for the way down, and the root turns around in registers.
 template <int MODE, int NA, int SA, int NB, int SB>
 __global__ void __launch_bounds__(64)
-tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, const int* __restrict__ level_ptr, int l0,
-                int l1, double* __restrict__ slab, double* __restrict__ rhs, int* __restrict__ fail) {
+tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, int pos0, int n, double* __restrict__ slab,
+                double* __restrict__ rhs, int* __restrict__ fail) {
   extern __shared__ double lds[];
-  for (int l = l0; l < l1; l++) {
-    const SnRec R = LoadRec(recs, level_ptr[l]);
-    const bool isA = RegisterShape(R.ns, R.nsep) == (NA << 8 | SA);
+  // One supernode per level: the chain's records are consecutive in level order (pos0 ..).  Each
+  // record is in flight while the step before it runs, and stays in LDS for the way back down.
+  constexpr int IMG = 65 * (NA > NB ? NA : NB);  // RootBackward's image (>= the pull image of 64 columns)
+  int* rec_lds = reinterpret_cast<int*>(lds + IMG);
+  const int lane = threadIdx.x & 63;
+#ifdef CXK_DEBUG_STAMPS
+  if (threadIdx.x == 0) g_cxk_stamp[80] = __builtin_amdgcn_s_memtime();
+#endif
+  int wnext = LoadRecWord(recs, pos0);
+  for (int q = 0; q < n; q++) {
+#ifdef CXK_DEBUG_STAMPS
+    if (threadIdx.x == 0) {
+      g_cxk_sel = 1;
+      g_cxk_lvl = q;
+      g_cxk_stamp[8 * q + 6] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+    const int w = wnext;
+    if (q + 1 < n) wnext = LoadRecWord(recs, pos0 + q + 1);
+    if (lane < 32) rec_lds[32 * q + lane] = w;
+    const SnRec R = DecodeRec(w);
+    const int shape = RegisterShape(R.ns, R.nsep);
+    const bool isA = shape == (NA << 8 | SA);
+    // the last step is the root (no separator): solved backward from the registers of its
+    // upward step (shape B; a root of another shape takes the steps through memory like the rest)
+    const bool root = q + 1 == n && shape == (NB << 8 | SB) && R.nsep == 0;
     if constexpr (MODE == 0) {
-      if (isA)
+      if (root)
+        FactorSupernodeLean<NB, SB, true, false, true>(P, R, slab, rhs, fail, lds);
+      else if (isA)
         FactorSupernodeLean<NA, SA, true>(P, R, slab, rhs, fail, lds);
       else
         FactorSupernodeLean<NB, SB, true>(P, R, slab, rhs, fail, lds);
     } else {
-      if (isA)
+      if (root)
+        ForwardSupernodeLean<NB, SB, true>(P, R, slab, rhs, lds);
+      else if (isA)
         ForwardSupernodeLean<NA, SA>(P, R, slab, rhs);
       else
         ForwardSupernodeLean<NB, SB>(P, R, slab, rhs);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#ifdef CXK_DEBUG_STAMPS
+    if (threadIdx.x == 0) g_cxk_stamp[8 * q + 7] = __builtin_amdgcn_s_memtime();
+#endif
+    if (root) n--;  // done with the root: the way down starts below it
   }
-  for (int l = l1 - 1; l >= l0; l--) {
-    const SnRec R = LoadRec(recs, level_ptr[l]);
+  WaveSync();
+#ifdef CXK_DEBUG_STAMPS
+  if (threadIdx.x == 0) g_cxk_sel = 2;
+#endif
+  for (int q = n - 1; q >= 0; q--) {
+    const SnRec R = DecodeRec(rec_lds[32 * q + (lane & 31)]);
     const bool isA = RegisterShape(R.ns, R.nsep) == (NA << 8 | SA);
     if (isA)
       BackwardSupernodeLean<NA, SA>(R, slab, rhs);
     else
       BackwardSupernodeLean<NB, SB>(R, slab, rhs);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#ifdef CXK_DEBUG_STAMPS
+    if (threadIdx.x == 0) g_cxk_stamp[72 + q] = __builtin_amdgcn_s_memtime();
+#endif
   }
 }
 

@@ -1978,17 +1978,20 @@ int LaunchTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
 // straight back down in one launch of one wavefront.  mode 0 factor + forward, mode 1 forward.
 int LaunchChain(cxk_context* ctx, int mode) {
   const int nlev = (int)ctx->level_ptr.size() - 1;
+  // one supernode per chain level: their records are consecutive in level order
+  const int pos0 = ctx->level_ptr[ctx->chain_level], nchain = nlev - ctx->chain_level;
     const int sa = ctx->chain_a, sb = ctx->chain_b;
     bool done = false;
 #define CXK_CHAIN(NA_, SA_, NB_, SB_)                                                                       \
   if (!done && sa == ((NA_) << 8 | (SA_)) && sb == ((NB_) << 8 | (SB_))) {                                  \
     done = true;                                                                                            \
+    const size_t lds = sizeof(double) * 65 * ((NA_) > (NB_) ? (NA_) : (NB_)) + sizeof(SnRec) * (size_t)nchain; \
     if (mode == 0)                                                                                          \
-      tree_chain_lean<0, NA_, SA_, NB_, SB_><<<1, 64, ctx->chol_lds, ctx->stream>>>(                        \
-          ctx->plan, ctx->p_rec.p, ctx->d_level_ptr.p, ctx->chain_level, nlev, ctx->slab.p, ctx->y.p, ctx->d_fail.p); \
+      tree_chain_lean<0, NA_, SA_, NB_, SB_><<<1, 64, lds, ctx->stream>>>(                                  \
+          ctx->plan, ctx->p_rec.p, pos0, nchain, ctx->slab.p, ctx->y.p, ctx->d_fail.p);                     \
     else                                                                                                    \
-      tree_chain_lean<1, NA_, SA_, NB_, SB_><<<1, 64, ctx->chol_lds, ctx->stream>>>(                        \
-          ctx->plan, ctx->p_rec.p, ctx->d_level_ptr.p, ctx->chain_level, nlev, ctx->slab.p, ctx->y.p, ctx->d_fail.p); \
+      tree_chain_lean<1, NA_, SA_, NB_, SB_><<<1, 64, lds, ctx->stream>>>(                                  \
+          ctx->plan, ctx->p_rec.p, pos0, nchain, ctx->slab.p, ctx->y.p, ctx->d_fail.p);                     \
   }
     CXK_CHAIN(8, 8, 8, 8)
     CXK_CHAIN(16, 8, 16, 8)
