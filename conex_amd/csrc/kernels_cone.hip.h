@@ -404,12 +404,35 @@ __global__ void static_schur(StaticGroup g, Arena ar) {
   }
 }
 
+// What the host reads after a round trip, written into its pinned mailbox by the first 64 threads
+// of a workgroup (all of them must call): the four reduction outputs, the six step scalars, the
+// factorization flag, then -- after a system-scope fence -- the sequence number the host spins on.
+struct MailboxArgs {
+  const double* red;   // [4]
+  const double* scal;  // [6]
+  const int* fail;     // [2]: flag, tag of a failed first-level pivot of a fused launch
+  int tag;
+  double seq;
+  double* mb;          // pinned host memory, 16 doubles; nullptr: no mailbox write
+};
+__device__ __forceinline__ void MailboxPack(const MailboxArgs& m) {
+  const int t = threadIdx.x;
+  if (t < 4) m.mb[t] = m.red[t];
+  if (t >= 4 && t < 10) m.mb[t] = m.scal[t - 4];
+  // fail[1] == tag: a pivot failed in the first factor level of the latest fused launch
+  if (t == 10) m.mb[10] = (m.fail[0] != 0 || (m.tag != 0 && m.fail[1] == m.tag)) ? 1.0 : 0.0;
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) m.mb[11] = m.seq;
+}
+
 // Fixed-order reduction of the per-constraint step outputs on one workgroup.
 // mode 0: info2 -> {sum normsqrd, max norminfd (init -1)}
 // mode 1: info4 -> {min lambda_min (init 30000), max lambda_max (init -30000), sum frob, sum trace}
+// With a mailbox the results travel to the host from this launch (no separate mailbox_pack).
 __global__ void __launch_bounds__(256)
 reduce_step_info(int K, int mode, const double* __restrict__ info, const unsigned char* __restrict__ mask,
-                 double* __restrict__ out) {
+                 double* __restrict__ out, MailboxArgs mbx) {
   __shared__ double red[8];
   __shared__ double red2[8];
   double a = 0, b = (mode == 0) ? -1.0 : 30000.0, c = -30000.0, d = 0;
@@ -473,6 +496,11 @@ reduce_step_info(int K, int mode, const double* __restrict__ info, const unsigne
       out[2] = a;
       out[3] = d;
     }
+  }
+  if (mbx.mb) {
+    __threadfence();  // out[] is read back below by other threads of this workgroup
+    __syncthreads();
+    MailboxPack(mbx);
   }
 }
 

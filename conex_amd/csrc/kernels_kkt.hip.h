@@ -52,8 +52,9 @@ struct GatherArgs {
   int K;
   const double* sc;
   double* sys_sc;
-  int with_rhs;
+  int with_rhs;  // 1: y = k (b bs + AQc cs) - 2 AW (build_rhs), 2: y = cb b + cq AQc + cw AW (build_rhs_comb)
   double k, bs, cs;
+  double cb, cq, cw;
   const double* b;
   double* y;
   int* fail;
@@ -93,7 +94,8 @@ __device__ __forceinline__ void GatherBody(const GatherArgs& a, int block, int n
     if (hp) {
       a.AW[var] = aw;
       a.AQc[var] = aq;
-      if (a.with_rhs) a.y[var] = a.k * (bp * a.bs + aq * a.cs) - 2 * aw;
+      if (a.with_rhs == 1) a.y[var] = a.k * (bp * a.bs + aq * a.cs) - 2 * aw;
+      if (a.with_rhs == 2) a.y[var] = a.cb * bp + a.cq * aq + a.cw * aw;
     }
   }
   if (block == 0) {  // <w,c> and <c,Qc>: fixed-order strided partial sums + block sum
@@ -299,6 +301,8 @@ struct AsmIn {
   const double *G, *AWc, *AQcc, *b;
   double *AW, *AQc;
   double k, bs, cs;   // y = k (b bs + AQc cs) - 2 AW  (cone_program.cc:409-411)
+  double cb, cq, cw;  // or (comb != 0) y = cb b + cq AQc + cw AW  (cone_program.cc:181, 504)
+  int comb;
   int tag;            // a failed pivot writes fail[1] = tag (fail[0] is being reset by the gather beside it)
 };
 
@@ -837,7 +841,13 @@ __device__ __forceinline__ void FactorSupernodeLean(const FactorPlan& P, const S
       ai->AW[R.start + lane] = awv;
       ai->AQc[R.start + lane] = aqv;
     }
-    if constexpr (RHS) rb = ai->k * (rb * ai->bs + aqv * ai->cs) - 2 * awv;
+    if constexpr (RHS) {
+      // the expressions of build_rhs / build_rhs_comb, term for term
+      if (ai->comb)
+        rb = ai->cb * rb + ai->cq * aqv + ai->cw * awv;
+      else
+        rb = ai->k * (rb * ai->bs + aqv * ai->cs) - 2 * awv;
+    }
   }
 #pragma unroll
   for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? a[j] : 0.0;

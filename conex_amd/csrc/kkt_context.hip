@@ -217,9 +217,11 @@ struct cxk_context {
   int64_t as_T2 = 0;
   int rs_N2 = 0;
   struct AsmPending {
-    bool on = false, with_rhs = false;
-    double k = 0, bs = 0, cs = 0;
+    bool on = false;
+    int with_rhs = 0;  // GatherArgs::with_rhs
+    double k = 0, bs = 0, cs = 0, cb = 0, cq = 0, cw = 0;
   } asm_pending;
+  bool asm_deferred = false;  // cxk_assemble ran the Schur kernels; the gather waits for the factorization that follows
   int asm_tag = 0;    // tag of the latest fused launch (a failed pivot there writes d_fail[1] = tag)
   int fail_tag = 0;   // what mailbox_pack compares d_fail[1] with: asm_tag, or 0 after any other factorization
   FactorPlan plan{};
@@ -1649,7 +1651,7 @@ int LaunchSchur(cxk_context* ctx) {
   return CXK_SUCCESS;
 }
 
-GatherArgs MakeGather(cxk_context* ctx, bool with_rhs, double k, double bs, double cs) {
+GatherArgs MakeGather(cxk_context* ctx, int with_rhs, double k, double bs, double cs) {
   GatherArgs a;
   a.T = ctx->as_T;
   a.rec = ctx->as_rec.p;
@@ -1671,6 +1673,7 @@ GatherArgs MakeGather(cxk_context* ctx, bool with_rhs, double k, double bs, doub
   a.k = k;
   a.bs = bs;
   a.cs = cs;
+  a.cb = a.cq = a.cw = 0;
   a.b = ctx->b.p;
   a.y = ctx->y.p;
   a.fail = ctx->d_fail.p;
@@ -1678,7 +1681,7 @@ GatherArgs MakeGather(cxk_context* ctx, bool with_rhs, double k, double bs, doub
 }
 
 int LaunchGather(cxk_context* ctx, bool with_rhs, double k, double bs, double cs) {
-  const GatherArgs a = MakeGather(ctx, with_rhs, k, bs, cs);
+  const GatherArgs a = MakeGather(ctx, with_rhs ? 1 : 0, k, bs, cs);
   assemble_gather<<<GridFor((size_t)std::max<int64_t>(ctx->as_T, ctx->md.N), 256), 256, 0,
                     ctx->stream>>>(a);
   CXK_TRY(hipGetLastError());
@@ -1837,6 +1840,9 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
           const cxk_context::AsmPending ap = ctx->asm_pending;
           ctx->asm_pending.on = false;
           GatherArgs ga = MakeGather(ctx, ap.with_rhs, ap.k, ap.bs, ap.cs);
+          ga.cb = ap.cb;
+          ga.cq = ap.cq;
+          ga.cw = ap.cw;
           ga.T = ctx->as_T2;
           ga.rec = ctx->as_rec2.p;
           ga.N = ctx->rs_N2;
@@ -1853,6 +1859,10 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
           ai.k = ap.k;
           ai.bs = ap.bs;
           ai.cs = ap.cs;
+          ai.cb = ap.cb;
+          ai.cq = ap.cq;
+          ai.cw = ap.cw;
+          ai.comb = ap.with_rhs == 2;
           ctx->asm_tag = ctx->asm_tag >= (1 << 30) ? 1 : ctx->asm_tag + 1;
           ai.tag = ctx->fail_tag = ctx->asm_tag;
           // 256 threads per workgroup whatever the level's size: the gather's fixed-order sums
@@ -1864,7 +1874,7 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
 #define CXK_LEVEL_ASM(NS_, S_)                                                                          \
   if (sh == ((NS_) << 8 | (S_))) {                                                                      \
     done = true;                                                                                        \
-    if (ap.with_rhs)                                                                                    \
+    if (ap.with_rhs != 0)                                                                               \
       tree_factor_level_asm<NS_, S_, true><<<g + gg, w * 64, lds, ctx->stream>>>(                       \
           ctx->plan, ctx->p_rec.p, sg.begin, cnt, ctx->slab.p, rhs, ctx->d_fail.p, per_wave, ai, ga, g); \
     else                                                                                                \
@@ -2304,9 +2314,25 @@ struct DeviceGuard {
   DeviceGuard(const DeviceGuard&) = delete;
   DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
-#define CXK_ENTER(ctx)                          \
+// cxk_kkt_solve_async and the factor-and-solve entry points fold the assembly into the first
+// factor level when the tree allows it (BuildPlans) and nothing needs the assembled system as
+// such: single GPU, Cholesky sweeps, no refinement copy.
+bool FusedAssembly(const cxk_context* ctx) {
+  return ctx->fused_asm && ctx->world == 1 && ctx->solver_mode != 2 && ctx->refine_iters <= 0 && !ctx->no_lean;
+}
+// cxk_assemble leaves the gather to the factorization that normally follows; any other entry point
+// that runs first gets the assembled system by the separate launch.
+int FlushDeferred(cxk_context* ctx) {
+  if (!ctx->asm_deferred) return CXK_SUCCESS;
+  ctx->asm_deferred = false;
+  return LaunchGather(ctx, false, 0, 0, 0);
+}
+#define CXK_ENTER_KEEP(ctx)                     \
   if (CheckReady(ctx)) return CXK_FAILURE;      \
   DeviceGuard cxk_device_guard_((ctx)->device)
+#define CXK_ENTER(ctx)   \
+  CXK_ENTER_KEEP(ctx);   \
+  if (FlushDeferred(ctx)) return CXK_FAILURE
 
 }  // namespace
 
@@ -2914,12 +2940,17 @@ int cxk_set_W(cxk_context* ctx, int i, const double* in) {
 
 // ------------------------------------------------------------- Newton step
 int cxk_assemble_local(cxk_context* ctx) {
-  CXK_ENTER(ctx);
+  CXK_ENTER_KEEP(ctx);
+  ctx->asm_deferred = false;  // a gather still pending would describe the previous Schur blocks
   if (LaunchSchur(ctx)) return CXK_FAILURE;
+  if (FusedAssembly(ctx)) {
+    ctx->asm_deferred = true;  // rides in the factorization that follows (or FlushDeferred)
+    return CXK_SUCCESS;
+  }
   return LaunchGather(ctx, false, 0, 0, 0);
 }
 
-int cxk_finish_assemble(cxk_context* ctx) { return CheckReady(ctx); }
+int cxk_finish_assemble(cxk_context* ctx) { return CheckReady(ctx); }  // (a deferred gather stays deferred)
 
 int cxk_assemble(cxk_context* ctx) {
   if (cxk_assemble_local(ctx)) return CXK_FAILURE;
@@ -2930,28 +2961,27 @@ __global__ void copy_doubles(int n, const double* __restrict__ src, double* __re
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-__global__ void mailbox_pack(const double* __restrict__ red, const double* __restrict__ scal,
-                             const int* __restrict__ fail, int tag, double seq, double* __restrict__ mb) {
-  const int t = threadIdx.x;
-  if (t < 4) mb[t] = red[t];
-  if (t >= 4 && t < 10) mb[t] = scal[t - 4];
-  // fail[1] == tag: a pivot failed in the first factor level of the latest fused launch
-  if (t == 10) mb[10] = (fail[0] != 0 || (tag != 0 && fail[1] == tag)) ? 1.0 : 0.0;
-  __threadfence_system();
-  __syncthreads();
-  if (t == 0) mb[11] = seq;
-}
+__global__ void mailbox_pack(MailboxArgs m) { MailboxPack(m); }
 
-// Waits until everything enqueued so far has run and the mailbox carries its results.
-int SyncMailbox(cxk_context* ctx) {
+// The mailbox write of the next host round trip: as arguments of the kernel that produces the
+// last results (reduce_step_info), or of mailbox_pack.
+int NextMailbox(cxk_context* ctx, MailboxArgs* m) {
   if (!ctx->mb) {
     CXK_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->mb), 16 * sizeof(double), hipHostMallocDefault));
     for (int i = 0; i < 16; i++) ctx->mb[i] = 0.0;
     ctx->mb[11] = -1.0;
   }
-  const long long want = ++ctx->seq;
-  mailbox_pack<<<1, 64, 0, ctx->stream>>>(ctx->red_out.p, ctx->scal_out.p, ctx->d_fail.p, ctx->fail_tag, (double)want, ctx->mb);
-  CXK_TRY(hipGetLastError());
+  m->red = ctx->red_out.p;
+  m->scal = ctx->scal_out.p;
+  m->fail = ctx->d_fail.p;
+  m->tag = ctx->fail_tag;
+  m->seq = (double)(++ctx->seq);
+  m->mb = ctx->mb;
+  return CXK_SUCCESS;
+}
+
+// Waits until the mailbox carries sequence number `want`.
+int WaitMailbox(cxk_context* ctx, long long want) {
   // spin on the sequence number (a stream synchronisation costs tens of microseconds of driver
   // wake-up); the stream is polled now and then so that a failed launch cannot hang the host
   volatile double* flag = ctx->mb + 11;
@@ -2967,6 +2997,39 @@ int SyncMailbox(cxk_context* ctx) {
   std::atomic_thread_fence(std::memory_order_acquire);
   ctx->mb_seen = want;
   return CXK_SUCCESS;
+}
+
+// Waits until everything enqueued so far has run and the mailbox carries its results.
+int SyncMailbox(cxk_context* ctx) {
+  MailboxArgs m;
+  if (NextMailbox(ctx, &m)) return CXK_FAILURE;
+  mailbox_pack<<<1, 64, 0, ctx->stream>>>(m);
+  CXK_TRY(hipGetLastError());
+  return WaitMailbox(ctx, ctx->seq);
+}
+
+// reduce_step_info, then the host round trip: one launch on a single GPU (the results go to the
+// mailbox from the reduction itself), reduction + all-reduces + mailbox_pack when sharded.
+int ReduceStepInfoAndSync(cxk_context* ctx, int mode, const double* info) {
+  MailboxArgs m;
+  m.mb = nullptr;
+  const bool fold = ctx->world <= 1;
+  if (fold && NextMailbox(ctx, &m)) return CXK_FAILURE;
+  reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), mode, info, ctx->d_mask.p, ctx->red_out.p, m);
+  CXK_TRY(hipGetLastError());
+  if (fold) return WaitMailbox(ctx, ctx->seq);
+  if (mode == 0) {
+    // sharded: sum of normsqrd, max of norminfd over the ranks (each reduced its own constraints)
+    if (ShardAllReduce(ctx, ctx->red_out.p, 1, kOpSum) || ShardAllReduce(ctx, ctx->red_out.p + 1, 1, kOpMax))
+      return CXK_FAILURE;
+  } else {
+    // sharded: {min lambda_min, max lambda_max, sum frob, sum trace} over the ranks
+    if (ShardAllReduce(ctx, ctx->red_out.p, 1, kOpMin) || ShardAllReduce(ctx, ctx->red_out.p + 1, 1, kOpMax) ||
+        ShardAllReduce(ctx, ctx->red_out.p + 2, 2, kOpSum))
+      return CXK_FAILURE;
+  }
+  ctx->seq++;
+  return SyncMailbox(ctx);
 }
 
 int cxk_factor_async(cxk_context* ctx) {
@@ -3006,32 +3069,54 @@ int cxk_step_scalars_async(cxk_context* ctx) {
 // cxk_kkt_solve_async): y <- K^-1 (cb b + cq AQc + cw AW).  With (k bs, k cs, -2) this is the Newton
 // direction, with (-bs, cs, 0) the right-hand side of ComputeMuFromDivergence (cone_program.cc:173-214).
 int cxk_factor_solve_async(cxk_context* ctx, double cb, double cq, double cw) {
-  CXK_ENTER(ctx);
+  CXK_ENTER_KEEP(ctx);
   const int N = ctx->md.N;
-  build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, cb, cq, cw, ctx->b.p, ctx->AQc.p, ctx->AW.p,
-                                                           ctx->y.p, ctx->d_fail.p);
-  CXK_TRY(hipGetLastError());
-  ctx->fail_tag = 0;
+  if (ctx->asm_deferred && FusedAssembly(ctx)) {  // gather and right-hand side ride in the first factor level
+    ctx->asm_deferred = false;
+    ctx->asm_pending.on = true;
+    ctx->asm_pending.with_rhs = 2;
+    ctx->asm_pending.cb = cb;
+    ctx->asm_pending.cq = cq;
+    ctx->asm_pending.cw = cw;
+  } else {
+    if (FlushDeferred(ctx)) return CXK_FAILURE;
+    build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, cb, cq, cw, ctx->b.p, ctx->AQc.p, ctx->AW.p,
+                                                             ctx->y.p, ctx->d_fail.p);
+    CXK_TRY(hipGetLastError());
+    ctx->fail_tag = 0;
+  }
   ctx->rhs_c[0] = cb;
   ctx->rhs_c[1] = cq;
   ctx->rhs_c[2] = cw;
   if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;
+  CXK_DEMAND(!ctx->asm_pending.on, "internal error: the folded assembly was not launched");
   ctx->factor_seq = ++ctx->seq;
   return CXK_SUCCESS;
 }
 
 // cxk_factor_async + cxk_newton_direction in one upward pass: y <- K^-1 (k (b bs + AQc cs) - 2 AW).
 int cxk_factor_direction_async(cxk_context* ctx, double k, double bs, double cs) {
-  CXK_ENTER(ctx);
+  CXK_ENTER_KEEP(ctx);
   const int N = ctx->md.N;
-  build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p, ctx->y.p,
-                                                      ctx->d_fail.p);
-  CXK_TRY(hipGetLastError());
-  ctx->fail_tag = 0;
+  if (ctx->asm_deferred && FusedAssembly(ctx)) {
+    ctx->asm_deferred = false;
+    ctx->asm_pending.on = true;
+    ctx->asm_pending.with_rhs = 1;
+    ctx->asm_pending.k = k;
+    ctx->asm_pending.bs = bs;
+    ctx->asm_pending.cs = cs;
+  } else {
+    if (FlushDeferred(ctx)) return CXK_FAILURE;
+    build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p, ctx->y.p,
+                                                        ctx->d_fail.p);
+    CXK_TRY(hipGetLastError());
+    ctx->fail_tag = 0;
+  }
   ctx->rhs_c[0] = k * bs;
   ctx->rhs_c[1] = k * cs;
   ctx->rhs_c[2] = -2.0;
   if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;
+  CXK_DEMAND(!ctx->asm_pending.on, "internal error: the folded assembly was not launched");
   ctx->factor_seq = ++ctx->seq;
   return CXK_SUCCESS;
 }
@@ -3158,10 +3243,10 @@ int cxk_kkt_solve_async(cxk_context* ctx, double k, double bs, double cs) {
   if (LaunchSchur(ctx)) return CXK_FAILURE;
   // single GPU, Cholesky, no refinement copies of the assembled system: the assembly rides in
   // the first factor level's launch (BuildPlans decides whether the tree allows it)
-  const bool fused = ctx->fused_asm && ctx->world == 1 && ctx->solver_mode != 2 && ctx->refine_iters <= 0 && !ctx->no_lean;
+  const bool fused = FusedAssembly(ctx);
   if (fused) {
     ctx->asm_pending.on = true;
-    ctx->asm_pending.with_rhs = true;
+    ctx->asm_pending.with_rhs = 1;
     ctx->asm_pending.k = k;
     ctx->asm_pending.bs = bs;
     ctx->asm_pending.cs = cs;
@@ -3246,13 +3331,7 @@ int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_wei
     CXK_TRY(hipMemcpy(ctx->y_at_prepare.data(), ctx->y.p, sizeof(double) * ctx->md.N, hipMemcpyDeviceToHost));
   }
   if (affine) return CXK_SUCCESS;
-  reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), 0, ctx->info2.p, ctx->d_mask.p,
-                                               ctx->red_out.p);
-  // sharded: sum of normsqrd, max of norminfd over the ranks (each reduced its own constraints)
-  if (ShardAllReduce(ctx, ctx->red_out.p, 1, kOpSum) || ShardAllReduce(ctx, ctx->red_out.p + 1, 1, kOpMax))
-    return CXK_FAILURE;
-  ctx->seq++;
-  if (SyncMailbox(ctx)) return CXK_FAILURE;
+  if (ReduceStepInfoAndSync(ctx, 0, ctx->info2.p)) return CXK_FAILURE;
   info[0] = ctx->mb[0];
   info[1] = ctx->mb[1];
   return CXK_SUCCESS;
@@ -3329,15 +3408,8 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
       soc_prepare<1><<<cnt, 64, sizeof(double) * (size_t)(g.m + 3 * (g.n + 1)), ctx->stream>>>(
           MakeVec(g), sa);
   }
-  reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), 1, ctx->info4.p, ctx->d_mask.p,
-                                               ctx->red_out.p);
   CXK_TRY(hipGetLastError());
-  // sharded: {min lambda_min, max lambda_max, sum frob, sum trace} over the ranks
-  if (ShardAllReduce(ctx, ctx->red_out.p, 1, kOpMin) || ShardAllReduce(ctx, ctx->red_out.p + 1, 1, kOpMax) ||
-      ShardAllReduce(ctx, ctx->red_out.p + 2, 2, kOpSum))
-    return CXK_FAILURE;
-  ctx->seq++;
-  if (SyncMailbox(ctx)) return CXK_FAILURE;
+  if (ReduceStepInfoAndSync(ctx, 1, ctx->info4.p)) return CXK_FAILURE;
   for (int i = 0; i < 4; i++) out[i] = ctx->mb[i];
   return CXK_SUCCESS;
 }

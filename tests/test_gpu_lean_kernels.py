@@ -90,6 +90,23 @@ def test_fused_assembly_equals_separate_assembly_launch():
     for k in (fused, plain):
         k.kkt_solve_async(0.7, 0.9, 0.8)
     assert np.array_equal(fused.step_scalars(), plain.step_scalars())
+    # the interior-point loop's order of calls: cxk_assemble leaves the gather to the factor-and-solve
+    # entry point that follows (right-hand side in either form); any other call in between takes
+    # the separate launch.  Same bits every way.
+    for call in ("factor_solve", "factor_direction", "scalars_first"):
+        ys = []
+        for k in (fused, plain):
+            k.assemble()
+            if call == "scalars_first":
+                sc = k.step_scalars()          # needs AW / AQc of the assembled system: flushes the gather
+            if call == "factor_direction":
+                k._check(k.L.cxk_factor_direction_async(k.h, 0.7, 0.9, 0.8), "factor_direction")
+            else:
+                k._check(k.L.cxk_factor_solve_async(k.h, -0.9, 0.8, 0.0), "factor_solve")
+            assert k.sync()
+            ys.append((k.get_y().copy(), k.slab().copy(), k.step_scalars()))
+        assert np.array_equal(ys[0][0], ys[1][0]) and np.array_equal(ys[0][1], ys[1][1], equal_nan=True)
+        assert np.array_equal(ys[0][2], ys[1][2])
     # an indefinite scaling point on a leaf: the factorization must report failure on both paths
     bad = W[prob_leaf(fused)].copy()
     bad[0, 0] = -1e3
