@@ -381,7 +381,10 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
   cxk_phase_timers(ctx, timers ? 1 : 0);
   if (cxk_set_solver_mode(ctx, cfg.kkt_solver)) return 0;  // solver->SetSolverMode(config.kkt_solver) :305
   double phase_prev[CXK_PHASE_COUNT] = {0, 0, 0, 0, 0};
-  if (timers) cxk_phase_read(ctx, phase_prev, 1);
+  if (timers) {  // start this solve's phase totals from zero
+    cxk_phase_read(ctx, phase_prev, 1);
+    for (int k = 0; k < CXK_PHASE_COUNT; k++) phase_prev[k] = 0;
+  }
   // solver.SetIterativeRefinementIterations(config.iterative_refinement_iterations)
   if (cxk_set_iterative_refinement(ctx, cfg.iterative_refinement_iterations > 0 ? cfg.iterative_refinement_iterations : 0))
     return 0;

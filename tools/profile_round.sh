@@ -16,6 +16,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench --
 python3 "$ROOT/bench.py" --workload c2 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -o bench -- \
   python3 "$ROOT/bench.py" --workload c2 --no-cpu --steps 50 > "$OUT/bench_c2_under_rocprof.log" 2>&1
+# timeline of one steady-state step; the interior-point loop through conex.h, wall and per kernel
+"$ROOT/tools/step_timeline.sh" c4 > "$OUT/step_timeline.txt" 2>&1
+python3 "$ROOT/tools/ipm_iteration.py" --timers > "$OUT/ipm_iteration.txt" 2>&1
+"$ROOT/tools/ipm_rocprof.sh" 2>&1 | grep -v "^[EW]20" > "$OUT/ipm_kernels.txt"
+cd /tmp
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU" \

@@ -24,7 +24,7 @@ def main():
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
     for name in ["bench_default.json", "bench_default_under_rocprof.log", "bench_c2.json",
-                 "bench_c2_under_rocprof.log"]:
+                 "bench_c2_under_rocprof.log", "step_timeline.txt", "ipm_iteration.txt", "ipm_kernels.txt"]:
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, name))
     for sub, out in [("stats", "bench_default_kernel_stats.csv"), ("stats_c2", "bench_c2_kernel_stats.csv")]:
@@ -34,7 +34,7 @@ def main():
     counters = {}
     for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             c = counters.setdefault(k, {}).setdefault(r["Counter_Name"], [0.0, 0])
             c[0] += float(r["Counter_Value"])
             c[1] += 1
@@ -47,10 +47,11 @@ def main():
                      for k, d in counters.items()},
     }
     for k, d in counters.items():
-        if "lmi_schur_fused" in k and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        key = "lmi_schur_mfma" if "lmi_schur_mfma" in k else ("lmi_schur_fused" if "lmi_schur_fused" in k else None)
+        if key and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             fetch = d["FETCH_SIZE"][0] / d["FETCH_SIZE"][1] * 1024
             write = d["WRITE_SIZE"][0] / d["WRITE_SIZE"][1] * 1024
-            summary["lmi_schur_fused"] = {
+            summary[key] = {
                 "FETCH_SIZE_bytes_raw": fetch,
                 "FETCH_SIZE_bytes_corrected_x2": 2 * fetch,
                 "WRITE_SIZE_bytes": write,
