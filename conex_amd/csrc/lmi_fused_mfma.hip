@@ -75,9 +75,12 @@ __device__ long long g_mfma_stamp[2 * 16 * 64];
 
 template <int N>
 struct MfmaCfg {
-  static_assert(N % 4 == 0 && N > 16 && N < 32, "one 16-column tile plus 4-column blocks");
+  static_assert(N % 4 == 0 && N >= 8 && N < 32, "one 16-column tile (part of it for N < 16) plus 4-column blocks");
   static constexpr int NK = N / 4;            // stage-1 k-steps = doubles of its row a lane holds
-  static constexpr int NC4 = (N - 16) / 4;    // 4-column blocks beside the 16-column tile
+  static constexpr int NC4 = N > 16 ? (N - 16) / 4 : 0;  // 4-column blocks beside the 16-column tile
+  static constexpr int NC4A = NC4 > 0 ? NC4 : 1;         // (array extent)
+  static constexpr int PIECES = 4 + NC4;      // stores per finished tile (StorePiece)
+  static constexpr bool NARROW = N < 16;      // the 16-column tile has columns past N: every store is masked
   static constexpr int LD = N + 1;            // odd row stride of the P image
   static constexpr int MS = N * LD + (6 - (N * LD) % 4) % 4;  // matrix stride = 2 (mod 4) doubles
   static constexpr int KSTEPS = N * N / 4;    // stage-2 k-steps
@@ -122,7 +125,8 @@ __device__ __forceinline__ void MakeGeom(TileGeom<N>& gm, int wave, int lane, in
     const bool real = t < nt1;
     t = real ? t : nt1 - 1;             // a slot past the last tile re-reads the last tile (results unused)
 #pragma unroll
-    for (int e = 0; e < 4; e++) gm.keep |= (real && 16 * t + q + 4 * e < rows ? 1u : 0u) << (8 * tt + e);
+    for (int e = 0; e < 4; e++)
+      gm.keep |= (real && 16 * t + q + 4 * e < rows && (!Cfg::NARROW || s < N) ? 1u : 0u) << (8 * tt + e);
     gm.keep |= (real && 16 * t + 4 * ((lane >> 2) & 3) + q < rows ? 1u : 0u) << (8 * tt + 4);
     int rho = 16 * t + s;
     rho = rho < rows ? rho : rows - 1;  // rows past the last matrix: any valid address, results unused
@@ -150,7 +154,7 @@ __device__ __forceinline__ void LoadTile(double (&a)[MfmaCfg<N>::NK], const Tile
 template <int N>
 struct WOps {  // stage-1 B operands of one constraint: k-step e uses W row q NK + e
   double w16[MfmaCfg<N>::NK];
-  double w4[MfmaCfg<N>::NC4][MfmaCfg<N>::NK];
+  double w4[MfmaCfg<N>::NC4A][MfmaCfg<N>::NK];
 };
 
 template <int N>
@@ -160,16 +164,20 @@ __device__ __forceinline__ void LoadW(WOps<N>& w, const double* __restrict__ Wg,
 #pragma unroll
   for (int e = 0; e < Cfg::NK; e++) {
     const double* row = Wg + (size_t)(q * Cfg::NK + e) * N;
-    w.w16[e] = row[s];
+    w.w16[e] = row[Cfg::NARROW && s >= N ? N - 1 : s];
 #pragma unroll
     for (int cb = 0; cb < Cfg::NC4; cb++) w.w4[cb][e] = row[16 + 4 * cb + j];
+  }
+  if constexpr (Cfg::NARROW) {  // columns past N of the 16-column tile: zero operand (their results are never stored)
+#pragma unroll
+    for (int e = 0; e < Cfg::NK; e++) w.w16[e] = s < N ? w.w16[e] : 0.0;
   }
 }
 
 template <int N>
 struct TileAcc {  // results of one tile: the 16-column MFMA tile and the 4-column blocks
   d4_t a16;
-  double a4[MfmaCfg<N>::NC4];
+  double a4[MfmaCfg<N>::NC4A];
 };
 
 // Piece e of a finished tile: pieces 0..3 are the 16x16x4 elements (rows (l >> 4) + 4 e, column
@@ -186,7 +194,8 @@ __device__ __forceinline__ void StorePiece(const TileAcc<N>& r, int e, double* _
 // Tile slot tt's MFMAs issue back to back; the stores of the PREVIOUS slot's results are dealt
 // into the gaps between them (an MFMA occupies the pipe for 64 / 16 cycles during which the wave
 // may issue LDS work), pinned there by the scheduling barriers.  A slot that still has MFMAs to
-// issue is never preceded by the ragged last tile, so these stores need no lane mask.
+// issue is never preceded by the ragged last tile, so these stores need no lane mask (orders below
+// 16 mask the tile's unused columns everywhere).
 template <int N, bool HAS_PREV>
 __device__ __forceinline__ void FullStep(TileAcc<N>& cur, const double (&a)[MfmaCfg<N>::NK], const WOps<N>& w,
                                          const TileAcc<N>& prev, double* __restrict__ Pb, const TileGeom<N>& gm, int tt) {
@@ -196,11 +205,16 @@ __device__ __forceinline__ void FullStep(TileAcc<N>& cur, const double (&a)[Mfma
   for (int e = 0; e < Cfg::NK; e++) {
     cur.a16 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], w.w16[e], e == 0 ? zero4 : cur.a16, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (HAS_PREV) StorePiece<N, false>(prev, e, Pb, gm, tt - 1);
+    if (HAS_PREV && e < Cfg::PIECES) StorePiece<N, Cfg::NARROW>(prev, e, Pb, gm, tt - 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int cb = 0; cb < Cfg::NC4; cb++)
       cur.a4[cb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[e], w.w4[cb][e], e == 0 ? 0.0 : cur.a4[cb], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (HAS_PREV && Cfg::PIECES > Cfg::NK) {  // fewer k-steps than pieces (N < 16): the rest follow
+#pragma unroll
+    for (int e = Cfg::NK; e < Cfg::PIECES; e++) StorePiece<N, Cfg::NARROW>(prev, e, Pb, gm, tt - 1);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -418,7 +432,7 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
         } else if (prev_ok) {
           // the wave's last tile (possibly the ragged last tile of the constraint: masked stores)
 #pragma unroll
-          for (int e = 0; e < NK; e++) StorePiece<N, true>(res[(tt & 1) ^ 1], e, Pb, gm, tt - 1);
+          for (int e = 0; e < Cfg::PIECES; e++) StorePiece<N, true>(res[(tt & 1) ^ 1], e, Pb, gm, tt - 1);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (it == 2) MSTAMP(49 + 2 * tt);
@@ -589,6 +603,9 @@ hipError_t LaunchT(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stre
 }  // namespace
 
 bool LmiMfmaSupports(int n, int m) {
+  if (n == 8) return SupportsT<8>(m);
+  if (n == 12) return SupportsT<12>(m);
+  if (n == 16) return SupportsT<16>(m);
   if (n == 20) return SupportsT<20>(m);
   if (n == 24) return SupportsT<24>(m);
   return false;
@@ -596,6 +613,9 @@ bool LmiMfmaSupports(int n, int m) {
 
 hipError_t LaunchLmiSchurMfma(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stream) {
   if (g.count <= 0) return hipSuccess;
+  if (g.n == 8) return LaunchT<8>(g, ar, cus, stream);
+  if (g.n == 12) return LaunchT<12>(g, ar, cus, stream);
+  if (g.n == 16) return LaunchT<16>(g, ar, cus, stream);
   if (g.n == 20) return LaunchT<20>(g, ar, cus, stream);
   if (g.n == 24) return LaunchT<24>(g, ar, cus, stream);
   return hipErrorNotSupported;

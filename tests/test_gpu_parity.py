@@ -120,7 +120,10 @@ def test_lmi_newton_step(K, n, m, b_, ov):
 
 
 @pytest.mark.parametrize("K,n,m,b_,ov", [(1, 20, 1, 2, 1), (7, 20, 9, 3, 2), (300, 20, 15, 4, 3), (5, 20, 16, 2, 4),
-                                          (70, 20, 20, 8, 5), (3, 24, 10, 2, 2), (9, 24, 14, 2, 5)])
+                                          (70, 20, 20, 8, 5), (3, 24, 10, 2, 2), (9, 24, 14, 2, 5),
+                                          # orders up to 16: part of one 16-column stage-1 tile, no 4x4x4 blocks there
+                                          (40, 8, 5, 3, 2), (300, 8, 23, 4, 3), (9, 12, 12, 2, 4), (60, 12, 20, 4, 5),
+                                          (1, 16, 1, 2, 1), (33, 16, 16, 3, 6), (270, 16, 21, 8, 5)])
 def test_lmi_mfma_kernel_shapes(K, n, m, b_, ov):
     """The persistent MFMA Schur kernel (lmi_fused_mfma.hip) takes the number of variables at run
     time: one 16 x 16 contraction tile up to 16 matrices (m + 1), the two-tile cover from 17 to 24;
