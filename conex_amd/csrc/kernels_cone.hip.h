@@ -223,7 +223,8 @@ __global__ void linear_take_step(VecGroup g, StepArgs sa) {
   for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < total;
        q += (size_t)gridDim.x * blockDim.x) {
     double d = g.T2[q];
-    if (sa.step_size != 1) d *= sa.step_size;
+    const double step = StepSizeOf(sa);
+    if (step != 1) d *= step;
     g.T2[q] = d;
     g.W[q] *= exp(d);
   }
@@ -370,8 +371,9 @@ __global__ void __launch_bounds__(64) soc_take_step(VecGroup g, StepArgs sa) {
       d[k] = D[k];
       w[k] = W[k];
     }
-    if (sa.step_size != 1.0) {
-      for (int k = 0; k < len; k++) d[k] *= sa.step_size;
+    const double step = StepSizeOf(sa);
+    if (step != 1.0) {
+      for (int k = 0; k < len; k++) d[k] *= step;
       for (int k = 1; k < len; k++) D[k] = d[k];  // the reference scales temp1_1 in place
     }
     SocSpectral(n, d[0], d + 1, 1, ex);
@@ -433,8 +435,7 @@ __device__ __forceinline__ void MailboxPack(const MailboxArgs& m) {
 __global__ void __launch_bounds__(256)
 reduce_step_info(int K, int mode, const double* __restrict__ info, const unsigned char* __restrict__ mask,
                  double* __restrict__ out, MailboxArgs mbx) {
-  __shared__ double red[8];
-  __shared__ double red2[8];
+  __shared__ double red[8], red2[8], red3[8], red4[8];
   double a = 0, b = (mode == 0) ? -1.0 : 30000.0, c = -30000.0, d = 0;
   // eight strided constraints per trip, loads issued together (a plain loop pays two dependent
   // round trips -- mask, values -- per element); accumulation order unchanged
@@ -470,31 +471,38 @@ reduce_step_info(int K, int mode, const double* __restrict__ info, const unsigne
       }
     }
   }
-  a = BlockSum(a, red);
-  d = BlockSum(d, red);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double bm = (mode == 0) ? WaveMax(b) : -WaveMax(-b);
-  double cm = WaveMax(c);
-  __syncthreads();
+  // the two BlockSums (wave sum, wave totals added in wave order) and the max / min reductions
+  // behind ONE barrier
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+  a = WaveSum(a);
+  d = WaveSum(d);
+  const double bm = (mode == 0) ? WaveMax(b) : -WaveMax(-b);
+  const double cm = WaveMax(c);
   if (lane == 0) {
     red[wave] = bm;
     red2[wave] = cm;
+    red3[wave] = a;
+    red4[wave] = d;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double B = red[0], C = red2[0];
-    for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
+    double B = red[0], C = red2[0], A = 0, D = 0;
+    for (int w = 1; w < nw; w++) {
       B = (mode == 0) ? fmax(B, red[w]) : fmin(B, red[w]);
       C = fmax(C, red2[w]);
     }
+    for (int w = 0; w < nw; w++) {
+      A += red3[w];
+      D += red4[w];
+    }
     if (mode == 0) {
-      out[0] = a;
+      out[0] = A;
       out[1] = B;
     } else {
       out[0] = B;
       out[1] = C;
-      out[2] = a;
-      out[3] = d;
+      out[2] = A;
+      out[3] = D;
     }
   }
   if (mbx.mb) {

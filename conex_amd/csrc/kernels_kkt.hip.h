@@ -143,12 +143,13 @@ __global__ void __launch_bounds__(1024)
 step_scalars(int N, const double* __restrict__ b, const double* __restrict__ AQc,
              const double* __restrict__ y, const double* __restrict__ sys_sc,
              double* __restrict__ out) {
-  __shared__ double red[16];
+  __shared__ double red[4][16];
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  // eight strided elements per trip, all loads issued before the first fma: a plain loop is one
-  // dependent memory round trip per element (15 in a row at C4).  Same fma order: same bits
-  // (out-of-range slots contribute fma(0, 0, s) = s).
-  constexpr int U = 8;
+  // sixteen strided elements per trip, all loads issued before the first fma: a plain loop is one
+  // dependent memory round trip per element (15 in a row at C4; with 16 slots C4 is ONE trip).
+  // Same fma order: same bits (out-of-range slots contribute fma(0, 0, s) = s).
+  constexpr int U = 16;
+  const double sc0 = sys_sc[0], sc1 = sys_sc[1];
   for (int p0 = threadIdx.x; p0 < N; p0 += U * blockDim.x) {
     double vb[U], vq[U], vy[U];
 #pragma unroll
@@ -167,18 +168,26 @@ step_scalars(int N, const double* __restrict__ b, const double* __restrict__ AQc
       s3 = fma(vq[u], vq[u], s3);
     }
   }
-  s0 = BlockSum(s0, red);
-  s1 = BlockSum(s1, red);
-  s2 = BlockSum(s2, red);
-  s3 = BlockSum(s3, red);
-  if (threadIdx.x == 0) {
-    out[0] = s0;
-    out[1] = s1;
-    out[2] = s2;
-    out[3] = s3;
-    out[4] = sys_sc[0];
-    out[5] = sys_sc[1];
+  // four BlockSums (wave sum, then the wave totals added in wave order) behind ONE barrier pair
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  s0 = WaveSum(s0);
+  s1 = WaveSum(s1);
+  s2 = WaveSum(s2);
+  s3 = WaveSum(s3);
+  if (lane == 0) {
+    red[0][wave] = s0;
+    red[1][wave] = s1;
+    red[2][wave] = s2;
+    red[3][wave] = s3;
   }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0;
+    for (int w = 0; w < nw; w++) t += red[threadIdx.x][w];
+    out[threadIdx.x] = t;
+  }
+  if (threadIdx.x == 4) out[4] = sc0;
+  if (threadIdx.x == 5) out[5] = sc1;
 }
 
 // y = AQc cs - b bs  (ComputeMuFromDivergence cone_program.cc:181)

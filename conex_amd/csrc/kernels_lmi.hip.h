@@ -452,7 +452,8 @@ __global__ void __launch_bounds__(256) lmi_take_step_generic(LmiGroup g, StepArg
     sW[q] = Wg[q];
     double x = T1[q];
     if (q % n == q / n) x += sa.e_weight;
-    if (sa.step_size != 1.0) x *= sa.step_size;
+    const double step = StepSizeOf(sa);
+    if (step != 1.0) x *= step;
     sX[q] = x;
   }
   __syncthreads();

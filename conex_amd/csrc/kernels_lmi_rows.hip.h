@@ -104,12 +104,13 @@ __global__ void __launch_bounds__(256) lmi_take_step_rows(LmiGroup g, StepArgs s
   const double* T1 = g.T1 + (size_t)mem * nn;
   const bool row = lane < n;
   const int r = row ? lane : 0;
+  const double step = StepSizeOf(sa);
   double x[N];
 #pragma unroll
   for (int j = 0; j < N; j++) {
     double v = (row && j < n) ? T1[r + j * n] : 0.0;
     if (row && j == r) v += sa.e_weight;
-    if (sa.step_size != 1.0) v *= sa.step_size;
+    if (step != 1.0) v *= step;
     x[j] = v;
   }
   double aug[2 * N];
@@ -167,12 +168,13 @@ __global__ void __launch_bounds__(256) lmi_take_step_rows_taylor(LmiGroup g, Ste
   const double* T1 = g.T1 + (size_t)mem * nn;
   const bool row = lane < n;
   const int r = row ? lane : 0;
+  const double step = StepSizeOf(sa);
   double x[N], v[N], t[N], y[N];
 #pragma unroll
   for (int j = 0; j < N; j++) {
     double e = (row && j < n) ? T1[r + j * n] : 0.0;
     if (row && j == r) e += sa.e_weight;
-    if (sa.step_size != 1.0) e *= sa.step_size;
+    if (step != 1.0) e *= step;
     x[j] = e;
     v[j] = e * 1.0 / 4.0;
   }

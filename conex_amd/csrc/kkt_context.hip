@@ -407,6 +407,7 @@ StepArgs MakeStep(cxk_context* ctx, double* info, int affine, double cw, double 
   s.c_weight = cw;
   s.e_weight = ew;
   s.step_size = ss;
+  s.step_from = nullptr;
   s.call = ctx->lanczos_calls;
   s.no_clamp = ctx->reference_identity > 0;
   return s;
@@ -3008,16 +3009,36 @@ int SyncMailbox(cxk_context* ctx) {
   return WaitMailbox(ctx, ctx->seq);
 }
 
+// TakeStep of every cone; step_from != nullptr: step length from the device (StepArgs::step_from).
+extern "C" {
+static int LaunchTakeStep(cxk_context* ctx, double e_weight, double step_size, const double* step_from);
+}
+// Whether TakeStep can read its step length from the device (every kernel of this program does).
+bool TakeStepFromDeviceOk(const cxk_context* ctx) {
+  if (ctx->world > 1 || ctx->use_ldlt) return false;
+  for (const Group& g : ctx->groups)
+    if (g.type == CXK_LMI && g.large && !g.ids.empty()) return false;  // its step argument kernel takes the value
+  return true;
+}
+
 // reduce_step_info, then the host round trip: one launch on a single GPU (the results go to the
 // mailbox from the reduction itself), reduction + all-reduces + mailbox_pack when sharded.
-int ReduceStepInfoAndSync(cxk_context* ctx, int mode, const double* info) {
+// take_e_weight != nullptr (mode 0): TakeStep with the step length of cone_program.cc:417-418 taken
+// from the reduced norms ON THE DEVICE is enqueued before the host waits, *took reports it.
+int ReduceStepInfoAndSync(cxk_context* ctx, int mode, const double* info, const double* take_e_weight = nullptr,
+                          int* took = nullptr) {
   MailboxArgs m;
   m.mb = nullptr;
   const bool fold = ctx->world <= 1;
   if (fold && NextMailbox(ctx, &m)) return CXK_FAILURE;
+  const long long want = ctx->seq;
   reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), mode, info, ctx->d_mask.p, ctx->red_out.p, m);
   CXK_TRY(hipGetLastError());
-  if (fold) return WaitMailbox(ctx, ctx->seq);
+  if (fold && take_e_weight && TakeStepFromDeviceOk(ctx)) {
+    if (LaunchTakeStep(ctx, *take_e_weight, 1.0, ctx->red_out.p)) return CXK_FAILURE;
+    if (took) *took = 1;
+  }
+  if (fold) return WaitMailbox(ctx, want);
   if (mode == 0) {
     // sharded: sum of normsqrd, max of norminfd over the ranks (each reduced its own constraints)
     if (ShardAllReduce(ctx, ctx->red_out.p, 1, kOpSum) || ShardAllReduce(ctx, ctx->red_out.p + 1, 1, kOpMax))
@@ -3300,7 +3321,17 @@ int cxk_set_y(cxk_context* ctx, const double* yh) {
   return CXK_SUCCESS;
 }
 
+static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double e_weight, double* info, bool take,
+                           int* took);
 int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_weight, double* info) {
+  return PrepareStepImpl(ctx, affine, c_weight, e_weight, info, false, nullptr);
+}
+int cxk_prepare_take_step(cxk_context* ctx, double c_weight, double e_weight, double* info, int* took) {
+  if (took) *took = 0;
+  return PrepareStepImpl(ctx, 0, c_weight, e_weight, info, true, took);
+}
+static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double e_weight, double* info, bool take,
+                           int* took) {
   CXK_ENTER(ctx);
   StepArgs sa = MakeStep(ctx, ctx->info2.p, affine, c_weight, e_weight, 1.0);
   ctx->lanczos_calls++;
@@ -3331,7 +3362,7 @@ int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_wei
     CXK_TRY(hipMemcpy(ctx->y_at_prepare.data(), ctx->y.p, sizeof(double) * ctx->md.N, hipMemcpyDeviceToHost));
   }
   if (affine) return CXK_SUCCESS;
-  if (ReduceStepInfoAndSync(ctx, 0, ctx->info2.p)) return CXK_FAILURE;
+  if (ReduceStepInfoAndSync(ctx, 0, ctx->info2.p, take ? &e_weight : nullptr, took)) return CXK_FAILURE;
   info[0] = ctx->mb[0];
   info[1] = ctx->mb[1];
   return CXK_SUCCESS;
@@ -3348,7 +3379,12 @@ int cxk_get_step_info(cxk_context* ctx, double* out2k) {
 int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_size) {
   CXK_ENTER(ctx);
   if (affine) return CXK_SUCCESS;  // the affine update is applied inside PrepareStep
-  StepArgs sa = MakeStep(ctx, ctx->info2.p, affine, 0.0, e_weight, step_size);
+  return LaunchTakeStep(ctx, e_weight, step_size, nullptr);
+}
+
+static int LaunchTakeStep(cxk_context* ctx, double e_weight, double step_size, const double* step_from) {
+  StepArgs sa = MakeStep(ctx, ctx->info2.p, 0, 0.0, e_weight, step_size);
+  sa.step_from = step_from;
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
     if (cnt == 0) continue;

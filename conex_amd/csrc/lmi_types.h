@@ -53,10 +53,23 @@ struct StepArgs {
   double c_weight;
   double e_weight;
   double step_size;
+  // not null: the step length is taken on the device from the reduced norms of the PrepareStep
+  // just before, step = min(1, 2 / norminfd^2) with norminfd = step_from[1] (cone_program.cc:417-418),
+  // so that TakeStep can be enqueued without a host round trip in between
+  const double* step_from;
   unsigned long long call;  // index of this PrepareStep / eigenvalue query (Hermitian start vectors)
   // reference identity (cxk_set_reference_identity / CXK_REFERENCE_QUIRKS=1): the Ritz values go
   // out exactly as approximate_eigenvalues.cc:178-239 produces them, without the Samuelson clamp
   int no_clamp;
 };
+
+#ifdef __HIPCC__
+__device__ __forceinline__ double StepSizeOf(const StepArgs& sa) {
+  if (!sa.step_from) return sa.step_size;
+  const double v = sa.step_from[1];
+  const double s = 2.0 / (v * v);
+  return s > 1 ? 1.0 : s;
+}
+#endif
 
 }  // namespace cxk

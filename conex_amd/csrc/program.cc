@@ -512,7 +512,16 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     c_weight = inv_sqrt_mu * c_scaling;
     double info[2];
     cxk_phase_mark(ctx, CXK_PHASE_UPDATE);
-    if (TIMED(5, cxk_prepare_step(ctx, 0, c_weight, e_weight, info))) return 0;
+    // When the factorization's outcome is already known (mu was updated: the flag came back with the
+    // mu selection) and no warm-start check is pending, TakeStep is enqueued behind PrepareStep with
+    // the step rule below evaluated on the device: the host round trip no longer separates them.
+    int took_step = 0;
+    const bool step_on_device = update_mu && !(i == 0 && cfg.initialization_mode == 1);
+    if (step_on_device) {
+      if (TIMED(5, cxk_prepare_take_step(ctx, c_weight, e_weight, info, &took_step))) return 0;
+    } else if (TIMED(5, cxk_prepare_step(ctx, 0, c_weight, e_weight, info))) {
+      return 0;
+    }
     if (!update_mu) {
       const int fo = factor_outcome();
       if (fo == kRetry) continue;
@@ -526,7 +535,7 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
       PRINTSTATUS("Aborting warmstart...");
       cxk_set_identity(ctx);
       warmstart_aborted = true;
-    } else {
+    } else if (!took_step) {
       if (TIMED(7, cxk_take_step(ctx, 0, e_weight, step_size))) return 0;
     }
     cxk_phase_mark(ctx, CXK_PHASE_OTHER);

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "cxk_set_y": (C.c_int, [C.c_void_p, c_double_p]),
     "cxk_prepare_step": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, c_double_p]),
     "cxk_take_step": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double]),
+    "cxk_prepare_take_step": (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_double_p, C.POINTER(C.c_int)]),
     "cxk_weighted_slack_eigenvalues": (C.c_int, [C.c_void_p, C.c_double, c_double_p]),
     "cxk_get_slab": (C.c_int, [C.c_void_p, c_double_p]),
     "cxk_set_slab": (C.c_int, [C.c_void_p, c_double_p]),
@@ -419,6 +420,17 @@ class KktContext:
         self._check(self.L.cxk_prepare_step(self.h, affine, c_weight, e_weight, _dp(info)),
                     "cxk_prepare_step")
         return info
+
+    def prepare_take_step(self, y, c_weight, e_weight=1.0):
+        """PrepareStep + TakeStep with the step length min(1, 2 / norminfd^2) evaluated on the device
+        (cxk_prepare_take_step) -> (normsqrd, norminfd, took)."""
+        if y is not None:
+            self.set_y(y)
+        info = np.zeros(2)
+        took = C.c_int(0)
+        self._check(self.L.cxk_prepare_take_step(self.h, c_weight, e_weight, _dp(info), C.byref(took)),
+                    "cxk_prepare_take_step")
+        return info[0], info[1], bool(took.value)
 
     def take_step(self, step_size, e_weight=1.0, affine=0):
         self._check(self.L.cxk_take_step(self.h, affine, e_weight, step_size), "cxk_take_step")

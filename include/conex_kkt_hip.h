@@ -173,6 +173,14 @@ int cxk_set_y(cxk_context* ctx, const double* y);
  * Uses the device-resident y.  Syncs (returns two scalars). */
 int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_weight,
                      double* info);
+/* cxk_prepare_step (affine = 0) followed by cxk_take_step with the step length of
+ * cone_program.cc:417-418, step = min(1, 2 / norminfd^2), evaluated ON THE DEVICE from the norms just
+ * reduced -- so TakeStep is enqueued before the host waits for `info` and no idle gap separates the
+ * two.  Same arithmetic, same bits as the two calls with the host computing the step.  *took = 1
+ * when TakeStep was enqueued; 0 on configurations where a kernel needs the value from the host
+ * (sharded contexts, equality constraints, LMI orders beyond LDS): the caller then runs
+ * cxk_take_step itself.  Only for iterations whose factorization outcome is already known. */
+int cxk_prepare_take_step(cxk_context* ctx, double c_weight, double e_weight, double* info, int* took);
 /* TakeStep (cone_program.h:92-97) */
 int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_size);
 /* GetWeightedSlackEigenvalues (cone_program.cc:31-57) on the device-resident y;

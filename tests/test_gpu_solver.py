@@ -761,3 +761,33 @@ def test_lp_dual_fails_slater(distance):
     else:
         assert np.allclose(y / np.linalg.norm(y), yo / np.linalg.norm(yo), rtol=1e-6, atol=1e-9)
     L.CONEX_DeleteConeProgram(p)
+
+
+@pytest.mark.parametrize("kind", ["lmi", "mixed"])
+def test_prepare_take_step_on_the_device_equals_the_two_calls(kind):
+    """cxk_prepare_take_step: TakeStep enqueued behind PrepareStep with step = min(1, 2 / norminfd^2)
+    (cone_program.cc:417-418) evaluated on the device -- the scaling points afterwards are the bits
+    of cxk_prepare_step + host step rule + cxk_take_step, for a long step (clipped to 1) and a short one."""
+    from conex_amd import KktContext, synthetic as syn
+    if kind == "lmi":
+        prob = syn.lmi_problem(K=40, n=20, m=20, branching=8, overlap=5, seed=5)
+        W = syn.scaling_points(40, 20, seed=6)
+    else:
+        prob = syn.mixed_problem(K=60, seed=5)
+        W = syn.mixed_scaling_points(prob, seed=6)
+    ctxs = [syn.build(KktContext, prob, kind, device=0) for _ in range(2)]
+    for k in ctxs:
+        for i in range(k.K):
+            k.set_W(i, W[i])
+    rng = np.random.default_rng(1)
+    for scale in (1e-3, 3.0):                      # norminfd small -> step 1; large -> step < 1
+        y = scale * rng.standard_normal(ctxs[0].N)
+        a, b = ctxs
+        info = a.prepare_step(y, 0.4, 1.0)
+        step = min(1.0, 2.0 / (info[1] * info[1]))
+        a.take_step(step, 1.0)
+        n2, ninf, took = b.prepare_take_step(y, 0.4, 1.0)
+        assert took and n2 == info[0] and ninf == info[1]
+        assert (step == 1.0) == (scale < 1)
+        for i in range(a.K):
+            assert np.array_equal(np.asarray(a.get_W(i)), np.asarray(b.get_W(i)))
