@@ -140,31 +140,55 @@ def main():
             prob = syn.sparsify(prob, args.density)
         W = syn.scaling_points(args.K, n_order)
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = KktContext(prob["num_vars"], device=local_rank, stream=stream)
-    for c, cl in enumerate(prob["cliques"]):
-        if kind == "lmi":
-            ctx.add_lmi(prob["A"][c], prob["C"][c], cl)
-        elif kind == "soc":
-            ctx.add_soc(prob["A"][c], prob["c"][c], cl)
-        elif prob["kinds"][c] == "herm":
-            ctx.add_hermitian(prob["A"][c], prob["C"][c], cl)
-        else:
-            ctx.add_soc(prob["A"][c], prob["C"][c], cl)
-    if world > 1:
-        # the library's own RCCL communicator: rank 0 makes the unique id, torch.distributed only
-        # carries the 128 bytes (and the timing barrier below); every collective of the step --
-        # the all-reduce of the packed top of the tree -- is issued by libconex.so on its stream
-        uid = [KktContext.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init_rccl(uid[0], rank, world)
-    elif sharded:
-        # --shard-path on one GPU: rank 0 of a virtual 2-rank world with a do-nothing all-reduce
-        # (half the tree is missing from the exchange, so only timing and the plumbing are
-        # meaningful, not the direction)
-        ctx.set_shard(0, 2)
-    ctx.initialize()
-    if sharded and world == 1:
-        ctx.comm_set_allreduce(lambda arr, op: arr)
+
+    def torch_allreduce(arr, op):
+        # fallback transport (see below): host copy -> device tensor -> torch.distributed -> back
+        t = torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+        dist.all_reduce(t, op=(dist.ReduceOp.SUM, dist.ReduceOp.MAX, dist.ReduceOp.MIN)[op])
+        return t.cpu().numpy()
+
+    def build_context(collective):
+        ctx = KktContext(prob["num_vars"], device=local_rank, stream=stream)
+        for c, cl in enumerate(prob["cliques"]):
+            if kind == "lmi":
+                ctx.add_lmi(prob["A"][c], prob["C"][c], cl)
+            elif kind == "soc":
+                ctx.add_soc(prob["A"][c], prob["c"][c], cl)
+            elif prob["kinds"][c] == "herm":
+                ctx.add_hermitian(prob["A"][c], prob["C"][c], cl)
+            else:
+                ctx.add_soc(prob["A"][c], prob["C"][c], cl)
+        if collective == "rccl":
+            # the library's own RCCL communicator: rank 0 makes the unique id, torch.distributed only
+            # carries the 128 bytes (and the timing barrier below); every collective of the step --
+            # the all-reduce of the packed top of the tree -- is issued by libconex.so on its stream
+            uid = [KktContext.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init_rccl(uid[0], rank, world)
+        elif collective == "torch":
+            ctx.set_shard(rank, world)
+        elif collective == "none":
+            # --shard-path on one GPU: rank 0 of a virtual 2-rank world with a do-nothing all-reduce
+            # (half the tree is missing from the exchange, so only timing and the plumbing are
+            # meaningful, not the direction)
+            ctx.set_shard(0, 2)
+        ctx.initialize()
+        if collective == "torch":
+            ctx.comm_set_allreduce(torch_allreduce)
+        elif collective == "none":
+            ctx.comm_set_allreduce(lambda arr, op: arr)
+        return ctx
+
+    collective = "rccl" if world > 1 else ("none" if sharded else "")
+    try:
+        ctx = build_context(collective)
+    except Exception as e:  # e.g. librccl.so not loadable from the library: same failure on every rank
+        if collective != "rccl":
+            raise
+        print("rank %d: in-library RCCL communicator failed (%s); falling back to torch.distributed "
+              "through the all-reduce callback" % (rank, e), file=sys.stderr, flush=True)
+        collective = "torch"
+        ctx = build_context(collective)
     for i in range(ctx.K):
         if not sharded or ctx.owns(i):
             ctx.set_W(i, W[i])
@@ -237,8 +261,11 @@ def main():
                                     "c5": "BASELINE config 5: 1600 complex Hermitian PSD order 12 (m=24) + 3000 SOC "
                                           "dim 10, 8-ary clique tree overlap 4, N=50004"}[args.workload],
                        "K": args.K, "n": n_order, "m": m_vars, "N": ctx.N,
-                       "parallelism": (f"elimination-subtree sharding x{world}, one RCCL all-reduce "
-                                       f"of {exch_bytes} B per solve, issued by libconex.so") if sharded
+                       "parallelism": (f"elimination-subtree sharding x{world}, one all-reduce of {exch_bytes} B "
+                                       "per solve, " + ("RCCL, issued by libconex.so" if collective == "rccl" else
+                                                        "torch.distributed through the all-reduce callback (FALLBACK)"
+                                                        if collective == "torch" else "no-op (single-GPU plumbing run)"))
+                       if sharded
                        else "single GPU",
                        "factor_ok": bool(ok)},
         }
