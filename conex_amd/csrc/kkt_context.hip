@@ -1086,7 +1086,7 @@ int BuildPlans(cxk_context* ctx) {
   // leaves of a clique tree.  Those supernodes then read G(max(pos_r, pos_c), min(..)) themselves
   // and the gather lists shrink to what the levels above need.
   ctx->fused_asm = false;
-  if (!sharded && !ctx->use_ldlt && !ctx->no_lean && !getenv("CXK_NO_FUSED_ASM") && nlev >= 2 &&
+  if ((!sharded || ctx->cut_level >= 1) && !ctx->use_ldlt && !ctx->no_lean && !getenv("CXK_NO_FUSED_ASM") && nlev >= 2 &&
       ctx->level_segs[0].size() == 1 && ctx->level_lean[0] && ctx->top_level >= 1 && ctx->chain_level >= 1 &&
       ctx->level_segs[0][0].shape != 0 && 4 * ctx->chol_lds <= kLdsLimit) {
     const int first = ctx->level_ptr[0], cnt0 = ctx->level_nh[0];
@@ -2317,9 +2317,9 @@ struct DeviceGuard {
 };
 // cxk_kkt_solve_async and the factor-and-solve entry points fold the assembly into the first
 // factor level when the tree allows it (BuildPlans) and nothing needs the assembled system as
-// such: single GPU, Cholesky sweeps, no refinement copy.
+// such: Cholesky sweeps, no refinement copy (sharded contexts: when the first level lies below the cut).
 bool FusedAssembly(const cxk_context* ctx) {
-  return ctx->fused_asm && ctx->world == 1 && ctx->solver_mode != 2 && ctx->refine_iters <= 0 && !ctx->no_lean;
+  return ctx->fused_asm && ctx->solver_mode != 2 && ctx->refine_iters <= 0 && !ctx->no_lean;
 }
 // cxk_assemble leaves the gather to the factorization that normally follows; any other entry point
 // that runs first gets the assembled system by the separate launch.

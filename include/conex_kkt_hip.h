@@ -318,7 +318,7 @@ int cxk_dense_top_columns(const cxk_context* ctx);
  * supernodal_assembler.cc:93-181 and the right-hand side of cone_program.cc:409-411) into the
  * launch of the first factor level: the leaves of the elimination tree read their panels straight
  * from the Schur blocks, the gather of everything else rides beside them as extra workgroups
- * (tree_factor_level_asm).  Decided per structure at cxk_finalize (single GPU, Cholesky, the first
+ * (tree_factor_level_asm).  Decided per structure at cxk_finalize (Cholesky, the first
  * level one register shape, every supernode in it fed by exactly one constraint); results are the
  * bits of the separate assembly launch.  CXK_NO_FUSED_ASM=1 keeps the separate launch. */
 int cxk_fused_assembly(const cxk_context* ctx);
