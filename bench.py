@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--shard-path", action="store_true",
                     help="run the sharded three-phase step (local / RCCL all-reduce / finish) even at "
                          "world size 1: exercises the multi-GPU code path on a single-GPU box")
+    ap.add_argument("--shard-world", type=int, default=2,
+                    help="with --shard-path: size of the virtual world this GPU is rank 0 of")
     ap.add_argument("--soc-tree", type=int, default=0,
                     help="with --workload c3: arrange the cones in a b-ary clique tree instead of a chain")
     ap.add_argument("--cold-copies", type=int, default=5,
@@ -168,15 +170,16 @@ def main():
         elif collective == "torch":
             ctx.set_shard(rank, world)
         elif collective == "none":
-            # --shard-path on one GPU: rank 0 of a virtual 2-rank world with a do-nothing all-reduce
-            # (half the tree is missing from the exchange, so only timing and the plumbing are
-            # meaningful, not the direction)
-            ctx.set_shard(0, 2)
+            # --shard-path on one GPU: rank 0 of a virtual --shard-world-rank world whose all-reduces
+            # run on a ONE-rank RCCL communicator (the other shards are missing from the exchange,
+            # so only timing and the plumbing are meaningful, not the direction)
+            ctx.set_shard(0, args.shard_world)
         ctx.initialize()
         if collective == "torch":
             ctx.comm_set_allreduce(torch_allreduce)
         elif collective == "none":
-            ctx.comm_set_allreduce(lambda arr, op: arr)
+            # real ncclAllReduce calls on a one-rank communicator (they return their input)
+            ctx.comm_init_rccl_solo()
         return ctx
 
     collective = "rccl" if world > 1 else ("none" if sharded else "")
@@ -264,7 +267,7 @@ def main():
                        "parallelism": (f"elimination-subtree sharding x{world}, one all-reduce of {exch_bytes} B "
                                        "per solve, " + ("RCCL, issued by libconex.so" if collective == "rccl" else
                                                         "torch.distributed through the all-reduce callback (FALLBACK)"
-                                                        if collective == "torch" else "no-op (single-GPU plumbing run)"))
+                                                        if collective == "torch" else "one-rank RCCL communicator (single-GPU plumbing run)"))
                        if sharded
                        else "single GPU",
                        "factor_ok": bool(ok)},

@@ -1985,6 +1985,7 @@ struct ExchangeArgs {
   int64_t n_xs;
   int n_xv;
   const int64_t* xs_off;
+  const int* xs_pt;   // exchange entry -> list of this rank's published updates into it (pt_ptr), -1 none
   const int* xv_idx;
   int64_t pt_T;
   const int64_t* pt_dst;
@@ -2008,8 +2009,18 @@ struct ExchangeArgs {
 __global__ void __launch_bounds__(256) exchange_pack(ExchangeArgs a) {
   const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  // slab entries: partial assembled value minus the updates of this rank's subtrees (exchange_fold)
-  for (int64_t i = gid; i < a.n_xs; i += stride) a.x[i] = a.slab[a.xs_off[i]];
+  // slab entries: partial assembled value minus the Schur updates of this rank's subtrees (summed
+  // in slot order, then subtracted: what a separate fold launch used to leave in the slab)
+  for (int64_t i = gid; i < a.n_xs; i += stride) {
+    double v = a.slab[a.xs_off[i]];
+    const int t = a.xs_pt[i];
+    if (t >= 0) {
+      double s = 0;
+      for (int q = a.pt_ptr[t]; q < a.pt_ptr[t + 1]; q++) s += a.upd[a.pt_src[q]];
+      v -= s;
+    }
+    a.x[i] = v;
+  }
   for (int64_t j = gid; j < a.n_xv; j += stride) {
     const int p = a.xv_idx[j];
     a.x[a.n_xs + j] = a.AW[p];
@@ -2024,17 +2035,6 @@ __global__ void __launch_bounds__(256) exchange_pack(ExchangeArgs a) {
     a.x[o + 1] = a.sys_sc[1];
     a.x[o + 2] = (double)(*a.fail);
     a.x[o + 3] = 0;
-  }
-}
-
-// runs BEFORE exchange_pack: subtracts the Schur updates of this rank's subtrees from its partial
-// top blocks, in place in the slab (one thread per top entry)
-__global__ void __launch_bounds__(256) exchange_fold(ExchangeArgs a) {
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < a.pt_T;
-       t += (int64_t)gridDim.x * blockDim.x) {
-    double s = 0;
-    for (int q = a.pt_ptr[t]; q < a.pt_ptr[t + 1]; q++) s += a.upd[a.pt_src[q]];
-    a.slab[a.pt_dst[t]] -= s;
   }
 }
 

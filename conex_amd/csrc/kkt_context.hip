@@ -205,7 +205,7 @@ struct cxk_context {
   DevBuf<int> pub_dst, pubb_dst;
   DevBuf<double> upd, updb, xbuf;
   DevBuf<int64_t> xs_off, pt_dst, pt_src;
-  DevBuf<int> xv_idx, pt_ptr, pf_ptr, pf_src;
+  DevBuf<int> xv_idx, pt_ptr, pf_ptr, pf_src, xs_pt;
   int64_t as_T = 0;
   // the assembly folded into the first factor level (tree_factor_level_asm): records of the level's
   // supernodes, and the gather lists without what those supernodes load themselves
@@ -708,6 +708,7 @@ int BuildPlans(cxk_context* ctx) {
 
   // ---- published-update slots: s(s+1)/2 Schur values and s forward values per supernode
   std::vector<int> h_tg_ptr, h_fs_ptr, h_bs_ptr, h_bs_c, h_bs_row;  // host copies for the per-supernode records
+  std::vector<int64_t> h_pt_dst;                                     // slab targets of the pre-contributed updates
   std::vector<int64_t> upd_off(K, 0);
   std::vector<int> updb_off(K, 0);
   int64_t upd_total = 0;
@@ -819,6 +820,7 @@ int BuildPlans(cxk_context* ctx) {
     CXK_TRY(ctx->tr_ptr.upload(tr_ptr));
     CXK_TRY(ctx->tr_src.upload(tr_src));
     CXK_TRY(ctx->pt_dst.upload(pt_dst));
+    h_pt_dst = pt_dst;
     CXK_TRY(ctx->pt_ptr.upload(pt_ptr));
     CXK_TRY(ctx->pt_src.upload(pt_src));
   }
@@ -884,6 +886,23 @@ int BuildPlans(cxk_context* ctx) {
     CXK_DEMAND(ctx->n_xs == (int64_t)xs.size() && ctx->n_xv == (int)xv.size(),
                "internal error: exchange layout mismatch");
     CXK_TRY(ctx->xs_off.upload(xs));
+    {
+      // exchange_pack folds this rank's own Schur updates into its partial top entries on the
+      // way out: entry i of the exchange -> its list of published values (pt_ptr), or -1
+      std::map<int64_t, int> list_of;
+      for (size_t t = 0; t < h_pt_dst.size(); t++) list_of[h_pt_dst[t]] = (int)t;
+      std::vector<int> xs_pt(xs.size() + 1, -1);
+      size_t found = 0;
+      for (size_t i = 0; i < xs.size(); i++) {
+        auto it = list_of.find(xs[i]);
+        if (it != list_of.end()) {
+          xs_pt[i] = it->second;
+          found++;
+        }
+      }
+      CXK_DEMAND(found == h_pt_dst.size(), "internal error: a pre-contributed update targets an entry outside the exchange");
+      CXK_TRY(ctx->xs_pt.upload(xs_pt));
+    }
     CXK_TRY(ctx->xv_idx.upload(xv));
     CXK_TRY(ctx->pf_ptr.upload(pf_ptr));
     CXK_TRY(ctx->pf_src.upload(pf_src));
@@ -1456,6 +1475,7 @@ ExchangeArgs MakeExchange(cxk_context* ctx, double k, double bs, double cs) {
   a.n_xs = ctx->n_xs;
   a.n_xv = ctx->n_xv;
   a.xs_off = ctx->xs_off.p;
+  a.xs_pt = ctx->xs_pt.p;
   a.xv_idx = ctx->xv_idx.p;
   a.pt_T = (int64_t)(ctx->pt_ptr.n > 0 ? ctx->pt_ptr.n - 1 : 0);
   a.pt_dst = ctx->pt_dst.p;
@@ -2258,7 +2278,6 @@ int ShardedTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
   a.cw = ctx->rhs_c[2];
   const size_t work = (size_t)std::max<int64_t>(std::max<int64_t>(ctx->n_xs, ctx->n_xv), 1);
   if (mode == 0) {
-    if (a.pt_T > 0) exchange_fold<<<GridFor((size_t)a.pt_T, 256), 256, 0, ctx->stream>>>(a);
     exchange_pack<<<GridFor(work, 256), 256, 0, ctx->stream>>>(a);
     CXK_TRY(hipGetLastError());
     if (ShardAllReduce(ctx, ctx->xbuf.p, (size_t)ExchangeCount(ctx), kOpSum)) return CXK_FAILURE;
@@ -2540,14 +2559,26 @@ int cxk_comm_unique_id(void* out128) {
   return get(static_cast<ncclUniqueId*>(out128)) == ncclSuccess ? CXK_SUCCESS : CXK_FAILURE;
 }
 
+static int CommInitImpl(cxk_context* ctx, const void* unique_id128, int rank, int world_size, bool solo);
 int cxk_comm_init_rccl(cxk_context* ctx, const void* unique_id128, int rank, int world_size) {
+  return CommInitImpl(ctx, unique_id128, rank, world_size, false);
+}
+// Diagnostic: a ONE-rank communicator on a context sharded as rank r of a larger (virtual) world --
+// its all-reduces are real ncclAllReduce calls that return their input, so the sharded step can be
+// timed on a single GPU (bench.py --shard-path); the results are those of one shard only.
+int cxk_comm_init_rccl_solo(cxk_context* ctx) {
+  char id[128];
+  if (cxk_comm_unique_id(id)) return CXK_FAILURE;
+  return CommInitImpl(ctx, id, 0, 1, true);
+}
+static int CommInitImpl(cxk_context* ctx, const void* unique_id128, int rank, int world_size, bool solo) {
   if (!ctx || !unique_id128 || world_size < 1 || rank < 0 || rank >= world_size) return CXK_FAILURE;
   CXK_DEMAND(ctx->device >= 0, "a communicator needs a HIP device");
-  if (!ctx->finalized) {
+  if (!ctx->finalized && !solo) {
     ctx->rank = rank;
     ctx->world = world_size;
   }
-  CXK_DEMAND(ctx->rank == rank && ctx->world == world_size, "communicator rank / size differ from cxk_set_shard");
+  CXK_DEMAND(solo || (ctx->rank == rank && ctx->world == world_size), "communicator rank / size differ from cxk_set_shard");
   DeviceGuard guard(ctx->device);
   auto& R = ctx->rccl;
   if (!R.lib) {
@@ -3536,7 +3567,6 @@ int cxk_kkt_local_async(cxk_context* ctx, double k, double bs, double cs) {
     if (LaunchSweep(ctx, l, l + 1, 0, false, true)) return CXK_FAILURE;
   ExchangeArgs a = MakeExchange(ctx, k, bs, cs);
   const size_t work = (size_t)std::max<int64_t>(ctx->n_xs, ctx->n_xv);
-  if (a.pt_T > 0) exchange_fold<<<GridFor((size_t)a.pt_T, 256), 256, 0, ctx->stream>>>(a);
   exchange_pack<<<GridFor(work, 256), 256, 0, ctx->stream>>>(a);
   CXK_TRY(hipGetLastError());
   ctx->factor_seq = ++ctx->seq;

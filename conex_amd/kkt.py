@@ -90,6 +90,7 @@ _SIGNATURES = {
     "cxk_count_sparse_lmi": (C.c_int, [C.c_void_p]),
     "cxk_count_lmi_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_fused_assembly": (C.c_int, [C.c_void_p]),
+    "cxk_comm_init_rccl_solo": (C.c_int, [C.c_void_p]),
     "cxk_set_reference_identity": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_set_solver_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_phase_timers": (C.c_int, [C.c_void_p, C.c_int]),
@@ -487,6 +488,10 @@ class KktContext:
         """RCCL communicator for this context's device; before initialize() it also sets the shard."""
         assert len(unique_id) == 128
         self._check(self.L.cxk_comm_init_rccl(self.h, C.c_char_p(unique_id), rank, world), "cxk_comm_init_rccl")
+
+    def comm_init_rccl_solo(self):
+        """Diagnostic: one-rank RCCL communicator under a larger virtual shard world (cxk_comm_init_rccl_solo)."""
+        self._check(self.L.cxk_comm_init_rccl_solo(self.h), "cxk_comm_init_rccl_solo")
 
     def comm_selftest(self, count=1000):
         self._check(self.L.cxk_comm_selftest(self.h, count), "cxk_comm_selftest")

@@ -227,6 +227,9 @@ typedef int (*cxk_allreduce_fn)(void* user, double* device_buffer, long count, i
 int cxk_comm_unique_id(void* out128);
 int cxk_comm_init_rccl(cxk_context* ctx, const void* unique_id128, int rank, int world_size);
 int cxk_comm_set_allreduce(cxk_context* ctx, cxk_allreduce_fn fn, void* user);
+/* diagnostic: a ONE-rank RCCL communicator on a context sharded as part of a larger (virtual) world:
+ * the sharded step with real ncclAllReduce calls on a single GPU (results: one shard's only) */
+int cxk_comm_init_rccl_solo(cxk_context* ctx);
 /* sum / max / min all-reduces of `count` doubles through the RCCL communicator, checked */
 int cxk_comm_selftest(cxk_context* ctx, int count);
 
