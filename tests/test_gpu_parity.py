@@ -111,7 +111,10 @@ def check_newton_step(o, k, b, inv_sqrt_mu=0.7, bs=0.9, cs=0.8, check_update=Tru
 
 # --------------------------------------------------------------------- LMI
 @pytest.mark.parametrize("K,n,m,b_,ov", [(1, 4, 3, 8, 1), (9, 6, 6, 8, 2), (30, 20, 20, 8, 5),
-                                          (40, 7, 9, 3, 4), (12, 33, 5, 2, 2), (11, 24, 24, 3, 6)])
+                                          (40, 7, 9, 3, 4), (12, 33, 5, 2, 2), (11, 24, 24, 3, 6),
+                                          # shapes on every Schur kernel: MFMA producer/consumer (12, 9), literal LDS
+                                          # (16 with 31 matrices; 28), batched GEMM pipeline (32)
+                                          (20, 12, 9, 3, 3), (14, 16, 30, 3, 8), (9, 28, 28, 2, 6), (8, 32, 20, 2, 5)])
 def test_lmi_newton_step(K, n, m, b_, ov):
     prob = syn.lmi_problem(K=K, n=n, m=m, branching=b_, overlap=ov, seed=100 + K)
     W = syn.scaling_points(K, n, seed=7 + K)
