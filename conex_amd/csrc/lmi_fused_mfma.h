@@ -8,7 +8,7 @@
 namespace cxk {
 
 // Shapes the persistent producer / consumer kernel covers: order n in {8, 12, 16, 20, 24}, any
-// number of variables m with m + 1 <= 24 matrices whose two P images fit LDS.
+// number of variables m with m + 1 <= 24 matrices (<= 32 for n <= 16) whose two P images fit LDS.
 bool LmiMfmaSupports(int n, int m);
 
 // ConstructSchurComplementSystem(DenseLMIConstraint*) for every member of the group

@@ -81,6 +81,7 @@ struct MfmaCfg {
   static constexpr int NC4A = NC4 > 0 ? NC4 : 1;         // (array extent)
   static constexpr int PIECES = 4 + NC4;      // stores per finished tile (StorePiece)
   static constexpr bool NARROW = N < 16;      // the 16-column tile has columns past N: every store is masked
+  static constexpr bool THREE_TILES = N <= 16;  // more than 24 matrices fit LDS (twice) only at these orders
   static constexpr int LD = N + 1;            // odd row stride of the P image
   static constexpr int MS = N * LD + (6 - (N * LD) % 4) % 4;  // matrix stride = 2 (mod 4) doubles
   static constexpr int KSTEPS = N * N / 4;    // stage-2 k-steps
@@ -372,7 +373,9 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
   const int M = g.m, M1 = M + 1, rows = M1 * N;
   const int nt1 = (rows + 15) >> 4;
   const int pbuf = M1 * MS;
-  const bool two = M1 > 16;
+  // contraction cover of the M1 x M1 lower triangle: one tile (M1 <= 16), one tile + two corner
+  // triangles (17..24), three tiles (25..32)
+  const bool two = M1 > 16 && M1 <= 24, three = Cfg::THREE_TILES && M1 > 24;
   double* P0 = lds;
   double* scratch = lds + 2 * (size_t)pbuf;  // 2 buffers x CONS partial tiles of 256 entries
   constexpr int SB = Cfg::CONS * 256;
@@ -457,15 +460,26 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
   const int ct = threadIdx.x - 64 * Cfg::PROD;  // 0 .. 255
   const int il = lane & 15, kq = lane >> 4;
   const int R = M1 - 16;
-  // Work split.  17 <= M1: waves 0-2 take a third of the K range each of the 16 x 16 tile
+  // Work split.  17 <= M1 <= 24: waves 0-2 take a third of the K range each of the 16 x 16 tile
   // (rows = matrices R .., columns = matrices 0 .. 15), wave 3 the two R x R triangles that tile
   // leaves out.  M1 <= 16: the four waves take the K quarters of the single tile (rows past M1
-  // alias M1 - 1).
-  const int parts = two ? Cfg::CONS - 1 : Cfg::CONS;
-  const int part = cw < parts ? cw : 0;
-  const int rr0 = part * N / parts, nrows = (part + 1) * N / parts - rr0;
-  const int ra = two ? (R + il) * MS : (il < M1 ? il : M1 - 1) * MS;
-  const int ca = two ? il * MS : ra;
+  // alias M1 - 1).  25 <= M1 <= 32: three tiles -- T00 (matrices 0..15 squared) on wave 0, T10
+  // (rows 16.., columns 0..15) in two K halves on waves 1 and 2, T11 (16.. squared) on wave 3.
+  int rr0, nrows, ra, ca;
+  if (three) {
+    const int hi = (16 + il < M1 ? 16 + il : M1 - 1) * MS;
+    ra = cw == 0 ? il * MS : hi;
+    ca = cw == 3 ? hi : il * MS;
+    rr0 = cw == 2 ? N / 2 : 0;
+    nrows = cw == 1 ? N / 2 : (cw == 2 ? N - N / 2 : N);
+  } else {
+    const int parts = two ? Cfg::CONS - 1 : Cfg::CONS;
+    const int part = cw < parts ? cw : 0;
+    rr0 = part * N / parts;
+    nrows = (part + 1) * N / parts - rr0;
+    ra = two ? (R + il) * MS : (il < M1 ? il : M1 - 1) * MS;
+    ca = two ? il * MS : ra;
+  }
   // Iteration 0 has nothing to consume: look up where this workgroup's constraints write (two
   // dependent loads each) and park the answers in LDS, off every later critical path.
   if (ct < kDestSlots && ct < cnt) {
@@ -490,6 +504,8 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
         const int u = a < 4 ? 0 : (b < 4 ? 1 : 2);
         off = 768 + 64 * u + 16 * (a & 3) + 8 * t + (b & 3);
       }
+    } else if (three) {
+      off = ii < 16 ? ii * 16 + jj : (jj < 16 ? 256 + (ii - 16) * 16 + jj : 768 + (ii - 16) * 16 + (jj - 16));
     } else {
       off = ii * 16 + jj;
     }
@@ -524,11 +540,16 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
       const int code = etab[e];
       const int off = code & 1023, kind = (code >> 10) & 3, dst = code >> 12;
       double sum;
-      if (two && off >= 768)
-        sum = sb[off] + sb[off + 4];
-      else
-        sum = (sb[off] + sb[off + 256]) + sb[off + 512];
-      if (!two) sum += sb[off + 768];
+      if (three) {
+        sum = sb[off];
+        if (off >= 256 && off < 768) sum += sb[off + 256];  // T10: two K halves
+      } else {
+        if (two && off >= 768)
+          sum = sb[off] + sb[off + 4];
+        else
+          sum = (sb[off] + sb[off + 256]) + sb[off + 512];
+        if (!two) sum += sb[off + 768];
+      }
       sum *= osc;
       if (kind == 0)
         G[dst] = sum;
@@ -551,7 +572,7 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
       else
         Triangles<N, false>(Pb, sb + 256 * (Cfg::CONS - 1), lane, M1);
     } else {
-      const d4_t acc = Contract<N, MAXROWS>(Pb, ra, ca, rr0, kq, nrows);
+      const d4_t acc = three ? Contract<N, N>(Pb, ra, ca, rr0, kq, nrows) : Contract<N, MAXROWS>(Pb, ra, ca, rr0, kq, nrows);
 #pragma unroll
       for (int e = 0; e < 4; e++)  // C/D layout: column = lane & 15, row = (lane >> 4) + 4 e
         sb[cw * 256 + (kq + 4 * e) * 16 + il] = acc[e];
@@ -581,7 +602,7 @@ constexpr size_t kLdsPerCu = 160 * 1024;
 template <int N>
 bool SupportsT(int m) {
   const int m1 = m + 1;
-  return m >= 1 && m1 <= 24 && (m1 * N + 15) / 16 <= MfmaCfg<N>::TPW * MfmaCfg<N>::PROD && MfmaLds<N>(m) <= kLdsPerCu;
+  return m >= 1 && m1 <= (MfmaCfg<N>::THREE_TILES ? 32 : 24) && (m1 * N + 15) / 16 <= MfmaCfg<N>::TPW * MfmaCfg<N>::PROD && MfmaLds<N>(m) <= kLdsPerCu;
 }
 
 template <int N>

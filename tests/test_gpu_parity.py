@@ -126,10 +126,13 @@ def test_lmi_newton_step(K, n, m, b_, ov):
                                           (70, 20, 20, 8, 5), (3, 24, 10, 2, 2), (9, 24, 14, 2, 5),
                                           # orders up to 16: part of one 16-column stage-1 tile, no 4x4x4 blocks there
                                           (40, 8, 5, 3, 2), (300, 8, 23, 4, 3), (9, 12, 12, 2, 4), (60, 12, 20, 4, 5),
-                                          (1, 16, 1, 2, 1), (33, 16, 16, 3, 6), (270, 16, 21, 8, 5)])
+                                          (1, 16, 1, 2, 1), (33, 16, 16, 3, 6), (270, 16, 21, 8, 5),
+                                          # 25 .. 32 matrices: three contraction tiles
+                                          (14, 16, 30, 3, 8), (300, 12, 31, 4, 6), (20, 8, 24, 3, 5), (5, 16, 27, 2, 9)])
 def test_lmi_mfma_kernel_shapes(K, n, m, b_, ov):
     """The persistent MFMA Schur kernel (lmi_fused_mfma.hip) takes the number of variables at run
-    time: one 16 x 16 contraction tile up to 16 matrices (m + 1), the two-tile cover from 17 to 24;
+    time: one 16 x 16 contraction tile up to 16 matrices (m + 1), a tile plus two corner triangles
+    from 17 to 24, three tiles from 25 to 32 (orders whose P images fit LDS twice);
     K = 300 gives the 256 workgroups two constraints each (both P images in use), K < 256 one."""
     prob = syn.lmi_problem(K=K, n=n, m=m, branching=b_, overlap=ov, seed=700 + K + m)
     W = syn.scaling_points(K, n, seed=17 + K)
