@@ -2807,7 +2807,7 @@ static int FinalizeImpl(cxk_context* ctx) {
   CXK_TRY(ctx->G.alloc((size_t)go));
   CXK_TRY(ctx->AWc.alloc((size_t)ro));
   CXK_TRY(ctx->AQcc.alloc((size_t)ro));
-  CXK_TRY(ctx->sc.alloc((size_t)2 * K));
+  CXK_TRY(ctx->sc.alloc((size_t)2 * K, true));  // entries of constraints owned by other ranks stay 0 (summed by the gather)
   CXK_TRY(ctx->d_g_off.upload(ctx->g_off));
   CXK_TRY(ctx->d_r_off.upload(ctx->r_off));
   CXK_TRY(ctx->slab.alloc((size_t)ctx->lay.slab_size));
