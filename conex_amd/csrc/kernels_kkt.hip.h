@@ -499,17 +499,20 @@ __device__ __forceinline__ double EvenRowsToOddRows(double v) {
 template <int NSMAX, int SMAX, int J>
 struct ElimSteps {
   static constexpr int LEN = NSMAX + SMAX + 1, RB = NSMAX + SMAX;
-  static __device__ __forceinline__ void run(double (&a)[LEN], int lane, bool& bad) {
+  // ns = columns of the supernode (wave-uniform): the padding pivots ns .. NSMAX-1 are identity
+  // steps (unit diagonal, zero column) and are skipped.
+  static __device__ __forceinline__ void run(double (&a)[LEN], int lane, bool& bad, int ns) {
     if constexpr (J == 0 && NSMAX > 0) {
       const double d = ReadLane(a[0], 0);
       bad |= !(d > 0.0);
       double root, inv;
       SqrtAndInverse(d, root, inv);
-      step(a, lane, bad, root, inv);
+      step(a, lane, bad, root, inv, ns);
     }
   }
-  static __device__ __forceinline__ void step(double (&a)[LEN], int lane, bool& bad, double root, double inv) {
+  static __device__ __forceinline__ void step(double (&a)[LEN], int lane, bool& bad, double root, double inv, int ns) {
     if constexpr (J < NSMAX) {
+      if (J >= ns) return;
       a[J] = (lane == J) ? root : a[J] * inv;
       double root1 = 1.0, inv1 = 1.0;
       auto next_pivot = [&]() {  // column J+1 is final for step J+1 once it has taken column J's term
@@ -570,7 +573,7 @@ struct ElimSteps {
         a[RB] = fma(-yj, a[J], a[RB]);
       else if (lane == J)
         a[RB] = yj;
-      ElimSteps<NSMAX, SMAX, J + 1>::step(a, lane, bad, root1, inv1);
+      ElimSteps<NSMAX, SMAX, J + 1>::step(a, lane, bad, root1, inv1, ns);
     }
   }
 };
@@ -701,7 +704,7 @@ __device__ inline void FactorSupernodeRows(const FactorPlan& P, const SnRec& R,
     if (j >= ns && lane == j) a[j] = 1.0;
   CXK_STAMP(2);
   bool bad = false;
-  ElimSteps<NSMAX, SMAX, 0>::run(a, lane, bad);
+  ElimSteps<NSMAX, SMAX, 0>::run(a, lane, bad, ns);
   CXK_STAMP(3);
   if (bad) {
     if (lane == 0) atomicExch(fail, 1);
@@ -894,7 +897,7 @@ __device__ __forceinline__ void FactorSupernodeLean(const FactorPlan& P, const S
     if (j >= ns && lane == j) a[j] = 1.0;
   CXK_STAMP(2);
   bool bad = false;
-  ElimSteps<NSMAX, SMAX, 0>::run(a, lane, bad);
+  ElimSteps<NSMAX, SMAX, 0>::run(a, lane, bad, ns);
   CXK_STAMP(3);
   if (bad) {
     if (lane == 0) {

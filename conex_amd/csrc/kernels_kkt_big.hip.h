@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(64) big_panel(double* __restrict__ D, double* 
   a[NB] = 0.0;
   bool bad = false;
   BPSTAMP(1);
-  ElimSteps<NB, 0, 0>::run(a, l32, bad);
+  ElimSteps<NB, 0, 0>::run(a, l32, bad, nb);
   BPSTAMP(2);
   if (bad && lane == 0) atomicExch(fail, 1);
   if (blockIdx.x == 0 && row && lane < NB) {
