@@ -1512,17 +1512,12 @@ tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, int pos0, int n, d
   int* rec_lds = reinterpret_cast<int*>(lds + IMG);
   const int lane = threadIdx.x & 63;
 #ifdef CXK_DEBUG_STAMPS
-  if (threadIdx.x == 0) g_cxk_stamp[80] = __builtin_amdgcn_s_memtime();
+  long long tstamp[8];  // held in registers, written once at the end: no memory traffic in between
+  int nstamp = 0;
+  tstamp[nstamp++] = __builtin_amdgcn_s_memtime();
 #endif
   int wnext = LoadRecWord(recs, pos0);
   for (int q = 0; q < n; q++) {
-#ifdef CXK_DEBUG_STAMPS
-    if (threadIdx.x == 0) {
-      g_cxk_sel = 1;
-      g_cxk_lvl = q;
-      g_cxk_stamp[8 * q + 6] = __builtin_amdgcn_s_memtime();
-    }
-#endif
     const int w = wnext;
     if (q + 1 < n) wnext = LoadRecWord(recs, pos0 + q + 1);
     if (lane < 32) rec_lds[32 * q + lane] = w;
@@ -1549,14 +1544,11 @@ tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, int pos0, int n, d
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #ifdef CXK_DEBUG_STAMPS
-    if (threadIdx.x == 0) g_cxk_stamp[8 * q + 7] = __builtin_amdgcn_s_memtime();
+    if (nstamp < 7) tstamp[nstamp++] = __builtin_amdgcn_s_memtime();
 #endif
     if (root) n--;  // done with the root: the way down starts below it
   }
   WaveSync();
-#ifdef CXK_DEBUG_STAMPS
-  if (threadIdx.x == 0) g_cxk_sel = 2;
-#endif
   for (int q = n - 1; q >= 0; q--) {
     const SnRec R = DecodeRec(rec_lds[32 * q + (lane & 31)]);
     const bool isA = RegisterShape(R.ns, R.nsep) == (NA << 8 | SA);
@@ -1566,9 +1558,13 @@ tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, int pos0, int n, d
       BackwardSupernodeLean<NB, SB>(R, slab, rhs);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #ifdef CXK_DEBUG_STAMPS
-    if (threadIdx.x == 0) g_cxk_stamp[72 + q] = __builtin_amdgcn_s_memtime();
+    if (nstamp < 8) tstamp[nstamp++] = __builtin_amdgcn_s_memtime();
 #endif
   }
+#ifdef CXK_DEBUG_STAMPS
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 8; i++) g_cxk_stamp[80 + i] = i < nstamp ? tstamp[i] : 0;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
