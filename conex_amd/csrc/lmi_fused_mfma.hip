@@ -295,7 +295,10 @@ __device__ __forceinline__ void Triangles(const double* __restrict__ Pb, double*
   using Cfg = MfmaCfg<N>;
   constexpr int NK = Cfg::NK, LD = Cfg::LD, MS = Cfg::MS;
   const int R = M1 - 16;
-  const int kq = lane >> 4, blk = (lane >> 2) & 3, i = lane & 3, t = blk >> 1, h = blk & 1;
+  const int blk = (lane >> 2) & 3, i = lane & 3, t = blk >> 1, h = blk & 1;
+  // which of a step's four columns a lane supplies: the second triangle's blocks take them rotated by
+  // two, or its matrices (16 further on: a multiple of 64 LDS banks) would alias the first's
+  const int kq = ((lane >> 4) + 2 * t) & 3;
   const int lo = (t ? 16 : 0) + (i < R ? i : R - 1), hi = (t ? 16 : 0) + (4 + i < R ? 4 + i : R - 1);
   // operand offsets: A-side P_x[r][4 bi + kq], B-side P_y[4 bi + kq][r], r = 2 p + h
   const int a_lo = lo * MS + h * LD + kq, a_hi = hi * MS + h * LD + kq;
