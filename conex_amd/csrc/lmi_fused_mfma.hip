@@ -251,9 +251,9 @@ __device__ __forceinline__ d4_t Contract(const double* __restrict__ Pb, int ra, 
   }
 #pragma unroll
   for (int r = 0; r < ROWS; r++) {
-    if (r >= nrows) break;  // wave-uniform (N rows do not always divide evenly)
     const int cb_ = r & 1, nb_ = cb_ ^ 1;
     const bool more = r + 1 < ROWS && r + 1 < nrows;
+    if (r < nrows)  // wave-uniform (N rows do not always divide evenly)
 #pragma unroll
     for (int bi = 0; bi < NK; bi++) {
       __builtin_amdgcn_sched_barrier(0);
