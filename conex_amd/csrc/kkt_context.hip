@@ -2709,7 +2709,7 @@ static int FinalizeImpl(cxk_context* ctx) {
       const char* force = getenv("CXK_SPARSE_LMI");
       const bool lds_resident = LmiTakeLds(c.n) <= kLdsLimit && LmiPrepareLds(c.n, c.m) <= kLdsLimit;
       c.sparse = force ? (atoi(force) != 0)
-                       : LmiSparsePays(c.n, c.m, nnz, lds_resident, LmiFusedSupports(c.n, c.m) || LmiMfmaSupports(c.n, c.m));
+                       : LmiSparsePays(c.n, c.m, nnz, lds_resident, LmiFusedSupports(c.n, c.m) || LmiMfmaSupports(c.n, c.m, c.herm_d));
       if (c.n > 65535) c.sparse = false;  // packed row | col << 16
       if (!c.symmetric) {
         // The reference accepts non-symmetric matrices and evaluates <W A_i W, A_j> as written;
@@ -2747,7 +2747,7 @@ static int FinalizeImpl(cxk_context* ctx) {
           // CXK_LMI_SCHUR = dpp | generic selects the older kernels (comparison runs, tests)
           const char* pick = getenv("CXK_LMI_SCHUR");
           const bool want_dpp = pick && !strcmp(pick, "dpp"), want_generic = pick && !strcmp(pick, "generic");
-          g.mfma = !g.sparse && !g.large && !g.literal && !want_dpp && !want_generic && LmiMfmaSupports(g.n, g.m);
+          g.mfma = !g.sparse && !g.large && !g.literal && !want_dpp && !want_generic && LmiMfmaSupports(g.n, g.m, g.herm_d);
           g.fused = !g.sparse && !g.large && !g.literal && !g.mfma && !want_generic && LmiFusedSupports(g.n, g.m);
         }
         g.schur_gemm = !g.sparse && !g.literal && (g.large || (!g.fused && !g.mfma && g.n >= 32 &&

@@ -9,7 +9,9 @@ namespace cxk {
 
 // Shapes the persistent producer / consumer kernel covers: order n in {8, 12, 16, 20, 24}, any
 // number of variables m with m + 1 <= 24 matrices (<= 32 for n <= 16) whose two P images fit LDS.
-bool LmiMfmaSupports(int n, int m);
+// herm_d == 2 (complex Hermitian cones in their real representation of order n = 24): the folded
+// form that reads and keeps the top half of every matrix only (any m <= 15 or 24 <= m <= 31).
+bool LmiMfmaSupports(int n, int m, int herm_d = 0);
 
 // ConstructSchurComplementSystem(DenseLMIConstraint*) for every member of the group
 // (dense_lmi_constraint.cc:72-103); `cus` = multiprocessors of the device the stream runs on.

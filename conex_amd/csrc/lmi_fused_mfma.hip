@@ -73,23 +73,34 @@ __device__ long long g_mfma_stamp[2 * 16 * 64];
   } while (0)
 #endif
 
-template <int N>
+// H: the matrices are real representations [[Re, -Im], [Im, Re]] of complex Hermitian ones
+// (hermitian_psd.cc: d = 2).  Products of such matrices have the same form, so only the TOP half of
+// the rows of every A_i is read and only the top half of every P_i is formed and kept; the
+// contraction over the full index space folds onto the top rows,
+//   tr(P_x P_y) = 2 [ sum_{r,c < N/2} P_x[r][c] P_y[c][r]  -  sum_{r,c < N/2} P_x[r][N/2+c] P_y[c][N/2+r] ],
+// (the bottom-left block is minus the top-right one): half the bytes, half the multiply-adds.
+template <int N, bool H = false>
 struct MfmaCfg {
   static_assert(N % 4 == 0 && N >= 8 && N < 32, "one 16-column tile (part of it for N < 16) plus 4-column blocks");
+  static_assert(!H || N % 8 == 0, "complex order N/2, whose k-steps split evenly between the two sums");
+  static constexpr int RPM = H ? N / 2 : N;   // rows of a matrix that are read / formed / kept
   static constexpr int NK = N / 4;            // stage-1 k-steps = doubles of its row a lane holds
   static constexpr int NC4 = N > 16 ? (N - 16) / 4 : 0;  // 4-column blocks beside the 16-column tile
   static constexpr int NC4A = NC4 > 0 ? NC4 : 1;         // (array extent)
   static constexpr int PIECES = 4 + NC4;      // stores per finished tile (StorePiece)
   static constexpr bool NARROW = N < 16;      // the 16-column tile has columns past N: every store is masked
-  static constexpr bool THREE_TILES = N <= 16;  // more than 24 matrices fit LDS (twice) only at these orders
+  static constexpr bool THREE_TILES = N <= 16 || H;  // more than 24 matrices fit LDS (twice) only then
   static constexpr int LD = N + 1;            // odd row stride of the P image
-  static constexpr int MS = N * LD + (6 - (N * LD) % 4) % 4;  // matrix stride = 2 (mod 4) doubles
+  static constexpr int MS = RPM * LD + (6 - (RPM * LD) % 4) % 4;  // matrix stride = 2 (mod 4) doubles
   static constexpr int KSTEPS = N * N / 4;    // stage-2 k-steps
   static constexpr int PROD = 8, CONS = 4;    // producer / consumer wavefronts (two / one per SIMD)
   static constexpr int TPW = 4;               // tiles per producer wave (<= 32 tiles of 16 rows)
   static constexpr int YSLOTS = 1;            // tile slots a producer keeps for phase Y
   static constexpr int THREADS = 64 * (PROD + CONS);
   static_assert(N % CONS == 0, "stage-2 rows (N/4 k-steps each) are dealt evenly to the consumer waves");
+  // offset of the B-side operand of k-step bi inside the row block of P_y (doubles): P_y[4 bi + kq][r],
+  // or for the second sum of the Hermitian form P_y[4 (bi - NK/2) + kq][N/2 + r]
+  static constexpr int BOfs(int bi) { return H && bi >= NK / 2 ? 4 * (bi - NK / 2) * LD + RPM : 4 * bi * LD; }
   static_assert(MS % 4 == 2, "both stage-2 operand reads are bank-conflict free only then");
 };
 
@@ -97,11 +108,11 @@ struct MfmaCfg {
 // release fence would also wait for the producers' prefetch loads (vmcnt).
 __device__ __forceinline__ void LdsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int N>
+template <int N, bool H>
 __device__ __forceinline__ int PAddr(int rho) {  // stacked row -> offset of its row in the P image
-  using Cfg = MfmaCfg<N>;
-  const int mat = rho / N;
-  return mat * Cfg::MS + (rho - mat * N) * Cfg::LD;
+  using Cfg = MfmaCfg<N, H>;
+  const int mat = rho / Cfg::RPM;
+  return mat * Cfg::MS + (rho - mat * Cfg::RPM) * Cfg::LD;
 }
 
 // Per-lane geometry of the producer's tiles: the same for every constraint, computed once.
@@ -115,9 +126,9 @@ struct TileGeom {
   unsigned keep;                  // bit 8 tt + e (e < 4): 16x16x4 element e is a real row; bit 8 tt + 4: the 4x4x4 row is
 };
 
-template <int N>
+template <int N, bool H>
 __device__ __forceinline__ void MakeGeom(TileGeom<N>& gm, int wave, int lane, int rows, int nt1) {
-  using Cfg = MfmaCfg<N>;
+  using Cfg = MfmaCfg<N, H>;
   const int s = lane & 15, q = lane >> 4;
   gm.keep = 0;
 #pragma unroll
@@ -131,12 +142,13 @@ __device__ __forceinline__ void MakeGeom(TileGeom<N>& gm, int wave, int lane, in
     gm.keep |= (real && 16 * t + 4 * ((lane >> 2) & 3) + q < rows ? 1u : 0u) << (8 * tt + 4);
     int rho = 16 * t + s;
     rho = rho < rows ? rho : rows - 1;  // rows past the last matrix: any valid address, results unused
-    gm.src[tt] = (unsigned)(rho * N + q * Cfg::NK) * 8u;
+    const int mat = rho / Cfg::RPM;  // (H: the kept rows of a matrix are its first RPM, matrices stay N x N apart)
+    gm.src[tt] = (unsigned)(mat * N * N + (rho - mat * Cfg::RPM) * N + q * Cfg::NK) * 8u;
     // 16x16x4 result: element e of lane l is (row (l >> 4) + 4 e, column l & 15)
 #pragma unroll
-    for (int e = 0; e < 4; e++) gm.p16[tt][e] = PAddr<N>(16 * t + q + 4 * e) + s;
+    for (int e = 0; e < 4; e++) gm.p16[tt][e] = PAddr<N, H>(16 * t + q + 4 * e) + s;
     // 4x4x4 result: lane l holds (row 4 ((l >> 2) & 3) + (l >> 4), column l & 3) of each block
-    gm.p4[tt] = PAddr<N>(16 * t + 4 * ((lane >> 2) & 3) + q) + 16 + (lane & 3);
+    gm.p4[tt] = PAddr<N, H>(16 * t + 4 * ((lane >> 2) & 3) + q) + 16 + (lane & 3);
   }
 }
 
@@ -236,18 +248,19 @@ __device__ __forceinline__ ConstraintPtrs Member(const LmiGroup& g, int mem, int
 // B-operand columns are the matrices at ca(lane).  The operands of the next row are read in the
 // gaps between this row's MFMAs (a lone wavefront issues a ds_read_b64 every ~17 cycles: a row's
 // reads up front would idle the pipe).
-template <int N, int ROWS>
+template <int N, int ROWS, bool H = false>
 __device__ __forceinline__ d4_t Contract(const double* __restrict__ Pb, int ra, int ca, int rr0, int kq, int nrows = ROWS) {
-  using Cfg = MfmaCfg<N>;
+  using Cfg = MfmaCfg<N, H>;
   constexpr int NK = Cfg::NK, LD = Cfg::LD;
   d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+  d4_t acc2 = (d4_t){0.0, 0.0, 0.0, 0.0};       // H: the second (subtracted) sum of the Hermitian form
   double a0[2][NK], b0[2][NK];
   const double* pa = Pb + ra + rr0 * LD + kq;   // A side: P_x[r][4 bi + kq]
-  const double* pb = Pb + ca + kq * LD + rr0;   // B side: P_y[4 bi + kq][r]
+  const double* pb = Pb + ca + kq * LD + rr0;   // B side: P_y[4 bi + kq][r]  (Cfg::BOfs)
 #pragma unroll
   for (int bi = 0; bi < NK; bi++) {
     a0[0][bi] = pa[4 * bi];
-    b0[0][bi] = pb[4 * bi * LD];
+    b0[0][bi] = pb[Cfg::BOfs(bi)];
   }
 #pragma unroll
   for (int r = 0; r < ROWS; r++) {
@@ -257,7 +270,10 @@ __device__ __forceinline__ d4_t Contract(const double* __restrict__ Pb, int ra, 
 #pragma unroll
     for (int bi = 0; bi < NK; bi++) {
       __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[cb_][bi], b0[cb_][bi], acc, 0, 0, 0);
+      if (H && bi >= NK / 2)
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[cb_][bi], b0[cb_][bi], acc2, 0, 0, 0);
+      else
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[cb_][bi], b0[cb_][bi], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
 #ifndef CXK_EXPERIMENT_NO_READS  // diagnostic: operands of the first row are reused (wrong results, MFMA-only timing)
       // next row's operands, two per LDS instruction (ds_read2_b64: neighbours share a base
@@ -266,10 +282,10 @@ __device__ __forceinline__ d4_t Contract(const double* __restrict__ Pb, int ra, 
         if ((bi & 1) == 0) {
           a0[nb_][bi] = pa[(r + 1) * LD + 4 * bi];
           if (bi + 1 < NK) a0[nb_][bi + 1] = pa[(r + 1) * LD + 4 * (bi + 1)];
-          if (bi + 1 == NK) b0[nb_][bi] = pb[4 * bi * LD + r + 1];
+          if (bi + 1 == NK) b0[nb_][bi] = pb[Cfg::BOfs(bi) + r + 1];
         } else {
-          b0[nb_][bi - 1] = pb[4 * (bi - 1) * LD + r + 1];
-          b0[nb_][bi] = pb[4 * bi * LD + r + 1];
+          b0[nb_][bi - 1] = pb[Cfg::BOfs(bi - 1) + r + 1];
+          b0[nb_][bi] = pb[Cfg::BOfs(bi) + r + 1];
         }
       }
 #else
@@ -278,6 +294,7 @@ __device__ __forceinline__ d4_t Contract(const double* __restrict__ Pb, int ra, 
 #endif
     }
   }
+  if constexpr (H) acc -= acc2;
   return acc;
 }
 
@@ -368,12 +385,12 @@ __device__ __forceinline__ void Triangles(const double* __restrict__ Pb, double*
   }
 }
 
-template <int N>
+template <int N, bool H>
 __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g, Arena ar) {
-  using Cfg = MfmaCfg<N>;
-  constexpr int NK = Cfg::NK, LD = Cfg::LD, MS = Cfg::MS, TPW = Cfg::TPW, NN = N * N;
+  using Cfg = MfmaCfg<N, H>;
+  constexpr int NK = Cfg::NK, LD = Cfg::LD, MS = Cfg::MS, TPW = Cfg::TPW, NN = N * N, RPM = Cfg::RPM;
   extern __shared__ double lds[];
-  const int M = g.m, M1 = M + 1, rows = M1 * N;
+  const int M = g.m, M1 = M + 1, rows = M1 * RPM;
   const int nt1 = (rows + 15) >> 4;
   const int pbuf = M1 * MS;
   // contraction cover of the M1 x M1 lower triangle: one tile (M1 <= 16), one tile + two corner
@@ -387,7 +404,8 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
   int64_t* dest = reinterpret_cast<int64_t*>(scratch + 2 * SB);
   int* etab = reinterpret_cast<int*>(dest + 3 * kDestSlots);
   const int nout = M1 * (M1 + 1) / 2;
-  const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;  // Hermitian cones: tr over the real representation
+  // Hermitian cones: tr over the real representation, divided by d; the folded form (H) sums half of it
+  const double osc = (g.herm_d > 1 ? 1.0 / g.herm_d : 1.0) * (H ? 2.0 : 1.0);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int first = blockIdx.x, stride = gridDim.x;
   const int cnt = (g.count - first + stride - 1) / stride;  // constraints of this workgroup (>= 1)
@@ -397,7 +415,7 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
     double a[TPW][NK];
     WOps<N> w, wn;
     TileGeom<N> gm;
-    MakeGeom<N>(gm, wave, lane, rows, nt1);
+    MakeGeom<N, H>(gm, wave, lane, rows, nt1);
     MSTAMP(0);
     {
       const ConstraintPtrs c0 = Member(g, first, NN);
@@ -473,13 +491,13 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
     const int hi = (16 + il < M1 ? 16 + il : M1 - 1) * MS;
     ra = cw == 0 ? il * MS : hi;
     ca = cw == 3 ? hi : il * MS;
-    rr0 = cw == 2 ? N / 2 : 0;
-    nrows = cw == 1 ? N / 2 : (cw == 2 ? N - N / 2 : N);
+    rr0 = cw == 2 ? RPM / 2 : 0;
+    nrows = cw == 1 ? RPM / 2 : (cw == 2 ? RPM - RPM / 2 : RPM);
   } else {
     const int parts = two ? Cfg::CONS - 1 : Cfg::CONS;
     const int part = cw < parts ? cw : 0;
-    rr0 = part * N / parts;
-    nrows = (part + 1) * N / parts - rr0;
+    rr0 = part * RPM / parts;
+    nrows = (part + 1) * RPM / parts - rr0;
     ra = two ? (R + il) * MS : (il < M1 ? il : M1 - 1) * MS;
     ca = two ? il * MS : ra;
   }
@@ -522,7 +540,7 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
     const double* Pc = P0 + (c & 1) * pbuf + ct * MS;
     double s0 = 0, s1 = 0;
 #pragma unroll
-    for (int r = 0; r < N; r += 2) {
+    for (int r = 0; r < RPM; r += 2) {
       s0 += Pc[r * LD + r];
       s1 += Pc[(r + 1) * LD + r + 1];
     }
@@ -564,18 +582,18 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
   };
   LdsBarrier();
   MSTAMP(0);
-  constexpr int MAXROWS = (N + Cfg::CONS - 2) / (Cfg::CONS - 1);
+  constexpr int MAXROWS = (RPM + Cfg::CONS - 2) / (Cfg::CONS - 1);
   for (int it = 1; it <= cnt; it++) {
     MSTAMP(1 + 4 * it);
     const double* Pb = P0 + ((it - 1) & 1) * pbuf;
     double* sb = scratch + ((it - 1) & 1) * SB;
-    if (two && cw == Cfg::CONS - 1) {
+    if (!H && two && cw == Cfg::CONS - 1) {  // (the folded Hermitian form has no 17 .. 24 instance: SupportsT)
       if (R > 4)
         Triangles<N, true>(Pb, sb + 256 * (Cfg::CONS - 1), lane, M1);
       else
         Triangles<N, false>(Pb, sb + 256 * (Cfg::CONS - 1), lane, M1);
     } else {
-      const d4_t acc = three ? Contract<N, N>(Pb, ra, ca, rr0, kq, nrows) : Contract<N, MAXROWS>(Pb, ra, ca, rr0, kq, nrows);
+      const d4_t acc = three ? Contract<N, RPM, H>(Pb, ra, ca, rr0, kq, nrows) : Contract<N, MAXROWS, H>(Pb, ra, ca, rr0, kq, nrows);
 #pragma unroll
       for (int e = 0; e < 4; e++)  // C/D layout: column = lane & 15, row = (lane >> 4) + 4 e
         sb[cw * 256 + (kq + 4 * e) * 16 + il] = acc[e];
@@ -592,9 +610,9 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
   MSTAMP(1 + 4 * (cnt + 1));
 }
 
-template <int N>
+template <int N, bool H>
 size_t MfmaLds(int m) {
-  using Cfg = MfmaCfg<N>;
+  using Cfg = MfmaCfg<N, H>;
   const int m1 = m + 1;
   return sizeof(double) * (2 * (size_t)m1 * Cfg::MS + 2 * (size_t)Cfg::CONS * 256 + 3 * kDestSlots) +
          sizeof(int) * (size_t)(m1 * (m1 + 1) / 2);
@@ -602,17 +620,20 @@ size_t MfmaLds(int m) {
 
 constexpr size_t kLdsPerCu = 160 * 1024;
 
-template <int N>
+template <int N, bool H>
 bool SupportsT(int m) {
+  using Cfg = MfmaCfg<N, H>;
   const int m1 = m + 1;
-  return m >= 1 && m1 <= (MfmaCfg<N>::THREE_TILES ? 32 : 24) && (m1 * N + 15) / 16 <= MfmaCfg<N>::TPW * MfmaCfg<N>::PROD && MfmaLds<N>(m) <= kLdsPerCu;
+  if (H && m1 > 16 && m1 <= 24) return false;  // the corner-triangle cover exists for the full form only
+  return m >= 1 && m1 <= (Cfg::THREE_TILES ? 32 : 24) && (m1 * Cfg::RPM + 15) / 16 <= Cfg::TPW * Cfg::PROD &&
+         MfmaLds<N, H>(m) <= kLdsPerCu;
 }
 
-template <int N>
+template <int N, bool H>
 hipError_t LaunchT(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stream) {
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lmi_schur_mfma<N>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lmi_schur_mfma<N, H>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
     if (e != hipSuccess) return e;
     configured = true;
@@ -620,28 +641,34 @@ hipError_t LaunchT(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stre
   int grid = g.count < cus ? g.count : cus;
   const int need = (g.count + kDestSlots - 1) / kDestSlots;  // at most kDestSlots constraints per workgroup
   if (grid < need) grid = need;
-  lmi_schur_mfma<N><<<grid, MfmaCfg<N>::THREADS, MfmaLds<N>(g.m), stream>>>(g, ar);
+  lmi_schur_mfma<N, H><<<grid, MfmaCfg<N>::THREADS, MfmaLds<N, H>(g.m), stream>>>(g, ar);
   return hipGetLastError();
 }
 
 }  // namespace
 
-bool LmiMfmaSupports(int n, int m) {
-  if (n == 8) return SupportsT<8>(m);
-  if (n == 12) return SupportsT<12>(m);
-  if (n == 16) return SupportsT<16>(m);
-  if (n == 20) return SupportsT<20>(m);
-  if (n == 24) return SupportsT<24>(m);
+// Complex Hermitian cones (herm_d == 2) whose real representation has order n take the folded form
+// when it has an instance; everything else the full form.
+static bool Folded(int n, int m, int herm_d) { return herm_d == 2 && n == 24 && SupportsT<24, true>(m); }
+
+bool LmiMfmaSupports(int n, int m, int herm_d) {
+  if (Folded(n, m, herm_d)) return true;
+  if (n == 8) return SupportsT<8, false>(m);
+  if (n == 12) return SupportsT<12, false>(m);
+  if (n == 16) return SupportsT<16, false>(m);
+  if (n == 20) return SupportsT<20, false>(m);
+  if (n == 24) return SupportsT<24, false>(m);
   return false;
 }
 
 hipError_t LaunchLmiSchurMfma(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stream) {
   if (g.count <= 0) return hipSuccess;
-  if (g.n == 8) return LaunchT<8>(g, ar, cus, stream);
-  if (g.n == 12) return LaunchT<12>(g, ar, cus, stream);
-  if (g.n == 16) return LaunchT<16>(g, ar, cus, stream);
-  if (g.n == 20) return LaunchT<20>(g, ar, cus, stream);
-  if (g.n == 24) return LaunchT<24>(g, ar, cus, stream);
+  if (Folded(g.n, g.m, g.herm_d)) return LaunchT<24, true>(g, ar, cus, stream);
+  if (g.n == 8) return LaunchT<8, false>(g, ar, cus, stream);
+  if (g.n == 12) return LaunchT<12, false>(g, ar, cus, stream);
+  if (g.n == 16) return LaunchT<16, false>(g, ar, cus, stream);
+  if (g.n == 20) return LaunchT<20, false>(g, ar, cus, stream);
+  if (g.n == 24) return LaunchT<24, false>(g, ar, cus, stream);
   return hipErrorNotSupported;
 }
 
