@@ -1407,6 +1407,37 @@ tree_factor_level_asm(FactorPlan P, const SnRec* __restrict__ recs, int base0, i
   FactorSupernodeLean<NSMAX, SMAX, RHS, true>(P, R, slab, rhs, fail, my, &ai, aw2);
 }
 
+// tree_factor_level_asm for a first level of TWO register shapes (programs mixing matrix cones with
+// second-order cones: config 5): workgroups [0, blocksA) shape A, [blocksA, fwgs) shape B, the rest
+// the gather.  AsmRec q belongs to level position q (segment B follows segment A).
+template <int NA, int SA, int NB, int SB>
+__global__ void __launch_bounds__(256)
+tree_factor_level2_asm(FactorPlan P, const SnRec* __restrict__ recs, int baseA, int cntA, int blocksA,
+                       int baseB, int cntB, double* __restrict__ slab, double* __restrict__ rhs,
+                       int* __restrict__ fail, int lds_per_wave, AsmIn ai, GatherArgs ga, int fwgs) {
+  extern __shared__ double lds[];
+  if ((int)blockIdx.x >= fwgs) {
+    GatherBody(ga, blockIdx.x - fwgs, gridDim.x - fwgs);
+    return;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  double* my = lds + (size_t)wave * lds_per_wave;
+  const int lane = threadIdx.x & 63;
+  if ((int)blockIdx.x < blocksA) {
+    const int idx = blockIdx.x * nw + wave;
+    if (idx >= cntA) return;
+    const int aw2 = reinterpret_cast<const int*>(ai.rec + idx)[lane < 24 ? lane : 0];
+    const SnRec R = LoadRec(recs, baseA + idx);
+    FactorSupernodeLean<NA, SA, true, true>(P, R, slab, rhs, fail, my, &ai, aw2);
+  } else {
+    const int idx = (blockIdx.x - blocksA) * nw + wave;
+    if (idx >= cntB) return;
+    const int aw2 = reinterpret_cast<const int*>(ai.rec + cntA + idx)[lane < 24 ? lane : 0];
+    const SnRec R = LoadRec(recs, baseB + idx);
+    FactorSupernodeLean<NB, SB, true, true>(P, R, slab, rhs, fail, my, &ai, aw2);
+  }
+}
+
 // The backward step of one level, same specialisation (no LDS).
 template <int NSMAX, int SMAX>
 __global__ void __launch_bounds__(256)

@@ -1106,8 +1106,9 @@ int BuildPlans(cxk_context* ctx) {
   // and the gather lists shrink to what the levels above need.
   ctx->fused_asm = false;
   if ((!sharded || ctx->cut_level >= 1) && !ctx->use_ldlt && !ctx->no_lean && !getenv("CXK_NO_FUSED_ASM") && nlev >= 2 &&
-      ctx->level_segs[0].size() == 1 && ctx->level_lean[0] && ctx->top_level >= 1 && ctx->chain_level >= 1 &&
-      ctx->level_segs[0][0].shape != 0 && 4 * ctx->chol_lds <= kLdsLimit) {
+      (ctx->level_segs[0].size() == 1 || ctx->level_segs[0].size() == 2) && ctx->level_lean[0] &&
+      ctx->top_level >= 1 && ctx->chain_level >= 1 && ctx->level_segs[0][0].shape != 0 &&
+      4 * ctx->chol_lds <= kLdsLimit) {
     const int first = ctx->level_ptr[0], cnt0 = ctx->level_nh[0];
     std::vector<AsmRec> arecs(cnt0);
     std::vector<char> slab_own(h_as_rec.size(), 0), var_own(N, 0);
@@ -1701,6 +1702,39 @@ GatherArgs MakeGather(cxk_context* ctx, int with_rhs, double k, double bs, doubl
   return a;
 }
 
+// Arguments of a first factor level with the assembly folded in: the gather of everything its own
+// supernodes do not load themselves, and what those need to load it (AsmIn).
+void MakeFusedAssembly(cxk_context* ctx, const cxk_context::AsmPending& ap, GatherArgs* gap, AsmIn* aip) {
+  GatherArgs ga = MakeGather(ctx, ap.with_rhs, ap.k, ap.bs, ap.cs);
+  ga.cb = ap.cb;
+  ga.cq = ap.cq;
+  ga.cw = ap.cw;
+  ga.T = ctx->as_T2;
+  ga.rec = ctx->as_rec2.p;
+  ga.N = ctx->rs_N2;
+  ga.rrec = ctx->rs_rec2.p;
+  ga.var_idx = ctx->rs_var2.p;
+  AsmIn ai;
+  ai.rec = ctx->asm_rec.p;
+  ai.G = ctx->G.p;
+  ai.AWc = ctx->AWc.p;
+  ai.AQcc = ctx->AQcc.p;
+  ai.b = ctx->b.p;
+  ai.AW = ctx->AW.p;
+  ai.AQc = ctx->AQc.p;
+  ai.k = ap.k;
+  ai.bs = ap.bs;
+  ai.cs = ap.cs;
+  ai.cb = ap.cb;
+  ai.cq = ap.cq;
+  ai.cw = ap.cw;
+  ai.comb = ap.with_rhs == 2;
+  ctx->asm_tag = ctx->asm_tag >= (1 << 30) ? 1 : ctx->asm_tag + 1;
+  ai.tag = ctx->fail_tag = ctx->asm_tag;
+  *gap = ga;
+  *aip = ai;
+}
+
 int LaunchGather(cxk_context* ctx, bool with_rhs, double k, double bs, double cs) {
   const GatherArgs a = MakeGather(ctx, with_rhs ? 1 : 0, k, bs, cs);
   assemble_gather<<<GridFor((size_t)std::max<int64_t>(ctx->as_T, ctx->md.N), 256), 256, 0,
@@ -1789,6 +1823,38 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
           const size_t lds = (size_t)w * ctx->chol_lds;
           const int sa = sg.shape, sb2 = sb.shape;
           bool done = false;
+          if (mode == 0 && lb == 0 && ctx->asm_pending.on && ctx->asm_pending.with_rhs != 0 && segs.size() == 2) {
+            // the assembly rides in this launch (see the one-shape case below)
+            const cxk_context::AsmPending ap = ctx->asm_pending;
+            ctx->asm_pending.on = false;
+            GatherArgs ga;
+            AsmIn ai;
+            MakeFusedAssembly(ctx, ap, &ga, &ai);
+            const int w4 = 4, gA4 = (cnt + w4 - 1) / w4, gB4 = (cntB + w4 - 1) / w4;
+            const size_t lds4 = (size_t)w4 * ctx->chol_lds;
+            const int gg = GridFor((size_t)std::max<int64_t>(std::max<int64_t>(ga.T, ga.N), 1), 256);
+#define CXK_PAIR_ASM(NA_, SA_, NB_, SB_)                                                                     \
+  if (!done && sa == ((NA_) << 8 | (SA_)) && sb2 == ((NB_) << 8 | (SB_))) {                                  \
+    done = true;                                                                                             \
+    tree_factor_level2_asm<NA_, SA_, NB_, SB_><<<gA4 + gB4 + gg, w4 * 64, lds4, ctx->stream>>>(              \
+        ctx->plan, ctx->p_rec.p, sg.begin, cnt, gA4, sb.begin, cntB, ctx->slab.p, rhs, ctx->d_fail.p,        \
+        per_wave, ai, ga, gA4 + gB4);                                                                        \
+  }
+            CXK_PAIR_ASM(8, 8, 16, 8)
+            CXK_PAIR_ASM(8, 8, 24, 0)
+            CXK_PAIR_ASM(8, 8, 24, 8)
+            CXK_PAIR_ASM(8, 8, 32, 16)
+            CXK_PAIR_ASM(16, 8, 24, 0)
+            CXK_PAIR_ASM(16, 8, 24, 8)
+            CXK_PAIR_ASM(16, 8, 32, 16)
+            CXK_PAIR_ASM(24, 0, 24, 8)
+            CXK_PAIR_ASM(24, 0, 32, 16)
+            CXK_PAIR_ASM(24, 8, 32, 16)
+#undef CXK_PAIR_ASM
+            CXK_DEMAND(done, "internal error: no tree_factor_level2_asm instance for the first level's shapes");
+            si++;
+            continue;
+          }
 #define CXK_PAIR(NA_, SA_, NB_, SB_)                                                                         \
   if (!done && sa == ((NA_) << 8 | (SA_)) && sb2 == ((NB_) << 8 | (SB_))) {                                  \
     done = true;                                                                                             \
@@ -1860,32 +1926,9 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
           // the Schur blocks, the others gather what the levels above need
           const cxk_context::AsmPending ap = ctx->asm_pending;
           ctx->asm_pending.on = false;
-          GatherArgs ga = MakeGather(ctx, ap.with_rhs, ap.k, ap.bs, ap.cs);
-          ga.cb = ap.cb;
-          ga.cq = ap.cq;
-          ga.cw = ap.cw;
-          ga.T = ctx->as_T2;
-          ga.rec = ctx->as_rec2.p;
-          ga.N = ctx->rs_N2;
-          ga.rrec = ctx->rs_rec2.p;
-          ga.var_idx = ctx->rs_var2.p;
+          GatherArgs ga;
           AsmIn ai;
-          ai.rec = ctx->asm_rec.p;
-          ai.G = ctx->G.p;
-          ai.AWc = ctx->AWc.p;
-          ai.AQcc = ctx->AQcc.p;
-          ai.b = ctx->b.p;
-          ai.AW = ctx->AW.p;
-          ai.AQc = ctx->AQc.p;
-          ai.k = ap.k;
-          ai.bs = ap.bs;
-          ai.cs = ap.cs;
-          ai.cb = ap.cb;
-          ai.cq = ap.cq;
-          ai.cw = ap.cw;
-          ai.comb = ap.with_rhs == 2;
-          ctx->asm_tag = ctx->asm_tag >= (1 << 30) ? 1 : ctx->asm_tag + 1;
-          ai.tag = ctx->fail_tag = ctx->asm_tag;
+          MakeFusedAssembly(ctx, ap, &ga, &ai);
           // 256 threads per workgroup whatever the level's size: the gather's fixed-order sums
           // (<w,c>, <c,Qc>) are dealt by thread index, and must come out as in assemble_gather
           const int w = 4, g = (cnt + w - 1) / w;
