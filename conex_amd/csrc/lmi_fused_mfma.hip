@@ -439,7 +439,10 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
       const int itn = it + 1 < cnt ? it + 1 : it;
       const ConstraintPtrs nx = Member(g, first + itn * stride, NN);
       w = wn;
-      LoadW<N>(wn, nx.Wg, lane);
+      // the next constraint's W operands: a whole iteration ahead where the registers allow it
+      // (N <= 20), behind this iteration's tiles otherwise (the order-24 instances spill with both
+      // sets live; W is 4.6 KB per constraint and shared by the eight waves: an L2 hit)
+      if constexpr (N <= 20) LoadW<N>(wn, nx.Wg, lane);
       __builtin_amdgcn_sched_barrier(0);
       double* Pb = P0 + (it & 1) * pbuf;
       TileAcc<N> res[2];
@@ -463,6 +466,10 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
 #ifndef CXK_EXPERIMENT_NO_RELOAD  // diagnostic: operands of the first constraint are reused (wrong results, compute-only timing)
         if (tt > 0) LoadTile<N>(a[tt - 1], gm, tt - 1, nx.block);
 #endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (N > 20) {
+        LoadW<N>(wn, nx.Wg, lane);
         __builtin_amdgcn_sched_barrier(0);
       }
       MSTAMP(2 + 4 * it);

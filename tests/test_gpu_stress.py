@@ -45,3 +45,14 @@ def test_repeated_kkt_solves_are_bit_identical_across_fresh_contexts():
             if ref is None:
                 ref = y.copy()
             assert np.array_equal(y, ref)
+
+
+def test_hermitian_newton_step_50_times():
+    """Round 2: tests/test_gpu_parity.py::test_hermitian_newton_step[7-6-5-2-2-2] failed once (output not
+    kept) in the run that followed a rebuild; 600 in-process repetitions, 16 repetitions of the whole
+    file and the NaN-filled runs did not reproduce it.  Kept under repetition here."""
+    import test_gpu_parity as tgp
+    for _ in range(REPS):
+        for d in (1, 2, 4):
+            tgp.test_hermitian_newton_step(d, 7, 6, 5, 2, 2)
+        tgp.test_hermitian_newton_step(2, 3, 12, 8, 2, 3)
