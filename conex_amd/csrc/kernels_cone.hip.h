@@ -262,42 +262,91 @@ __device__ inline void SocQuadRep(int len, const double* x, const double* y, dou
   for (int i = 0; i < len; i++) out[i] = (2 * xy) * x[i] + (i == 0 ? -det * y[i] : det * y[i]);
 }
 
-__global__ void __launch_bounds__(64) soc_schur(VecGroup g, Arena ar) {
-  extern __shared__ double lds[];
+// The two maps above dealt to the lanes of one wavefront: the reductions stay one lane's fma chain
+// (their order is the single-thread order: same bits), the per-element work -- above all the n
+// divisions of the spectral map -- runs one element per lane.  A SIMD issues a vector instruction
+// in the same 4-8 cycles whether one lane or all are active, and with five single-lane cones
+// resident per SIMD the serial forms cost 16 us per launch of 5000 cones.  x / y may be global or
+// LDS; z / out LDS (read back by other lanes: the caller synchronises the wavefront afterwards).
+__device__ __forceinline__ void SocSpectralWave(int n, double x0, const double* x1, int op, double* z, int lane) {
+  double nq = 0;
+  for (int i = 0; i < n; i++) nq = fma(x1[i], x1[i], nq);  // every lane the same chain: no broadcast needed
+  nq = sqrt(nq);
+  const double e0 = x0 + nq, e1 = x0 - nq;
+  const double f0 = op == 0 ? sqrt(e0) : exp(e0);
+  const double f1 = op == 0 ? sqrt(e1) : exp(e1);
+  if (lane == 0) z[0] = f0 * .5 + f1 * .5;
+  for (int i = lane; i < n; i += 64) {
+    const double q = nq > 0 ? x1[i] / nq : 0.0;
+    z[1 + i] = nq > 0 ? f0 * (.5 * q) + f1 * (-.5 * q) : 0.0;
+  }
+}
+__device__ __forceinline__ void SocQuadRepWave(int len, const double* x, const double* y, double* out, int lane) {
+  double t2 = 0, xy = 0;
+  for (int i = 1; i < len; i++) t2 = fma(x[i], x[i], t2);
+  for (int i = 0; i < len; i++) xy = fma(x[i], y[i], xy);
+  const double det = x[0] * x[0] - t2;
+  for (int i = lane; i < len; i += 64) out[i] = (2 * xy) * x[i] + (i == 0 ? -det * y[i] : det * y[i]);
+}
+
+// One wavefront per cone, four cones per workgroup.
+// STAGED: the cone's data (A, c, W) is copied to LDS in one round trip first; large cones whose
+// staged image would not fit read their operands where they are.
+template <bool STAGED>
+__global__ void __launch_bounds__(256) soc_schur(VecGroup g, Arena ar) {
+  extern __shared__ double lds_all[];
   const int len = g.len, n = len - 1, m = g.m;
-  const int mem = blockIdx.x, id = g.ids[mem];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int mem = blockIdx.x * nw + wave;
+  if (mem >= g.count) return;  // wave-uniform; only wavefront-level synchronisation below
+  double* lds = lds_all + (size_t)wave * (len * (STAGED ? 2 * m + 4 : m + 2));
+  const int id = g.ids[mem];
   const double* A = g.A + (size_t)mem * len * m;
   const double* c = g.c + (size_t)mem * len;
   const double* W = g.W + (size_t)mem * len;
   double* wsqrt = lds;            // len
   double* wc = wsqrt + len;       // len
   double* WA = wc + len;          // len x m
+  const double *sA = A, *sW = W, *sC = c;
   double* G = ar.G + ar.g_off[id];
   double* AW = ar.AWc + ar.r_off[id];
   double* AQc = ar.AQcc + ar.r_off[id];
-  if (threadIdx.x == 0) {
-    SocSpectral(n, W[0], W + 1, 0, wsqrt);
-    SocQuadRep(len, wsqrt, c, wc);
+  if constexpr (STAGED) {  // (otherwise the phases below fetch their operands themselves: four dependent round trips)
+    double* tA = WA + len * m;  // len x m
+    double* tW = tA + len * m;  // len
+    double* tC = tW + len;      // len
+    for (int q = lane; q < len * m; q += 64) tA[q] = A[q];
+    for (int q = lane; q < len; q += 64) {
+      tW[q] = W[q];
+      tC[q] = c[q];
+    }
+    sA = tA;
+    sW = tW;
+    sC = tC;
+    WaveSync();
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < m; i += blockDim.x) SocQuadRep(len, wsqrt, A + (size_t)i * len, WA + i * len);
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < m * m; idx += blockDim.x) {
+  SocSpectralWave(n, sW[0], sW + 1, 0, wsqrt, lane);
+  WaveSync();
+  SocQuadRepWave(len, wsqrt, sC, wc, lane);
+  WaveSync();
+  for (int i = lane; i < m; i += 64) SocQuadRep(len, wsqrt, sA + (size_t)i * len, WA + i * len);
+  WaveSync();
+  for (int idx = lane; idx < m * m; idx += 64) {
     const int i = idx % m, j = idx / m;
     double s = 0;
     for (int k = 0; k < len; k++) s = fma(WA[k + i * len], WA[k + j * len], s);
     G[idx] = 2 * s;
   }
-  for (int i = threadIdx.x; i < m; i += blockDim.x) {
+  for (int i = lane; i < m; i += 64) {
     double a = 0, q = 0;
     for (int k = 0; k < len; k++) {
-      a = fma(A[k + (size_t)i * len], W[k], a);
+      a = fma(sA[k + (size_t)i * len], sW[k], a);
       q = fma(WA[k + i * len], wc[k], q);
     }
     AW[i] = 2 * a;
     AQc[i] = 2 * q;
   }
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     double s = 0;
     for (int k = 0; k < len; k++) s = fma(wc[k], wc[k], s);
     ar.sc[2 * id] = 2 * wc[0];

@@ -1455,7 +1455,8 @@ hipError_t RaiseLdsLimits() {
         reinterpret_cast<const void*>(&tree_sweep_block_ldlt<0>),
         reinterpret_cast<const void*>(&tree_sweep_block_ldlt<1>),
         reinterpret_cast<const void*>(&tree_sweep_block_ldlt<2>),
-        reinterpret_cast<const void*>(&soc_schur),
+        reinterpret_cast<const void*>(&soc_schur<true>),
+        reinterpret_cast<const void*>(&soc_schur<false>),
     };
     for (const void* k : ks) {
       hipFuncAttributes attr;
@@ -1661,8 +1662,18 @@ int LaunchSchur(cxk_context* ctx) {
         linear_schur<<<count, 256, 0, ctx->stream>>>(MakeVec(g), ar);
         break;
       case CXK_SOC:
-        soc_schur<<<count, 64, sizeof(double) * (size_t)((g.n + 1) * (g.m + 2)), ctx->stream>>>(
-            MakeVec(g), ar);
+      {
+        // one wavefront per cone, up to four cones per workgroup; the cone's data staged in LDS when
+        // four staged images fit, read in place otherwise
+        const size_t staged = sizeof(double) * (size_t)(g.n + 1) * (2 * g.m + 4);
+        const size_t plain = sizeof(double) * (size_t)(g.n + 1) * (g.m + 2);
+        if (4 * staged <= kLdsLimit) {
+          soc_schur<true><<<(count + 3) / 4, 256, 4 * staged, ctx->stream>>>(MakeVec(g), ar);
+        } else {
+          const int w = (int)std::max<size_t>(1, std::min<size_t>(4, kLdsLimit / plain));
+          soc_schur<false><<<(count + w - 1) / w, 64 * w, w * plain, ctx->stream>>>(MakeVec(g), ar);
+        }
+      }
         break;
       case CXK_STATIC:
         static_schur<<<count, 64, 0, ctx->stream>>>(MakeStatic(g), ar);
