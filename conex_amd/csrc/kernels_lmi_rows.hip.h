@@ -295,16 +295,32 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa)
 #pragma unroll
   for (int u = 0; u < CH; u++) acc[u] = make_double2(0.0, 0.0);
   const double2* base = reinterpret_cast<const double2*>(g.A + (size_t)mem * g.a_stride);
-#pragma unroll 5
-  for (int i = 0; i < m; i++) {
-    const double yi = ReadLaneUniform(yv, i);
+  // Ten matrices per batch, every load of a batch issued before its first use, unconditionally
+  // from clamped addresses (chunks past the matrix and matrices past m re-read valid data and
+  // are masked in the arithmetic): the rolled loop this replaces waited for each matrix's four
+  // loads before asking for the next -- twenty dependent round trips per constraint.  Same sums in
+  // the same order.
+  constexpr int BATCH = 10;
+  int eo[CH];
 #pragma unroll
-    for (int u = 0; u < CH; u++) {
-      const int e = lane + 64 * u;
-      if (e < HALF) {
-        const double2 v = base[(size_t)i * HALF + e];
-        acc[u].x += yi * v.x;
-        acc[u].y += yi * v.y;
+  for (int u = 0; u < CH; u++) eo[u] = lane + 64 * u < HALF ? lane + 64 * u : HALF - 1;
+  for (int i0 = 0; i0 < m; i0 += BATCH) {
+    double2 v[BATCH][CH];
+#pragma unroll
+    for (int b = 0; b < BATCH; b++) {
+      const int i = i0 + b < m ? i0 + b : m - 1;
+#pragma unroll
+      for (int u = 0; u < CH; u++) v[b][u] = base[(size_t)i * HALF + eo[u]];
+    }
+#pragma unroll
+    for (int b = 0; b < BATCH; b++) {
+      if (i0 + b < m) {  // wave-uniform
+        const double yi = ReadLaneUniform(yv, i0 + b);
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+          acc[u].x += yi * v[b][u].x;
+          acc[u].y += yi * v[b][u].y;
+        }
       }
     }
   }
