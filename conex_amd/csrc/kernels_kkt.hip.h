@@ -979,6 +979,21 @@ __device__ inline void BackwardSupernodeRows(const FactorPlan& P, const SnRec& R
   if (active) rhs[R.start + lane] = acc;
 }
 
+// Where a solve-only sweep takes its right-hand side: form 0 from `rhs` (someone built it), form 1 /
+// 2 each supernode forms its own rows on the fly -- the expressions of build_rhs / build_rhs_comb,
+// term for term -- so that the separate launch that used to fill `rhs` first disappears.
+struct RhsIn {
+  int form;
+  const double *b, *AQc, *AW;
+  double k, bs, cs;    // form 1: k (b bs + AQc cs) - 2 AW   (cone_program.cc:409-411)
+  double cb, cq, cw;   // form 2: cb b + cq AQc + cw AW      (cone_program.cc:181, 504)
+};
+__device__ __forceinline__ double RhsValue(const RhsIn& ri, const double* __restrict__ rhs, int p) {
+  if (ri.form == 0) return rhs[p];
+  const double bp = ri.b[p], aq = ri.AQc[p], aw = ri.AW[p];
+  return ri.form == 1 ? ri.k * (bp * ri.bs + aq * ri.cs) - 2 * aw : ri.cb * bp + ri.cq * aq + ri.cw * aw;
+}
+
 // ForwardSupernodeWave (b_j <- L_j^{-1} (b_j - pulled forward updates), publish t[c] = off[:,c].b)
 // in the row-per-lane register layout with a straight-line load phase: lane r < ns holds row r of
 // L, lane NSMAX + c holds column c of the off block.  Operations and their order are those of the
@@ -987,7 +1002,8 @@ __device__ inline void BackwardSupernodeRows(const FactorPlan& P, const SnRec& R
 template <int NSMAX, int SMAX, bool ROOTBACK = false>
 __device__ __forceinline__ void ForwardSupernodeLean(const FactorPlan& P, const SnRec& R,
                                                      const double* __restrict__ slab,
-                                                     double* __restrict__ rhs, double* __restrict__ my = nullptr) {
+                                                     double* __restrict__ rhs, const RhsIn& ri,
+                                                     double* __restrict__ my = nullptr) {
   constexpr int MFMAX = kFastSlots;
   const int lane = threadIdx.x & 63;
   const int ns = R.ns, s = R.nsep;
@@ -1004,7 +1020,7 @@ __device__ __forceinline__ void ForwardSupernodeLean(const FactorPlan& P, const 
 #pragma unroll
   for (int j = 0; j < NSMAX; j++) a[j] = base[(j < lim) ? o0 + j * st : 0u];
   double dg = base[is_row ? (unsigned)lane * (unsigned)(ns + 1) : 0u];
-  double b = rhs[R.start + (is_row ? lane : 0)];
+  double b = RhsValue(ri, rhs, R.start + (is_row ? lane : 0));
   int pdstb = 0;
   if constexpr (SMAX > 0) pdstb = P.pubb_dst[R.updb_off + (is_sep ? sc : 0)];
   const int mflast = R.mf > 0 ? R.mf - 1 : 0;
@@ -1456,29 +1472,29 @@ tree_backward_level(const SnRec* __restrict__ recs, int base0, int cnt0, const d
 template <int NSMAX, int SMAX>
 __global__ void __launch_bounds__(256)
 tree_forward_level(FactorPlan P, const SnRec* __restrict__ recs, int base0, int cnt0,
-                   const double* __restrict__ slab, double* __restrict__ rhs) {
+                   const double* __restrict__ slab, double* __restrict__ rhs, RhsIn ri) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const int idx = blockIdx.x * nw + wave;
   if (idx >= cnt0) return;
   const SnRec R = LoadRec(recs, base0 + idx);
-  ForwardSupernodeLean<NSMAX, SMAX>(P, R, slab, rhs);
+  ForwardSupernodeLean<NSMAX, SMAX>(P, R, slab, rhs, ri);
 }
 
 template <int NA, int SA, int NB, int SB>
 __global__ void __launch_bounds__(256)
 tree_forward_level2(FactorPlan P, const SnRec* __restrict__ recs, int baseA, int cntA, int blocksA,
-                    int baseB, int cntB, const double* __restrict__ slab, double* __restrict__ rhs) {
+                    int baseB, int cntB, const double* __restrict__ slab, double* __restrict__ rhs, RhsIn ri) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   if ((int)blockIdx.x < blocksA) {
     const int idx = blockIdx.x * nw + wave;
     if (idx >= cntA) return;
     const SnRec R = LoadRec(recs, baseA + idx);
-    ForwardSupernodeLean<NA, SA>(P, R, slab, rhs);
+    ForwardSupernodeLean<NA, SA>(P, R, slab, rhs, ri);
   } else {
     const int idx = (blockIdx.x - blocksA) * nw + wave;
     if (idx >= cntB) return;
     const SnRec R = LoadRec(recs, baseB + idx);
-    ForwardSupernodeLean<NB, SB>(P, R, slab, rhs);
+    ForwardSupernodeLean<NB, SB>(P, R, slab, rhs, ri);
   }
 }
 
@@ -1535,7 +1551,7 @@ tree_backward_level2(const SnRec* __restrict__ recs, int baseA, int cntA, int bl
 template <int MODE, int NA, int SA, int NB, int SB>
 __global__ void __launch_bounds__(64)
 tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, int pos0, int n, double* __restrict__ slab,
-                double* __restrict__ rhs, int* __restrict__ fail) {
+                double* __restrict__ rhs, int* __restrict__ fail, RhsIn ri) {
   extern __shared__ double lds[];
   // One supernode per level: the chain's records are consecutive in level order (pos0 ..).  Each
   // record is in flight while the step before it runs, and stays in LDS for the way back down.
@@ -1567,11 +1583,11 @@ tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, int pos0, int n, d
         FactorSupernodeLean<NB, SB, true>(P, R, slab, rhs, fail, lds);
     } else {
       if (root)
-        ForwardSupernodeLean<NB, SB, true>(P, R, slab, rhs, lds);
+        ForwardSupernodeLean<NB, SB, true>(P, R, slab, rhs, ri, lds);
       else if (isA)
-        ForwardSupernodeLean<NA, SA>(P, R, slab, rhs);
+        ForwardSupernodeLean<NA, SA>(P, R, slab, rhs, ri);
       else
-        ForwardSupernodeLean<NB, SB>(P, R, slab, rhs);
+        ForwardSupernodeLean<NB, SB>(P, R, slab, rhs, ri);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #ifdef CXK_DEBUG_STAMPS

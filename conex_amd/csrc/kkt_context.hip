@@ -222,6 +222,10 @@ struct cxk_context {
     double k = 0, bs = 0, cs = 0, cb = 0, cq = 0, cw = 0;
   } asm_pending;
   bool asm_deferred = false;  // cxk_assemble ran the Schur kernels; the gather waits for the factorization that follows
+  // solve-only sweeps whose every forward launch is a lean kernel form the right-hand side inside
+  // those kernels (RhsIn) instead of in a launch of their own
+  bool forward_all_lean = false;
+  RhsIn rhs_in{};  // form 0 unless such a sweep is being enqueued
   int asm_tag = 0;    // tag of the latest fused launch (a failed pivot there writes d_fail[1] = tag)
   int fail_tag = 0;   // what mailbox_pack compares d_fail[1] with: asm_tag, or 0 after any other factorization
   FactorPlan plan{};
@@ -1098,6 +1102,19 @@ int BuildPlans(cxk_context* ctx) {
       }
     }
   }
+  // ---- solve-only sweeps: does every forward launch run a lean kernel (then the right-hand side is
+  // formed inside them, RhsIn)?  Levels below the chain must be all-lean single launches, the
+  // rest must be the chain (no one-workgroup top, no supernode beyond LDS).
+  {
+    bool all = !sharded && !ctx->use_ldlt && !ctx->no_lean && ctx->top_level == nlev;
+    const int up_end = ctx->chain_level < nlev ? ctx->chain_level : nlev;
+    for (int l = 0; l < up_end && all; l++) {
+      all = ctx->level_lean[l] && !ctx->level_big[l] &&
+            ctx->level_nh[l] == ctx->level_ptr[l + 1] - ctx->level_ptr[l] && ctx->level_segs[l].size() <= 2;
+    }
+    ctx->forward_all_lean = all && nlev >= 1;
+  }
+
   // ---- assembly folded into the first factor level.  Taken when level 0 is ONE segment of a
   // register shape with dense pulls, launched on its own (not part of a chain / dense top), and
   // every supernode in it is a leaf whose panel entries and right-hand-side rows have exactly one
@@ -1874,7 +1891,7 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
           ctx->p_rec.p, sg.begin, cnt, gA, sb.begin, cntB, ctx->slab.p, rhs);                                \
     else if (mode == 1)                                                                                      \
       tree_forward_level2<NA_, SA_, NB_, SB_><<<gA + gB, w * 64, 0, ctx->stream>>>(                          \
-          ctx->plan, ctx->p_rec.p, sg.begin, cnt, gA, sb.begin, cntB, ctx->slab.p, rhs);                     \
+          ctx->plan, ctx->p_rec.p, sg.begin, cnt, gA, sb.begin, cntB, ctx->slab.p, rhs, ctx->rhs_in);        \
     else if (rhs)                                                                                            \
       tree_factor_level2<NA_, SA_, NB_, SB_, true><<<gA + gB, w * 64, lds, ctx->stream>>>(                   \
           ctx->plan, ctx->p_rec.p, sg.begin, cnt, gA, sb.begin, cntB, ctx->slab.p, rhs, ctx->d_fail.p, per_wave); \
@@ -1924,7 +1941,7 @@ int LaunchSweep(cxk_context* ctx, int lb, int le, int mode, bool then_backward, 
                                                                   ctx->slab.p, rhs);                    \
     else if (mode == 1)                                                                                 \
       tree_forward_level<NS_, S_><<<g, w * 64, 0, ctx->stream>>>(ctx->plan, ctx->p_rec.p, sg.begin,     \
-                                                                 cnt, ctx->slab.p, rhs);                \
+                                                                 cnt, ctx->slab.p, rhs, ctx->rhs_in);   \
     else if (rhs)                                                                                       \
       tree_factor_level<NS_, S_, true><<<g, w * 64, lds, ctx->stream>>>(                                \
           ctx->plan, ctx->p_rec.p, sg.begin, cnt, ctx->slab.p, rhs, ctx->d_fail.p, per_wave);           \
@@ -2073,10 +2090,10 @@ int LaunchChain(cxk_context* ctx, int mode) {
     const size_t lds = sizeof(double) * 65 * ((NA_) > (NB_) ? (NA_) : (NB_)) + sizeof(SnRec) * (size_t)nchain; \
     if (mode == 0)                                                                                          \
       tree_chain_lean<0, NA_, SA_, NB_, SB_><<<1, 64, lds, ctx->stream>>>(                                  \
-          ctx->plan, ctx->p_rec.p, pos0, nchain, ctx->slab.p, ctx->y.p, ctx->d_fail.p);                     \
+          ctx->plan, ctx->p_rec.p, pos0, nchain, ctx->slab.p, ctx->y.p, ctx->d_fail.p, RhsIn{});            \
     else                                                                                                    \
       tree_chain_lean<1, NA_, SA_, NB_, SB_><<<1, 64, lds, ctx->stream>>>(                                  \
-          ctx->plan, ctx->p_rec.p, pos0, nchain, ctx->slab.p, ctx->y.p, ctx->d_fail.p);                     \
+          ctx->plan, ctx->p_rec.p, pos0, nchain, ctx->slab.p, ctx->y.p, ctx->d_fail.p, ctx->rhs_in);        \
   }
     CXK_CHAIN(8, 8, 8, 8)
     CXK_CHAIN(16, 8, 16, 8)
@@ -3262,20 +3279,50 @@ int cxk_set_cost(cxk_context* ctx, const double* b) {
   return CXK_SUCCESS;
 }
 
+// Solve-only sweep of y <- K^-1 rhs with rhs in one of the two forms of RhsIn: formed inside the
+// forward kernels when all of them are lean ones, by a launch of its own otherwise.
+static int SolveWithRhs(cxk_context* ctx, const RhsIn& form) {
+  const int N = ctx->md.N;
+  const bool inline_rhs = ctx->forward_all_lean && ctx->world == 1 && ctx->solver_mode != 2 &&
+                          ctx->refine_iters <= 0 && !ctx->no_lean;
+  if (inline_rhs) {
+    ctx->rhs_in = form;
+  } else if (form.form == 1) {
+    build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, form.k, form.bs, form.cs, ctx->b.p, ctx->AQc.p, ctx->AW.p,
+                                                        ctx->y.p);
+  } else {
+    build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, form.cb, form.cq, form.cw, ctx->b.p, ctx->AQc.p,
+                                                             ctx->AW.p, ctx->y.p);
+  }
+  const int rc = LaunchTree(ctx, 1, true, true);
+  ctx->rhs_in = RhsIn{};
+  return rc;
+}
+
 int cxk_newton_direction(cxk_context* ctx, double k, double bs, double cs) {
   CXK_ENTER(ctx);
-  const int N = ctx->md.N;
-  build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, k, bs, cs, ctx->b.p, ctx->AQc.p, ctx->AW.p,
-                                                      ctx->y.p);
-  return LaunchTree(ctx, 1, true, true);
+  RhsIn f{};
+  f.form = 1;
+  f.b = ctx->b.p;
+  f.AQc = ctx->AQc.p;
+  f.AW = ctx->AW.p;
+  f.k = k;
+  f.bs = bs;
+  f.cs = cs;
+  return SolveWithRhs(ctx, f);
 }
 
 int cxk_solve_rhs(cxk_context* ctx, double cb, double cq, double cw) {
   CXK_ENTER(ctx);
-  const int N = ctx->md.N;
-  build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, cb, cq, cw, ctx->b.p, ctx->AQc.p,
-                                                           ctx->AW.p, ctx->y.p);
-  return LaunchTree(ctx, 1, true, true);
+  RhsIn f{};
+  f.form = 2;
+  f.b = ctx->b.p;
+  f.AQc = ctx->AQc.p;
+  f.AW = ctx->AW.p;
+  f.cb = cb;
+  f.cq = cq;
+  f.cw = cw;
+  return SolveWithRhs(ctx, f);
 }
 
 // ComputeMuFromLineSearch cone_program.cc:118-160.  *result = the admissible inv_sqrt_mu, or -1
