@@ -211,6 +211,9 @@ __device__ int g_cxk_sel, g_cxk_want, g_cxk_lvl;
 #define CXK_STAMP_SELECT(lb, mode) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_cxk_lvl = 0; const int kind = (lb) == 0 ? 0 : (gridDim.x > 1 ? 1 : 2); g_cxk_sel = (kind == g_cxk_want) ? ((mode) == 0 ? 1 : ((mode) == 2 ? 2 : 0)) : 0; } } while (0)
 #define CXK_STAMP_LEVEL(l) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_cxk_lvl = (l); } while (0)
 #else
+#ifdef CXK_CHAIN_STAMPS  // only the chain kernel's register-held stamps (tree_chain_lean)
+__device__ long long g_cxk_stamp[96];
+#endif
 #define CXK_STAMP(i) do { } while (0)
 #define CXK_STAMPB(i) do { } while (0)
 #define CXK_STAMP_SELECT(lb, mode) do { } while (0)
@@ -1558,7 +1561,7 @@ tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, int pos0, int n, d
   constexpr int IMG = 65 * (NA > NB ? NA : NB);  // RootBackward's image (>= the pull image of 64 columns)
   int* rec_lds = reinterpret_cast<int*>(lds + IMG);
   const int lane = threadIdx.x & 63;
-#ifdef CXK_DEBUG_STAMPS
+#if defined(CXK_DEBUG_STAMPS) || defined(CXK_CHAIN_STAMPS)
   long long tstamp[8];  // held in registers, written once at the end: no memory traffic in between
   int nstamp = 0;
   tstamp[nstamp++] = __builtin_amdgcn_s_memtime();
@@ -1590,7 +1593,7 @@ tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, int pos0, int n, d
         ForwardSupernodeLean<NB, SB>(P, R, slab, rhs, ri);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#ifdef CXK_DEBUG_STAMPS
+#if defined(CXK_DEBUG_STAMPS) || defined(CXK_CHAIN_STAMPS)
     if (nstamp < 7) tstamp[nstamp++] = __builtin_amdgcn_s_memtime();
 #endif
     if (root) n--;  // done with the root: the way down starts below it
@@ -1604,11 +1607,11 @@ tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, int pos0, int n, d
     else
       BackwardSupernodeLean<NB, SB>(R, slab, rhs);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#ifdef CXK_DEBUG_STAMPS
+#if defined(CXK_DEBUG_STAMPS) || defined(CXK_CHAIN_STAMPS)
     if (nstamp < 8) tstamp[nstamp++] = __builtin_amdgcn_s_memtime();
 #endif
   }
-#ifdef CXK_DEBUG_STAMPS
+#if defined(CXK_DEBUG_STAMPS) || defined(CXK_CHAIN_STAMPS)
   if (threadIdx.x == 0)
     for (int i = 0; i < 8; i++) g_cxk_stamp[80 + i] = i < nstamp ? tstamp[i] : 0;
 #endif

@@ -3811,6 +3811,12 @@ int cxk_assembly_work(const cxk_context* ctx, double* bytes, double* flops) {
   return CXK_SUCCESS;
 }
 
+#ifdef CXK_CHAIN_STAMPS
+int cxk_debug_stamps(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cxk_stamp), 96 * sizeof(long long)) == hipSuccess ? 0 : 1;
+}
+int cxk_debug_select(int) { return 0; }
+#endif
 #ifdef CXK_DEBUG_STAMPS
 int cxk_debug_fused_stamps(long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamp), 64 * sizeof(long long)) == hipSuccess ? 0 : 1;
