@@ -468,10 +468,23 @@ struct MailboxArgs {
 };
 __device__ __forceinline__ void MailboxPack(const MailboxArgs& m) {
   const int t = threadIdx.x;
-  if (t < 4) m.mb[t] = m.red[t];
-  if (t >= 4 && t < 10) m.mb[t] = m.scal[t - 4];
+  double v = 0.0;
+  if (t < 4) v = m.red[t];
+  if (t >= 4 && t < 10) v = m.scal[t - 4];
   // fail[1] == tag: a pivot failed in the first factor level of the latest fused launch
-  if (t == 10) m.mb[10] = (m.fail[0] != 0 || (m.tag != 0 && m.fail[1] == m.tag)) ? 1.0 : 0.0;
+  if (t == 10) v = (m.fail[0] != 0 || (m.tag != 0 && m.fail[1] == m.tag)) ? 1.0 : 0.0;
+  if (t <= 10) m.mb[t] = v;
+  // The host must not trust the ORDER in which these writes and the sequence number below arrive
+  // (they cross PCIe as posted writes; on a cold box the sequence number was seen ahead of the
+  // data about once in a thousand round trips): slot 12 carries the XOR of the eleven bit patterns
+  // and the sequence number's, which the host checks before it accepts the mailbox.
+  if (t < 64) {
+    unsigned long long x = t <= 10 ? (unsigned long long)__double_as_longlong(v) : 0ull;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) x ^= (unsigned long long)__shfl_xor((long long)x, d, 64);
+    if (t == 0)
+      reinterpret_cast<unsigned long long*>(m.mb)[12] = x ^ (unsigned long long)__double_as_longlong(m.seq);
+  }
   __threadfence_system();
   __syncthreads();
   if (t == 0) m.mb[11] = m.seq;

@@ -287,6 +287,7 @@ struct cxk_context {
   // picked up by the host without a D2H copy.  seq counts enqueued producers; mb_seen is the
   // value the mailbox carried when the host last waited for it.
   double* mb = nullptr;
+  double mbv[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // the last validated snapshot of the mailbox (WaitMailbox)
   double* pin_y = nullptr;  // pinned staging of y for cxk_get_y
   long long seq = 0, mb_seen = -1, factor_seq = -1, scal_seq = -1;
 };
@@ -3086,15 +3087,37 @@ int NextMailbox(cxk_context* ctx, MailboxArgs* m) {
 // Waits until the mailbox carries sequence number `want`.
 int WaitMailbox(cxk_context* ctx, long long want) {
   // spin on the sequence number (a stream synchronisation costs tens of microseconds of driver
-  // wake-up); the stream is polled now and then so that a failed launch cannot hang the host
+  // wake-up); the stream is polled now and then so that a failed launch cannot hang the host.
+  // The data slots are accepted only with a matching checksum (MailboxPack): their writes and the
+  // sequence number's are separate posted writes to host memory and have been observed out of order.
   volatile double* flag = ctx->mb + 11;
+  volatile unsigned long long* raw = reinterpret_cast<volatile unsigned long long*>(ctx->mb);
   static const bool no_spin = getenv("CXK_NO_SPIN") != nullptr;
   if (no_spin) CXK_TRY(hipStreamSynchronize(ctx->stream));
+  double dw = (double)want;
+  unsigned long long wbits;
+  memcpy(&wbits, &dw, sizeof(wbits));
+  bool synced = no_spin;
   for (unsigned spins = 1;; spins++) {
-    if (*flag == (double)want) break;
+    if (*flag == dw) {
+      unsigned long long snap[13], x = wbits;
+      for (int i = 0; i <= 10; i++) {
+        snap[i] = raw[i];
+        x ^= snap[i];
+      }
+      snap[12] = raw[12];
+      if (x == snap[12] || synced) {
+        memcpy(ctx->mbv, snap, sizeof(double) * 11);
+        break;
+      }
+    }
     if ((spins & 0xfff) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) {
-      CXK_TRY(hipStreamSynchronize(ctx->stream));
-      break;
+      CXK_TRY(hipStreamSynchronize(ctx->stream));  // everything has run: whatever is there now is final
+      synced = true;
+      if (*flag != dw) {  // (a launch failed: report what the mailbox holds)
+        for (int i = 0; i <= 10; i++) ctx->mbv[i] = ctx->mb[i];
+        break;
+      }
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -3167,7 +3190,7 @@ int cxk_factor_async(cxk_context* ctx) {
 int cxk_factor_status(cxk_context* ctx, int* ok) {
   CXK_ENTER(ctx);
   if (ctx->mb_seen < ctx->factor_seq && SyncMailbox(ctx)) return CXK_FAILURE;
-  if (ok) *ok = ctx->mb ? (ctx->mb[10] == 0.0) : 1;
+  if (ok) *ok = ctx->mb ? (ctx->mbv[10] == 0.0) : 1;
   return CXK_SUCCESS;
 }
 
@@ -3253,7 +3276,7 @@ int cxk_sync(cxk_context* ctx, int* factor_ok) {
   CXK_ENTER(ctx);
   if (SyncMailbox(ctx)) return CXK_FAILURE;
   CXK_TRY(hipStreamSynchronize(ctx->stream));  // the stream is idle: cheap, and later host-side copies rely on it
-  if (factor_ok) *factor_ok = ctx->mb[10] == 0.0;
+  if (factor_ok) *factor_ok = ctx->mbv[10] == 0.0;
   // fold finished timing samples
   for (size_t k = 0; k < ctx->ev_used; k++) {
     float ms = 0;
@@ -3386,7 +3409,7 @@ int cxk_step_scalars(cxk_context* ctx, double* out6) {
   CXK_ENTER(ctx);
   if (ctx->scal_seq < 0 && cxk_step_scalars_async(ctx)) return CXK_FAILURE;  // not enqueued yet
   if (ctx->mb_seen < ctx->scal_seq && SyncMailbox(ctx)) return CXK_FAILURE;
-  for (int i = 0; i < 6; i++) out6[i] = ctx->mb[4 + i];
+  for (int i = 0; i < 6; i++) out6[i] = ctx->mbv[4 + i];
   ctx->scal_seq = -1;  // consumed: the next call computes them afresh
   return CXK_SUCCESS;
 }
@@ -3495,8 +3518,8 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
   }
   if (affine) return CXK_SUCCESS;
   if (ReduceStepInfoAndSync(ctx, 0, ctx->info2.p, take ? &e_weight : nullptr, took)) return CXK_FAILURE;
-  info[0] = ctx->mb[0];
-  info[1] = ctx->mb[1];
+  info[0] = ctx->mbv[0];
+  info[1] = ctx->mbv[1];
   return CXK_SUCCESS;
 }
 
@@ -3578,7 +3601,7 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
   }
   CXK_TRY(hipGetLastError());
   if (ReduceStepInfoAndSync(ctx, 1, ctx->info4.p)) return CXK_FAILURE;
-  for (int i = 0; i < 4; i++) out[i] = ctx->mb[i];
+  for (int i = 0; i < 4; i++) out[i] = ctx->mbv[i];
   return CXK_SUCCESS;
 }
 
