@@ -1,9 +1,9 @@
-"""Repetition tests for the one unexplained failure recorded in round 1 (one of nine
-runs of tests/test_gpu_solver.py failed around test_sparse_sdp_equals_dense_formulation, output
-not kept).  Fifty in-process repetitions of that test and its neighbours, with the lean kernels
-and the host spin-wait both on and off, and bit-equality of repeated solves: a race or a read of
-unwritten memory would show up as a changed bit.  (The debugging aid that goes with it:
-CXK_DEBUG_FILL_NAN=1 makes every scratch buffer of a context start as NaN.)
+"""Repetition tests for the rare failures recorded in rounds 1 and 2 (cause: the
+host accepted the pinned mailbox before all of its value slots had arrived).  Fifty in-process
+repetitions of the tests that failed and their neighbours, with the lean kernels and the host
+spin-wait both on and off, and bit-equality of repeated solves: a race or a read of unwritten memory
+shows up as a changed bit.  (The debugging aid that goes with it: CXK_DEBUG_FILL_NAN=1 makes every
+scratch buffer of a context start as NaN.)
 """
 import os
 
@@ -48,11 +48,45 @@ def test_repeated_kkt_solves_are_bit_identical_across_fresh_contexts():
 
 
 def test_hermitian_newton_step_50_times():
-    """Round 2: tests/test_gpu_parity.py::test_hermitian_newton_step[7-6-5-2-2-2] failed once (output not
-    kept) in the run that followed a rebuild; 600 in-process repetitions, 16 repetitions of the whole
-    file and the NaN-filled runs did not reproduce it.  Kept under repetition here."""
+    """Round 2: tests/test_gpu_parity.py::test_hermitian_newton_step[7-6-5-2-2-2] failed once in the run
+    that followed a rebuild (the mailbox ordering of DESIGN.md §8 item 0).  Kept under repetition."""
     import test_gpu_parity as tgp
     for _ in range(REPS):
         for d in (1, 2, 4):
             tgp.test_hermitian_newton_step(d, 7, 6, 5, 2, 2)
         tgp.test_hermitian_newton_step(2, 3, 12, 8, 2, 3)
+
+
+def test_interior_point_solve_200_times_bit_identical():
+    """the host used to accept the pinned mailbox when its sequence number had
+    overtaken a value slot (≈1 in 1000 solves on a cold box).  The iterate, the status and the
+    iteration count of every repetition equal the first one's bit for bit."""
+    import ctypes as C
+    from conex_amd import capi as ca
+    L = ca.api()
+    rng = np.random.default_rng(1)
+    cfg = ca.default_config()
+    cfg.prepare_dual_variables = 1
+    cfg.inv_sqrt_mu_max = 5e5
+    cfg.divergence_upper_bound = 1000
+    cfg.dinf_upper_bound = 1.35
+    cfg.final_centering_tolerance = 1
+    probs = []
+    for i in range(6):
+        nv, nc = 5, 6 + 2 * i
+        A = rng.uniform(-1, 1, (nc, nv))
+        c = np.abs(rng.uniform(-1, 1, nc))
+        x0 = np.abs(rng.uniform(-1, 1, nc))
+        x0 *= 0.01 / np.linalg.norm(x0)
+        probs.append((A, c, A.T @ x0, nv, nc))
+    ref = {}
+    for rep in range(200):
+        for k, (A, c, b, nv, nc) in enumerate(probs):
+            p = L.CONEX_CreateConeProgram()
+            assert L.CONEX_AddDenseLinearConstraint(p, ca.dp(ca.colmajor(A)), nc, nv, ca.dp(c), nc) == 0
+            ok, y = tgs._maximize(L, p, b, cfg)
+            st = ca.IterationStats()
+            L.CONEX_GetIterationStats(p, C.byref(st), -1)
+            L.CONEX_DeleteConeProgram(p)
+            key = (ok, st.iteration_number, y.tobytes())
+            assert ref.setdefault(k, key) == key, (rep, k)
