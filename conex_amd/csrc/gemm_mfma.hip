@@ -239,21 +239,49 @@ __device__ __forceinline__ void MakeDmaLane(DmaLane& d, int wave, int lane, int 
 }
 
 template <bool TA, bool TB, int BK>
-__global__ void __launch_bounds__(256) gemm_f64_dma(GemmArgs g) {
+__global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) gemm_f64_dma(GemmArgs g) {  // four / two workgroups per CU (LDS)
   constexpr int kDmaBK = BK, kDmaTile = 64 * BK, NI = BK / 8;
   extern __shared__ double lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_m = (g.M + kGemmBM - 1) / kGemmBM;
-  const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+  // Workgroups are dealt round-robin over the 8 XCDs (observed; speed only): relabel them so that
+  // the tiles, splits and neighbouring matrices of a batch -- which read the same operand panels
+  // -- run on one XCD and meet in its L2 (bijective for any grid size).
+  int tile, split, bz;
+  {
+    const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+    const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    tile = id % gx;
+    split = (id / gx) % gy;
+    bz = id / (gx * gy);
+  }
+  int tm, tn;
+  if (g.lower_only && gridDim.x != (unsigned)(tiles_m * ((g.N + kGemmBN - 1) / kGemmBN))) {
+    // compact grid of a square lower-only call: tile columns one after the other, column tn holds
+    // the tile rows tn .. tiles_m - 1
+    int rem = tile, len = tiles_m;
+    tn = 0;
+    while (rem >= len) {
+      rem -= len;
+      len--;
+      tn++;
+    }
+    tm = tn + rem;
+  } else {
+    tm = tile % tiles_m;
+    tn = tile / tiles_m;
+  }
   const int m_base = tm * kGemmBM, n_base = tn * kGemmBN;
   if (g.lower_only && m_base + kGemmBM - 1 < n_base) return;  // uniform per workgroup
-  const int b1 = blockIdx.z / g.inner, b2 = blockIdx.z % g.inner;
+  const int b1 = bz / g.inner, b2 = bz % g.inner;
   const double* A = g.A + b1 * g.sA1 + b2 * g.sA2;
   const double* B = g.B + b1 * g.sB1 + b2 * g.sB2;
   // K range of this split, in whole kGemmBK steps (as the general kernel deals them)
   const int ksteps = (g.K + kGemmBK - 1) / kGemmBK;
   const int per = (ksteps + g.splits - 1) / g.splits;
-  const int k_lo = min(g.K, (int)blockIdx.y * per * kGemmBK), k_hi = min(g.K, k_lo + per * kGemmBK);
+  const int k_lo = min(g.K, split * per * kGemmBK), k_hi = min(g.K, k_lo + per * kGemmBK);
   const int nstage = (k_hi - k_lo + kDmaBK - 1) / kDmaBK;
 
   // A tile: rows = m; stored m-major when !TA (A(m,k) at m + k lda), k-major when TA (k + m lda)
@@ -305,6 +333,36 @@ __global__ void __launch_bounds__(256) gemm_f64_dma(GemmArgs g) {
     bo[i] = ImageOffset<BKM, BK>(wn + 16 * i + l15, kq);
   }
 
+  // The old C values of an accumulating call (beta != 0) are fetched before the K loop, in the
+  // layout of the coalesced epilogue below: their latency rides on the first operand stage's.
+  double* C = g.C + b1 * g.sC1 + b2 * g.sC2 + (g.splits > 1 ? split * g.sCs : 0);
+  const bool partial = g.splits > 1;
+  const bool accumulate = !partial && g.beta != 0.0;
+  // (the trailing-update form C -= L L^T only: the 32 registers cost the other forms a spill)
+  constexpr bool kEarlyC = !TA && TB;
+  double c0[16];
+  auto load_c = [&]() {
+    const int m = m_base + (tid & 63);
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int n = n_base + (tid >> 6) + 4 * u;
+      const bool on = m < g.M && n < g.N && (!g.lower_only || m >= n);
+      c0[u] = (on && accumulate) ? C[m + (int64_t)n * g.ldc] : 0.0;
+    }
+  };
+  if constexpr (kEarlyC) load_c();
+  // 16 x 16 sub-tiles of this wave that hold an entry to be written (inside M x N and, for a
+  // lower-only call, on or below the diagonal); the others' MFMAs are skipped (wave-uniform).
+  bool act[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int m_lo = m_base + wm + 16 * i, n_lo = n_base + wn + 16 * j;
+      act[i][j] = m_lo < g.M && n_lo < g.N && (!g.lower_only || m_lo + 15 >= n_lo);
+    }
+  const bool any_act = act[0][0] || act[0][1] || act[1][0] || act[1][1];
+
   if (nstage > 0) issue(0);
   for (int s = 0; s < nstage; s++) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage s has landed
@@ -333,6 +391,7 @@ __global__ void __launch_bounds__(256) gemm_f64_dma(GemmArgs g) {
         }
       }
     };
+    if (!any_act) continue;
     fetch(0, 0);
 #pragma unroll
     for (int sub = 0; sub < kDmaBK / 4; sub++) {
@@ -343,7 +402,8 @@ __global__ void __launch_bounds__(256) gemm_f64_dma(GemmArgs g) {
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sub & 1][i], b[sub & 1][j], acc[i][j], 0, 0, 0);
+          if (act[i][j])
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sub & 1][i], b[sub & 1][j], acc[i][j], 0, 0, 0);
     }
   }
   // result tile -> LDS (row m, column n at m + 65 n), then coalesced global writes
@@ -356,19 +416,16 @@ __global__ void __launch_bounds__(256) gemm_f64_dma(GemmArgs g) {
       for (int e = 0; e < 4; e++)
         lds[(wm + 16 * i + kq + 4 * e) + 65 * (wn + 16 * j + l15)] = acc[i][j][e];
   __syncthreads();
-  double* C = g.C + b1 * g.sC1 + b2 * g.sC2 + (g.splits > 1 ? blockIdx.y * g.sCs : 0);
-  const bool partial = g.splits > 1;
   {
-    // 16 elements per thread, loads of the old C values issued together (beta != 0)
+    // 16 elements per thread
     const int mm = tid & 63, m = m_base + mm;
-    double v[16], c0[16];
+    double v[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) {
-      const int nn = (tid >> 6) + 4 * u, n = n_base + nn;
+      const int nn = (tid >> 6) + 4 * u;
       v[u] = lds[mm + 65 * nn];
-      const bool on = m < g.M && n < g.N && (!g.lower_only || m >= n);
-      c0[u] = (on && !partial && g.beta != 0.0) ? C[m + (int64_t)n * g.ldc] : 0.0;
     }
+    if constexpr (!kEarlyC) load_c();
 #pragma unroll
     for (int u = 0; u < 16; u++) {
       const int nn = (tid >> 6) + 4 * u, n = n_base + nn;
@@ -440,6 +497,8 @@ hipError_t LaunchGemm(const GemmArgs& g, bool ta, bool tb, int batch, hipStream_
   const int tiles = ((g.M + kGemmBM - 1) / kGemmBM) * ((g.N + kGemmBN - 1) / kGemmBN);
   dim3 grid(tiles, g.splits > 1 ? g.splits : 1, batch);
   if (DmaEligible(g, ta, tb)) {
+    const int tiles_m = (g.M + kGemmBM - 1) / kGemmBM;
+    if (g.lower_only && g.M == g.N) grid.x = tiles_m * (tiles_m + 1) / 2;  // lower tiles only
     if (!ta && !tb) return LaunchDma<false, false>(g, grid, stream);
     if (ta && !tb) return LaunchDma<true, false>(g, grid, stream);
     if (!ta && tb) return LaunchDma<false, true>(g, grid, stream);
