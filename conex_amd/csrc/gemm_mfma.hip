@@ -323,7 +323,13 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) gemm_f64_dma(GemmArgs g
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++) acc[i][j] = gemm_d4{0.0, 0.0, 0.0, 0.0};
-  const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+  // A product of at most 32 x 32 (the Gram matrices of the LMI assembly: m + 1 <= 32 columns over
+  // K = n^2) has work for one wave's quadrant only: there the four waves share that quadrant and
+  // deal the k sub-steps of every stage among themselves; their partial tiles are summed in wave
+  // order in the epilogue.
+  // (compiled into the Gram form X^T Y only: the other forms' registers are spoken for)
+  const bool shared_quadrant = TA && !TB && g.M <= 32 && g.N <= 32 && !g.Ct;
+  const int wm = shared_quadrant ? 0 : (wave & 1) * 32, wn = shared_quadrant ? 0 : (wave >> 1) * 32;
   const int l15 = lane & 15, kq = lane >> 4;
   // operand read offsets of this lane at k-sub-step 0 (the k-step offsets are compile-time constants)
   int ao[2], bo[2];
@@ -392,6 +398,22 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) gemm_f64_dma(GemmArgs g
       }
     };
     if (!any_act) continue;
+    if (shared_quadrant) {
+#pragma unroll
+      for (int t = 0; t < (kDmaBK / 4 + 3) / 4; t++) {
+        const int sub = wave + 4 * t;
+        if (sub < kDmaBK / 4) {
+          fetch(0, sub);
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+              if (act[i][j])
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+        }
+      }
+      continue;
+    }
     fetch(0, 0);
 #pragma unroll
     for (int sub = 0; sub < kDmaBK / 4; sub++) {
@@ -405,6 +427,30 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) gemm_f64_dma(GemmArgs g
           if (act[i][j])
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sub & 1][i], b[sub & 1][j], acc[i][j], 0, 0, 0);
     }
+  }
+  if (shared_quadrant) {
+    // the waves' partial 32 x 32 tiles side by side in LDS (1024 doubles each), summed in wave order
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) lds[wave * 1024 + (16 * i + kq + 4 * e) + 32 * (16 * j + l15)] = acc[i][j][e];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = tid + 256 * u, m = m_base + (e & 31), n = n_base + (e >> 5);
+      if (m < g.M && n < g.N && (!g.lower_only || m >= n)) {
+        const double v = ((lds[e] + lds[1024 + e]) + lds[2048 + e]) + lds[3072 + e];
+        double* dst = C + m + (int64_t)n * g.ldc;
+        if (partial)
+          *dst = v;
+        else
+          *dst = (g.beta == 0.0) ? g.alpha * v : g.alpha * v + g.beta * *dst;
+      }
+    }
+    return;
   }
   // result tile -> LDS (row m, column n at m + 65 n), then coalesced global writes
   __syncthreads();

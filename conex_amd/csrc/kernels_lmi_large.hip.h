@@ -40,8 +40,28 @@ lmi_large_reduce_finalize(LmiGroup g, Arena ar, LmiLargeWs ws, const double* __r
                           int64_t sCs) {
   const int n = g.n, m = g.m, m1 = m + 1, nn = n * n;
   const int mem = blockIdx.y, id = g.ids[mem];
-  const int lane = threadIdx.x & 63, w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  int w = blockIdx.x * 4 + (threadIdx.x >> 6);
   const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;  // exact (power of two)
+  if (splits <= 1) {
+    // nothing to reduce: a THREAD per output element (waves [0, ew)), then a wave per trace.  (The
+    // wave-per-element form below would return the same bits -- one addend and 63 zeros -- at
+    // 64 times the wavefronts: 95 us of dispatch at 1000 constraints of order 28, m = 28.)
+    const int ew = (m1 * m1 + 63) >> 6;
+    if (w < ew) {
+      const int e = w * 64 + lane, i = e % m1, j = e / m1;
+      if (e >= m1 * m1 || i < j) return;
+      const double acc = src[(size_t)mem * m1 * m1 + e] * osc;
+      if (i < m)
+        ar.G[ar.g_off[id] + i + (size_t)j * m] = acc;
+      else if (j < m)
+        ar.AQcc[ar.r_off[id] + j] = acc;
+      else
+        ar.sc[2 * id + 1] = acc;
+      return;
+    }
+    w += m1 * m1 - ew;  // the trace branch below
+  }
   if (w < m1 * m1) {
     const int i = w % m1, j = w / m1;
     if (i < j) return;
@@ -666,7 +686,7 @@ inline hipError_t LmiLargeSchur(const LmiGroup& g, const Arena& ar, const LmiLar
     const bool split = a.splits > 1;
     if (split) a.C = ws.part;  // partials; reduced by lmi_large_reduce_finalize
     if ((e = LaunchGemm(a, true, false, g.count, st)) != hipSuccess) return e;
-    const int waves = m1 * m1 + m1;
+    const int waves = (split ? m1 * m1 : (m1 * m1 + 63) / 64) + m1;
     lmi_large_reduce_finalize<<<dim3((waves + 3) / 4, g.count), 256, 0, st>>>(g, ar, ws, split ? ws.part : ws.Gf,
                                                                             a.splits, a.sCs);
   }

@@ -2816,14 +2816,18 @@ static int FinalizeImpl(cxk_context* ctx) {
         c_sz = w_sz = (size_t)g.n * g.n;
         g.large = !(LmiTakeLds(g.n) <= kLdsLimit && LmiPrepareLds(g.n, g.m) <= kLdsLimit);
         {
+          const int gemm_min_n = getenv("CXK_GEMM_MIN_N") ? atoi(getenv("CXK_GEMM_MIN_N")) : 25;
+          // orders past the register kernels' instances assemble through the batched GEMM (measured
+          // 1.5 - 2.6x faster than lmi_schur_generic from order 25 up, 1000 constraints; CXK_GEMM_MIN_N
+          // moves the threshold for comparison runs)
           // CXK_LMI_SCHUR = dpp | generic selects the older kernels (comparison runs, tests)
           const char* pick = getenv("CXK_LMI_SCHUR");
           const bool want_dpp = pick && !strcmp(pick, "dpp"), want_generic = pick && !strcmp(pick, "generic");
           g.mfma = !g.sparse && !g.large && !g.literal && !want_dpp && !want_generic && LmiMfmaSupports(g.n, g.m, g.herm_d);
           g.fused = !g.sparse && !g.large && !g.literal && !g.mfma && !want_generic && LmiFusedSupports(g.n, g.m);
+          g.schur_gemm = !g.sparse && !g.literal && (g.large || (!g.fused && !g.mfma && g.n >= gemm_min_n &&
+                                     cnt * 2 * ((size_t)g.m + 1) * g.n * g.n * sizeof(double) <= ((size_t)8 << 30)));
         }
-        g.schur_gemm = !g.sparse && !g.literal && (g.large || (!g.fused && !g.mfma && g.n >= 32 &&
-                                   cnt * 2 * ((size_t)g.m + 1) * g.n * g.n * sizeof(double) <= ((size_t)8 << 30)));
         break;
       case CXK_LINEAR:
         a_sz = (size_t)g.n * g.m;
