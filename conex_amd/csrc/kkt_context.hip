@@ -92,6 +92,7 @@ struct Group {
   int type = 0, n = 0, m = 0;
   std::vector<int> ids;
   DevBuf<double> A, C, W, T1, T2;
+  DevBuf<double> Apad;  // lmi_schur_mfma at a padded order: [A_1 .. A_m | C] per member, zero-padded (LmiMfmaPaddedOrder)
   DevBuf<int> dids;
   int herm_d = 0;
   bool fused = false;
@@ -1667,7 +1668,13 @@ int LaunchSchur(cxk_context* ctx) {
         } else if (g.schur_gemm) {
           CXK_TRY(LmiLargeSchur(MakeLmi(g), ar, MakeLargeWs(g), ctx->stream));
         } else if (g.mfma) {
-          CXK_TRY(LaunchLmiSchurMfma(MakeLmi(g), ar, ctx->cus, ctx->stream));
+          LmiGroup lg = MakeLmi(g);
+          if (g.Apad.p) {  // the order runs on the next instance up (masked W loads in the kernel)
+            const int np = LmiMfmaPaddedOrder(g.n);
+            lg.A = g.Apad.p;
+            lg.a_stride = (long long)(g.m + 1) * np * np;
+          }
+          CXK_TRY(LaunchLmiSchurMfma(lg, ar, ctx->cus, ctx->stream));
         } else if (g.fused) {
           CXK_TRY(LaunchLmiSchurFused(MakeLmi(g), ar, ctx->stream));
         } else {
@@ -2858,6 +2865,20 @@ static int FinalizeImpl(cxk_context* ctx) {
     }
     CXK_TRY(g.A.upload(hA));
     CXK_TRY(g.C.upload(hC));
+    if (g.type == CXK_LMI && g.mfma && LmiMfmaPaddedOrder(g.n) != g.n && !(g.herm_d == 2 && g.n == 24)) {
+      const int np = LmiMfmaPaddedOrder(g.n), n = g.n;
+      const size_t blk = (size_t)(g.m + 1) * np * np;
+      std::vector<double> hp(blk * cnt, 0.0);
+      for (size_t k = 0; k < cnt; k++) {
+        const ConstraintRec& c = ctx->cons[g.ids[k]];
+        for (int i = 0; i <= g.m; i++) {
+          const double* src = i < g.m ? c.A.data() + (size_t)i * n * n : c.C.data();
+          double* dst = hp.data() + k * blk + (size_t)i * np * np;
+          for (int col = 0; col < n; col++) std::copy(src + (size_t)col * n, src + (size_t)col * n + n, dst + (size_t)col * np);
+        }
+      }
+      CXK_TRY(g.Apad.upload(hp));
+    }
     CXK_TRY(g.W.alloc(w_sz * cnt));
     CXK_TRY(g.T1.alloc(w_sz * cnt));
     CXK_TRY(g.T2.alloc(g.type == CXK_LINEAR ? w_sz * cnt : 0));

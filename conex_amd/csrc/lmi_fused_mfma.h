@@ -7,10 +7,14 @@
 
 namespace cxk {
 
-// Shapes the persistent producer / consumer kernel covers: order n in {8, 12, 16, 20, 24}, any
-// number of variables m with m + 1 <= 24 matrices (<= 32 for n <= 16) whose two P images fit LDS.
+// Shapes the persistent producer / consumer kernel covers: instances of order 8, 12, 16, 20, 24;
+// any other order 2 <= n <= 24 runs on the next instance up (LmiMfmaPaddedOrder) -- the caller then
+// passes zero-padded copies of [A_1 .. A_m | C] in g.A / g.a_stride while g.n and g.W keep the
+// order itself (the kernel masks its W loads).  Any number of variables m with m + 1 <= 24
+// matrices (<= 32 for instances <= 16) whose two P images fit LDS.
 // herm_d == 2 (complex Hermitian cones in their real representation of order n = 24): the folded
 // form that reads and keeps the top half of every matrix only (any m <= 15 or 24 <= m <= 31).
+int LmiMfmaPaddedOrder(int n);
 bool LmiMfmaSupports(int n, int m, int herm_d = 0);
 
 // ConstructSchurComplementSystem(DenseLMIConstraint*) for every member of the group

@@ -170,10 +170,29 @@ struct WOps {  // stage-1 B operands of one constraint: k-step e uses W row q NK
   double w4[MfmaCfg<N>::NC4A][MfmaCfg<N>::NK];
 };
 
+// nr = the order W is stored in (nr x nr, nr <= N): an order that is not a multiple of four runs on
+// the next instance up, its A_i zero-padded by the host and W zero-padded here (P = A W then
+// carries zero rows and columns, which add nothing to any trace).
 template <int N>
-__device__ __forceinline__ void LoadW(WOps<N>& w, const double* __restrict__ Wg, int lane) {
+__device__ __forceinline__ void LoadW(WOps<N>& w, const double* __restrict__ Wg, int lane, int nr) {
   using Cfg = MfmaCfg<N>;
   const int s = lane & 15, q = lane >> 4, j = lane & 3;
+  if (nr != N) {  // uniform
+#pragma unroll
+    for (int e = 0; e < Cfg::NK; e++) {
+      const int r = q * Cfg::NK + e;
+      const double* row = Wg + (size_t)(r < nr ? r : nr - 1) * nr;
+      const double v = row[s < nr ? s : nr - 1];
+      w.w16[e] = (r < nr && s < nr) ? v : 0.0;
+#pragma unroll
+      for (int cb = 0; cb < Cfg::NC4; cb++) {
+        const int c = 16 + 4 * cb + j;
+        const double u = row[c < nr ? c : nr - 1];
+        w.w4[cb][e] = (r < nr && c < nr) ? u : 0.0;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < Cfg::NK; e++) {
     const double* row = Wg + (size_t)(q * Cfg::NK + e) * N;
@@ -388,7 +407,7 @@ __device__ __forceinline__ void Triangles(const double* __restrict__ Pb, double*
 template <int N, bool H>
 __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g, Arena ar) {
   using Cfg = MfmaCfg<N, H>;
-  constexpr int NK = Cfg::NK, LD = Cfg::LD, MS = Cfg::MS, TPW = Cfg::TPW, NN = N * N, RPM = Cfg::RPM;
+  constexpr int NK = Cfg::NK, LD = Cfg::LD, MS = Cfg::MS, TPW = Cfg::TPW, RPM = Cfg::RPM;
   extern __shared__ double lds[];
   const int M = g.m, M1 = M + 1, rows = M1 * RPM;
   const int nt1 = (rows + 15) >> 4;
@@ -418,12 +437,12 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
     MakeGeom<N, H>(gm, wave, lane, rows, nt1);
     MSTAMP(0);
     {
-      const ConstraintPtrs c0 = Member(g, first, NN);
+      const ConstraintPtrs c0 = Member(g, first, g.n * g.n);
       // Issue order matters: waits count loads in flight in issue order, and the loop below
       // reloads the slots in the order 0, 1, ...; the scheduling barriers keep the compiler from
       // permuting these independent loads (it emitted them last-slot-first, which made every
       // iteration wait for ALL of its operands before its first MFMA).
-      LoadW<N>(wn, c0.Wg, lane);
+      LoadW<N>(wn, c0.Wg, lane, g.n);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tt = 0; tt < TPW; tt++) {
@@ -437,12 +456,12 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
       // count of loads in flight is the same on every path and each wait can be exact.
       MSTAMP(1 + 4 * it);
       const int itn = it + 1 < cnt ? it + 1 : it;
-      const ConstraintPtrs nx = Member(g, first + itn * stride, NN);
+      const ConstraintPtrs nx = Member(g, first + itn * stride, g.n * g.n);
       w = wn;
       // the next constraint's W operands: a whole iteration ahead where the registers allow it
       // (N <= 20), behind this iteration's tiles otherwise (the order-24 instances spill with both
       // sets live; W is 4.6 KB per constraint and shared by the eight waves: an L2 hit)
-      if constexpr (N <= 20) LoadW<N>(wn, nx.Wg, lane);
+      if constexpr (N <= 20) LoadW<N>(wn, nx.Wg, lane, g.n);
       __builtin_amdgcn_sched_barrier(0);
       double* Pb = P0 + (it & 1) * pbuf;
       TileAcc<N> res[2];
@@ -469,7 +488,7 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (N > 20) {
-        LoadW<N>(wn, nx.Wg, lane);
+        LoadW<N>(wn, nx.Wg, lane, g.n);
         __builtin_amdgcn_sched_barrier(0);
       }
       MSTAMP(2 + 4 * it);
@@ -658,24 +677,34 @@ hipError_t LaunchT(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stre
 // when it has an instance; everything else the full form.
 static bool Folded(int n, int m, int herm_d) { return herm_d == 2 && n == 24 && SupportsT<24, true>(m); }
 
+// The instance an order runs on: itself when it has one, the next multiple of four (at least 8)
+// otherwise -- the host then hands the kernel zero-padded copies of the A_i (LmiMfmaPaddedOrder).
+int LmiMfmaPaddedOrder(int n) { return n <= 8 ? 8 : (n + 3) / 4 * 4; }
+
 bool LmiMfmaSupports(int n, int m, int herm_d) {
   if (Folded(n, m, herm_d)) return true;
-  if (n == 8) return SupportsT<8, false>(m);
-  if (n == 12) return SupportsT<12, false>(m);
-  if (n == 16) return SupportsT<16, false>(m);
-  if (n == 20) return SupportsT<20, false>(m);
-  if (n == 24) return SupportsT<24, false>(m);
+  if (n < 2 || n > 24) return false;
+  switch (LmiMfmaPaddedOrder(n)) {
+    case 8: return SupportsT<8, false>(m);
+    case 12: return SupportsT<12, false>(m);
+    case 16: return SupportsT<16, false>(m);
+    case 20: return SupportsT<20, false>(m);
+    case 24: return SupportsT<24, false>(m);
+  }
   return false;
 }
 
+// g.A / g.a_stride: [A_1 .. A_m | C] per member at the PADDED order; g.n, g.W: the order itself.
 hipError_t LaunchLmiSchurMfma(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stream) {
   if (g.count <= 0) return hipSuccess;
   if (Folded(g.n, g.m, g.herm_d)) return LaunchT<24, true>(g, ar, cus, stream);
-  if (g.n == 8) return LaunchT<8, false>(g, ar, cus, stream);
-  if (g.n == 12) return LaunchT<12, false>(g, ar, cus, stream);
-  if (g.n == 16) return LaunchT<16, false>(g, ar, cus, stream);
-  if (g.n == 20) return LaunchT<20, false>(g, ar, cus, stream);
-  if (g.n == 24) return LaunchT<24, false>(g, ar, cus, stream);
+  switch (LmiMfmaPaddedOrder(g.n)) {
+    case 8: return LaunchT<8, false>(g, ar, cus, stream);
+    case 12: return LaunchT<12, false>(g, ar, cus, stream);
+    case 16: return LaunchT<16, false>(g, ar, cus, stream);
+    case 20: return LaunchT<20, false>(g, ar, cus, stream);
+    case 24: return LaunchT<24, false>(g, ar, cus, stream);
+  }
   return hipErrorNotSupported;
 }
 

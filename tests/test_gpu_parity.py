@@ -128,7 +128,11 @@ def test_lmi_newton_step(K, n, m, b_, ov):
                                           (40, 8, 5, 3, 2), (300, 8, 23, 4, 3), (9, 12, 12, 2, 4), (60, 12, 20, 4, 5),
                                           (1, 16, 1, 2, 1), (33, 16, 16, 3, 6), (270, 16, 21, 8, 5),
                                           # 25 .. 32 matrices: three contraction tiles
-                                          (14, 16, 30, 3, 8), (300, 12, 31, 4, 6), (20, 8, 24, 3, 5), (5, 16, 27, 2, 9)])
+                                          (14, 16, 30, 3, 8), (300, 12, 31, 4, 6), (20, 8, 24, 3, 5), (5, 16, 27, 2, 9),
+                                          # orders without an instance run zero-padded on the next one up
+                                          (40, 7, 9, 3, 4), (300, 22, 14, 8, 5), (33, 10, 18, 3, 6), (9, 13, 28, 2, 7),
+                                          (270, 17, 6, 4, 3), (12, 23, 14, 2, 5), (25, 5, 4, 3, 2), (7, 3, 2, 2, 1),
+                                          (300, 19, 20, 4, 6), (16, 9, 31, 3, 8)])
 def test_lmi_mfma_kernel_shapes(K, n, m, b_, ov):
     """The persistent MFMA Schur kernel (lmi_fused_mfma.hip) takes the number of variables at run
     time: one 16 x 16 contraction tile up to 16 matrices (m + 1), a tile plus two corner triangles
