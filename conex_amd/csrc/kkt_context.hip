@@ -2823,10 +2823,12 @@ static int FinalizeImpl(cxk_context* ctx) {
         c_sz = w_sz = (size_t)g.n * g.n;
         g.large = !(LmiTakeLds(g.n) <= kLdsLimit && LmiPrepareLds(g.n, g.m) <= kLdsLimit);
         {
-          const int gemm_min_n = getenv("CXK_GEMM_MIN_N") ? atoi(getenv("CXK_GEMM_MIN_N")) : 25;
-          // orders past the register kernels' instances assemble through the batched GEMM (measured
-          // 1.5 - 2.6x faster than lmi_schur_generic from order 25 up, 1000 constraints; CXK_GEMM_MIN_N
-          // moves the threshold for comparison runs)
+          const int gemm_min_n = getenv("CXK_GEMM_MIN_N") ? atoi(getenv("CXK_GEMM_MIN_N")) : 9;
+          // shapes past the register kernels' instances assemble through the batched GEMM (measured
+          // 1.5 - 3.3x faster than lmi_schur_generic at 1000 constraints: orders 25 up, and smaller
+          // orders with more variables than lmi_schur_mfma's LDS images hold, e.g. order 22, m = 20
+          // 285 -> 133 us, order 10, m = 60 496 -> 148 us; CXK_GEMM_MIN_N moves the threshold for
+          // comparison runs)
           // CXK_LMI_SCHUR = dpp | generic selects the older kernels (comparison runs, tests)
           const char* pick = getenv("CXK_LMI_SCHUR");
           const bool want_dpp = pick && !strcmp(pick, "dpp"), want_generic = pick && !strcmp(pick, "generic");
