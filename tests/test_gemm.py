@@ -47,6 +47,25 @@ def test_lower_only_syrk_shape():
     check(150, 150, 64, 2, False, True, alpha=-1.0, beta=1.0, lower_only=True)
 
 
+@pytest.mark.parametrize("shape", [(29, 29, 784, True), (21, 17, 100, False), (32, 32, 1024, True), (5, 31, 36, False),
+                                   (16, 16, 400, True)])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_gram_products_share_one_quadrant(shape, splits):
+    """X^T Y of at most 32 x 32 (the LMI assembly's Gram matrices, kernels_lmi_large.hip.h): the four
+    waves of a workgroup deal the k sub-steps of the one occupied tile quadrant among themselves."""
+    M, N, K, lower = shape
+    for batch in (1, 13):   # 13 workgroups: a grid that is not a multiple of the 8 XCDs
+        check(M, N, K, batch, True, False, lower_only=lower, splits=splits, seed=K + batch)
+
+
+@pytest.mark.parametrize("n", [64, 65, 200, 257])
+def test_lower_only_launches_the_lower_tiles_only(n):
+    """A square lower-only call: compact grid of T (T + 1) / 2 tiles, relabelled over the XCDs."""
+    for batch in (1, 3):
+        check(n, n, 48, batch, False, True, alpha=-1.0, beta=1.0, lower_only=True, seed=n + batch)
+        check(n, n, 40, batch, True, False, lower_only=True, seed=n)
+
+
 @pytest.mark.parametrize("splits", [2, 7, 64])
 def test_split_k_ordered_reduction(splits):
     check(51, 51, 4000, 2, True, False, splits=splits)
