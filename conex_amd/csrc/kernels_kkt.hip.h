@@ -982,6 +982,12 @@ __device__ inline void BackwardSupernodeRows(const FactorPlan& P, const SnRec& R
   if (active) rhs[R.start + lane] = acc;
 }
 
+template <int NSMAX, int SMAX>
+__device__ __forceinline__ void BackwardSupernodeLean(const SnRec& R, const double* __restrict__ slab,
+                                                      double* __restrict__ rhs) {
+  BackwardSupernodeLeanSync<NSMAX, SMAX, false>(R, slab, rhs, [] {});
+}
+
 // Where a solve-only sweep takes its right-hand side: form 0 from `rhs` (someone built it), form 1 /
 // 2 each supernode forms its own rows on the fly -- the expressions of build_rhs / build_rhs_comb,
 // term for term -- so that the separate launch that used to fill `rhs` first disappears.
@@ -1063,9 +1069,16 @@ __device__ __forceinline__ void ForwardSupernodeLean(const FactorPlan& P, const 
 // BackwardSupernodeRows with a straight-line load phase (see FactorSupernodeLean): column of L,
 // off-block entries and the separator values y[sep] all load unconditionally from clamped
 // addresses, masks are applied afterwards.  Needs the inline separator list (R.nsep_inline == count).
-template <int NSMAX, int SMAX>
-__device__ __forceinline__ void BackwardSupernodeLean(const SnRec& R, const double* __restrict__ slab,
-                                                      double* __restrict__ rhs) {
+// `sync` runs between the loads that depend on nothing this launch computes (the supernode's own
+// panel and forward-solved values) and the loads of the separator's solution: tree_backward_pair
+// passes the workgroup barrier behind which the parent's solution becomes visible.
+// FRESH: the separator's solution may have been written by another wavefront of this launch.  Its
+// addresses are wave-uniform, so the compiler fetches it with SCALAR loads, and the scalar cache
+// is not coherent with vector stores (a line another workgroup pulled in before the parent wrote
+// it stays stale): workgroup-scope atomic loads go through the vector path instead.
+template <int NSMAX, int SMAX, bool FRESH, typename Sync>
+__device__ __forceinline__ void BackwardSupernodeLeanSync(const SnRec& R, const double* __restrict__ slab,
+                                                          double* __restrict__ rhs, Sync sync) {
   const int lane = threadIdx.x & 63;
   const int ns = R.ns;
   const bool active = lane < ns;
@@ -1083,11 +1096,19 @@ __device__ __forceinline__ void BackwardSupernodeLean(const SnRec& R, const doub
 #pragma unroll
   for (int q = 0; q < QN; q++) {
     const unsigned w = q < cnt ? (unsigned)R.sep[q] : 0u;
-    yv[q] = rhs[w & 0x3ffffffu];
     // unused slots read the diagonal block instead: a supernode without separator has no off
     // block, and the root's would start at the end of the slab
     const double* src = q < cnt ? B + (size_t)(w >> 26) * ns : D;
     bv[q] = src[0];
+  }
+  sync();
+#pragma unroll
+  for (int q = 0; q < QN; q++) {
+    const unsigned w = q < cnt ? (unsigned)R.sep[q] : 0u;
+    if constexpr (FRESH)
+      yv[q] = __hip_atomic_load(rhs + (w & 0x3ffffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+      yv[q] = rhs[w & 0x3ffffffu];
   }
   // ---- consumers
 #pragma unroll
@@ -1540,6 +1561,55 @@ tree_backward_level2(const SnRec* __restrict__ recs, int baseA, int cntA, int bl
     if (idx >= cntB) return;
     const SnRec R = LoadRec(recs, baseB + idx);
     BackwardSupernodeLean<NB, SB>(R, slab, rhs);
+  }
+}
+
+// Two consecutive levels of the way DOWN in one launch.  Workgroup g (nine wavefronts) owns one
+// supernode of the upper level and the supernodes of the lower level that read its solution
+// (BackPairEntry; the host orders a level so that they are consecutive): wavefront 0 solves the
+// parent while wavefronts 1 .. 8 already fetch their children's panels, the workgroup barrier
+// publishes the parent's solution, the children finish.  Lower-level supernodes that read nothing
+// of the upper level ride in parentless workgroups.  Same device function as tree_backward_level
+// on the same records: same bits, one launch and one cold start fewer per pair.
+struct BackPairEntry {
+  int parent;  // record position of the upper-level supernode, -1: none
+  int first;   // record position of the first lower-level supernode of this workgroup
+  int count;   // how many (consecutive)
+  int pad;
+};
+
+template <int NP, int SP, int NC, int SC>
+__global__ void __launch_bounds__(576)
+tree_backward_pair(const SnRec* __restrict__ recs, const BackPairEntry* __restrict__ tab,
+                   const double* __restrict__ slab, double* __restrict__ rhs) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const BackPairEntry e = tab[blockIdx.x];
+  const bool with_parent = e.parent >= 0;
+  if (wave == 0) {
+    if (!with_parent) return;
+    const SnRec R = LoadRec(recs, e.parent);
+    BackwardSupernodeLean<NP, SP>(R, slab, rhs);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    return;
+  }
+  int i = wave - 1;
+  if (i >= e.count) {
+    if (with_parent) __syncthreads();  // every wavefront of the workgroup meets the one barrier
+    return;
+  }
+  {
+    const SnRec R = LoadRec(recs, e.first + i);
+    BackwardSupernodeLeanSync<NC, SC, true>(R, slab, rhs, [&] {
+      if (with_parent) {
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      }
+    });
+  }
+  for (i += 8; i < e.count; i += 8) {
+    const SnRec R = LoadRec(recs, e.first + i);
+    BackwardSupernodeLeanSync<NC, SC, true>(R, slab, rhs, [] {});
   }
 }
 

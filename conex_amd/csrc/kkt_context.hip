@@ -10,10 +10,12 @@
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <string>
@@ -173,6 +175,12 @@ struct cxk_context {
   // the chain at the top: levels [chain_level, nlev) hold one lean supernode each and are swept by
   // one wavefront in one launch (tree_chain_lean); chain_a / chain_b = the (at most two) shapes
   int chain_level = 0, chain_a = 0, chain_b = 0;
+  // two consecutive downward levels in one launch (tree_backward_pair): indexed by the UPPER level
+  struct BackPair {
+    int nwg = 0, shape_p = 0, shape_c = 0;
+    DevBuf<BackPairEntry> tab;
+  };
+  std::vector<std::unique_ptr<BackPair>> back_pairs;
   // supernodes whose panel exceeds LDS sit at the END of their level list and are swept one by
   // one through the blocked HBM path (kernels_kkt_big.hip.h); level_nh = count of the others
   std::vector<int> level_nh;
@@ -988,6 +996,27 @@ int BuildPlans(cxk_context* ctx) {
     for (int e : huge) ctx->level_sn.push_back(e);
     ctx->level_ptr[l + 1] = (int)ctx->level_sn.size();
   }
+  // Inside a segment, supernodes that read the solution of the same supernode of the level above
+  // sit next to each other (tree_backward_pair hands them to one workgroup); top-down, so that
+  // the level above already has its final order.
+  {
+    std::vector<int> pos_of(K, -1), key(K, 0);
+    for (int l = nlev - 2; l >= 0; l--) {
+      for (int pos = ctx->level_ptr[l + 1]; pos < ctx->level_ptr[l + 2]; pos++) pos_of[ctx->level_sn[pos]] = pos;
+      const auto first = ctx->level_sn.begin() + ctx->level_ptr[l], last = first + ctx->level_nh[l];
+      for (auto it = first; it != last; ++it) {
+        int best = INT_MAX;
+        for (int v : L.separators[*it]) {
+          const int p = L.var_to_sn[v];
+          if (ctx->t_level[p] == l + 1 && pos_of[p] >= 0) best = std::min(best, pos_of[p]);
+        }
+        key[*it] = best;
+      }
+      std::stable_sort(first, last, [&](int a, int b) {
+        return std::make_tuple(seg_key(a), key[a]) < std::make_tuple(seg_key(b), key[b]);
+      });
+    }
+  }
   if (big_ws > 0) {
     CXK_DEMAND(!sharded, "supernodes beyond LDS are single-GPU for now");
     CXK_TRY(ctx->big_ws.alloc(big_ws));
@@ -1101,6 +1130,67 @@ int BuildPlans(cxk_context* ctx) {
         ctx->chain_level = c0;
         ctx->chain_a = sa;
         ctx->chain_b = sb == 0 ? sa : sb;
+      }
+    }
+    // pairs of downward levels, from the leaves up: both one lean segment, every lower supernode
+    // reads at most one supernode of the upper level, and those that read the same one are consecutive
+    ctx->back_pairs.clear();
+    ctx->back_pairs.resize(nlev);
+    if (!sharded && !ctx->use_ldlt && !ctx->no_lean && top == nlev && !getenv("CXK_NO_BACK_PAIRS")) {
+      const int up_end = ctx->chain_level < nlev ? ctx->chain_level : nlev;
+      auto plain = [&](int l) {
+        return ctx->level_lean[l] && !ctx->level_big[l] && ctx->level_segs[l].size() == 1 &&
+               ctx->level_nh[l] == ctx->level_ptr[l + 1] - ctx->level_ptr[l];
+      };
+      std::vector<int> pos_of(K, -1);
+      for (int l = 0; l + 1 < up_end;) {
+        bool ok = plain(l) && plain(l + 1);
+        std::vector<BackPairEntry> tab;
+        if (ok) {
+          for (int pos = ctx->level_ptr[l + 1]; pos < ctx->level_ptr[l + 2]; pos++) pos_of[ctx->level_sn[pos]] = pos;
+          std::vector<int> dep(ctx->level_ptr[l + 1] - ctx->level_ptr[l], -1);
+          for (int pos = ctx->level_ptr[l]; pos < ctx->level_ptr[l + 1] && ok; pos++) {
+            int d = -1;
+            for (int v : L.separators[ctx->level_sn[pos]]) {
+              const int p = L.var_to_sn[v];
+              if (ctx->t_level[p] != l + 1) continue;
+              if (pos_of[p] < 0 || (d >= 0 && d != pos_of[p])) ok = false;
+              d = pos_of[p];
+            }
+            dep[pos - ctx->level_ptr[l]] = d;
+          }
+          // runs of equal dependence; a parent's children must form ONE run
+          std::vector<char> seen(ctx->level_ptr[l + 2] - ctx->level_ptr[l + 1], 0);
+          for (int i = 0; i < (int)dep.size() && ok;) {
+            int j = i;
+            while (j < (int)dep.size() && dep[j] == dep[i]) j++;
+            if (dep[i] >= 0) {
+              char& sn = seen[dep[i] - ctx->level_ptr[l + 1]];
+              if (sn) ok = false;
+              sn = 1;
+              tab.push_back(BackPairEntry{dep[i], ctx->level_ptr[l] + i, j - i, 0});
+            } else {
+              for (int q = i; q < j; q += 8) tab.push_back(BackPairEntry{-1, ctx->level_ptr[l] + q, std::min(8, j - q), 0});
+            }
+            i = j;
+          }
+          // a supernode of the upper level nobody below reads (cannot happen by the definition of a
+          // level; kept for safety): solved by a workgroup without children
+          for (size_t q = 0; q < seen.size() && ok; q++)
+            if (!seen[q]) tab.push_back(BackPairEntry{ctx->level_ptr[l + 1] + (int)q, ctx->level_ptr[l], 0, 0});
+        }
+        if (ok) {
+          auto bp = std::make_unique<cxk_context::BackPair>();
+          bp->nwg = (int)tab.size();
+          bp->shape_p = ctx->level_segs[l + 1][0].shape;
+          bp->shape_c = ctx->level_segs[l][0].shape;
+          CXK_TRY(bp->tab.upload(tab));
+          if (getenv("CXK_DEBUG_LEVELS")) fprintf(stderr, "backward pair: levels %d + %d in %d workgroups\n", l + 1, l, bp->nwg);
+          ctx->back_pairs[l + 1] = std::move(bp);
+          l += 2;
+        } else {
+          l += 1;
+        }
       }
     }
   }
@@ -2086,6 +2176,30 @@ int LaunchTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
 
 // The chain at the top of the tree (levels [chain_level, nlev), one supernode each): up and
 // straight back down in one launch of one wavefront.  mode 0 factor + forward, mode 1 forward.
+int LaunchBackPair(cxk_context* ctx, const cxk_context::BackPair& bp) {
+  bool done = false;
+#define CXK_BACK_PAIR(NP_, SP_, NC_, SC_)                                                              \
+  if (!done && bp.shape_p == ((NP_) << 8 | (SP_)) && bp.shape_c == ((NC_) << 8 | (SC_))) {             \
+    done = true;                                                                                       \
+    tree_backward_pair<NP_, SP_, NC_, SC_><<<bp.nwg, 576, 0, ctx->stream>>>(ctx->p_rec.p, bp.tab.p,    \
+                                                                            ctx->slab.p, ctx->y.p);    \
+  }
+#define CXK_BACK_PAIR_ROW(NP_, SP_)                                                                    \
+  CXK_BACK_PAIR(NP_, SP_, 8, 8)                                                                        \
+  CXK_BACK_PAIR(NP_, SP_, 16, 8)                                                                       \
+  CXK_BACK_PAIR(NP_, SP_, 24, 0) CXK_BACK_PAIR(NP_, SP_, 24, 8) CXK_BACK_PAIR(NP_, SP_, 32, 16)
+  CXK_BACK_PAIR_ROW(8, 8)
+  CXK_BACK_PAIR_ROW(16, 8)
+  CXK_BACK_PAIR_ROW(24, 0)
+  CXK_BACK_PAIR_ROW(24, 8)
+  CXK_BACK_PAIR_ROW(32, 16)
+#undef CXK_BACK_PAIR_ROW
+#undef CXK_BACK_PAIR
+  CXK_DEMAND(done, "internal error: no tree_backward_pair instance for the levels' shapes");
+  CXK_TRY(hipGetLastError());
+  return CXK_SUCCESS;
+}
+
 int LaunchChain(cxk_context* ctx, int mode) {
   const int nlev = (int)ctx->level_ptr.size() - 1;
   // one supernode per chain level: their records are consecutive in level order
@@ -2172,6 +2286,12 @@ int LaunchTreeCore(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
     for (auto it = order.rbegin(); it != order.rend(); ++it) {
       if (dense && it->first >= ctx->dense_level) continue;  // solved inside the dense kernel
       if (chain && it->first >= ctx->chain_level) continue;  // solved inside the chain kernel
+      if (!it->second && it->first >= 1 && it->first < (int)ctx->back_pairs.size() && ctx->back_pairs[it->first] &&
+          std::next(it) != order.rend() && std::next(it)->first == it->first - 1 && !std::next(it)->second) {
+        if (LaunchBackPair(ctx, *ctx->back_pairs[it->first])) return CXK_FAILURE;
+        ++it;  // the lower level went with it
+        continue;
+      }
       if (it->second ? LaunchRange(ctx, *it->second, 2, true) : LaunchSweep(ctx, it->first, it->first + 1, 2, false, true))
         return CXK_FAILURE;
     }

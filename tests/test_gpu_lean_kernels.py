@@ -160,3 +160,30 @@ def test_random_structures_lean_equals_generic(seed):
     prob = random_program(2000 + seed)
     lean, generic = both_paths(lambda: build_random(KktContext, prob, device=0))
     assert_same_bits(lean, generic, prob["b"])
+
+
+def test_backward_pair_launch_equals_level_by_level(monkeypatch):
+    """tree_backward_pair (two downward levels in one launch, children behind a workgroup barrier)
+    returns the bits of the level-by-level sweep: 20 solves each on two shapes, every one compared
+    (the first version read the parent's solution through the scalar cache and was stale about one
+    time in five)."""
+    for K, n, m, br, ov in ((300, 8, 6, 4, 2), (120, 12, 9, 8, 3)):
+        prob = syn.lmi_problem(K=K, n=n, m=m, branching=br, overlap=ov, seed=5 + K)
+        W = syn.scaling_points(K, n, seed=6 + K)
+        ys = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("CXK_NO_BACK_PAIRS", "1")
+            else:
+                monkeypatch.delenv("CXK_NO_BACK_PAIRS", raising=False)
+            k = syn.build(KktContext, prob, "lmi", device=0)
+            for i in range(k.K):
+                k.set_W(i, W[i])
+            out = []
+            for _ in range(20):
+                ok, y = k.kkt_solve(prob["b"], 0.5, 0.9, 0.8)
+                assert ok == 1
+                out.append(y.copy())
+            ys.append(out)
+        for a in ys[0] + ys[1]:
+            assert np.array_equal(a, ys[1][0])
