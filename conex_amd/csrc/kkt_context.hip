@@ -1136,7 +1136,7 @@ int BuildPlans(cxk_context* ctx) {
     // reads at most one supernode of the upper level, and those that read the same one are consecutive
     ctx->back_pairs.clear();
     ctx->back_pairs.resize(nlev);
-    if (!sharded && !ctx->use_ldlt && !ctx->no_lean && top == nlev && !getenv("CXK_NO_BACK_PAIRS")) {
+    if (!ctx->use_ldlt && !ctx->no_lean && top == nlev && !getenv("CXK_NO_BACK_PAIRS")) {
       const int up_end = ctx->chain_level < nlev ? ctx->chain_level : nlev;
       auto plain = [&](int l) {
         return ctx->level_lean[l] && !ctx->level_big[l] && ctx->level_segs[l].size() == 1 &&
@@ -2502,8 +2502,15 @@ int ShardedTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
     if (LaunchSweep(ctx, top, nlev, mode, backward, rhs)) return CXK_FAILURE;
   }
   if (backward)
-    for (int l = std::min(top, up_end) - 1; l >= 0; l--)
+    for (int l = std::min(top, up_end) - 1; l >= 0; l--) {
+      if (l >= 1 && l < (int)ctx->back_pairs.size() && ctx->back_pairs[l]) {
+        // (a rank's level lists hold its own subtrees and the replicated top: a pair is local either way)
+        if (LaunchBackPair(ctx, *ctx->back_pairs[l])) return CXK_FAILURE;
+        l--;
+        continue;
+      }
       if (LaunchSweep(ctx, l, l + 1, 2, false, true)) return CXK_FAILURE;
+    }
   return CXK_SUCCESS;
 }
 
