@@ -103,7 +103,7 @@ struct Group {
   // orders beyond the LDS-resident kernels: HBM-resident matrices + MFMA GEMM pipeline
   bool large = false;
   // assembly through the batched MFMA GEMM pipeline (always when `large`; also for LDS-resident
-  // orders >= 32 without a fused instance, where it measured 1.5-2.7x faster than the LDS kernel)
+  // shapes from order 9 up without a register-kernel instance, where it measured 1.5-3.3x faster than the LDS kernel)
   bool schur_gemm = false;
   DevBuf<double> ws_main, ws_gf, ws_part;
   DevBuf<int> ws_piv;
