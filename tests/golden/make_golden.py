@@ -50,6 +50,15 @@ def cases():
            (rng.uniform(-1, 1, (1, 6)), rng.uniform(-0.1, 0.1, 1), prob["cliques"][7]),
            (rng.uniform(-1, 1, (1, 3)), rng.uniform(-0.1, 0.1, 1), prob["cliques"][11][:3])]
     out["lmi_with_equalities"] = ("lmi", prob, syn.scaling_points(12, 6, seed=4), eqs)
+    # round 2: shapes on the kernels added then -- an order without an lmi_schur_mfma instance (18: runs
+    # zero-padded at 20), an order past the register kernels (28: batched GEMM assembly), an order 22
+    # with more variables than the kernel's LDS images hold (batched GEMM as well)
+    out["lmi_order18"] = ("lmi", syn.lmi_problem(K=10, n=18, m=12, branching=3, overlap=4, seed=618),
+                          syn.scaling_points(10, 18, seed=619), [])
+    out["lmi_order28"] = ("lmi", syn.lmi_problem(K=6, n=28, m=10, branching=2, overlap=3, seed=628),
+                          syn.scaling_points(6, 28, seed=629), [])
+    out["lmi_order22_m20"] = ("lmi", syn.lmi_problem(K=5, n=22, m=20, branching=2, overlap=5, seed=622),
+                              syn.scaling_points(5, 22, seed=623), [])
     return out
 
 
