@@ -1751,7 +1751,8 @@ int LaunchSchur(cxk_context* ctx) {
           e0 = ctx->ev_pool[ctx->ev_used].first;
           e1 = ctx->ev_pool[ctx->ev_used].second;
           ctx->ev_used++;
-          CXK_TRY(hipEventRecord(e0, ctx->stream));
+          // (lmi_schur_mfma carries the pair on its dispatch instead: no marker packets)
+          if (!(g.mfma && !g.sparse && !g.schur_gemm)) CXK_TRY(hipEventRecord(e0, ctx->stream));
         }
         if (g.sparse) {
           CXK_TRY(LaunchLmiSchurSparse(g, ar, ctx->stream));
@@ -1764,13 +1765,13 @@ int LaunchSchur(cxk_context* ctx) {
             lg.A = g.Apad.p;
             lg.a_stride = (long long)(g.m + 1) * np * np;
           }
-          CXK_TRY(LaunchLmiSchurMfma(lg, ar, ctx->cus, ctx->stream));
+          CXK_TRY(LaunchLmiSchurMfma(lg, ar, ctx->cus, ctx->stream, e0, e1));
         } else if (g.fused) {
           CXK_TRY(LaunchLmiSchurFused(MakeLmi(g), ar, ctx->stream));
         } else {
           lmi_schur_generic<<<count, 256, LmiGenericLds(g.n), ctx->stream>>>(MakeLmi(g), ar);
         }
-        if (sample) CXK_TRY(hipEventRecord(e1, ctx->stream));
+        if (sample && !(g.mfma && !g.sparse && !g.schur_gemm)) CXK_TRY(hipEventRecord(e1, ctx->stream));
         break;
       }
       case CXK_LINEAR:

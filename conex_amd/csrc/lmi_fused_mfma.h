@@ -19,6 +19,9 @@ bool LmiMfmaSupports(int n, int m, int herm_d = 0);
 
 // ConstructSchurComplementSystem(DenseLMIConstraint*) for every member of the group
 // (dense_lmi_constraint.cc:72-103); `cus` = multiprocessors of the device the stream runs on.
-hipError_t LaunchLmiSchurMfma(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stream);
+// ev_start / ev_stop (both or neither): HIP events attached to the dispatch (hipExtLaunchKernel), whose
+// elapsed time is the kernel's own duration.
+hipError_t LaunchLmiSchurMfma(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stream,
+                              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 }  // namespace cxk
