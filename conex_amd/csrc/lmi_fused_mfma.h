@@ -11,7 +11,8 @@ namespace cxk {
 // any other order 2 <= n <= 24 runs on the next instance up (LmiMfmaPaddedOrder) -- the caller then
 // passes zero-padded copies of [A_1 .. A_m | C] in g.A / g.a_stride while g.n and g.W keep the
 // order itself (the kernel masks its W loads).  Any number of variables m with m + 1 <= 24
-// matrices (<= 32 for instances <= 16) whose two P images fit LDS.
+// matrices (<= 32 for instances <= 16) and at most 512 stacked rows whose P image fits LDS -- twice
+// (stage 2 of a constraint overlaps stage 1 of the next) or, failing that, once (they take turns).
 // herm_d == 2 (complex Hermitian cones in their real representation of order n = 24): the folded
 // form that reads and keeps the top half of every matrix only (any m <= 15 or 24 <= m <= 31).
 int LmiMfmaPaddedOrder(int n);

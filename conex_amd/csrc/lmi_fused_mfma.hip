@@ -407,7 +407,13 @@ __device__ __forceinline__ void Triangles(const double* __restrict__ Pb, double*
 }
 
 template <int N, bool H>
-__global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g, Arena ar) {
+// single != 0: ONE P image instead of two (more matrices than fit LDS twice): the producers then wait
+// at the top of an iteration until the consumers have contracted the image they are about to
+// overwrite -- a second barrier per constraint, stages 1 and 2 no longer overlap.
+// (Tried on top of it: one buffer of partial tiles as well, which halves a workgroup's LDS, and TWO
+// workgroups per CU -- 26.9 us instead of 22.2 at C4: symmetric workgroups fill and drain together,
+// so neither hides the other's waits, and the first loads double.)
+__global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g, Arena ar, int single) {
   using Cfg = MfmaCfg<N, H>;
   constexpr int NK = Cfg::NK, LD = Cfg::LD, MS = Cfg::MS, TPW = Cfg::TPW, RPM = Cfg::RPM;
   extern __shared__ double lds[];
@@ -418,7 +424,7 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
   // triangles (17..24), three tiles (25..32)
   const bool two = M1 > 16 && M1 <= 24, three = Cfg::THREE_TILES && M1 > 24;
   double* P0 = lds;
-  double* scratch = lds + 2 * (size_t)pbuf;  // 2 buffers x CONS partial tiles of 256 entries
+  double* scratch = lds + (single ? 1 : 2) * (size_t)pbuf;  // 2 buffers x CONS partial tiles of 256 entries
   constexpr int SB = Cfg::CONS * 256;
   // where this workgroup's constraints write (kDestSlots x {id, g_off, r_off}) and the epilogue
   // table, both filled by the consumers in iteration 0
@@ -465,7 +471,8 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
       // sets live; W is 4.6 KB per constraint and shared by the eight waves: an L2 hit)
       if constexpr (N <= 20) LoadW<N>(wn, nx.Wg, lane, g.n);
       __builtin_amdgcn_sched_barrier(0);
-      double* Pb = P0 + (it & 1) * pbuf;
+      double* Pb = P0 + (single ? 0 : (it & 1) * pbuf);
+      if (single && it > 0) LdsBarrier();  // the consumers are done with the image
       TileAcc<N> res[2];
 #pragma unroll
       for (int tt = 0; tt <= TPW; tt++) {
@@ -565,7 +572,7 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
   // AW(i) = tr(P_i), <w,c> = tr(P_C) from the image being contracted: one lane per matrix.
   auto traces = [&](int c) {
     if (ct >= M1) return;
-    const double* Pc = P0 + (c & 1) * pbuf + ct * MS;
+    const double* Pc = P0 + (single ? 0 : (c & 1) * pbuf) + ct * MS;
     double s0 = 0, s1 = 0;
 #pragma unroll
     for (int r = 0; r < RPM; r += 2) {
@@ -613,7 +620,7 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
   constexpr int MAXROWS = (RPM + Cfg::CONS - 2) / (Cfg::CONS - 1);
   for (int it = 1; it <= cnt; it++) {
     MSTAMP(1 + 4 * it);
-    const double* Pb = P0 + ((it - 1) & 1) * pbuf;
+    const double* Pb = P0 + (single ? 0 : ((it - 1) & 1) * pbuf);
     double* sb = scratch + ((it - 1) & 1) * SB;
     if (!H && two && cw == Cfg::CONS - 1) {  // (the folded Hermitian form has no 17 .. 24 instance: SupportsT)
       if (R > 4)
@@ -630,6 +637,7 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
     // The consumers finish their contraction well before the producers their tiles: the results
     // leave in that slack.
     traces(it - 1);
+    if (single && it < cnt) LdsBarrier();  // the image is free for the next constraint
     if (it >= 2) epilogue(it - 2);
     MSTAMP(4 + 4 * it);
     LdsBarrier();
@@ -639,10 +647,10 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
 }
 
 template <int N, bool H>
-size_t MfmaLds(int m) {
+size_t MfmaLds(int m, int single = 0) {
   using Cfg = MfmaCfg<N, H>;
   const int m1 = m + 1;
-  return sizeof(double) * (2 * (size_t)m1 * Cfg::MS + 2 * (size_t)Cfg::CONS * 256 + 3 * kDestSlots) +
+  return sizeof(double) * ((single ? 1 : 2) * (size_t)m1 * Cfg::MS + 2 * (size_t)Cfg::CONS * 256 + 3 * kDestSlots) +
          sizeof(int) * (size_t)(m1 * (m1 + 1) / 2);
 }
 
@@ -653,8 +661,9 @@ bool SupportsT(int m) {
   using Cfg = MfmaCfg<N, H>;
   const int m1 = m + 1;
   if (H && m1 > 16 && m1 <= 24) return false;  // the corner-triangle cover exists for the full form only
+  // (two P images where they fit, one otherwise: LaunchT)
   return m >= 1 && m1 <= (Cfg::THREE_TILES ? 32 : 24) && (m1 * Cfg::RPM + 15) / 16 <= Cfg::TPW * Cfg::PROD &&
-         MfmaLds<N, H>(m) <= kLdsPerCu;
+         MfmaLds<N, H>(m, 1) <= kLdsPerCu;
 }
 
 template <int N, bool H>
@@ -670,13 +679,15 @@ hipError_t LaunchT(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stre
   int grid = g.count < cus ? g.count : cus;
   const int need = (g.count + kDestSlots - 1) / kDestSlots;  // at most kDestSlots constraints per workgroup
   if (grid < need) grid = need;
+  const int single = MfmaLds<N, H>(g.m) > kLdsPerCu ? 1 : 0;
+  const size_t lds = MfmaLds<N, H>(g.m, single);
   if (ev_start && ev_stop)
     // the events ride on the dispatch itself (its own begin / end time stamps, what rocprofv3
     // reports): no marker packets around the kernel, no ~5.7 us bubble behind a bracketed launch
-    hipExtLaunchKernelGGL((lmi_schur_mfma<N, H>), dim3(grid), dim3(MfmaCfg<N>::THREADS), (uint32_t)MfmaLds<N, H>(g.m),
-                          stream, ev_start, ev_stop, 0, g, ar);
+    hipExtLaunchKernelGGL((lmi_schur_mfma<N, H>), dim3(grid), dim3(MfmaCfg<N>::THREADS), (uint32_t)lds, stream, ev_start,
+                          ev_stop, 0, g, ar, single);
   else
-    lmi_schur_mfma<N, H><<<grid, MfmaCfg<N>::THREADS, MfmaLds<N, H>(g.m), stream>>>(g, ar);
+    lmi_schur_mfma<N, H><<<grid, MfmaCfg<N>::THREADS, lds, stream>>>(g, ar, single);
   return hipGetLastError();
 }
 

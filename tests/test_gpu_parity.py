@@ -132,7 +132,10 @@ def test_lmi_newton_step(K, n, m, b_, ov):
                                           # orders without an instance run zero-padded on the next one up
                                           (40, 7, 9, 3, 4), (300, 22, 14, 8, 5), (33, 10, 18, 3, 6), (9, 13, 28, 2, 7),
                                           (270, 17, 6, 4, 3), (12, 23, 14, 2, 5), (25, 5, 4, 3, 2), (7, 3, 2, 2, 1),
-                                          (300, 19, 20, 4, 6), (16, 9, 31, 3, 8)])
+                                          (300, 19, 20, 4, 6), (16, 9, 31, 3, 8),
+                                          # more matrices than fit LDS twice: ONE P image (stages 1 and 2 take turns)
+                                          (300, 20, 23, 4, 6), (270, 24, 20, 8, 5), (40, 22, 17, 3, 4), (9, 18, 22, 2, 7),
+                                          (600, 24, 15, 4, 3)])
 def test_lmi_mfma_kernel_shapes(K, n, m, b_, ov):
     """The persistent MFMA Schur kernel (lmi_fused_mfma.hip) takes the number of variables at run
     time: one 16 x 16 contraction tile up to 16 matrices (m + 1), a tile plus two corner triangles
