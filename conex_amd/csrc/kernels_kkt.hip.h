@@ -1621,15 +1621,20 @@ tree_backward_pair(const SnRec* __restrict__ recs, const BackPairEntry* __restri
 // supernodes.  Dependent memory round trips are what a step costs (~1.2 us each), so: the
 // records come from consecutive positions (no table look-up), each is fetched while the step
 // before it runs and kept in LDS for the way down, and the root turns around in registers.
+constexpr int kChainRing = 64;  // records of the chain's last steps kept in LDS for the way down
+
 template <int MODE, int NA, int SA, int NB, int SB>
 __global__ void __launch_bounds__(64)
 tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, int pos0, int n, double* __restrict__ slab,
                 double* __restrict__ rhs, int* __restrict__ fail, RhsIn ri) {
   extern __shared__ double lds[];
   // One supernode per level: the chain's records are consecutive in level order (pos0 ..).  Each
-  // record is in flight while the step before it runs, and stays in LDS for the way back down.
+  // record is in flight while the step before it runs; the last kChainRing of them stay in LDS for
+  // the way back down, the ones below are fetched again, one step ahead as on the way up (a chain
+  // may be thousands of levels long: BASELINE config 3 as the reference arranges it).
   constexpr int IMG = 65 * (NA > NB ? NA : NB);  // RootBackward's image (>= the pull image of 64 columns)
   int* rec_lds = reinterpret_cast<int*>(lds + IMG);
+  const int ntop = n;  // upward steps
   const int lane = threadIdx.x & 63;
 #if defined(CXK_DEBUG_STAMPS) || defined(CXK_CHAIN_STAMPS)
   long long tstamp[8];  // held in registers, written once at the end: no memory traffic in between
@@ -1640,7 +1645,7 @@ tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, int pos0, int n, d
   for (int q = 0; q < n; q++) {
     const int w = wnext;
     if (q + 1 < n) wnext = LoadRecWord(recs, pos0 + q + 1);
-    if (lane < 32) rec_lds[32 * q + lane] = w;
+    if (lane < 32) rec_lds[32 * (q & (kChainRing - 1)) + lane] = w;
     const SnRec R = DecodeRec(w);
     const int shape = RegisterShape(R.ns, R.nsep);
     const bool isA = shape == (NA << 8 | SA);
@@ -1669,8 +1674,12 @@ tree_chain_lean(FactorPlan P, const SnRec* __restrict__ recs, int pos0, int n, d
     if (root) n--;  // done with the root: the way down starts below it
   }
   WaveSync();
+  const int first_cached = ntop - kChainRing;  // records q >= first_cached are in the ring
+  int wdown = (n - 1 >= 0 && n - 1 < first_cached) ? LoadRecWord(recs, pos0 + n - 1) : 0;
   for (int q = n - 1; q >= 0; q--) {
-    const SnRec R = DecodeRec(rec_lds[32 * q + (lane & 31)]);
+    const int wq = q >= first_cached ? rec_lds[32 * (q & (kChainRing - 1)) + (lane & 31)] : wdown;
+    if (q - 1 >= 0 && q - 1 < first_cached) wdown = LoadRecWord(recs, pos0 + q - 1);
+    const SnRec R = DecodeRec(wq);
     const bool isA = RegisterShape(R.ns, R.nsep) == (NA << 8 | SA);
     if (isA)
       BackwardSupernodeLean<NA, SA>(R, slab, rhs);

@@ -359,6 +359,14 @@ int GridFor(size_t work, int block) {
   return static_cast<int>(g);
 }
 
+// two-shape chains tree_chain_lean is compiled for (LaunchChain): a pair holding <24,0>, or <8,8> with
+// <16,8> (second-order cones of dimension 10 with a root of 10 columns: BASELINE config 3)
+bool ChainPairCompiled(int sa, int sb) {
+  if (sb == 0 || sa == sb) return true;
+  if (sa > sb) std::swap(sa, sb);
+  return sa == (24 << 8) || sb == (24 << 8) || (sa == (8 << 8 | 8) && sb == (16 << 8 | 8));
+}
+
 LmiGroup MakeLmi(Group& g) {
   LmiGroup d;
   d.n = g.n;
@@ -446,7 +454,7 @@ size_t LmiPrepareLds(int n, int m) {
 }
 size_t LmiTakeLds(int n) { return sizeof(double) * (size_t)(5 * n * n); }
 constexpr size_t kLdsLimit = 160 * 1024 - 512;
-constexpr int kChainMaxLevels = 64;  // levels of one supernode each swept by one wavefront (tree_chain_lean)
+constexpr int kChainMaxLevels = 1 << 30;  // no limit: the kernel keeps the last kChainRing records in LDS and re-reads the rest
 constexpr int kSplitTopLevels = 8;  // tops of at most this many levels may be swept level by level
 
 
@@ -1105,6 +1113,27 @@ int BuildPlans(cxk_context* ctx) {
       for (int l = top; l < nlev; l++) all = all && ctx->level_lean[l];
       if (all) top = nlev;
     }
+    // A narrow top that is a pure chain -- one lean supernode per level, at most two shapes -- goes to
+    // the chain kernel whatever its length (one launch of one wavefront, records prefetched, no
+    // workgroup barriers): BASELINE config 3 as the reference arranges it is 5000 such levels.
+    if (!ctx->use_ldlt && !ctx->no_lean && !getenv("CXK_NO_CHAIN") && !getenv("CXK_KEEP_TOP") && top < nlev) {
+      int c0 = nlev, sa = 0, sb = 0;
+      const int floor_level = sharded ? ctx->cut_level : 0;
+      while (c0 > floor_level) {
+        const int l = c0 - 1;
+        if (ctx->level_ptr[l + 1] - ctx->level_ptr[l] != 1 || !ctx->level_lean[l]) break;
+        const int sh = ctx->level_segs[l][0].shape;
+        if (sa == 0 || sh == sa) {
+          sa = sh;
+        } else if (sb == 0 || sh == sb) {
+          sb = sh;
+        } else {
+          break;
+        }
+        c0--;
+      }
+      if (c0 <= top && nlev - c0 >= 2 && ChainPairCompiled(sa, sb)) top = nlev;
+    }
     ctx->top_level = top;
     // chain at the top (single GPU, Cholesky, top swept level by level)
     ctx->chain_level = nlev;
@@ -1125,8 +1154,7 @@ int BuildPlans(cxk_context* ctx) {
         c0--;
       }
       if (sb != 0 && sb < sa) std::swap(sa, sb);
-      const bool pair_ok = sb == 0 || sa == (24 << 8) || sb == (24 << 8);  // compiled pairs hold <24,0>
-      if (nlev - c0 >= 2 && pair_ok) {
+      if (nlev - c0 >= 2 && ChainPairCompiled(sa, sb)) {
         ctx->chain_level = c0;
         ctx->chain_a = sa;
         ctx->chain_b = sb == 0 ? sa : sb;
@@ -2210,7 +2238,7 @@ int LaunchChain(cxk_context* ctx, int mode) {
 #define CXK_CHAIN(NA_, SA_, NB_, SB_)                                                                       \
   if (!done && sa == ((NA_) << 8 | (SA_)) && sb == ((NB_) << 8 | (SB_))) {                                  \
     done = true;                                                                                            \
-    const size_t lds = sizeof(double) * 65 * ((NA_) > (NB_) ? (NA_) : (NB_)) + sizeof(SnRec) * (size_t)nchain; \
+    const size_t lds = sizeof(double) * 65 * ((NA_) > (NB_) ? (NA_) : (NB_)) + sizeof(SnRec) * (size_t)std::min(nchain, kChainRing); \
     if (mode == 0)                                                                                          \
       tree_chain_lean<0, NA_, SA_, NB_, SB_><<<1, 64, lds, ctx->stream>>>(                                  \
           ctx->plan, ctx->p_rec.p, pos0, nchain, ctx->slab.p, ctx->y.p, ctx->d_fail.p, RhsIn{});            \
@@ -2225,6 +2253,7 @@ int LaunchChain(cxk_context* ctx, int mode) {
     CXK_CHAIN(32, 16, 32, 16)
     CXK_CHAIN(8, 8, 24, 0)
     CXK_CHAIN(16, 8, 24, 0)
+    CXK_CHAIN(8, 8, 16, 8)
     CXK_CHAIN(24, 0, 24, 8)
     CXK_CHAIN(24, 0, 32, 16)
 #undef CXK_CHAIN
