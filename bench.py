@@ -8,9 +8,12 @@ Cholesky -> right-hand side -> forward/backward block solves, all on device-resi
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 launch under torch.distributed.run (one rank per GPU, RCCL); the constraints of
-the ONE program are sharded across ranks (strong scaling).
-Prints one JSON line on rank 0.
+N > 1: one process per GPU.  Started under torch.distributed.run the script is one rank; started
+plainly (`python bench.py --gpus N`) it launches torch.distributed.run on itself as a child
+process BEFORE anything touches a GPU, relays the ranks' output and exits with their status.
+The constraints of the ONE program are sharded across ranks (strong scaling); the only
+thing that touches the GPUs' links is the library's own RCCL communicator (a `gloo` group on the
+CPU ships its 128-byte id and carries the timing barrier).  Prints one JSON line on rank 0.
 """
 import argparse
 import json
@@ -92,13 +95,24 @@ def main():
     ap.add_argument("--cold-copies", type=int, default=5,
                     help="c4, one GPU: also time the step cycling this many copies of the program "
                          "(5 x 64 MB of A > the 256 MiB Infinity Cache), reported as \"cold_cache\"; 0/1 = off")
-    ap.add_argument("--event-period", type=int, default=0,
-                    help="hipEvent-bracket every P-th launch of the dominant kernel in the timed region "
-                         "(a bracketed launch is followed by a ~5.7 us bubble); 0 = a third of the steps, "
-                         "at most 25: 8 samples in 200 steps, 3 in 20")
+    ap.add_argument("--event-samples", type=int, default=20,
+                    help="launches of the dominant kernel timed with a hipEvent pair in a separate pass "
+                         "AFTER the timed region (at most --steps)")
     args = ap.parse_args()
-    if args.event_period <= 0:
-        args.event_period = max(1, min(25, (args.steps + 2) // 3))
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain start: become the launcher.  Nothing in this process has touched a GPU (no HIP call,
+        # not even `import torch`), the ranks are children, their status is ours.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL needs dmabuf IPC on this host driver
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import numpy as np
     import torch
@@ -109,15 +123,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE)")
+    ndev = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+    if ndev < max(world, 1) or local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: need {world} devices for --gpus {world}, this node shows {ndev}")
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world > 1 or args.shard_path
     if sharded:
+        # control plane only: the unique id of the library's RCCL communicator and the barriers /
+        # max over ranks of the timing travel over gloo on the CPU; no torch process group on the GPUs
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     kind = "lmi"
     if args.workload != "c4" and world > 1:
@@ -149,9 +168,9 @@ def main():
 
     def torch_allreduce(arr, op):
         # fallback transport (see below): host copy -> device tensor -> torch.distributed -> back
-        t = torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+        t = torch.from_numpy(np.ascontiguousarray(arr))
         dist.all_reduce(t, op=(dist.ReduceOp.SUM, dist.ReduceOp.MAX, dist.ReduceOp.MIN)[op])
-        return t.cpu().numpy()
+        return t.numpy()
 
     def build_context(collective):
         ctx = KktContext(prob["num_vars"], device=local_rank, stream=stream)
@@ -209,6 +228,7 @@ def main():
         ctx.kkt_solve_async(0.7, 0.9, 0.8)
 
     def fence():
+        torch.cuda.synchronize()
         if sharded:
             dist.barrier()
         torch.cuda.synchronize()
@@ -216,21 +236,27 @@ def main():
     for _ in range(args.warmup):
         step()
     ok = ctx.sync()
-    ctx.enable_timing(args.event_period)   # hipEvent pair around every P-th lmi_schur launch
-    ctx.kernel_time(reset=True)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps):      # the timed region carries no instrumentation
         step()
     fence()
     elapsed = time.perf_counter() - t0
     ok = ctx.sync() and ok
-    ctx.enable_timing(False)
     if sharded:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the dominant kernel's duration: a SEPARATE, untimed pass of the same step with a hipEvent pair
+    # on every launch of it (a bracketed launch costs the stream a ~5 us bubble, which is why it
+    # stays out of the timed region)
+    ctx.enable_timing(1)
+    ctx.kernel_time(reset=True)
+    for _ in range(max(1, min(args.event_samples, args.steps))):
+        step()
+    ok = ctx.sync() and ok
+    ctx.enable_timing(False)
     nsamp, kern_ms = ctx.kernel_time(reset=True)
     abytes, aflops = ctx.assembly_work()
     y = ctx.get_y() if not sharded else None
@@ -274,6 +300,7 @@ def main():
                                                         if collective == "torch" else "one-rank RCCL communicator (single-GPU plumbing run)"))
                        if sharded
                        else "single GPU",
+                       "n_ranks_seen": ctx.comm_count() if sharded else 1,
                        "factor_ok": bool(ok)},
         }
         if nsamp > 0 and kern_ms > 0:
@@ -369,6 +396,10 @@ def main():
                                  "ms_per_step": 1e3 * el / (reps * len(copies)),
                                  "kernel_ms": km2, "kernel_samples": ns2,
                                  "achieved_GBps": (abytes / (km2 * 1e-3) / 1e9) if km2 > 0 else None}
+            if km2 > 0 and "roofline" in out:
+                # both fractions side by side: `frac` with A (64 MB) resident in the 256 MiB Infinity
+                # Cache as a back-to-back loop leaves it, `frac_cold_cache` with the operands from DRAM
+                out["roofline"]["frac_cold_cache"] = abytes / (km2 * 1e-3) / 1e9 / HBM_PEAK_GBS
             del copies
         if not args.no_cpu and not sharded:
             cb, yo = cpu_baseline(prob, W, kind=kind)

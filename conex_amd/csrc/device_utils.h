@@ -2,11 +2,31 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 
 namespace cxk {
 
 constexpr int kWave = 64;
+
+// Function attributes (hipFuncSetAttribute: dynamic LDS above 64 KB) are PER DEVICE, and a process
+// may hold contexts on several GPUs and call from several threads: a launcher keeps one of these
+// per kernel and configures the kernel once on every device it meets.  (Setting an attribute twice
+// from two racing threads is harmless; launching before it is set is not.)
+struct PerDeviceOnce {
+  std::atomic<unsigned long long> done{0};
+  template <typename F>
+  hipError_t run(F&& configure) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = configure();
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+  }
+};
 
 // Cross-lane exchange steps of the 64-lane butterfly without LDS traffic (ds_bpermute costs a
 // full LDS round trip per step): xor 1 / xor 2 are DPP quad permutes, the 4- and 8-lane steps use

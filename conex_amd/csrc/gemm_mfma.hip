@@ -517,13 +517,12 @@ bool DmaEligible(const GemmArgs& g, bool ta, bool tb) {
 template <bool TA, bool TB, int BK>
 hipError_t LaunchDmaBK(const GemmArgs& g, dim3 grid, hipStream_t stream) {
   constexpr size_t lds = sizeof(double) * (4 * 64 * BK > 64 * 65 ? 4 * 64 * BK : 64 * 65);
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_dma<TA, TB, BK>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = true;
-  }
+  static PerDeviceOnce once;
+  const hipError_t ec = once.run([] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_dma<TA, TB, BK>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  if (ec != hipSuccess) return ec;
   gemm_f64_dma<TA, TB, BK><<<grid, 256, lds, stream>>>(g);
   return hipGetLastError();
 }

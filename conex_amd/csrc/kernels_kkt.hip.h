@@ -2130,6 +2130,7 @@ struct ExchangeArgs {
   double* y;
   double* sys_sc;
   int* fail;
+  int tag;  // a failed pivot in a first level with the assembly folded in is reported as fail[1] == tag
   double* x;
   double cb, cq, cw;
 };
@@ -2161,7 +2162,9 @@ __global__ void __launch_bounds__(256) exchange_pack(ExchangeArgs a) {
     const int64_t o = a.n_xs + 3 * (int64_t)a.n_xv;
     a.x[o] = a.sys_sc[0];
     a.x[o + 1] = a.sys_sc[1];
-    a.x[o + 2] = (double)(*a.fail);
+    // both forms of a failed pivot travel: fail[0] (level kernels) and the tagged word of the
+    // fused first level -- otherwise only the failing rank would know and the ranks would part ways
+    a.x[o + 2] = (a.fail[0] != 0 || (a.tag != 0 && a.fail[1] == a.tag)) ? 1.0 : 0.0;
     a.x[o + 3] = 0;
   }
 }

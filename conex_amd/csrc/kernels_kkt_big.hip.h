@@ -311,17 +311,16 @@ inline hipError_t BigSupernodeSweep(const FactorPlan& P, const SnRec& R, int mod
   hipError_t e;
   const size_t solve_lds = sizeof(double) * (size_t)ns;
   if (solve_lds > 150 * 1024) return hipErrorNotSupported;  // right-hand side block held in LDS
-  static bool configured = false;
-  if (!configured) {
+  static PerDeviceOnce once;
+  e = once.run([] {
     const int lim = 150 * 1024;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&big_solve_fwd),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, lim)) != hipSuccess)
-      return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&big_solve_bwd),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, lim)) != hipSuccess)
-      return e;
-    configured = true;
-  }
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&big_solve_fwd),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+    if (e2 != hipSuccess) return e2;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&big_solve_bwd),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  });
+  if (e != hipSuccess) return e;
   if (mode == 2) {
     big_backsep<<<(ns + 255) / 256, 256, 0, st>>>(P, R, slab, rhs);
     big_solve_bwd<<<1, 1024, solve_lds, st>>>(D, b, ns);

@@ -1,8 +1,8 @@
 // Dense-LMI (real PSD cone) kernels, LDS-resident formulation for small orders.
 // One 256-thread workgroup per constraint; W, one A_i and two n x n temporaries live in
 // LDS.  These are the shape-generic kernels (any n with 4 n^2 doubles <= LDS budget);
-// kernels_lmi_fused.hip.h holds the row-per-lane DPP + MFMA specialisation used for the
-// benchmark shape, kernels_lmi_large.hip.h the HBM-resident path for orders beyond LDS.
+// lmi_fused_mfma.hip holds the fp64-MFMA kernel of the register-resident orders (the benchmark
+// shape among them), kernels_lmi_large.hip.h the HBM-resident path for orders beyond LDS.
 //
 // Reference semantics reproduced here:
 //   ConstructSchurComplementSystem(DenseLMIConstraint*)  dense_lmi_constraint.cc:72-103

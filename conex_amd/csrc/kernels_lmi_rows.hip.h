@@ -17,9 +17,18 @@
 // rounding (tests/test_gpu_parity.py, <= 1e-11).
 #pragma once
 #include "kernels_kkt.hip.h"
-#include "kernels_lmi_fused.hip.h"
+#include "kernels_lmi.hip.h"
 
 namespace cxk {
+
+// acc += w_bcast * v, W operand = lane J of each 16-lane row of `w` (DPP row_newbcast: the one DPP
+// mode gfx90a+ allows on fp64).
+template <int J>
+__device__ __forceinline__ void FmaBcast(double& acc, double w, double v) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc)
+               : "v"(w), "v"(v), "n"(J));
+}
 
 template <int N, int J>
 struct RowDotSteps {  // acc += sum_{j >= J} M[j][c] row[j]

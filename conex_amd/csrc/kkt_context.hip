@@ -28,7 +28,6 @@
 #include "kernels_kkt.hip.h"
 #include "kernels_kkt_big.hip.h"
 #include "kernels_lmi.hip.h"
-#include "kernels_lmi_fused.hip.h"
 #include "lmi_fused_mfma.h"
 #include "kernels_lmi_sparse.hip.h"
 #include "kernels_lmi_rows.hip.h"
@@ -97,8 +96,7 @@ struct Group {
   DevBuf<double> Apad;  // lmi_schur_mfma at a padded order: [A_1 .. A_m | C] per member, zero-padded (LmiMfmaPaddedOrder)
   DevBuf<int> dids;
   int herm_d = 0;
-  bool fused = false;
-  bool mfma = false;     // lmi_schur_mfma (lmi_fused_mfma.hip) instead of lmi_schur_fused
+  bool mfma = false;     // lmi_schur_mfma (lmi_fused_mfma.hip)
   bool literal = false;  // non-symmetric data: literal kernels only
   // orders beyond the LDS-resident kernels: HBM-resident matrices + MFMA GEMM pipeline
   bool large = false;
@@ -236,6 +234,7 @@ struct cxk_context {
   bool forward_all_lean = false;
   RhsIn rhs_in{};  // form 0 unless such a sweep is being enqueued
   int asm_tag = 0;    // tag of the latest fused launch (a failed pivot there writes d_fail[1] = tag)
+  bool fail_clean = false;  // d_fail[0] was cleared by the latest gather and no factorization has run since
   int fail_tag = 0;   // what mailbox_pack compares d_fail[1] with: asm_tag, or 0 after any other factorization
   FactorPlan plan{};
   // index of the next PrepareStep / eigenvalue query (keys the Hermitian start vectors)
@@ -254,6 +253,7 @@ struct cxk_context {
     void* lib = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclComm_t comm = nullptr;
@@ -1554,7 +1554,8 @@ int BuildPlans(cxk_context* ctx) {
 
 // Kernels that may be launched with more than the default 64 KB of dynamic LDS.
 hipError_t RaiseLdsLimits() {
-  static hipError_t status = [] {
+  static PerDeviceOnce once;  // function attributes are per device: every device a context is built on
+  return once.run([] {
     const int lim = (int)kLdsLimit;
     const void* ks[] = {
         reinterpret_cast<const void*>(&lmi_schur_generic),
@@ -1605,8 +1606,7 @@ hipError_t RaiseLdsLimits() {
       if (e != hipSuccess) return e;
     }
     return hipSuccess;
-  }();
-  return status;
+  });
 }
 
 ExchangeArgs MakeExchange(cxk_context* ctx, double k, double bs, double cs) {
@@ -1631,6 +1631,7 @@ ExchangeArgs MakeExchange(cxk_context* ctx, double k, double bs, double cs) {
   a.y = ctx->y.p;
   a.sys_sc = ctx->sys_sc.p;
   a.fail = ctx->d_fail.p;
+  a.tag = ctx->fail_tag;
   a.x = ctx->xbuf.p;
   a.cb = k * bs;
   a.cq = k * cs;
@@ -1794,8 +1795,6 @@ int LaunchSchur(cxk_context* ctx) {
             lg.a_stride = (long long)(g.m + 1) * np * np;
           }
           CXK_TRY(LaunchLmiSchurMfma(lg, ar, ctx->cus, ctx->stream, e0, e1));
-        } else if (g.fused) {
-          CXK_TRY(LaunchLmiSchurFused(MakeLmi(g), ar, ctx->stream));
         } else {
           lmi_schur_generic<<<count, 256, LmiGenericLds(g.n), ctx->stream>>>(MakeLmi(g), ar);
         }
@@ -1896,6 +1895,7 @@ int LaunchGather(cxk_context* ctx, bool with_rhs, double k, double bs, double cs
                     ctx->stream>>>(a);
   CXK_TRY(hipGetLastError());
   ctx->fail_tag = 0;
+  ctx->fail_clean = true;
   return CXK_SUCCESS;
 }
 
@@ -2173,6 +2173,7 @@ int QrFactor(cxk_context* ctx);
 int QrSolve(cxk_context* ctx);
 
 int LaunchTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
+  if (mode == 0) ctx->fail_clean = false;  // (whatever this factorization reports stays until the next gather)
   if (ctx->solver_mode == 2) {  // CONEX_QR_FACTORIZATION
     if (mode == 0 && QrFactor(ctx)) return CXK_FAILURE;
     if ((mode != 0 || with_rhs) && backward) return QrSolve(ctx);
@@ -2823,6 +2824,7 @@ static int CommInitImpl(cxk_context* ctx, const void* unique_id128, int rank, in
     CXK_DEMAND(R.lib != nullptr, "librccl.so not found");
     R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(dlsym(R.lib, "ncclCommInitRank"));
     R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(dlsym(R.lib, "ncclCommDestroy"));
+    R.CommCount = reinterpret_cast<decltype(R.CommCount)>(dlsym(R.lib, "ncclCommCount"));
     R.AllReduce = reinterpret_cast<decltype(R.AllReduce)>(dlsym(R.lib, "ncclAllReduce"));
     R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(dlsym(R.lib, "ncclGetErrorString"));
     CXK_DEMAND(R.CommInitRank && R.CommDestroy && R.AllReduce, "librccl.so lacks ncclCommInitRank / ncclAllReduce");
@@ -2841,6 +2843,14 @@ static int CommInitImpl(cxk_context* ctx, const void* unique_id128, int rank, in
     return CXK_FAILURE;
   }
   return CXK_SUCCESS;
+}
+
+// Ranks of the attached RCCL communicator as RCCL itself counts them (ncclCommCount); 0 when the
+// context has no RCCL communicator (single GPU, or a caller-supplied all-reduce).
+int cxk_comm_count(const cxk_context* ctx) {
+  if (!ctx || !ctx->rccl.comm || !ctx->rccl.CommCount) return 0;
+  int n = 0;
+  return ctx->rccl.CommCount(ctx->rccl.comm, &n) == ncclSuccess ? n : 0;
 }
 
 __global__ void comm_selftest_fill(int n, double* x) {
@@ -2945,7 +2955,7 @@ static int FinalizeImpl(cxk_context* ctx) {
       const char* force = getenv("CXK_SPARSE_LMI");
       const bool lds_resident = LmiTakeLds(c.n) <= kLdsLimit && LmiPrepareLds(c.n, c.m) <= kLdsLimit;
       c.sparse = force ? (atoi(force) != 0)
-                       : LmiSparsePays(c.n, c.m, nnz, lds_resident, LmiFusedSupports(c.n, c.m) || LmiMfmaSupports(c.n, c.m, c.herm_d));
+                       : LmiSparsePays(c.n, c.m, nnz, lds_resident, LmiMfmaSupports(c.n, c.m, c.herm_d));
       if (c.n > 65535) c.sparse = false;  // packed row | col << 16
       if (!c.symmetric) {
         // The reference accepts non-symmetric matrices and evaluates <W A_i W, A_j> as written;
@@ -2986,12 +2996,11 @@ static int FinalizeImpl(cxk_context* ctx) {
           // orders with more variables than lmi_schur_mfma's LDS images hold, e.g. order 22, m = 20
           // 285 -> 133 us, order 10, m = 60 496 -> 148 us; CXK_GEMM_MIN_N moves the threshold for
           // comparison runs)
-          // CXK_LMI_SCHUR = dpp | generic selects the older kernels (comparison runs, tests)
+          // CXK_LMI_SCHUR=generic selects the LDS-resident literal kernel (comparison runs, tests)
           const char* pick = getenv("CXK_LMI_SCHUR");
-          const bool want_dpp = pick && !strcmp(pick, "dpp"), want_generic = pick && !strcmp(pick, "generic");
-          g.mfma = !g.sparse && !g.large && !g.literal && !want_dpp && !want_generic && LmiMfmaSupports(g.n, g.m, g.herm_d);
-          g.fused = !g.sparse && !g.large && !g.literal && !g.mfma && !want_generic && LmiFusedSupports(g.n, g.m);
-          g.schur_gemm = !g.sparse && !g.literal && (g.large || (!g.fused && !g.mfma && g.n >= gemm_min_n &&
+          const bool want_generic = pick && !strcmp(pick, "generic");
+          g.mfma = !g.sparse && !g.large && !g.literal && !want_generic && LmiMfmaSupports(g.n, g.m, g.herm_d);
+          g.schur_gemm = !g.sparse && !g.literal && (g.large || (!g.mfma && g.n >= gemm_min_n &&
                                      cnt * 2 * ((size_t)g.m + 1) * g.n * g.n * sizeof(double) <= ((size_t)8 << 30)));
         }
         break;
@@ -3364,7 +3373,9 @@ int ReduceStepInfoAndSync(cxk_context* ctx, int mode, const double* info, const 
 
 int cxk_factor_async(cxk_context* ctx) {
   CXK_ENTER(ctx);
-  CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));
+  // the gather that assembled the system has cleared the failure flag (GatherBody); a factorization
+  // of a slab that came another way (cxk_set_slab, a second factorization) clears it here
+  if (!ctx->fail_clean) CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, sizeof(int), ctx->stream));
   ctx->fail_tag = 0;
   if (LaunchTree(ctx, 0, false, false)) return CXK_FAILURE;
   ctx->factor_seq = ++ctx->seq;
@@ -3996,7 +4007,7 @@ int cxk_count_lmi_kernel(const cxk_context* ctx, int which) {
   int k = 0;
   for (const Group& g : ctx->groups) {
     if (g.type != CXK_LMI) continue;
-    const int kind = g.sparse ? 4 : g.schur_gemm ? 3 : g.mfma ? 2 : g.fused ? 1 : 0;
+    const int kind = g.sparse ? 4 : g.schur_gemm ? 3 : g.mfma ? 2 : 0;
     if (kind == which) k += (int)g.ids.size();
   }
   return k;
@@ -4025,9 +4036,6 @@ int cxk_debug_stamps(long long* out) {
 int cxk_debug_select(int) { return 0; }
 #endif
 #ifdef CXK_DEBUG_STAMPS
-int cxk_debug_fused_stamps(long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_stamp), 64 * sizeof(long long)) == hipSuccess ? 0 : 1;
-}
 int cxk_debug_sparse_stamps(long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sparse_stamp), 8 * sizeof(long long)) == hipSuccess ? 0 : 1;
 }
@@ -4074,7 +4082,7 @@ int cxk_phase_timers(cxk_context* ctx, int on) {
 
 int cxk_phase_mark(cxk_context* ctx, int phase) {
   if (!ctx || !ctx->phase_on) return CXK_SUCCESS;
-  CXK_ENTER(ctx);
+  CXK_ENTER_KEEP(ctx);  // only records an event: a deferred gather stays deferred (the timed run takes the untimed run's path)
   CXK_DEMAND(phase >= 0 && phase < CXK_PHASE_COUNT, "unknown phase");
   hipEvent_t ev;
   if (!ctx->phase_pool.empty()) {
@@ -4090,7 +4098,7 @@ int cxk_phase_mark(cxk_context* ctx, int phase) {
 
 int cxk_phase_read(cxk_context* ctx, double* us, int reset) {
   if (!ctx || !us) return CXK_FAILURE;
-  CXK_ENTER(ctx);
+  CXK_ENTER_KEEP(ctx);
   if (!ctx->phase_marks.empty()) {
     CXK_TRY(hipEventSynchronize(ctx->phase_marks.back().first));
     for (size_t k = 0; k + 1 < ctx->phase_marks.size(); k++) {

@@ -296,7 +296,6 @@ __device__ __forceinline__ d4_t Contract(const double* __restrict__ Pb, int ra, 
       else
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[cb_][bi], b0[cb_][bi], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-#ifndef CXK_EXPERIMENT_NO_READS  // diagnostic: operands of the first row are reused (wrong results, MFMA-only timing)
       // next row's operands, two per LDS instruction (ds_read2_b64: neighbours share a base
       // register): the A-side pair after an even k-step, the B-side pair after an odd one
       if (more) {
@@ -309,10 +308,6 @@ __device__ __forceinline__ d4_t Contract(const double* __restrict__ Pb, int ra, 
           b0[nb_][bi] = pb[Cfg::BOfs(bi) + r + 1];
         }
       }
-#else
-      a0[nb_][bi] = a0[cb_][bi];
-      b0[nb_][bi] = b0[cb_][bi];
-#endif
     }
   }
   if constexpr (H) acc -= acc2;
@@ -491,9 +486,7 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
         }
         __builtin_amdgcn_sched_barrier(0);
         if (it == 2) MSTAMP(49 + 2 * tt);
-#ifndef CXK_EXPERIMENT_NO_RELOAD  // diagnostic: operands of the first constraint are reused (wrong results, compute-only timing)
         if (tt > 0) LoadTile<N>(a[tt - 1], gm, tt - 1, nx.block);
-#endif
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (N > 20) {
@@ -669,13 +662,12 @@ bool SupportsT(int m) {
 template <int N, bool H>
 hipError_t LaunchT(const LmiGroup& g, const Arena& ar, int cus, hipStream_t stream, hipEvent_t ev_start,
                    hipEvent_t ev_stop) {
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lmi_schur_mfma<N, H>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
-    if (e != hipSuccess) return e;
-    configured = true;
-  }
+  static PerDeviceOnce once;
+  const hipError_t ec = once.run([] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&lmi_schur_mfma<N, H>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+  });
+  if (ec != hipSuccess) return ec;
   int grid = g.count < cus ? g.count : cus;
   const int need = (g.count + kDestSlots - 1) / kDestSlots;  // at most kDestSlots constraints per workgroup
   if (grid < need) grid = need;

@@ -809,6 +809,11 @@ CONEX_STATUS CONEX_NewLinearMatrixInequality(void* x, int order, int hyper_compl
   CAST_PROGRAM(x, p);
   if (hyper_complex_dim == 8)
     CONEX_DEMAND(order <= 3, "Order of octonion algebra cannot be greater than 3.");
+  // The octonion algebra is not associative and has no real matrix representation: the reference
+  // itself runs it on heuristics (hermitian_psd.cc:108-168).  Not on the device: refused HERE, when
+  // the constraint is created, not when the program is solved.
+  CONEX_DEMAND(hyper_complex_dim != 8,
+               "Octonion LMIs are not supported by the HIP build (hypercomplex dimension 1, 2 or 4 only).");
   Cone k;
   k.kind = kLmi;
   k.order = order;

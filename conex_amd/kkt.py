@@ -100,6 +100,7 @@ _SIGNATURES = {
     "cxk_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "cxk_comm_set_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cxk_comm_selftest": (C.c_int, [C.c_void_p, C.c_int]),
+    "cxk_comm_count": (C.c_int, [C.c_void_p]),
     "cxk_dense_top_columns": (C.c_int, [C.c_void_p]),
     "cxk_factor_async": (C.c_int, [C.c_void_p]),
     "cxk_factor_solve_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
@@ -492,6 +493,10 @@ class KktContext:
     def comm_init_rccl_solo(self):
         """Diagnostic: one-rank RCCL communicator under a larger virtual shard world (cxk_comm_init_rccl_solo)."""
         self._check(self.L.cxk_comm_init_rccl_solo(self.h), "cxk_comm_init_rccl_solo")
+
+    def comm_count(self):
+        """Ranks the attached RCCL communicator holds (ncclCommCount); 0 without one."""
+        return int(self.L.cxk_comm_count(self.h))
 
     def comm_selftest(self, count=1000):
         self._check(self.L.cxk_comm_selftest(self.h, count), "cxk_comm_selftest")

@@ -166,6 +166,8 @@ int cxk_kkt_solve_async(cxk_context* ctx, double inv_sqrt_mu, double b_scaling,
 int cxk_sync(cxk_context* ctx, int* factor_ok);
 /* SolveInPlace on a host vector of length N (copy in, solve, copy out). */
 int cxk_solve_inplace(cxk_context* ctx, double* y);
+/* (sharded context with a communicator: a COLLECTIVE -- a sum all-reduce of N doubles assembles the
+ * whole vector, so every rank must call it, in the same order relative to its other cxk_* calls) */
 int cxk_get_y(cxk_context* ctx, double* y /* N, original variable order */);
 int cxk_set_y(cxk_context* ctx, const double* y);
 
@@ -232,6 +234,8 @@ int cxk_comm_set_allreduce(cxk_context* ctx, cxk_allreduce_fn fn, void* user);
 int cxk_comm_init_rccl_solo(cxk_context* ctx);
 /* sum / max / min all-reduces of `count` doubles through the RCCL communicator, checked */
 int cxk_comm_selftest(cxk_context* ctx, int count);
+/* ranks of the attached RCCL communicator as RCCL counts them (ncclCommCount); 0 without one */
+int cxk_comm_count(const cxk_context* ctx);
 
 /* SupernodalKKTSolver::SetSolverMode (kkt_solver.h:41; SolverConfiguration::kkt_solver): 0 / 1 the
  * supernodal LLT / LDLT (chosen by the structure, as kkt_solver.cc:180-193 does), 2

@@ -135,15 +135,16 @@ def test_complex_and_quaternion_lmi_solve_matches_oracle(d, order, m):
     L.CONEX_DeleteConeProgram(p)
 
 
-def test_octonion_lmi_is_rejected_loudly():
+def test_octonion_lmi_is_rejected_when_it_is_created():
+    """Octonion LMIs (the reference's heuristic path, hermitian_psd.cc:108-168) are not built:
+    CONEX_NewLinearMatrixInequality refuses them with CONEX_FAILURE -- not the solve, later."""
     L = ca.api()
     p = L.CONEX_CreateConeProgram()
     assert L.CONEX_SetNumberOfVariables(p, 1) == 0
-    cid = C.c_int()
-    assert L.CONEX_NewLinearMatrixInequality(p, 3, 8, C.byref(cid)) == 0   # accepted by the builder
-    assert L.CONEX_UpdateLinearOperator(p, cid.value, 1.0, 0, 0, 0, 0) == 0
-    ok, _ = _maximize(L, p, np.ones(1))
-    assert ok == 0                                                          # ... refused at solve time
+    cid = C.c_int(-7)
+    assert L.CONEX_NewLinearMatrixInequality(p, 3, 8, C.byref(cid)) == 1
+    assert cid.value == -7                                                  # no constraint was added
+    assert L.CONEX_NewLinearMatrixInequality(p, 3, 4, C.byref(cid)) == 0 and cid.value == 0
     L.CONEX_DeleteConeProgram(p)
 
 

@@ -226,6 +226,44 @@ def test_sharded_newton_iteration_through_the_library_collectives(kind, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_a_failed_leaf_pivot_on_one_rank_is_seen_by_every_rank(world):
+    """A leaf whose scaling point is singular makes its Schur block singular; its supernode is
+    factored by ONE rank, inside the first level with the assembly folded in, which reports through
+    the tagged flag word.  The flag must cross the exchange: ranks that disagree about Factor()
+    take different branches of the IPM loop and issue mismatched collectives."""
+    prob, W = _program("c4", 13)
+    K = len(prob["cliques"])
+    bad = K - 1                                   # a leaf of the clique tree
+    Wbad = np.zeros((20, 20))                     # G = 0: the leaf's first pivot is not positive
+
+    def body(rank, allreduce):
+        k = KktContext(prob["num_vars"], device=0)
+        for c, cl in enumerate(prob["cliques"]):
+            k.add_lmi(prob["A"][c], prob["C"][c], cl)
+        k.set_shard(rank, world)
+        k.initialize()
+        k.comm_set_allreduce(allreduce)
+        k.set_cost(prob["b"])
+        for i in range(k.K):
+            if k.owns(i):
+                k.set_W(i, W[i])
+        ok_good, _ = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+        if k.owns(bad):
+            k.set_W(bad, Wbad)
+        ok_bad, _ = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+        if k.owns(bad):
+            k.set_W(bad, W[bad])
+        ok_again, _ = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+        return ok_good, ok_bad, ok_again, bool(k.owns(bad)), k.fused_assembly()
+
+    res = ThreadRanks(world).run(body)
+    assert sum(r[3] for r in res) == 1
+    for ok_good, ok_bad, ok_again, _, _ in res:
+        assert ok_good == 1 and ok_bad == 0 and ok_again == 1
+
+
+@pytest.mark.gpu
 def test_sharded_equality_constraints_take_the_ldlt_path():
     """Multipliers make the KKT matrix indefinite: block LDLT under sharding (the LQR program of
     assembly_test.cc:67-106 with 40 stages) against the single-context solve."""
