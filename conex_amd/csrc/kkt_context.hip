@@ -33,6 +33,7 @@
 #include "kernels_lmi_rows.hip.h"
 #include "kernels_kkt_top.hip.h"
 #include "kernels_lmi_large.hip.h"
+#include "tree_fused.h"
 #include "symbolic.h"
 
 using namespace cxk;
@@ -228,6 +229,20 @@ struct cxk_context {
     int with_rhs = 0;  // GatherArgs::with_rhs
     double k = 0, bs = 0, cs = 0, cb = 0, cq = 0, cw = 0;
   } asm_pending;
+  // The whole tree in one launch (tree_fused.hip): records, the lists of entries / variables with
+  // several sources, the two sets of hand-off slots and their initial images (re-uploaded after a
+  // wait ran out), the run counter whose parity picks the set
+  bool fused_tree = false;
+  bool fused_sweep = false;  // solve-only sweeps in one launch too (CXK_NO_FUSED_SWEEP=1 turns this part off)
+  int fused_sa = 0, fused_sb = 0;
+  DevBuf<int> fx_rec, fx_xreg;
+  DevBuf<long long> fx_xsrc, fx_rsrc;
+  DevBuf<int> fx_pub, fx_pprobe;
+  DevBuf<double> fx_hand, fx_ysig;
+  std::vector<double> fx_hand_init;
+  long long fx_updb_base = 0;
+  unsigned fused_gen = 0;
+  double* fx_flag = nullptr;  // pinned host word the kernel sets when a wait ran out
   bool asm_deferred = false;  // cxk_assemble ran the Schur kernels; the gather waits for the factorization that follows
   // solve-only sweeps whose every forward launch is a lean kernel form the right-hand side inside
   // those kernels (RhsIn) instead of in a launch of their own
@@ -1316,6 +1331,206 @@ int BuildPlans(cxk_context* ctx) {
       ctx->fused_asm = true;
     }
   }
+  // ---- the whole tree in one launch (tree_fused.hip).  Taken when every supernode has a register
+  // kernel (at most two shapes) with dense pulls and an inline separator list, sits alone in its
+  // constraint's Schur block at non-negative positions (no fill-in rows), its entries take their
+  // first source from that block, the lists of further sources fit the dense slots, and the grid
+  // is resident at once (the way back down waits for HIGHER positions).
+  ctx->fused_tree = false;
+  ctx->fused_sweep = false;
+  if (!sharded && !ctx->use_ldlt && !ctx->no_lean && !getenv("CXK_NO_FUSED_TREE") && nlev >= 1 && N < (1 << 26)) {
+    const int cnt_all = (int)ctx->level_sn.size();
+    bool ok = cnt_all > 0 && cnt_all == ctx->level_ptr[nlev];
+    int sa = 0, sb = 0;
+    for (int l = 0; l < nlev && ok; l++) {
+      ok = ctx->level_lean[l] && !ctx->level_big[l] && ctx->level_nh[l] == ctx->level_ptr[l + 1] - ctx->level_ptr[l];
+      for (auto& sg : ctx->level_segs[l]) {
+        if (sa == 0 || sg.shape == sa) {
+          sa = sg.shape;
+        } else if (sb == 0 || sg.shape == sb) {
+          sb = sg.shape;
+        } else {
+          ok = false;
+        }
+      }
+    }
+    if (sb != 0 && sb < sa) std::swap(sa, sb);
+    if (sb == 0) sb = sa;
+    ok = ok && FusedTreeCompiled(sa, sb);
+    std::vector<int> recs((size_t)cnt_all * kFusedRecWords, 0), xreg;
+    std::vector<long long> xsrc, rsrc;
+    for (int pos = 0; pos < cnt_all && ok; pos++) {
+      const int e = ctx->level_sn[pos];
+      const int i = md.clique_order[e];
+      const int m = ctx->cons[i].m;
+      const IntList& r = md.supernodes_pos[e];
+      const IntList& sp = md.separators_pos[e];
+      const int nse = (int)r.size(), nsp = (int)sp.size();
+      const int nsm = RegisterShape(ns[e], nsep[e]) >> 8;
+      ok = nse == ns[e] && nsp == nsep[e] && nse + nsp <= 72 && m <= 255 && ctx->owned[i] && nsm > 0;
+      if (!ok) break;
+      int* w = recs.data() + (size_t)pos * kFusedRecWords;
+      memcpy(w, &h_recs[pos], sizeof(SnRec));
+      AsmRec ar;
+      memset(&ar, 0, sizeof(ar));
+      ar.g_off = ctx->g_off[i];
+      ar.r_off = ctx->r_off[i];
+      ar.m = m;
+      for (int a = 0; a < nse && ok; a++) {
+        ok = r[a] >= 0 && r[a] < m;
+        ar.pos[a] = (unsigned char)r[a];
+      }
+      for (int a = 0; a < nsp && ok; a++) {
+        ok = sp[a] >= 0 && sp[a] < m;
+        ar.pos[nse + a] = (unsigned char)sp[a];
+      }
+      if (!ok) break;
+      memcpy(w + 32, &ar, sizeof(AsmRec));
+      // entries with further sources, in the order of the panel (columns of the diagonal block, then
+      // the off block): (image location, sources)
+      std::vector<std::pair<int, std::vector<int64_t>>> extra;
+      auto visit = [&](int64_t off, int pa, int pb, int reg) {
+        const int t = entry_of[off];
+        if (t < 0) return false;
+        const GatherRec& g = h_as_rec[t];
+        const int hi = std::max(pa, pb), lo = std::min(pa, pb);
+        if (g.first != ar.g_off + hi + (int64_t)lo * m) return false;
+        if (g.extra > 0) {
+          extra.emplace_back(reg, std::vector<int64_t>(as_src.begin() + g.beg, as_src.begin() + g.beg + g.extra));
+        }
+        return true;
+      };
+      for (int j = 0; j < nse && ok; j++)
+        for (int i2 = j; i2 < nse && ok; i2++) ok = visit(L.diag_off[e] + (int64_t)j * nse + i2, r[i2], r[j], 64 * j + i2);
+      for (int j = 0; j < nsp && ok; j++)
+        for (int i2 = 0; i2 < nse && ok; i2++) ok = visit(L.offd_off[e] + (int64_t)j * nse + i2, r[i2], sp[j], 64 * i2 + nsm + j);
+      size_t mx = 0;
+      for (auto& x : extra) mx = std::max(mx, x.second.size());
+      ok = ok && extra.size() <= (size_t)kFusedExtraTargets && mx <= (size_t)kFusedExtraSlots;
+      // variables that several constraints share: all their sources, in the gather's order
+      size_t mr = 0;
+      for (int a = 0; a < nse && ok; a++) {
+        const auto& lst = per[start[e] + a];
+        if (lst.size() == 1)
+          ok = lst[0] == ar.r_off + r[a];
+        else
+          ok = !lst.empty() && std::find(lst.begin(), lst.end(), ar.r_off + r[a]) != lst.end();
+        if (lst.size() > 1) mr = std::max(mr, lst.size());
+      }
+      ok = ok && mr <= (size_t)kFusedExtraSlots;
+      if (!ok) break;
+      const int64_t xbase = (int64_t)xsrc.size();
+      w[56] = (int)xreg.size();
+      w[57] = (int)extra.size();
+      w[58] = (int)mx;
+      w[59] = (int)rsrc.size();
+      w[60] = (int)mr;
+      w[61] = (int)(xbase & 0xffffffffll);
+      w[62] = (int)(xbase >> 32);
+      w[63] = ctx->t_level[e];
+      for (auto& x : extra) {
+        xreg.push_back(x.first);
+        for (size_t q2 = 0; q2 < mx; q2++) xsrc.push_back(q2 < x.second.size() ? (long long)x.second[q2] : -1ll);
+      }
+      if (mr > 0)
+        for (int a = 0; a < nse; a++) {
+          const auto& lst = per[start[e] + a];
+          for (size_t q2 = 0; q2 < mr; q2++) rsrc.push_back(lst.size() > 1 && q2 < lst.size() ? (long long)lst[q2] : -1ll);
+        }
+      ok = rsrc.size() < (size_t)INT32_MAX && xreg.size() < (size_t)INT32_MAX;
+    }
+    // who consumes a supernode's published values: the supernodes that own its separator variables
+    // (at most 8).  Every (publisher, consumer) pair gets an arrival word; a consumer's are consecutive.
+    std::vector<int> pub, pprobe((size_t)cnt_all * 8, -1);
+    const size_t us = (size_t)slots + 1 + kPullPad, ubs = (size_t)slotsb + 2 + kPullPad;
+    size_t nprobe = 0;
+    if (ok) {
+      std::vector<int> pos_of(K, -1);
+      for (int pos = 0; pos < cnt_all; pos++) pos_of[ctx->level_sn[pos]] = pos;
+      std::vector<std::vector<int>> cons_of(K), kids(K);
+      for (int pos = 0; pos < cnt_all && ok; pos++) {
+        const int e = ctx->level_sn[pos];
+        for (int v : L.separators[e]) {
+          const int p = L.var_to_sn[v];
+          if (std::find(cons_of[e].begin(), cons_of[e].end(), p) == cons_of[e].end()) {
+            cons_of[e].push_back(p);
+            kids[p].push_back(e);
+          }
+          ok = ok && pos_of[p] > pos;  // (waits go to lower positions on the way up)
+        }
+        ok = ok && cons_of[e].size() <= 8;
+      }
+      std::vector<int> pbase(K, 0);
+      for (int pos = 0; pos < cnt_all && ok; pos++) {
+        const int e = ctx->level_sn[pos];
+        pbase[e] = (int)(us + ubs + nprobe);
+        nprobe += kids[e].size();
+        ok = kids[e].size() <= 64;
+      }
+      ok = ok && us + ubs + nprobe + 8 < (size_t)INT32_MAX;
+      for (int pos = 0; pos < cnt_all && ok; pos++) {
+        const int e = ctx->level_sn[pos];
+        int* w = recs.data() + (size_t)pos * kFusedRecWords;
+        w[21] = pbase[e];
+        w[22] = (int)kids[e].size();
+        w[23] = (int)pub.size();
+        for (int64_t t = 0; t < (int64_t)nsep[e] * (nsep[e] + 1) / 2; t++) pub.push_back(pub_dst[(size_t)(upd_off[e] + t)]);
+        for (int c = 0; c < nsep[e]; c++) pub.push_back((int)us + pubb_dst[(size_t)(updb_off[e] + c)]);
+        for (size_t q2 = 0; q2 < cons_of[e].size(); q2++) {
+          const int p = cons_of[e][q2];
+          const int idx = (int)(std::find(kids[p].begin(), kids[p].end(), e) - kids[p].begin());
+          pprobe[(size_t)pos * 8 + q2] = pbase[p] + idx;
+        }
+      }
+    }
+    if (ok) {
+      // residency: every workgroup (one wavefront each, one more for the scalars) at once, with a
+      // CU's worth of margin per slot count the occupancy query may overstate
+      const int occ = FusedTreeOccupancy(sa, sb);
+      ok = occ >= 2 && (int64_t)cnt_all + 1 <= (int64_t)(occ - 1) * ctx->cus;
+    }
+    if (ok) {
+      xreg.resize(xreg.size() + kPullPad, 0);
+      xsrc.resize(xsrc.size() + kPullPad * kFusedExtraSlots, -1ll);
+      rsrc.resize(rsrc.size() + 64 * kFusedExtraSlots, -1ll);
+      pub.resize(pub.size() + 64, (int)slots);
+      // hand-off slots: every slot with a producer starts as the sentinel in BOTH sets, the rest 0.0
+      const double sent = [] {
+        double d;
+        const unsigned long long bits = kFusedSentinel;
+        memcpy(&d, &bits, sizeof(d));
+        return d;
+      }();
+      const size_t hs = us + ubs + nprobe + 8;
+      ctx->fx_updb_base = (long long)us;
+      ctx->fx_hand_init.assign(2 * hs, 0.0);
+      for (size_t t = 0; t + 64 < pub.size(); t++) {
+        const int d = pub[t];
+        if (d != (int)slots && d != (int)us + slotsb) ctx->fx_hand_init[d] = ctx->fx_hand_init[hs + d] = sent;
+      }
+      for (size_t t = 0; t < nprobe; t++) ctx->fx_hand_init[us + ubs + t] = ctx->fx_hand_init[hs + us + ubs + t] = sent;
+      CXK_TRY(ctx->fx_rec.upload(recs));
+      CXK_TRY(ctx->fx_xreg.upload(xreg));
+      CXK_TRY(ctx->fx_xsrc.upload(xsrc));
+      CXK_TRY(ctx->fx_rsrc.upload(rsrc));
+      CXK_TRY(ctx->fx_pub.upload(pub));
+      CXK_TRY(ctx->fx_pprobe.upload(pprobe));
+      CXK_TRY(ctx->fx_hand.upload(ctx->fx_hand_init));
+      CXK_TRY(ctx->fx_ysig.upload(std::vector<double>(2 * (size_t)N, sent)));
+      if (!ctx->fx_flag) {
+        CXK_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->fx_flag), 64, hipHostMallocDefault));
+        *ctx->fx_flag = 0.0;
+      }
+      ctx->fused_sa = sa;
+      ctx->fused_sb = sb;
+      ctx->fused_gen = 0;
+      ctx->fused_tree = true;
+      ctx->fused_sweep = getenv("CXK_NO_FUSED_SWEEP") == nullptr;
+      if (getenv("CXK_DEBUG_LEVELS"))
+        fprintf(stderr, "whole tree in one launch: %d supernodes, shapes <%d,%d> <%d,%d>, %zu entries / %zu variables with further sources\n",
+                cnt_all, sa >> 8, sa & 255, sb >> 8, sb & 255, xreg.size() - kPullPad, rsrc.size());
+    }
+  }
   // ---- the top as one dense T x T factorization (single GPU, Cholesky): tables for
   // tree_top_dense.  Rows = the variables of the top supernodes in elimination order.
   // Used where the supernode-by-supernode kernels are weak: when the last levels hold a mid-size
@@ -2263,7 +2478,97 @@ int LaunchChain(cxk_context* ctx, int mode) {
   return CXK_SUCCESS;
 }
 
+// Arguments of a whole-tree launch (tree_fused.hip); rebuilds the hand-off slots first when an
+// earlier launch reported that a wait ran out.
+int MakeFusedTreeArgs(cxk_context* ctx, FusedTreeArgs* out) {
+  if (*ctx->fx_flag != 0.0) {
+    // a wait ran out in an earlier launch (reported as a failed factorization): the hand-off slots
+    // may hold anything -- rebuild both sets before they are trusted again
+    CXK_TRY(hipStreamSynchronize(ctx->stream));
+    CXK_TRY(hipMemcpy(ctx->fx_hand.p, ctx->fx_hand_init.data(), sizeof(double) * ctx->fx_hand_init.size(), hipMemcpyHostToDevice));
+    unsigned long long bits = kFusedSentinel;
+    double sent;
+    memcpy(&sent, &bits, sizeof(sent));
+    std::vector<double> ys(ctx->fx_ysig.n, sent);
+    CXK_TRY(hipMemcpy(ctx->fx_ysig.p, ys.data(), sizeof(double) * ys.size(), hipMemcpyHostToDevice));
+    *ctx->fx_flag = 0.0;
+  }
+  FusedTreeArgs& a = *out;
+  a.rec = ctx->fx_rec.p;
+  a.count = (int)ctx->level_sn.size();
+  a.G = ctx->G.p;
+  a.AWc = ctx->AWc.p;
+  a.AQcc = ctx->AQcc.p;
+  a.b = ctx->b.p;
+  a.AW = ctx->AW.p;
+  a.AQc = ctx->AQc.p;
+  a.slab = ctx->slab.p;
+  a.y = ctx->y.p;
+  a.pub = ctx->fx_pub.p;
+  a.pprobe = ctx->fx_pprobe.p;
+  a.tg_reg = ctx->tg_reg.p;
+  a.xreg = ctx->fx_xreg.p;
+  a.xsrc = ctx->fx_xsrc.p;
+  a.rsrc = ctx->fx_rsrc.p;
+  a.hand = ctx->fx_hand.p;
+  a.hand_stride = (long long)(ctx->fx_hand.n / 2);
+  a.updb_base = ctx->fx_updb_base;
+  a.ysig = ctx->fx_ysig.p;
+  a.ysig_stride = (long long)(ctx->fx_ysig.n / 2);
+  a.gen = (int)(ctx->fused_gen++ & 1u);
+  a.fail = ctx->d_fail.p;
+  a.tag = ctx->fail_tag;
+  a.k = a.bs = a.cs = a.cb = a.cq = a.cw = 0;
+  a.comb = 0;
+  a.form = 0;
+  a.sc = ctx->sc.p;
+  a.sys_sc = ctx->sys_sc.p;
+  a.K = (int)ctx->cons.size();
+  a.host_flag = ctx->fx_flag;
+  return CXK_SUCCESS;
+}
+
+// Assembly gather, factorization with the first right-hand side, back substitution: one launch.
+// Consumes the pending assembly.
+int LaunchFusedTreeSolve(cxk_context* ctx) {
+  const cxk_context::AsmPending ap = ctx->asm_pending;
+  ctx->asm_pending.on = false;
+  FusedTreeArgs a;
+  if (MakeFusedTreeArgs(ctx, &a)) return CXK_FAILURE;
+  ctx->asm_tag = ctx->asm_tag >= (1 << 30) ? 1 : ctx->asm_tag + 1;
+  a.tag = ctx->fail_tag = ctx->asm_tag;
+  a.k = ap.k;
+  a.bs = ap.bs;
+  a.cs = ap.cs;
+  a.cb = ap.cb;
+  a.cq = ap.cq;
+  a.cw = ap.cw;
+  a.comb = ap.with_rhs == 2;
+  CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, false, ctx->stream));
+  return CXK_SUCCESS;
+}
+
+// A solve-only sweep on the stored factor: forward and back substitution, one launch.  The
+// right-hand side is in y, or formed inside the kernel (ctx->rhs_in, SolveWithRhs).
+int LaunchFusedTreeSweep(cxk_context* ctx) {
+  FusedTreeArgs a;
+  if (MakeFusedTreeArgs(ctx, &a)) return CXK_FAILURE;
+  const RhsIn& ri = ctx->rhs_in;
+  a.form = ri.form;
+  a.k = ri.k;
+  a.bs = ri.bs;
+  a.cs = ri.cs;
+  a.cb = ri.cb;
+  a.cq = ri.cq;
+  a.cw = ri.cw;
+  CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, true, ctx->stream));
+  return CXK_SUCCESS;
+}
+
 int LaunchTreeCore(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
+  if (mode == 0 && with_rhs && backward && ctx->fused_tree && ctx->asm_pending.on && ctx->asm_pending.with_rhs != 0)
+    return LaunchFusedTreeSolve(ctx);
+  if (mode == 1 && backward && ctx->fused_tree && ctx->fused_sweep) return LaunchFusedTreeSweep(ctx);
   if (ctx->use_ldlt && mode == 0) CXK_TRY(hipMemsetAsync(ctx->d_reg.p, 0, sizeof(int), ctx->stream));
   const int nlev = (int)ctx->level_ptr.size() - 1;
   const int top = ctx->top_level;
@@ -2575,7 +2880,7 @@ struct DeviceGuard {
 // factor level when the tree allows it (BuildPlans) and nothing needs the assembled system as
 // such: Cholesky sweeps, no refinement copy (sharded contexts: when the first level lies below the cut).
 bool FusedAssembly(const cxk_context* ctx) {
-  return ctx->fused_asm && ctx->solver_mode != 2 && ctx->refine_iters <= 0 && !ctx->no_lean;
+  return (ctx->fused_asm || ctx->fused_tree) && ctx->solver_mode != 2 && ctx->refine_iters <= 0 && !ctx->no_lean;
 }
 // cxk_assemble leaves the gather to the factorization that normally follows; any other entry point
 // that runs first gets the assembled system by the separate launch.
@@ -2631,6 +2936,7 @@ void cxk_destroy(cxk_context* ctx) {
   if (ctx->rccl.comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->rccl.comm);
   if (ctx->mb) (void)hipHostFree(ctx->mb);
   if (ctx->pin_y) (void)hipHostFree(ctx->pin_y);
+  if (ctx->fx_flag) (void)hipHostFree(ctx->fx_flag);
   delete ctx;
 }
 
@@ -3385,7 +3691,7 @@ int cxk_factor_async(cxk_context* ctx) {
 int cxk_factor_status(cxk_context* ctx, int* ok) {
   CXK_ENTER(ctx);
   if (ctx->mb_seen < ctx->factor_seq && SyncMailbox(ctx)) return CXK_FAILURE;
-  if (ok) *ok = ctx->mb ? (ctx->mbv[10] == 0.0) : 1;
+  if (ok) *ok = (ctx->mb ? (ctx->mbv[10] == 0.0) : 1) && !(ctx->fx_flag && *ctx->fx_flag != 0.0);
   return CXK_SUCCESS;
 }
 
@@ -3471,7 +3777,7 @@ int cxk_sync(cxk_context* ctx, int* factor_ok) {
   CXK_ENTER(ctx);
   if (SyncMailbox(ctx)) return CXK_FAILURE;
   CXK_TRY(hipStreamSynchronize(ctx->stream));  // the stream is idle: cheap, and later host-side copies rely on it
-  if (factor_ok) *factor_ok = ctx->mbv[10] == 0.0;
+  if (factor_ok) *factor_ok = ctx->mbv[10] == 0.0 && !(ctx->fx_flag && *ctx->fx_flag != 0.0);
   // fold finished timing samples
   for (size_t k = 0; k < ctx->ev_used; k++) {
     float ms = 0;
@@ -3501,7 +3807,7 @@ int cxk_set_cost(cxk_context* ctx, const double* b) {
 // forward kernels when all of them are lean ones, by a launch of its own otherwise.
 static int SolveWithRhs(cxk_context* ctx, const RhsIn& form) {
   const int N = ctx->md.N;
-  const bool inline_rhs = ctx->forward_all_lean && ctx->world == 1 && ctx->solver_mode != 2 &&
+  const bool inline_rhs = (ctx->forward_all_lean || ctx->fused_tree) && ctx->world == 1 && ctx->solver_mode != 2 &&
                           ctx->refine_iters <= 0 && !ctx->no_lean;
   if (inline_rhs) {
     ctx->rhs_in = form;
@@ -4001,6 +4307,8 @@ int cxk_count_sparse_lmi(const cxk_context* ctx) {
 }
 
 int cxk_fused_assembly(const cxk_context* ctx) { return ctx && ctx->fused_asm ? 1 : 0; }
+/* 1 when assembly, factorization and solve of a KKT solve run as one launch (tree_fused.hip) */
+int cxk_fused_tree(const cxk_context* ctx) { return ctx && ctx->fused_tree ? 1 : 0; }
 
 int cxk_count_lmi_kernel(const cxk_context* ctx, int which) {
   if (!ctx || !ctx->device_ready) return -1;

@@ -1,0 +1,77 @@
+// The whole elimination tree in ONE launch: assembly gather, supernodal Cholesky with the forward
+// substitution riding in it, and the back substitution (tree_fused.hip).  Host-side interface.
+//
+// Reference semantics: SupernodalKKTSolver::Assemble / Factor / SolveInPlace
+// (kkt_solver.cc:164-170, 180-193, 220-263), BlockCholeskyInPlace and the block solves
+// (block_triangular_operations.cc:114-219), AssembleSchurComplementResiduals
+// (constraint_manager.h:107-124), the right-hand side of cone_program.cc:409-411 / :181.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace cxk {
+
+// A published value doubles as its own "ready" flag: slots start as this bit pattern (a signalling
+// NaN no arithmetic produces) and the consumer polls until it is gone.
+constexpr unsigned long long kFusedSentinel = 0x7FF4C0DEC0DE5EEDull;
+
+constexpr int kFusedRecWords = 64;   // one record per supernode: 256 bytes, one dword per lane
+constexpr int kFusedExtraTargets = 128;  // panel entries with more than one source (two per lane)
+constexpr int kFusedExtraSlots = 8;      // further sources per such entry / sources per shared variable
+
+// Words of a record (position = dependency order: a supernode only waits for lower positions):
+//   [0, 32)   SnRec (kernels_kkt.hip.h); its spare words: 21 first arrival word of this supernode's
+//             publishers (consecutive), 22 their number, 23 pub_beg
+//   [32, 56)  AsmRec: the Schur block of the supernode's own constraint and the position of every
+//             panel row in it
+//   56 xt_beg  57 nxt  58 mx   panel entries with further sources: image location xreg[xt_beg + t],
+//   61,62 xbase                sources xsrc[xbase + t * mx + i] (index into G, -1 none), gather order
+//   59 rbase   60 mr           variables shared with other constraints: ALL their sources in gather
+//                              order rsrc[rbase + row * mr + i] (index into AWc / AQcc, -1 none); a
+//                              row whose list is empty has its own constraint as the one source
+struct FusedTreeArgs {
+  const int* rec;
+  int count;  // supernodes = workgroups (one more workgroup sums the two scalars)
+  const double *G, *AWc, *AQcc, *b;
+  double *AW, *AQc;
+  double* slab;
+  double* y;
+  const int* pub;      // pub[pub_beg + t]: hand-off slot of a supernode's published value number t
+  const int* pprobe;   // pprobe[8 position + q]: arrival word of the q-th consumer of its values, -1 none
+  const int* tg_reg;
+  const int* xreg;
+  const long long* xsrc;
+  const long long* rsrc;
+  // Hand-off slots, two sets (run parity, see tree_fused.hip): [0, updb_base) the consumer-ordered
+  // Schur-update slots of BuildPlans, then the forward-value slots, then one arrival word per
+  // (publisher, consumer) pair; and the solution entries a descendant's back substitution reads.
+  double* hand;
+  long long hand_stride;
+  long long updb_base;
+  double* ysig;
+  long long ysig_stride;
+  int gen;  // parity of this run
+  int* fail;
+  int tag;  // a failed pivot writes fail[1] = tag
+  double k, bs, cs;   // y = k (b bs + AQc cs) - 2 AW  (cone_program.cc:409-411)
+  double cb, cq, cw;  // or (comb != 0) y = cb b + cq AQc + cw AW  (cone_program.cc:181, 504)
+  int comb;
+  int form;  // solve-only sweeps: 0 the right-hand side is in y, 1 k (b bs + AQc cs) - 2 AW, 2 cb b + cq AQc + cw AW
+  const double* sc;  // per-constraint <w,c>, <c,Qc>
+  double* sys_sc;
+  int K;
+  double* host_flag;  // pinned host word: set to 1.0 when a wait ran out (the sets are then rebuilt)
+};
+
+// Register shapes (NSMAX << 8 | SMAX) of the tree's supernodes: at most two.  False when no
+// instance is compiled for the pair.
+bool FusedTreeCompiled(int shape_a, int shape_b);
+size_t FusedTreeLds(int shape_a, int shape_b);
+// Workgroups per CU the hardware can hold of the instance (0 on error).
+int FusedTreeOccupancy(int shape_a, int shape_b);
+// solve_only: forward and back substitution on the stored factor (FusedTreeArgs::form picks the
+// right-hand side) instead of assembly + factorization + solve.
+hipError_t LaunchFusedTree(const FusedTreeArgs& a, int shape_a, int shape_b, bool solve_only, hipStream_t stream);
+
+}  // namespace cxk

@@ -1,0 +1,780 @@
+// tree_fused<NA, SA, NB, SB>: assembly gather + supernodal Cholesky (+ forward substitution) + back
+// substitution of the WHOLE elimination tree in one launch, one wavefront per supernode.
+//
+// Reference semantics (order of every sum included): SupernodalKKTSolver::Assemble
+// (kkt_solver.cc:164-170, supernodal_assembler.cc:113-165), AssembleSchurComplementResiduals
+// (constraint_manager.h:107-124), BlockCholeskyInPlace (block_triangular_operations.cc:184-219),
+// ApplyBlockInverseInPlace / ...OfTransposeInPlace (:114-182), right-hand side cone_program.cc:409-411.
+//
+// Why one launch.  The level-by-level sweeps (kernels_kkt.hip.h) pay, per level of the tree, a
+// kernel boundary (~1.5 us), a record round trip and a data round trip before ~2 us of elimination
+// -- 46 us of dependency latency at BASELINE config 4 (5 levels up, 4 down) in which the chip is
+// nearly idle.  Here every supernode's wavefront is resident from the start: it fetches its
+// record, its panel (straight from the Schur blocks: own block by position, further sources from
+// a dense list), its publish destinations and pull locations while its descendants still work,
+// and then only WAITS for their values.
+//
+// Hand-off without flags or fences.  A published value is its own "ready" flag: every slot a
+// consumer reads starts as kFusedSentinel (a signalling-NaN bit pattern no arithmetic produces),
+// the producer overwrites it with ONE 8-byte write-through store (sc1: agent scope), the consumer
+// polls with sc1 loads until no slot of its own shows the sentinel.  An aligned 8-byte store is
+// not torn, and each value is waited for individually, so no ordering between values is needed
+// (MI355X_MICROARCH.md, "data-tagged granules").  Slots come in TWO sets used by alternate runs:
+// run g publishes into set g & 1 and re-arms the same slot of the other set, which nobody reads
+// before the next launch -- no consumer ever writes, and re-arming needs no ordering either.
+// Three families of slots: Schur updates (upd2, the consumer-ordered slots of BuildPlans), forward
+// values (updb2), and the solution entries a descendant's back substitution reads (ysig).
+//
+// Deadlock freedom: a supernode waits only for supernodes at LOWER positions (the records are in
+// level order), workgroup index = position, and every wait is bounded (kFusedSpinLimit polls):
+// when it runs out the wavefront reports failure (fail[1] = tag and the pinned host word) and
+// carries on with what it has, so the grid always drains.
+//
+// Arithmetic is FactorSupernodeLean's and BackwardSupernodeLean's (same expressions in the same
+// order): the factor, the direction and AW / AQc / <w,c> / <c,Qc> are the bits the level kernels
+// with the separate gather produce.
+#include <hip/hip_runtime.h>
+
+#define CXK_DEVICE_FUNCTIONS_ONLY
+#include "kernels_kkt.hip.h"
+#include "tree_fused.h"
+
+namespace cxk {
+
+constexpr int kFusedSpinLimit = 1 << 18;
+
+// Diagnostic build (-DCXK_FUSED_STAMPS, `make dbg`): every wavefront keeps seven time stamps
+// (s_memrealtime: 100 MHz, one clock for the whole chip) in registers and writes them at its end to
+// a buffer nothing else reads (tools/fused_tree_stamps.py).
+#ifdef CXK_FUSED_STAMPS
+constexpr int kFusedStampWaves = 8192;
+__device__ long long g_fused_tree_stamp[kFusedStampWaves * 16];
+#define FT_STAMP(i) ft_stamp[i] = __builtin_amdgcn_s_memrealtime()
+#define FT_COUNT(i, v) ft_stamp[i] = (v)
+#define FT_STAMP_DECL long long ft_stamp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define FT_STAMP_FLUSH(level)                                                              \
+  do {                                                                                     \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < kFusedStampWaves) {                        \
+      ft_stamp[15] = (level);                                                              \
+      for (int i_ = 0; i_ < 16; i_++) g_fused_tree_stamp[blockIdx.x * 16 + i_] = ft_stamp[i_]; \
+    }                                                                                      \
+  } while (0)
+#else
+#define FT_STAMP(i) do { } while (0)
+#define FT_COUNT(i, v) do { } while (0)
+#define FT_STAMP_DECL do { } while (0)
+#define FT_STAMP_FLUSH(level) do { } while (0)
+#endif
+
+__device__ __forceinline__ double LoadAgent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void StoreAgent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool IsSentinel(double v) {
+  return (unsigned long long)__double_as_longlong(v) == kFusedSentinel;
+}
+__device__ __forceinline__ double SentinelValue() { return __longlong_as_double((long long)kFusedSentinel); }
+__device__ __forceinline__ int64_t Join64(int lo, int hi) { return ((int64_t)hi << 32) | (uint32_t)lo; }
+
+__device__ __forceinline__ void ReportTimeout(const FusedTreeArgs& A) {
+  if ((threadIdx.x & 63) == 0) {
+    atomicExch(A.fail + 1, A.tag);
+    __hip_atomic_store(A.host_flag, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// One supernode: w = this lane's word of its record (kFusedRecWords dwords, one per lane).
+template <int NSMAX, int SMAX>
+__device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int w, double* __restrict__ my) {
+  static_assert(NSMAX + SMAX <= 64, "one lane per panel row");
+  constexpr int RB = NSMAX + SMAX, MMAX = kFastSlots, MFMAX = kFastSlots, XMAX = kFusedExtraSlots;
+  constexpr int NVMAX = SMAX * (SMAX + 1) / 2 + SMAX;  // values a supernode publishes
+  constexpr int PR = (NVMAX + 63) / 64;                // ... in this many store instructions
+  const int lane = threadIdx.x & 63;
+  FT_STAMP_DECL;
+  FT_STAMP(0);
+  const SnRec R = DecodeRec(w);
+  FT_STAMP(1);  // the record is here
+  auto f = [&](int i) { return __builtin_amdgcn_readlane(w, 32 + i); };
+  const int ns = R.ns, s = R.nsep;
+  const bool is_row = lane < ns;
+  const int sc = lane - NSMAX;
+  const bool is_sep = sc >= 0 && sc < s;
+  double* base = A.slab + R.diag_off;
+  const unsigned rel = (unsigned)(R.offd_off - R.diag_off);
+  const unsigned o0 = is_row ? (unsigned)lane : (is_sep ? rel + (unsigned)(sc * ns) : 0u);
+  const unsigned st = is_row ? (unsigned)ns : 1u;
+  const int lim = is_row ? lane + 1 : (is_sep ? ns : 0);  // valid j < lim
+  const int gen = A.gen;
+  double* handG = A.hand + (int64_t)gen * A.hand_stride;        // this run's set of hand-off slots
+  double* handO = A.hand + (int64_t)(gen ^ 1) * A.hand_stride;  // the other one: re-armed at the end
+  double* ysG = A.ysig + (int64_t)gen * A.ysig_stride;
+  double* ysO = A.ysig + (int64_t)(gen ^ 1) * A.ysig_stride;
+  const int probe_base = __builtin_amdgcn_readlane(w, 21), nch = __builtin_amdgcn_readlane(w, 22);
+  const int pub_beg = __builtin_amdgcn_readlane(w, 23);
+  const int npairs = s * (s + 1) / 2, nv = npairs + s;
+
+  // ---- load phase, first trip: everything whose address follows from the record
+  const double* Gk = A.G + Join64(f(0), f(1));
+  const int64_t roff = Join64(f(2), f(3));
+  const int M = f(4);
+  const int q = is_row ? lane : (is_sep ? ns + sc : 0);
+  const int myp = (__builtin_amdgcn_ds_bpermute(4 * (32 + 6 + (q >> 2)), w) >> (8 * (q & 3))) & 255;
+  double a[NSMAX + SMAX + 1];
+  {
+    // entry (row, j) of the panel is G(max(p_row, p_j), min(..)) of the own block (lower triangle,
+    // column-major).  EVERY lane / column pair gives an address inside the block (positions of
+    // padding rows and columns read as 0), so no load needs a predicate or a clamp -- the entries
+    // that do not exist are masked after the loads -- and three integer instructions make an address:
+    // byte offsets from a scalar base, positions pre-scaled by 8
+    const char* gb = reinterpret_cast<const char*>(Gk);
+    const unsigned myp8 = 8u * (unsigned)myp;
+#pragma unroll
+    for (int j = 0; j < NSMAX; j++) {
+      const unsigned pj8 = 8u * (unsigned)((f(6 + (j >> 2)) >> (8 * (j & 3))) & 255);  // wave-uniform
+      const unsigned hi8 = myp8 > pj8 ? myp8 : pj8, lo8 = myp8 > pj8 ? pj8 : myp8;
+      a[j] = *reinterpret_cast<const double*>(gb + (__umul24(lo8, (unsigned)M) + hi8));
+    }
+  }
+  const int pr = is_row ? myp : (f(6) & 255);
+  double awv = A.AWc[roff + pr];
+  double aqv = A.AQcc[roff + pr];
+  double rb = A.b[R.start + (is_row ? lane : 0)];
+  // where this supernode's values go: lane t of round r publishes value number t + 64 r (the
+  // s (s + 1) / 2 Schur updates in the reference's S_S enumeration, then the s forward values);
+  // lanes 0 .. 7: the arrival words of the supernodes that consume them
+  int pd[PR > 0 ? PR : 1];
+  pd[0] = 0;
+#pragma unroll
+  for (int r = 0; r < PR; r++) pd[r] = A.pub[pub_beg + (lane + 64 * r < nv ? lane + 64 * r : 0)];
+  const int ppr = A.pprobe[(size_t)blockIdx.x * 8 + (lane & 7)];
+  const int ntg = R.tg_end - R.tg_beg;
+  int ploc0 = 0, ploc1 = 0;
+  if (ntg > 0) {
+    ploc0 = A.tg_reg[R.tg_beg + (lane < ntg ? lane : 0)];
+    if (ntg > 64) ploc1 = A.tg_reg[R.tg_beg + (lane + 64 < ntg ? lane + 64 : 0)];
+  }
+  const int xt_beg = f(24), nxt = f(25), mx = f(26), rbase = f(27), mr = f(28);
+  const int64_t xbase = Join64(f(29), f(30));
+  // ---- entries with further sources (descendants' separator blocks) and shared variables: the
+  // lists, then the values (two more trips, while the descendants are still at work)
+  int xloc0 = 0, xloc1 = 0;
+  double gx0[XMAX], gx1[XMAX];
+#pragma unroll
+  for (int i = 0; i < XMAX; i++) gx0[i] = gx1[i] = 0.0;
+  if (nxt > 0) {
+    const int mxl = mx > 0 ? mx - 1 : 0;
+    {
+      const int ts = lane < nxt ? lane : 0;
+      xloc0 = A.xreg[xt_beg + ts];
+      long long xs[XMAX];
+#pragma unroll
+      for (int i = 0; i < XMAX; i++) xs[i] = A.xsrc[xbase + (int64_t)ts * mx + (i < mx ? i : mxl)];
+#pragma unroll
+      for (int i = 0; i < XMAX; i++) {
+        const double v = A.G[xs[i] >= 0 ? xs[i] : 0];
+        gx0[i] = (i < mx && xs[i] >= 0 && lane < nxt) ? v : 0.0;
+      }
+    }
+    if (nxt > 64) {
+      const int ts = lane + 64 < nxt ? lane + 64 : 0;
+      xloc1 = A.xreg[xt_beg + ts];
+      long long xs[XMAX];
+#pragma unroll
+      for (int i = 0; i < XMAX; i++) xs[i] = A.xsrc[xbase + (int64_t)ts * mx + (i < mx ? i : mxl)];
+#pragma unroll
+      for (int i = 0; i < XMAX; i++) {
+        const double v = A.G[xs[i] >= 0 ? xs[i] : 0];
+        gx1[i] = (i < mx && xs[i] >= 0 && lane + 64 < nxt) ? v : 0.0;
+      }
+    }
+  }
+  // what assemble_gather would have produced: sums that start from +0.0 (a -0.0 source ends up
+  // +0.0); a variable that several constraints share takes ALL its sources from the list, in the
+  // gather's order
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++) a[j] = 0.0 + a[j];
+  awv = 0.0 + awv;
+  aqv = 0.0 + aqv;
+  if (mr > 0) {
+    const int mrl = mr - 1;
+    long long rs[XMAX];
+#pragma unroll
+    for (int i = 0; i < XMAX; i++) rs[i] = A.rsrc[rbase + (is_row ? lane : 0) * mr + (i < mr ? i : mrl)];
+    double ax[XMAX], qx[XMAX];
+#pragma unroll
+    for (int i = 0; i < XMAX; i++) {
+      ax[i] = A.AWc[rs[i] >= 0 ? rs[i] : 0];
+      qx[i] = A.AQcc[rs[i] >= 0 ? rs[i] : 0];
+    }
+    if (rs[0] >= 0) {  // (a listed row: the own constraint is one of the listed sources)
+      awv = 0.0;
+      aqv = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < XMAX; i++)
+      if (i < mr && rs[i] >= 0) {
+        awv += ax[i];
+        aqv += qx[i];
+      }
+  }
+  // the expressions of build_rhs / build_rhs_comb, term for term
+  if (A.comb)
+    rb = A.cb * rb + A.cq * aqv + A.cw * awv;
+  else
+    rb = A.k * (rb * A.bs + aqv * A.cs) - 2 * awv;
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? a[j] : 0.0;
+#pragma unroll
+  for (int c = 0; c < SMAX; c++) a[NSMAX + c] = 0.0;
+  a[RB] = is_row ? rb : 0.0;
+  FT_STAMP(2);  // panel and right-hand side assembled (own block; further sources still to add)
+
+  const bool pulls = ntg > 0 || R.mf > 0;
+  if (nxt > 0 || ntg > 0) {
+    // the register-shaped LDS image (my[64 j + lane]): further sources are added, pulled Schur
+    // updates subtracted, each in its list's order
+#pragma unroll
+    for (int j = 0; j < NSMAX; j++) my[64 * j + lane] = a[j];
+    WaveSync();
+    if (nxt > 0) {
+      if (lane < nxt) {
+        double acc = my[xloc0];
+#pragma unroll
+        for (int i = 0; i < XMAX; i++) acc += gx0[i];  // (absent sources add +0.0: exact)
+        my[xloc0] = acc;
+      }
+      if (lane + 64 < nxt) {
+        double acc = my[xloc1];
+#pragma unroll
+        for (int i = 0; i < XMAX; i++) acc += gx1[i];
+        my[xloc1] = acc;
+      }
+      WaveSync();
+    }
+  }
+  if (pulls) {
+    // ---- wait for the descendants.  Stage 1: one arrival word per publishing supernode (ONE load
+    // per poll: a poll of every value took 1 - 2 us).  Stage 2: the values themselves, each checked
+    // against the sentinel (an arrival word says its supernode has ISSUED its values, not that they
+    // are visible), again until none is missing.
+    {
+      const double* src = handG + probe_base + (lane < nch ? lane : 0);
+      for (int spin = 0;; spin++) {
+        const double v = LoadAgent(src);
+        if (__ballot(lane < nch && IsSentinel(v)) == 0) {
+          FT_COUNT(13, spin);
+          break;
+        }
+        if (spin >= kFusedSpinLimit) {
+          ReportTimeout(A);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    double pv0[MMAX], pv1[MMAX], pb[MFMAX];
+    const double* src0 = handG + R.ubase + (int64_t)(lane < ntg ? lane : 0) * R.m;
+    const double* src1 = handG + R.ubase + (int64_t)(lane + 64 < ntg ? lane + 64 : 0) * R.m;
+    const double* srcb = handG + A.updb_base + R.fbase + (is_row ? lane : 0) * R.mf;
+    for (int spin = 0;; spin++) {
+      bool pending = false;
+#pragma unroll
+      for (int i = 0; i < MMAX; i++) pv0[i] = pv1[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < MFMAX; i++) pb[i] = 0.0;
+      // (wave-uniform guards: only the slots in use are loaded)
+      if (ntg > 0) {
+#pragma unroll
+        for (int i = 0; i < MMAX; i++)
+          if (i < R.m) pv0[i] = LoadAgent(src0 + i);
+      }
+      if (ntg > 64) {
+#pragma unroll
+        for (int i = 0; i < MMAX; i++)
+          if (i < R.m) pv1[i] = LoadAgent(src1 + i);
+      }
+#pragma unroll
+      for (int i = 0; i < MFMAX; i++)
+        if (i < R.mf) pb[i] = LoadAgent(srcb + i);
+#pragma unroll
+      for (int i = 0; i < MMAX; i++) {
+        pending = pending || (lane < ntg && IsSentinel(pv0[i]));
+        pending = pending || (lane + 64 < ntg && IsSentinel(pv1[i]));
+      }
+#pragma unroll
+      for (int i = 0; i < MFMAX; i++) pending = pending || (is_row && IsSentinel(pb[i]));
+      if (__ballot(pending) == 0) {
+        FT_COUNT(12, spin);
+        break;
+      }
+      if (spin >= kFusedSpinLimit) {
+        ReportTimeout(A);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (ntg > 0) {
+      if (lane < ntg) {
+        double acc = my[ploc0];
+#pragma unroll
+        for (int i = 0; i < MMAX; i++) acc -= pv0[i];  // (slots not in use subtract 0.0: exact)
+        my[ploc0] = acc;
+      }
+      if (lane + 64 < ntg) {
+        double acc = my[ploc1];
+#pragma unroll
+        for (int i = 0; i < MMAX; i++) acc -= pv1[i];
+        my[ploc1] = acc;
+      }
+      WaveSync();
+    }
+#pragma unroll
+    for (int i = 0; i < MFMAX; i++) a[RB] -= is_row ? pb[i] : 0.0;
+  }
+  if (nxt > 0 || ntg > 0) {
+#pragma unroll
+    for (int j = 0; j < NSMAX; j++) a[j] = my[64 * j + lane];
+    WaveSync();  // (the image is reused below)
+  }
+  // padding pivots: unit diagonal
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++)
+    if (j >= ns && lane == j) a[j] = 1.0;
+  FT_STAMP(3);  // descendants' values are in
+  bool bad = false;
+  ElimSteps<NSMAX, SMAX, 0>::run(a, lane, bad, ns);
+  FT_STAMP(4);  // eliminated
+  if (bad && lane == 0) atomicExch(A.fail + 1, A.tag);  // (carries on: everybody above must still drain)
+  // ---- publish (the ancestors are waiting): the values sit in the separator lanes' registers --
+  // value (k, c), c >= k, in a[NSMAX + c] of lane NSMAX + k -- and leave through LDS so that ONE
+  // store instruction carries 64 of them (a store costs a lone wavefront ~70 cycles of issue)
+  if constexpr (SMAX > 0) {
+    if (s > 0) {
+      if (is_sep) {
+        const int t0 = sc * s - sc * (sc - 1) / 2 - sc;  // value (k, c) is number t0 + c
+#pragma unroll
+        for (int c = 0; c < SMAX; c++)
+          if (c >= sc && c < s) my[t0 + c] = -a[NSMAX + c];
+        my[npairs + sc] = -a[RB];
+      }
+      WaveSync();
+#pragma unroll
+      for (int r = 0; r < PR; r++) {
+        const int t = lane + 64 * r;
+        if (t < nv) StoreAgent(handG + pd[r], my[t]);
+      }
+      if (lane < 8 && ppr >= 0) StoreAgent(handG + ppr, 1.0);
+      WaveSync();
+    }
+  }
+  FT_STAMP(7);  // published
+  // ---- the way back down: rows of L become columns through an LDS image with an odd stride
+  // (RootBackward's), lane i owns y_i; the separator's solution comes from the ancestors
+  const int cnt = R.bs_end - R.bs_beg;
+  const bool active = is_row;
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++) my[65 * j + lane] = a[j];
+  WaveSync();
+  if (cnt > 0) {
+    // (the root keeps its factor for after its back substitution: everybody waits for that)
+#pragma unroll
+    for (int j = 0; j < NSMAX; j++)
+      if (j < lim) base[o0 + j * st] = a[j];
+  }
+  FT_STAMP(8);  // factor stored
+  const int li = active ? lane : 0;
+  double col[NSMAX];
+#pragma unroll
+  for (int k = 0; k < NSMAX; k++) col[k] = my[65 * li + k];
+  double dg = my[66 * li];
+  FT_STAMP(9);  // columns of L back from the image
+  constexpr int QN = SMAX < 8 ? SMAX : 8;
+  double bv[QN > 0 ? QN : 1], yv[QN > 0 ? QN : 1];
+  bv[0] = yv[0] = 0.0;
+  if constexpr (QN > 0) {
+#pragma unroll
+    for (int qq = 0; qq < QN; qq++) {
+      const unsigned sw = qq < cnt ? (unsigned)R.sep[qq] : 0u;
+      bv[qq] = my[65 * li + NSMAX + (int)(sw >> 26)];
+    }
+    if (cnt > 0) {
+      // lane qq < cnt polls the solution entry of separator variable qq
+      const int sepw = __builtin_amdgcn_ds_bpermute(4 * (24 + (lane < 8 ? lane : 0)), w);
+      const double* src = ysG + (lane < cnt ? (sepw & 0x3ffffff) : (R.sep[0] & 0x3ffffff));
+      double v;
+      for (int spin = 0;; spin++) {
+        v = LoadAgent(src);
+        if (__ballot(lane < cnt && IsSentinel(v)) == 0) {
+          FT_COUNT(14, spin);
+          break;
+        }
+        if (spin >= kFusedSpinLimit) {
+          ReportTimeout(A);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int qq = 0; qq < QN; qq++) yv[qq] = ReadLane(v, qq);
+    }
+  }
+  FT_STAMP(5);  // the separator's solution is in
+#pragma unroll
+  for (int k = 0; k < NSMAX; k++) col[k] = (active && k > lane && k < ns) ? col[k] : 0.0;
+  dg = active ? dg : 1.0;
+  double acc = active ? a[RB] : 0.0;
+  if constexpr (QN > 0) {
+#pragma unroll
+    for (int qq = 0; qq < QN; qq++) acc -= ((qq < cnt && active) ? bv[qq] : 0.0) * (qq < cnt ? yv[qq] : 0.0);
+  }
+  const double dinv = 1.0 / dg;
+#pragma unroll
+  for (int k = NSMAX - 1; k >= 0; k--) {
+    if (lane == k) acc *= dinv;
+    acc = fma(-col[k], ReadLane(acc, k), acc);  // col[k] is zero for lanes >= k
+  }
+  if (active) StoreAgent(ysG + R.start + lane, acc);
+  FT_STAMP(6);
+  // ---- nobody waits for the rest: the solution and AW / AQc for the kernels that follow, the
+  // root's factor, the re-armed slots of the other set
+  if (active) {
+    A.y[R.start + lane] = acc;
+    A.AW[R.start + lane] = awv;
+    A.AQc[R.start + lane] = aqv;
+    StoreAgent(ysO + R.start + lane, SentinelValue());
+  }
+  if (cnt == 0) {
+#pragma unroll
+    for (int j = 0; j < NSMAX; j++)
+      if (j < lim) base[o0 + j * st] = a[j];
+  }
+  if constexpr (SMAX > 0) {
+    if (s > 0) {
+#pragma unroll
+      for (int r = 0; r < PR; r++)
+        if (lane + 64 * r < nv) StoreAgent(handO + pd[r], SentinelValue());
+      if (lane < 8 && ppr >= 0) StoreAgent(handO + ppr, SentinelValue());
+    }
+  }
+  FT_STAMP_FLUSH(f(31));
+}
+
+// The solve-only sweep on a stored factor (mu selection, Newton direction after it, line search,
+// refinement corrections): forward substitution up the tree, back substitution down, one launch,
+// the same hand-off slots (forward values, arrival words, solution entries).  Arithmetic and its
+// order are ForwardSupernodeLean's and BackwardSupernodeLean's.  The rows of L (forward) and its
+// columns (backward) both come straight from the slab.
+template <int NSMAX, int SMAX>
+__device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, const int w) {
+  static_assert(NSMAX + SMAX <= 64, "one lane per panel row");
+  constexpr int MFMAX = kFastSlots;
+  constexpr int NVMAX = SMAX * (SMAX + 1) / 2 + SMAX;
+  constexpr int PR = (NVMAX + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const SnRec R = DecodeRec(w);
+  const int ns = R.ns, s = R.nsep;
+  const bool is_row = lane < ns;
+  const int sc = lane - NSMAX;
+  const bool is_sep = sc >= 0 && sc < s;
+  const double* base = A.slab + R.diag_off;
+  const unsigned rel = (unsigned)(R.offd_off - R.diag_off);
+  const unsigned o0 = is_row ? (unsigned)lane : (is_sep ? rel + (unsigned)(sc * ns) : 0u);
+  const unsigned st = is_row ? (unsigned)ns : 1u;
+  const int lim = is_row ? lane : (is_sep ? ns : 0);  // strictly lower part of a row; a whole off column
+  const int gen = A.gen;
+  double* handG = A.hand + (int64_t)gen * A.hand_stride;
+  double* handO = A.hand + (int64_t)(gen ^ 1) * A.hand_stride;
+  double* ysG = A.ysig + (int64_t)gen * A.ysig_stride;
+  double* ysO = A.ysig + (int64_t)(gen ^ 1) * A.ysig_stride;
+  const int probe_base = __builtin_amdgcn_readlane(w, 21), nch = __builtin_amdgcn_readlane(w, 22);
+  const int pub_beg = __builtin_amdgcn_readlane(w, 23);
+  const int npairs = s * (s + 1) / 2, nv = npairs + s;
+  const int cnt = R.bs_end - R.bs_beg;
+  // ---- one trip: rows of L, right-hand side, columns of L, off-block entries, destinations
+  double a[NSMAX > 0 ? NSMAX : 1];
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++) a[j] = base[(j < lim) ? o0 + j * st : 0u];
+  double dg = base[is_row ? (unsigned)lane * (unsigned)(ns + 1) : 0u];
+  const int p = R.start + (is_row ? lane : 0);
+  double b;
+  if (A.form == 0) {
+    b = A.y[p];
+  } else {
+    const double bp = A.b[p], aq = A.AQc[p], aw = A.AW[p];
+    b = A.form == 1 ? A.k * (bp * A.bs + aq * A.cs) - 2 * aw : A.cb * bp + A.cq * aq + A.cw * aw;
+  }
+  const bool active = is_row;
+  const double* D = A.slab + R.diag_off + (size_t)(active ? lane : 0) * ns;  // column `lane`
+  const double* B = A.slab + R.offd_off + (active ? lane : 0);
+  double col[NSMAX];
+#pragma unroll
+  for (int k = 0; k < NSMAX; k++) col[k] = D[(active && k > lane && k < ns) ? k : 0];
+  constexpr int QN = SMAX < 8 ? SMAX : 8;
+  double bv[QN > 0 ? QN : 1], yv[QN > 0 ? QN : 1];
+  bv[0] = yv[0] = 0.0;
+#pragma unroll
+  for (int qq = 0; qq < QN; qq++) {
+    const unsigned sw = qq < cnt ? (unsigned)R.sep[qq] : 0u;
+    const double* src = qq < cnt ? B + (size_t)(sw >> 26) * ns : D;
+    bv[qq] = src[0];
+  }
+  int pdb = 0;
+  if constexpr (SMAX > 0) pdb = A.pub[pub_beg + npairs + (is_sep ? sc : 0)];
+  const int ppr = A.pprobe[(size_t)blockIdx.x * 8 + (lane & 7)];
+  // ---- wait for the descendants' forward values (arrival words, then the values, as in the factor sweep)
+  double pb[MFMAX];
+#pragma unroll
+  for (int i = 0; i < MFMAX; i++) pb[i] = 0.0;
+  if (R.mf > 0) {
+    {
+      const double* src = handG + probe_base + (lane < nch ? lane : 0);
+      for (int spin = 0;; spin++) {
+        const double v = LoadAgent(src);
+        if (__ballot(lane < nch && IsSentinel(v)) == 0) break;
+        if (spin >= kFusedSpinLimit) {
+          ReportTimeout(A);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    const double* srcb = handG + A.updb_base + R.fbase + (is_row ? lane : 0) * R.mf;
+    for (int spin = 0;; spin++) {
+      bool pending = false;
+#pragma unroll
+      for (int i = 0; i < MFMAX; i++)
+        if (i < R.mf) pb[i] = LoadAgent(srcb + i);
+#pragma unroll
+      for (int i = 0; i < MFMAX; i++) pending = pending || (is_row && IsSentinel(pb[i]));
+      if (__ballot(pending) == 0) break;
+      if (spin >= kFusedSpinLimit) {
+        ReportTimeout(A);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  // ---- forward substitution (ForwardSupernodeLean)
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? a[j] : 0.0;
+  b = is_row ? b : 0.0;
+#pragma unroll
+  for (int i = 0; i < MFMAX; i++) b -= (is_row && i < R.mf) ? pb[i] : 0.0;
+  const double dinvf = is_row ? 1.0 / dg : 0.0;
+  double dot = 0.0;
+#pragma unroll
+  for (int k = 0; k < NSMAX; k++) {
+    if (lane == k) b *= dinvf;
+    const double bk = ReadLane(b, k);  // 0.0 for padding rows k >= ns
+    if (is_sep)
+      dot = fma(a[k], bk, dot);
+    else
+      b -= a[k] * bk;  // a[k] is zero for lanes <= k
+  }
+  if constexpr (SMAX > 0) {
+    if (s > 0) {
+      if (is_sep) StoreAgent(handG + pdb, dot);
+      // (issued behind the values, not ordered with them: the consumer checks every value it reads)
+      if (lane < 8 && ppr >= 0) StoreAgent(handG + ppr, 1.0);
+    }
+  }
+  // ---- back substitution (BackwardSupernodeLean)
+  if constexpr (QN > 0) {
+    if (cnt > 0) {
+      const int sepw = __builtin_amdgcn_ds_bpermute(4 * (24 + (lane < 8 ? lane : 0)), w);
+      const double* src = ysG + (lane < cnt ? (sepw & 0x3ffffff) : (R.sep[0] & 0x3ffffff));
+      double v;
+      for (int spin = 0;; spin++) {
+        v = LoadAgent(src);
+        if (__ballot(lane < cnt && IsSentinel(v)) == 0) break;
+        if (spin >= kFusedSpinLimit) {
+          ReportTimeout(A);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int qq = 0; qq < QN; qq++) yv[qq] = ReadLane(v, qq);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NSMAX; k++) col[k] = (active && k > lane && k < ns) ? col[k] : 0.0;
+  dg = active ? dg : 1.0;
+  double acc = active ? b : 0.0;
+  if constexpr (QN > 0) {
+#pragma unroll
+    for (int qq = 0; qq < QN; qq++) acc -= ((qq < cnt && active) ? bv[qq] : 0.0) * (qq < cnt ? yv[qq] : 0.0);
+  }
+  const double dinv = 1.0 / dg;
+#pragma unroll
+  for (int k = NSMAX - 1; k >= 0; k--) {
+    if (lane == k) acc *= dinv;
+    acc = fma(-col[k], ReadLane(acc, k), acc);  // col[k] is zero for lanes >= k
+  }
+  if (active) {
+    StoreAgent(ysG + R.start + lane, acc);
+    A.y[R.start + lane] = acc;
+    StoreAgent(ysO + R.start + lane, SentinelValue());
+  }
+  // re-arm the other set: ALL of this supernode's slots, the Schur-update ones too (a factor sweep
+  // may be the next run)
+  if constexpr (SMAX > 0) {
+    if (s > 0) {
+#pragma unroll
+      for (int r = 0; r < PR; r++) {
+        const int t = lane + 64 * r;
+        const int d = A.pub[pub_beg + (t < nv ? t : 0)];
+        if (t < nv) StoreAgent(handO + d, SentinelValue());
+      }
+      if (lane < 8 && ppr >= 0) StoreAgent(handO + ppr, SentinelValue());
+    }
+  }
+}
+
+// <w,c> and <c,Qc> as assemble_gather's workgroup 0 sums them (256 threads there: four wavefronts'
+// strided partial sums, wave totals added in wave order), and the failure flag's reset.
+__device__ __forceinline__ void FusedScalars(const FusedTreeArgs& A) {
+  const int lane = threadIdx.x & 63;
+  double t0 = 0, t1 = 0;
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    double s0 = 0, s1 = 0;
+    for (int i = 64 * v + lane; i < A.K; i += 256) {
+      s0 += A.sc[2 * i];
+      s1 += A.sc[2 * i + 1];
+    }
+    t0 += WaveSum(s0);
+    t1 += WaveSum(s1);
+  }
+  if (lane == 0) {
+    A.sys_sc[0] = t0;
+    A.sys_sc[1] = t1;
+    *A.fail = 0;
+  }
+}
+
+template <int NA, int SA, int NB, int SB>
+__global__ void __launch_bounds__(64) tree_fused(FusedTreeArgs A) {
+  extern __shared__ double lds[];
+  const int pos = blockIdx.x;
+  if (pos >= A.count) {
+    FusedScalars(A);
+    return;
+  }
+  const int w = A.rec[(size_t)pos * kFusedRecWords + (threadIdx.x & 63)];
+  const int ns = __builtin_amdgcn_readlane(w, 1), s = __builtin_amdgcn_readlane(w, 2);
+  if (RegisterShape(ns, s) == (NA << 8 | SA))
+    FusedSupernode<NA, SA>(A, w, lds);
+  else
+    FusedSupernode<NB, SB>(A, w, lds);
+}
+
+template <int NA, int SA>
+__global__ void __launch_bounds__(64) tree_fused1(FusedTreeArgs A) {
+  extern __shared__ double lds[];
+  const int pos = blockIdx.x;
+  if (pos >= A.count) {
+    FusedScalars(A);
+    return;
+  }
+  const int w = A.rec[(size_t)pos * kFusedRecWords + (threadIdx.x & 63)];
+  FusedSupernode<NA, SA>(A, w, lds);
+}
+
+template <int NA, int SA, int NB, int SB>
+__global__ void __launch_bounds__(64) tree_fused_solve(FusedTreeArgs A) {
+  const int pos = blockIdx.x;
+  const int w = A.rec[(size_t)pos * kFusedRecWords + (threadIdx.x & 63)];
+  const int ns = __builtin_amdgcn_readlane(w, 1), s = __builtin_amdgcn_readlane(w, 2);
+  if (RegisterShape(ns, s) == (NA << 8 | SA))
+    FusedSolveSupernode<NA, SA>(A, w);
+  else
+    FusedSolveSupernode<NB, SB>(A, w);
+}
+
+template <int NA, int SA>
+__global__ void __launch_bounds__(64) tree_fused_solve1(FusedTreeArgs A) {
+  const int pos = blockIdx.x;
+  const int w = A.rec[(size_t)pos * kFusedRecWords + (threadIdx.x & 63)];
+  FusedSolveSupernode<NA, SA>(A, w);
+}
+
+namespace {
+template <typename F>
+bool ForPair(int sa, int sb, F&& fn) {
+#define CXK_FUSED_ONE(NA_, SA_)                                                     \
+  if (sa == ((NA_) << 8 | (SA_)) && sb == sa) {                                     \
+    fn(reinterpret_cast<const void*>(&tree_fused1<NA_, SA_>),                       \
+       reinterpret_cast<const void*>(&tree_fused_solve1<NA_, SA_>), 65 * (NA_));    \
+    return true;                                                                    \
+  }
+#define CXK_FUSED_PAIR(NA_, SA_, NB_, SB_)                                                          \
+  if (sa == ((NA_) << 8 | (SA_)) && sb == ((NB_) << 8 | (SB_))) {                                   \
+    fn(reinterpret_cast<const void*>(&tree_fused<NA_, SA_, NB_, SB_>),                              \
+       reinterpret_cast<const void*>(&tree_fused_solve<NA_, SA_, NB_, SB_>),                        \
+       65 * ((NA_) > (NB_) ? (NA_) : (NB_)));                                                       \
+    return true;                                                                                    \
+  }
+  CXK_FUSED_ONE(8, 8)
+  CXK_FUSED_ONE(16, 8)
+  CXK_FUSED_ONE(24, 0)
+  CXK_FUSED_ONE(24, 8)
+  CXK_FUSED_ONE(32, 16)
+  CXK_FUSED_PAIR(8, 8, 16, 8)
+  CXK_FUSED_PAIR(8, 8, 24, 0)
+  CXK_FUSED_PAIR(16, 8, 24, 0)
+  CXK_FUSED_PAIR(16, 8, 24, 8)
+  CXK_FUSED_PAIR(24, 0, 24, 8)
+  CXK_FUSED_PAIR(24, 0, 32, 16)
+#undef CXK_FUSED_ONE
+#undef CXK_FUSED_PAIR
+  return false;
+}
+}  // namespace
+
+bool FusedTreeCompiled(int sa, int sb) {
+  return ForPair(sa, sb, [](const void*, const void*, int) {});
+}
+
+size_t FusedTreeLds(int sa, int sb) {
+  size_t lds = 0;
+  ForPair(sa, sb, [&](const void*, const void*, int doubles) { lds = sizeof(double) * (size_t)doubles; });
+  return lds;
+}
+
+int FusedTreeOccupancy(int sa, int sb) {
+  int nb = 0;
+  ForPair(sa, sb, [&](const void* k, const void* ks, int doubles) {
+    int nbs = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64, sizeof(double) * (size_t)doubles) != hipSuccess) nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, ks, 64, 0) != hipSuccess) nbs = 0;
+    nb = nb < nbs ? nb : nbs;
+  });
+  return nb;
+}
+
+hipError_t LaunchFusedTree(const FusedTreeArgs& a, int sa, int sb, bool solve_only, hipStream_t stream) {
+  const void* kern = nullptr;
+  size_t lds = 0;
+  if (!ForPair(sa, sb, [&](const void* k, const void* ks, int doubles) {
+        kern = solve_only ? ks : k;
+        lds = solve_only ? 0 : sizeof(double) * (size_t)doubles;
+      }))
+    return hipErrorInvalidValue;
+  FusedTreeArgs args = a;
+  void* params[] = {&args};
+  // (the factor sweep's extra workgroup sums the two scalars)
+  return hipLaunchKernel(kern, dim3(a.count + (solve_only ? 0 : 1)), dim3(64), params, lds, stream);
+}
+
+}  // namespace cxk
+
+#ifdef CXK_FUSED_STAMPS
+extern "C" int cxk_debug_fused_tree_stamps(long long* out, int waves) {
+  if (waves > cxk::kFusedStampWaves) waves = cxk::kFusedStampWaves;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(cxk::g_fused_tree_stamp), sizeof(long long) * 16 * (size_t)waves) == hipSuccess ? 0 : 1;
+}
+#endif

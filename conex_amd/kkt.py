@@ -90,6 +90,7 @@ _SIGNATURES = {
     "cxk_count_sparse_lmi": (C.c_int, [C.c_void_p]),
     "cxk_count_lmi_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_fused_assembly": (C.c_int, [C.c_void_p]),
+    "cxk_fused_tree": (C.c_int, [C.c_void_p]),
     "cxk_comm_init_rccl_solo": (C.c_int, [C.c_void_p]),
     "cxk_set_reference_identity": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_set_solver_mode": (C.c_int, [C.c_void_p, C.c_int]),
@@ -383,6 +384,14 @@ class KktContext:
         self._check(self.L.cxk_newton_direction(self.h, inv_sqrt_mu, b_scaling, c_scaling),
                     "cxk_newton_direction")
 
+    def factor_solve_async(self, cb, cq, cw):
+        """Factor and solve y <- K^-1 (cb b + cq AQc + cw AW) in one upward pass (cxk_factor_solve_async)."""
+        self._check(self.L.cxk_factor_solve_async(self.h, cb, cq, cw), "cxk_factor_solve_async")
+
+    def factor_direction_async(self, inv_sqrt_mu, b_scaling=1.0, c_scaling=1.0):
+        self._check(self.L.cxk_factor_direction_async(self.h, inv_sqrt_mu, b_scaling, c_scaling),
+                    "cxk_factor_direction_async")
+
     def solve_rhs(self, cb, cq, cw):
         self._check(self.L.cxk_solve_rhs(self.h, cb, cq, cw), "cxk_solve_rhs")
 
@@ -577,6 +586,10 @@ class KktContext:
     def fused_assembly(self):
         """True when the assembly rides in the first factor level's launch (cxk_fused_assembly)."""
         return bool(self.L.cxk_fused_assembly(self.h))
+
+    def fused_tree(self):
+        """True when a KKT solve runs as one launch over the whole elimination tree (cxk_fused_tree)."""
+        return bool(self.L.cxk_fused_tree(self.h))
 
     def count_lmi_kernel(self, which):
         """Constraints whose Schur block comes from kernel `which` (cxk_count_lmi_kernel): 0 literal,

@@ -329,6 +329,9 @@ int cxk_dense_top_columns(const cxk_context* ctx);
  * level one register shape, every supernode in it fed by exactly one constraint); results are the
  * bits of the separate assembly launch.  CXK_NO_FUSED_ASM=1 keeps the separate launch. */
 int cxk_fused_assembly(const cxk_context* ctx);
+/* 1 when a KKT solve (assembly gather + factorization + solve) runs as ONE launch over the whole
+ * elimination tree (tree_fused.hip); CXK_NO_FUSED_TREE=1 in the environment turns it off */
+int cxk_fused_tree(const cxk_context* ctx);
 
 /* ---- timing / roofline accounting -------------------------------------- */
 /* algorithmic bytes and flops of one dense-LMI assembly launch (SURVEY 8d formulas) */

@@ -1,0 +1,135 @@
+"""The whole elimination tree in one launch (tree_fused.hip): assembly gather,
+supernodal Cholesky with the first right-hand side, back substitution -- one wavefront per
+supernode, published values handed upward / downward through sentinel-armed slots.
+
+It restates the level kernels' arithmetic in their order, so direction, factor, AW / AQc and the two
+scalars must equal the level-by-level path's (CXK_NO_FUSED_TREE=1, read when a context is
+initialized) BIT FOR BIT; both are held against the oracle elsewhere (test_gpu_parity.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conex_amd import KktContext
+from conex_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def both_paths(make):
+    os.environ.pop("CXK_NO_FUSED_TREE", None)
+    fused = make()
+    os.environ["CXK_NO_FUSED_TREE"] = "1"
+    try:
+        levels = make()
+    finally:
+        os.environ.pop("CXK_NO_FUSED_TREE", None)
+    assert fused.fused_tree() and not levels.fused_tree()
+    return fused, levels
+
+
+def snapshot(k):
+    AW, AQc, sc = k.residuals()
+    return k.get_y().copy(), k.slab().copy(), AW, AQc, sc
+
+
+def assert_same(a, b):
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
+@pytest.mark.parametrize("K,n,branching,overlap", [(100, 20, 8, 5), (73, 20, 3, 5), (30, 20, 1, 5),
+                                                   (200, 8, 8, 4), (41, 12, 2, 7), (1, 20, 8, 5)])
+def test_fused_tree_equals_level_kernels(K, n, branching, overlap):
+    prob = syn.lmi_problem(K=K, n=n, m=20, branching=branching, overlap=overlap, seed=31)
+    W = syn.scaling_points(K, n, seed=32)
+
+    def make():
+        k = syn.build(KktContext, prob, "lmi", device=0)
+        for i in range(k.K):
+            k.set_W(i, W[i])
+        k.set_cost(prob["b"])
+        return k
+
+    fused, levels = both_paths(make)
+    # several runs: the hand-off slots alternate between their two sets
+    for mu in (0.7, 0.4, 0.9, 0.55, 0.61):
+        for k in (fused, levels):
+            k.kkt_solve_async(mu, 0.9, 0.8)
+            assert k.sync()
+        assert_same(snapshot(fused), snapshot(levels))
+    # the interior-point loop's order: assemble (gather deferred), then factor with the first solve
+    for k in (fused, levels):
+        k.assemble()
+        k.factor_solve_async(-0.9, 0.8, 0.0)
+        assert k.sync()
+    assert_same(snapshot(fused), snapshot(levels))
+    # a solve-only sweep on the factor the fused launch stored
+    for k in (fused, levels):
+        k.solve_rhs(0.3, -0.2, 1.5)
+        assert k.sync()
+    assert np.array_equal(fused.get_y(), levels.get_y())
+
+
+def test_fused_tree_against_the_oracle_and_two_runs_agree():
+    prob = syn.lmi_problem(K=150, n=20, m=20, branching=8, overlap=5, seed=5)
+    W = syn.scaling_points(150, 20, seed=6)
+    k = syn.build(KktContext, prob, "lmi", device=0)
+    o = syn.build(ol.Program, prob, "lmi")
+    for i in range(k.K):
+        k.set_W(i, W[i])
+        o.set_W(i, W[i])
+    assert k.fused_tree()
+    ok, y = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    oko, yo = o.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    assert ok == 1 and oko == 1
+    assert np.linalg.norm(y - yo) <= 1e-10 * np.linalg.norm(yo)
+    ok2, y2 = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    assert ok2 == 1 and np.array_equal(y, y2)
+
+
+def test_fused_tree_reports_a_failed_pivot_and_recovers():
+    prob = syn.lmi_problem(K=120, n=20, m=20, branching=8, overlap=5, seed=7)
+    W = syn.scaling_points(120, 20, seed=8)
+    k = syn.build(KktContext, prob, "lmi", device=0)
+    for i in range(k.K):
+        k.set_W(i, W[i])
+    assert k.fused_tree()
+    ok, y = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    assert ok == 1
+    for bad in (k.K - 1, 0, 17):                 # a leaf, the root's constraint, one in between
+        k.set_W(bad, np.zeros((20, 20)))         # G = 0: a pivot that is not positive
+        okb, _ = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+        assert okb == 0
+        k.set_W(bad, W[bad])
+        ok2, y2 = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+        assert ok2 == 1 and np.array_equal(y, y2)
+
+
+def test_fused_tree_on_the_mixed_program_shapes():
+    """Second-order cones (shape <8,8>) next to matrix cones: two register shapes in one launch."""
+    prob = syn.mixed_problem(K=230, seed=3)
+    W = syn.mixed_scaling_points(prob, seed=32)
+
+    def make():
+        k = syn.build(KktContext, prob, "mixed", device=0)
+        for i in range(k.K):
+            k.set_W(i, W[i])
+        k.set_cost(prob["b"])
+        return k
+
+    os.environ.pop("CXK_NO_FUSED_TREE", None)
+    fused = make()
+    if not fused.fused_tree():
+        pytest.skip("no whole-tree instance for this program's shapes")
+    os.environ["CXK_NO_FUSED_TREE"] = "1"
+    try:
+        levels = make()
+    finally:
+        os.environ.pop("CXK_NO_FUSED_TREE", None)
+    for mu in (0.7, 0.4, 0.9):
+        for k in (fused, levels):
+            k.kkt_solve_async(mu, 0.9, 0.8)
+            assert k.sync()
+        assert_same(snapshot(fused), snapshot(levels))

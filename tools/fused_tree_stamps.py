@@ -1,0 +1,47 @@
+"""In-kernel timeline of tree_fused on the C4 workload (diagnostic build: make -C conex_amd/csrc dbg).
+
+Every wavefront (= supernode) stamps s_memrealtime (100 MHz, chip-wide) at: 0 entry, 1 record
+decoded, 2 own panel assembled, 3 descendants' values in, 4 eliminated, 5 separator's solution in,
+6 done.  Printed per tree level: median / max of each stamp in microseconds since the first entry.
+Run on the GPU box:  python tools/fused_tree_stamps.py [K]
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import conex_amd.kkt as kk
+
+kk.LIB_PATH = os.path.join(os.path.dirname(kk.LIB_PATH), os.environ.get("CXK_DBG_LIB", "libconex_dbg.so"))
+from conex_amd import KktContext, synthetic as syn
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+L = kk.load_library()
+prob = syn.lmi_problem(K=K, n=20, m=20, branching=8, overlap=5)
+W = syn.scaling_points(K, 20)
+ctx = syn.build(KktContext, prob, "lmi", device=0)
+assert ctx.fused_tree()
+for i in range(ctx.K):
+    ctx.set_W(i, W[i])
+ctx.set_cost(prob["b"])
+for _ in range(30):
+    ctx.kkt_solve_async(0.7, 0.9, 0.8)
+assert ctx.sync()
+L.cxk_debug_fused_tree_stamps.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+buf = (C.c_longlong * (16 * K))()
+assert L.cxk_debug_fused_tree_stamps(buf, K) == 0
+s = np.array(buf[:], dtype=np.int64).reshape(K, 16)
+t0 = s[:, 0].min()
+lev = s[:, 15]
+order = [0, 1, 2, 3, 4, 7, 8, 9, 5, 6]
+us = (s[:, order] - t0) / 100.0
+names = ["entry", "record", "assembled", "pulls in", "eliminated", "published", "L stored", "L columns", "y(sep) in", "done"]
+print("level  count | " + " | ".join("%-13s" % n for n in names) + "   (median / max, us since the first entry)")
+for l in sorted(set(lev.tolist())):
+    sel = us[lev == l]
+    print("%5d %6d | " % (l, len(sel)) + " | ".join("%5.2f / %5.2f" % (np.median(sel[:, i]), sel[:, i].max()) for i in range(len(order))))
+    print("             polls until the descendants' values were in: median %d max %d; until the separator's solution was in: median %d max %d"
+          % (np.median(s[lev == l, 13]), s[lev == l, 13].max(), np.median(s[lev == l, 14]), s[lev == l, 14].max()))
+print("span %.2f us" % us[:, -1].max())
