@@ -66,6 +66,10 @@ def api():
         "CONEX_NewQuadraticCost": (ci, [vp, ip]),
         "CONEX_UpdateQuadraticCostMatrix": (ci, [vp, ci, cd, ci, ci]),
         "CONEX_SetNumberOfVariables": (ci, [vp, ci]),
+        # not in conex.h (the reference reaches these cones through its C++ API only)
+        "CONEX_HIP_AddQuadraticConstraint": (ci, [vp, c_double_p, ci, c_double_p, ci, ci, c_double_p, ci,
+                                                  C.POINTER(C.c_long), ci]),
+        "CONEX_HIP_AddQuadraticCostEpigraph": (ci, [vp, c_double_p, ci, C.POINTER(C.c_long), C.c_long]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

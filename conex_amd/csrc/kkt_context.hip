@@ -33,6 +33,7 @@
 #include "kernels_lmi_rows.hip.h"
 #include "kernels_kkt_top.hip.h"
 #include "kernels_lmi_large.hip.h"
+#include "kernels_quad.hip.h"
 #include "tree_fused.h"
 #include "symbolic.h"
 
@@ -45,6 +46,7 @@ struct ConstraintRec {
   int herm_d = 0;  // Hermitian PSD over R/C/H: number of real planes d; n is then d * order
   int eq_rows = 0; // CXK_STATIC built from EqualityConstraints: number of multipliers (last clique entries)
   std::vector<double> A, C;
+  std::vector<double> Q;  // CXK_QUAD: n x n inner-product matrix, empty = identity
   int group = -1, member = -1;
   bool sparse = false;  // LMI evaluated from its nonzeros (kernels_lmi_sparse.hip.h)
   // every A_i and C equals its transpose.  The fast kernels use tr(W A_i W A_j) = tr(P_i P_j),
@@ -96,6 +98,8 @@ struct Group {
   DevBuf<double> A, C, W, T1, T2;
   DevBuf<double> Apad;  // lmi_schur_mfma at a padded order: [A_1 .. A_m | C] per member, zero-padded (LmiMfmaPaddedOrder)
   DevBuf<int> dids;
+  bool has_q = false;             // CXK_QUAD: the members carry an inner-product matrix Q
+  DevBuf<double> qQ, qGram, qS;   // CXK_QUAD: Q, A1' Q A1, the state kept between PrepareStep and TakeStep
   int herm_d = 0;
   bool mfma = false;     // lmi_schur_mfma (lmi_fused_mfma.hip)
   bool literal = false;  // non-symmetric data: literal kernels only
@@ -402,9 +406,24 @@ LmiGroup MakeLmi(Group& g) {
   d.sp_pval = g.sparse ? g.sp_pval.p : nullptr;
   return d;
 }
+QuadGroup MakeQuad(Group& g) {
+  QuadGroup d;
+  d.n = g.n;
+  d.m = g.m;
+  d.count = static_cast<int>(g.ids.size());
+  d.A = g.A.p;
+  d.c = g.C.p;
+  d.Q = g.has_q ? g.qQ.p : nullptr;
+  d.Agram = g.qGram.p;
+  d.W = g.W.p;
+  d.D = g.T1.p;
+  d.S = g.qS.p;
+  d.ids = g.dids.p;
+  return d;
+}
 VecGroup MakeVec(Group& g) {
   VecGroup d;
-  d.len = g.type == CXK_SOC ? g.n + 1 : g.n;
+  d.len = (g.type == CXK_SOC || g.type == CXK_QUAD) ? g.n + 1 : g.n;
   d.m = g.m;
   d.count = static_cast<int>(g.ids.size());
   d.A = g.A.p;
@@ -510,6 +529,7 @@ double ConstraintWork(const ConstraintRec& c) {
     case CXK_LMI: return 4 * n * n * n * (m + 1) + n * n * m * m;
     case CXK_LINEAR: return n * m * m;
     case CXK_SOC: return (n + 1) * m * m;
+    case CXK_QUAD: return (n + 1) * m * m;
     default: return m * m;
   }
 }
@@ -2036,6 +2056,9 @@ int LaunchSchur(cxk_context* ctx) {
       case CXK_STATIC:
         static_schur<<<count, 64, 0, ctx->stream>>>(MakeStatic(g), ar);
         break;
+      case CXK_QUAD:
+        quad_schur<<<count, 64, sizeof(double) * (size_t)(2 * g.n + g.m + 4), ctx->stream>>>(MakeQuad(g), ar);
+        break;
     }
   }
   CXK_TRY(hipGetLastError());
@@ -3028,6 +3051,18 @@ int cxk_add_soc(cxk_context* ctx, int n, int m, const double* A, const double* c
   return AddConstraint(ctx, std::move(r), vars);
 }
 
+int cxk_add_quadratic(cxk_context* ctx, int n, int m, const double* Q, const double* A, const double* c, const int* vars) {
+  if (!ctx || n < 1 || m < 0 || !A || !c) return -1;
+  ConstraintRec r;
+  r.type = CXK_QUAD;
+  r.n = n;
+  r.m = m;
+  r.A.assign(A, A + (size_t)(n + 1) * m);
+  r.C.assign(c, c + n + 1);
+  if (Q) r.Q.assign(Q, Q + (size_t)n * n);
+  return AddConstraint(ctx, std::move(r), vars);
+}
+
 int cxk_add_static(cxk_context* ctx, int m, const double* G, const int* vars) {
   if (!ctx || m < 1 || !G) return -1;
   ConstraintRec r;
@@ -3271,7 +3306,8 @@ static int FinalizeImpl(cxk_context* ctx) {
                                  "the large-order kernels use tr(W A_i W A_j) = tr(P_i P_j), which needs A_i = A_i^T");
       }
     }
-    auto key = std::make_tuple(c.type, c.n, c.m, c.herm_d + (c.sparse ? 16 : 0) + (c.type == CXK_LMI && !c.symmetric ? 32 : 0));
+    auto key = std::make_tuple(c.type, c.n, c.m, c.herm_d + (c.sparse ? 16 : 0) + (c.type == CXK_LMI && !c.symmetric ? 32 : 0) +
+                                                     (c.type == CXK_QUAD && !c.Q.empty() ? 64 : 0));
     auto it = gmap.find(key);
     if (it == gmap.end()) {
       it = gmap.emplace(key, (int)ctx->groups.size()).first;
@@ -3282,6 +3318,7 @@ static int FinalizeImpl(cxk_context* ctx) {
       ctx->groups.back().herm_d = c.herm_d;
       ctx->groups.back().sparse = c.sparse;
       ctx->groups.back().literal = c.type == CXK_LMI && !c.symmetric;
+      ctx->groups.back().has_q = c.type == CXK_QUAD && !c.Q.empty();
     }
     c.group = it->second;
     c.member = (int)ctx->groups[it->second].ids.size();
@@ -3322,6 +3359,10 @@ static int FinalizeImpl(cxk_context* ctx) {
         a_sz = (size_t)g.m * g.m;
         c_sz = (size_t)g.m;  // constant AQc (zeros for a quadratic-cost block)
         break;
+      case CXK_QUAD:
+        a_sz = (size_t)(g.n + 1) * g.m;
+        c_sz = w_sz = (size_t)(g.n + 1);
+        break;
     }
     if (g.type == CXK_LMI && g.sparse) {
       if (UploadSparseLmi(ctx, g)) return CXK_FAILURE;
@@ -3352,6 +3393,33 @@ static int FinalizeImpl(cxk_context* ctx) {
         }
       }
       CXK_TRY(g.Apad.upload(hp));
+    }
+    if (g.type == CXK_QUAD) {
+      // A_gram = A1' (Q A1), made once (QuadraticConstraintBase::Initialize, quadratic_cone_constraint.cc:216-219)
+      const int n = g.n, m = g.m, len = n + 1;
+      std::vector<double> hQ(g.has_q ? (size_t)n * n * cnt : 0), hG((size_t)m * m * cnt, 0.0), qa((size_t)n);
+      for (size_t k = 0; k < cnt; k++) {
+        const ConstraintRec& c = ctx->cons[g.ids[k]];
+        if (g.has_q) std::copy(c.Q.begin(), c.Q.end(), hQ.begin() + k * (size_t)n * n);
+        for (int j = 0; j < m; j++) {
+          const double* aj = c.A.data() + (size_t)j * len + 1;
+          for (int i = 0; i < n; i++) {
+            double s2 = g.has_q ? 0.0 : aj[i];
+            if (g.has_q)
+              for (int q2 = 0; q2 < n; q2++) s2 += c.Q[(size_t)q2 * n + i] * aj[q2];
+            qa[(size_t)i] = s2;
+          }
+          for (int i = 0; i < m; i++) {
+            const double* ai = c.A.data() + (size_t)i * len + 1;
+            double s2 = 0;
+            for (int q2 = 0; q2 < n; q2++) s2 += ai[q2] * qa[(size_t)q2];
+            hG[k * (size_t)m * m + (size_t)j * m + i] = s2;
+          }
+        }
+      }
+      CXK_TRY(g.qQ.upload(hQ));
+      CXK_TRY(g.qGram.upload(hG));
+      CXK_TRY(g.qS.alloc(w_sz * cnt));
     }
     CXK_TRY(g.W.alloc(w_sz * cnt));
     CXK_TRY(g.T1.alloc(w_sz * cnt));
@@ -3474,6 +3542,7 @@ int cxk_dual_size(const cxk_context* ctx, int i) {
     case CXK_LMI: return c.herm_d ? (c.n / c.herm_d) * (c.n / c.herm_d) * c.herm_d : c.n * c.n;
     case CXK_LINEAR: return c.n;
     case CXK_SOC: return c.n + 1;
+    case CXK_QUAD: return c.n + 1;
     case CXK_STATIC: return c.eq_rows;  // lambda_ of an equality block; 0 for a quadratic cost
     default: return 0;
   }
@@ -3486,9 +3555,9 @@ int cxk_set_identity(cxk_context* ctx) {
     if (cnt == 0) continue;
     if (g.type == CXK_LMI)
       lmi_set_identity<<<GridFor(cnt * g.n * g.n, 256), 256, 0, ctx->stream>>>(MakeLmi(g));
-    else if (g.type == CXK_LINEAR || g.type == CXK_SOC)
+    else if (g.type == CXK_LINEAR || g.type == CXK_SOC || g.type == CXK_QUAD)
       vec_set_identity<<<GridFor(cnt * (g.n + 1), 256), 256, 0, ctx->stream>>>(MakeVec(g),
-                                                                               g.type == CXK_SOC);
+                                                                               g.type != CXK_LINEAR);
   }
   CXK_TRY(hipGetLastError());
   return CXK_SUCCESS;
@@ -4010,6 +4079,8 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
     else if (g.type == CXK_SOC)
       soc_prepare<0><<<cnt, 64, sizeof(double) * (size_t)(g.m + 3 * (g.n + 1)), ctx->stream>>>(
           MakeVec(g), sa);
+    else if (g.type == CXK_QUAD)
+      quad_prepare<0><<<cnt, 64, sizeof(double) * (size_t)(g.m + 4 * (g.n + 1)), ctx->stream>>>(MakeQuad(g), sa);
   }
   CXK_TRY(hipGetLastError());
   if (ctx->use_ldlt) {  // lambda_ = y.tail(rows) (equality_constraint.cc:32-37)
@@ -4071,6 +4142,8 @@ static int LaunchTakeStep(cxk_context* ctx, double e_weight, double step_size, c
       linear_take_step<<<GridFor((size_t)cnt * g.n, 256), 256, 0, ctx->stream>>>(MakeVec(g), sa);
     else if (g.type == CXK_SOC)
       soc_take_step<<<cnt, 64, sizeof(double) * (size_t)(4 * (g.n + 1)), ctx->stream>>>(MakeVec(g), sa);
+    else if (g.type == CXK_QUAD)
+      quad_take_step<<<cnt, 64, sizeof(double) * (size_t)(3 * (g.n + 1)), ctx->stream>>>(MakeQuad(g), sa);
   }
   CXK_TRY(hipGetLastError());
   return CXK_SUCCESS;
@@ -4099,6 +4172,8 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
     else if (g.type == CXK_SOC)
       soc_prepare<1><<<cnt, 64, sizeof(double) * (size_t)(g.m + 3 * (g.n + 1)), ctx->stream>>>(
           MakeVec(g), sa);
+    else if (g.type == CXK_QUAD)
+      quad_prepare<1><<<cnt, 64, sizeof(double) * (size_t)(g.m + 4 * (g.n + 1)), ctx->stream>>>(MakeQuad(g), sa);
   }
   CXK_TRY(hipGetLastError());
   if (ReduceStepInfoAndSync(ctx, 1, ctx->info4.p)) return CXK_FAILURE;

@@ -44,7 +44,7 @@ bool Verbose() {
   return g_verbose == 1;
 }
 
-enum ConeKind { kLmi, kLinear, kSoc, kQuadCost, kEquality };
+enum ConeKind { kLmi, kLinear, kSoc, kQuadCost, kEquality, kQuadCone };
 
 struct Cone {
   ConeKind kind = kLmi;
@@ -60,6 +60,7 @@ struct Cone {
   int cols = 0;         // linear / SOC: number of columns currently allocated in `A`
   std::vector<double> A;
   std::vector<double> c;
+  std::vector<double> Q;  // kQuadCone: inner-product matrix (order x order), empty = identity
 };
 
 struct Program {
@@ -155,6 +156,7 @@ int RankOf(const Cone& c) {
     case kLmi: return c.order;
     case kLinear: return c.order;
     case kSoc: return 2;
+    case kQuadCone: return 2;  // quadratic_cone_constraint.h:38
     default: return 0;
   }
 }
@@ -224,6 +226,10 @@ int BuildContext(Program* p) {
       }
       case kQuadCost:
         id = cxk_add_static(p->ctx, m, c.A.data(), c.vars.data());
+        break;
+      case kQuadCone:
+        id = cxk_add_quadratic(p->ctx, c.order, m, c.Q.empty() ? nullptr : c.Q.data(), c.A.data(), c.c.data(),
+                               c.vars.data());
         break;
       case kEquality: {
         std::vector<double> A((size_t)c.order * m, 0.0);
@@ -1020,6 +1026,7 @@ int CONEX_GetDualVariableSize(void* x, int i) {
     case kLmi: return k.order * k.order;
     case kLinear: return k.order;
     case kSoc: return k.order + 1;
+    case kQuadCone: return k.order + 1;
     default: return 0;
   }
 }
@@ -1062,6 +1069,56 @@ void CONEX_GetIterationStats(void* x, CONEX_IterationStats* stats, int iter_num_
   }
   stats->mu = 1.0 / (p->sqrt_inv_mu[iter_num] * p->sqrt_inv_mu[iter_num]);
   stats->iteration_number = iter_num;
+}
+
+/* not part of conex.h (the reference reaches these cones through its C++ API only):
+ *   CONEX_HIP_AddQuadraticConstraint   prog.AddConstraint(QuadraticConstraint(Q, A, c), vars)
+ *       c - A y in { (x0, x1) : x0 >= sqrt(x1' Q x1) }   (quadratic_cone_constraint.h:11-86);
+ *       Q: n x n column-major or NULL (identity), A: (n + 1) x num_vars column-major, c: n + 1,
+ *       vars: num_vars variable ids (NULL: all variables in order)
+ *   CONEX_HIP_AddQuadraticCostEpigraph  AddQuadraticCostEpigraph(&prog, Qi, z, epigraph)
+ *       (quadratic_cone_constraint.h:88-117): y[epigraph] >= 1/2 y[z]' Qi y[z] as such a cone
+ * Both return the constraint id, -1 on invalid arguments. */
+int CONEX_HIP_AddQuadraticConstraint(void* x, const double* Q, int n, const double* A, int Ar, int Ac,
+                                     const double* c, int cr, const long* vars, int num_vars) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || p->magic != 0xC0DEC0DEu || n < 1 || !A || !c || Ar != n + 1 || cr != n + 1 || Ac < 1) return -1;
+  if (vars ? num_vars != Ac : Ac != p->num_vars) return -1;
+  Cone k;
+  k.kind = kQuadCone;
+  k.order = n;
+  k.cols = Ac;
+  k.A.assign(A, A + (size_t)(n + 1) * Ac);
+  k.c.assign(c, c + n + 1);
+  if (Q) k.Q.assign(Q, Q + (size_t)n * n);
+  if (vars) {
+    for (int i = 0; i < Ac; i++) {
+      if (vars[i] < 0 || vars[i] >= p->num_vars) return -1;
+      k.vars.push_back((int)vars[i]);
+    }
+  } else {
+    k.vars = AllVars(*p);
+  }
+  return AddCone(p, std::move(k));
+}
+
+int CONEX_HIP_AddQuadraticCostEpigraph(void* x, const double* Qi, int nz, const long* z, long epigraph) {
+  if (!Qi || !z || nz < 1) return -1;
+  // inner-product matrix Q = diag(1, Qi); (A, b) with b - A (z, t) in L  <=>  t >= 1/2 z' Qi z:
+  //   (.5 t + 1)^2 >= (.5 t - 1)^2 + z' Qi z
+  const int n = nz + 1, len = nz + 2, cols = nz + 1;
+  std::vector<double> Q((size_t)n * n, 0.0), A((size_t)len * cols, 0.0), b((size_t)len, 0.0);
+  Q[0] = 1;
+  for (int j = 0; j < nz; j++)
+    for (int i = 0; i < nz; i++) Q[(size_t)(j + 1) * n + (i + 1)] = Qi[(size_t)j * nz + i];
+  A[(size_t)nz * len + 0] = -0.5;  // topRightCorner(2, 1) << -.5, -.5
+  A[(size_t)nz * len + 1] = -0.5;
+  for (int j = 0; j < nz; j++) A[(size_t)j * len + 2 + j] = 1;  // bottomLeftCorner = I
+  b[0] = 1;
+  b[1] = -1;
+  std::vector<long> vars(z, z + nz);
+  vars.push_back(epigraph);
+  return CONEX_HIP_AddQuadraticConstraint(x, Q.data(), n, A.data(), len, cols, b.data(), len, vars.data(), cols);
 }
 
 /* not part of conex.h: lets a host pick the HIP device ordinal before the first solve */

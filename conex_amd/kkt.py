@@ -35,6 +35,7 @@ _SIGNATURES = {
     "cxk_add_lmi": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
     "cxk_add_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
     "cxk_add_soc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
+    "cxk_add_quadratic": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]),
     "cxk_add_equality": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
     "cxk_factor_regularized": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "cxk_add_hermitian": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p,
@@ -241,6 +242,19 @@ class KktContext:
         r = self.L.cxk_add_soc(self.h, n1 - 1, m, _dp(a), _dp(cc), vp)
         if r >= 0:
             self.cons.append(("soc", n1 - 1, m))
+        return r
+
+    def add_quadratic(self, Q, A, c, vars_=None):
+        """QuadraticConstraint(Q, A, c): Q (n, n) or None (identity), A (n + 1, m), c (n + 1,)."""
+        A = np.asarray(A, dtype=np.float64)
+        n1, m = A.shape
+        a = _colmajor(A)
+        cc = np.ascontiguousarray(np.asarray(c, dtype=np.float64).ravel())
+        q = None if Q is None else _colmajor(np.asarray(Q, dtype=np.float64))
+        keep, vp = self._vars(vars_)
+        r = self.L.cxk_add_quadratic(self.h, n1 - 1, m, None if q is None else _dp(q), _dp(a), _dp(cc), vp)
+        if r >= 0:
+            self.cons.append(("quad", n1 - 1, m))
         return r
 
     def add_static(self, G, vars_):

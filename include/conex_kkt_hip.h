@@ -33,8 +33,10 @@ enum {
   CXK_LMI = 0,    /* DenseLMIConstraint  dense_lmi_constraint.h:24-41 */
   CXK_LINEAR = 1, /* LinearConstraint    linear_constraint.h:14-84 */
   CXK_SOC = 2,    /* SOCConstraint       soc_constraint.h:6-54 */
-  CXK_STATIC = 3  /* constant Schur block: QuadraticFunction quadratic_cost.cc:18-69,
+  CXK_STATIC = 3, /* constant Schur block: QuadraticFunction quadratic_cost.cc:18-69,
                      SupernodalAssemblerStatic supernodal_assembler.h:122-129 */
+  CXK_QUAD = 4    /* QuadraticConstraint quadratic_cone_constraint.h:11-86: Lorentz cone
+                     x0 >= sqrt(x1' Q x1) with an inner-product matrix Q on the vector part */
 };
 
 /* ---- lifetime --------------------------------------------------------- */
@@ -75,6 +77,10 @@ int cxk_add_linear(cxk_context* ctx, int rows, int m, const double* A /* rows x 
 int cxk_add_soc(cxk_context* ctx, int n, int m, const double* A /* (n+1) x m */,
                 const double* c /* n+1 */, const int* vars);
 int cxk_add_static(cxk_context* ctx, int m, const double* G /* m x m */, const int* vars);
+/* QuadraticConstraint(Q, A, c): c - A y in { (x0, x1) : x0 >= sqrt(x1' Q x1) }.  Q: n x n column-major,
+ * symmetric positive definite, or NULL for the identity (the reference's two-argument constructor) */
+int cxk_add_quadratic(cxk_context* ctx, int n, int m, const double* Q /* n x n or NULL */,
+                      const double* A /* (n+1) x m */, const double* c /* n+1 */, const int* vars);
 int cxk_num_constraints(const cxk_context* ctx);
 
 /* Multi-GPU sharding (no reference counterpart -- the reference is single

@@ -16,7 +16,8 @@ enum {
   CXO_SOC = 2,       /* SOCConstraint        soc_constraint.{h,cc} */
   CXO_STATIC = 3,    /* SupernodalAssemblerStatic supernodal_assembler.h:122-129 (fixed G) */
   CXO_HERMITIAN = 4, /* HermitianPsdConstraint<Real|Complex|Quaternions> hermitian_psd.{h,cc} */
-  CXO_EQUALITY = 5   /* EqualityConstraints equality_constraint.{h,cc} (multipliers -> LDLT path) */
+  CXO_EQUALITY = 5,  /* EqualityConstraints equality_constraint.{h,cc} (multipliers -> LDLT path) */
+  CXO_QUADRATIC = 6  /* QuadraticConstraint  quadratic_cone_constraint.{h,cc}: Lorentz cone x0 >= sqrt(x1' Q x1) */
 };
 
 /* cone_program.h:17-38 */
@@ -57,6 +58,10 @@ int cxo_add_linear(cxo_program* p, int r, int m, const double* A, const double* 
                    const int* vars);
 /* A: (n+1) x m col-major, c: n+1 */
 int cxo_add_soc(cxo_program* p, int n, int m, const double* A, const double* c, const int* vars);
+/* QuadraticConstraint(Q, A, c): Q n x n col-major or NULL (identity: the two-argument constructor),
+ * A: (n+1) x m col-major (row 0 = A0, the rest A1), c: n+1 */
+int cxo_add_quadratic(cxo_program* p, int n, int m, const double* Q, const double* A, const double* c,
+                      const int* vars);
 /* A y[vars] = b with r rows: appends r multipliers to the KKT system (constraint_manager.h:66-90);
  * the factorization switches to BlockLDLTInPlace (kkt_solver.cc:180-193).  dual size = r (lambda). */
 int cxo_add_equality(cxo_program* p, int r, int m, const double* A, const double* b,

@@ -7,6 +7,7 @@
  *   conex/psd_constraint.cc:13-128           GeodesicUpdate/AffineUpdate/PrepareStep/TakeStep/eigs
  *   conex/linear_constraint.cc:108-205       linear cone
  *   conex/soc_constraint.cc:14-303           second-order cone (spin factor)
+ *   conex/quadratic_cone_constraint.cc:14-297  Lorentz cone with inner-product matrix Q
  *   conex/supernodal_assembler.cc:23-165     Set/SetLowerTri/Scatter/GetCoeff/UpdateBlocks/Bind
  *   conex/supernodal_solver.h:36-62          DoBind
  *   conex/kkt_solver.cc:133-269              Assemble/Factor/SolveInPlace/KKTMatrix (LLT mode)
@@ -50,7 +51,10 @@ typedef struct {
   double* temp1;  /* LMI n*n ; linear n ; SOC temp1_1 (n) */
   double* temp2;
   double* wa;     /* linear weighted_constraints n*m ; SOC scratch */
-  double d0;      /* SOC */
+  double d0;      /* SOC, quadratic cone */
+  double* Q;      /* quadratic cone: n*n or NULL (identity) */
+  double* Agram;  /* quadratic cone: A1' Q A1 (m*m), QuadraticConstraintBase::Initialize */
+  double wsq_norm_sqr; /* quadratic cone: workspace_.wsqrt_q1_norm_sqr */
   int hd;         /* Hermitian: number of real planes d (1 real, 2 complex, 4 quaternion) */
   /* Schur workspace (newton_step.h:55-109) */
   double* G_own;  /* m*m */
@@ -157,6 +161,8 @@ static void constraint_free(cxo_constraint* c) {
   free(c->temp1);
   free(c->temp2);
   free(c->wa);
+  free(c->Q);
+  free(c->Agram);
   free(c->G_own);
   free(c->AW);
   free(c->AQc);
@@ -326,6 +332,33 @@ int cxo_add_soc(cxo_program* p, int n, int m, const double* A, const double* cc,
   return p->K - 1;
 }
 
+/* QuadraticConstraintBase ctor + Initialize, quadratic_cone_constraint.h:15-30, .cc:216-219 */
+static void quad_apply_Q(const cxo_constraint* o, const double* x, double* out);
+int cxo_add_quadratic(cxo_program* p, int n, int m, const double* Q, const double* A, const double* cc,
+                      const int* vars) {
+  if (!vars && m != p->num_vars) return -1;
+  cxo_constraint* c = new_constraint(p, m, vars);
+  if (!c) return -1;
+  const int len = n + 1;
+  c->type = CXO_QUADRATIC;
+  c->n = n;
+  c->A = dupd(A, (size_t)len * m);
+  c->C = dupd(cc, (size_t)len);
+  c->Q = Q ? dupd(Q, (size_t)n * n) : NULL;
+  c->W = (double*)calloc((size_t)len, sizeof(double));
+  c->temp1 = (double*)calloc((size_t)len, sizeof(double));  /* d_q1 (temp2_1 of the reference) */
+  c->temp2 = (double*)calloc((size_t)len, sizeof(double));  /* wsqrt_q1 (temp3_1) */
+  c->wa = (double*)calloc((size_t)len * 4 + (size_t)m * 2, sizeof(double));
+  c->Agram = (double*)calloc((size_t)m * m, sizeof(double));
+  double* qa = (double*)malloc(sizeof(double) * (size_t)n);
+  for (int j = 0; j < m; j++) {  /* A_gram = A1' (Q A1) */
+    quad_apply_Q(c, c->A + (size_t)j * len + 1, qa);
+    for (int i = 0; i < m; i++) c->Agram[(size_t)j * m + i] = dotn((size_t)n, c->A + (size_t)i * len + 1, qa);
+  }
+  free(qa);
+  return p->K - 1;
+}
+
 int cxo_add_static(cxo_program* p, int m, const double* G, const int* vars) {
   if (!vars && m != p->num_vars) return -1;
   cxo_constraint* c = new_constraint(p, m, vars);
@@ -353,6 +386,10 @@ static void set_identity_one(cxo_constraint* c) {
       for (int i = 0; i < c->n; i++) c->W[i] = 1;
       break;
     case CXO_SOC: /* soc_constraint.h:25-28 */
+      memset(c->W, 0, sizeof(double) * (size_t)(c->n + 1));
+      c->W[0] = 1;
+      break;
+    case CXO_QUADRATIC: /* quadratic_cone_constraint.cc:292-295 */
       memset(c->W, 0, sizeof(double) * (size_t)(c->n + 1));
       c->W[0] = 1;
       break;
@@ -455,6 +492,7 @@ int cxo_dual_size(const cxo_program* p, int i) {
     case CXO_EQUALITY: return c->n;
     case CXO_LINEAR: return c->n;
     case CXO_SOC: return c->n + 1;
+    case CXO_QUADRATIC: return c->n + 1;
     default: return 0;
   }
 }
@@ -558,6 +596,163 @@ static void schur_soc(cxo_constraint* o) {
   o->ip_cQc = 2 * dotn((size_t)len, WsqrtC, WsqrtC);
 }
 
+/* --- Lorentz cone with inner-product matrix Q on the vector part, quadratic_cone_constraint.cc --- */
+static void quad_apply_Q(const cxo_constraint* o, const double* x, double* out) { /* Q x, or x when Q = I */
+  const int n = o->n;
+  if (!o->Q) {
+    memcpy(out, x, sizeof(double) * (size_t)n);
+    return;
+  }
+  for (int i = 0; i < n; i++) out[i] = 0;
+  for (int j = 0; j < n; j++)
+    for (int i = 0; i < n; i++) out[i] += o->Q[(size_t)j * n + i] * x[j];
+}
+static double quad_ip(const cxo_constraint* o, const double* x, const double* y) { /* InnerProduct :35-44, SquaredNorm :14-22 */
+  double* qy = (double*)malloc(sizeof(double) * (size_t)o->n);
+  quad_apply_Q(o, y, qy);
+  const double r = dotn((size_t)o->n, x, qy);
+  free(qy);
+  return r;
+}
+static double quad_norm(const cxo_constraint* o, const double* x) { return sqrt(fabs(quad_ip(o, x, x))); } /* :24-33 */
+/* QuadraticRepresentation :46-61 */
+static void quad_quadrep(int n, double x1_norm_sq, double ip_x1_y1, double x0, const double* x1, double y0,
+                         const double* y1, double* z0, double* z1) {
+  const double det_x = x0 * x0 - x1_norm_sq;
+  const double scale = 2 * (x0 * y0 + ip_x1_y1);
+  *z0 = scale * x0 - det_x * y0;
+  for (int i = 0; i < n; i++) z1[i] = scale * x1[i] + det_x * y1[i];
+}
+static void quad_exp(int n, double k, double* x0, double* x1) { /* :63-70 */
+  if (k > 0) {
+    const double f = .5 * (exp(*x0 + k) - exp(*x0 - k)) / k;
+    for (int i = 0; i < n; i++) x1[i] *= f;
+  }
+  *x0 = .5 * (exp(*x0 + k) + exp(*x0 - k));
+}
+static void quad_sqrt(int n, double k, double* x0, double* x1) { /* :72-79, square_root = sqrt(fabs(.)) */
+  if (k > 0) {
+    const double f = .5 * (sqrt(fabs(*x0 + k)) - sqrt(fabs(*x0 - k))) / k;
+    for (int i = 0; i < n; i++) x1[i] *= f;
+  }
+  *x0 = .5 * (sqrt(fabs(*x0 + k)) + sqrt(fabs(*x0 - k)));
+}
+static void quad_negative_slack(const cxo_constraint* o, double k, const double* y, double* s0, double* s1) { /* :131-139 */
+  const int len = o->n + 1;
+  double a0 = 0;
+  for (int j = 0; j < o->m; j++) a0 += o->A[(size_t)j * len] * y[j];
+  *s0 = a0 - o->C[0] * k;
+  for (int i = 0; i < o->n; i++) s1[i] = 0;
+  for (int j = 0; j < o->m; j++)
+    for (int i = 0; i < o->n; i++) s1[i] += o->A[(size_t)j * len + 1 + i] * y[j];
+  for (int i = 0; i < o->n; i++) s1[i] -= o->C[1 + i] * k;
+}
+/* ConstructSchurComplementSystem(QuadraticConstraintBase*, initialize = true) :240-290, SchurComplement :88-100 */
+static void schur_quadratic(cxo_constraint* o) {
+  const int n = o->n, m = o->m, len = n + 1;
+  const double W0 = o->W[0];
+  const double* W1 = o->W + 1;
+  const double C0 = o->C[0];
+  const double* C1 = o->C + 1;
+  double* QW1 = o->wa;             /* n */
+  double* QC1 = o->wa + len;       /* n */
+  double* A_dot_x = o->wa + 2 * len;       /* m */
+  double* v = A_dot_x + m;                 /* m : A_dot_x + A0 W0 */
+  quad_apply_Q(o, W1, QW1);
+  quad_apply_Q(o, C1, QC1);
+  const double c_dot_x = dotn((size_t)n, C1, QW1);
+  for (int i = 0; i < m; i++) A_dot_x[i] = dotn((size_t)n, o->A + (size_t)i * len + 1, QW1);
+  const double det_w = W0 * W0 - dotn((size_t)n, W1, QW1);
+  for (int i = 0; i < m; i++) v[i] = A_dot_x[i] + o->A[(size_t)i * len] * W0;
+  for (int j = 0; j < m; j++)
+    for (int i = 0; i < m; i++) {
+      const double a0a0 = o->A[(size_t)i * len] * o->A[(size_t)j * len];
+      double g = (a0a0 - o->Agram[(size_t)j * m + i]) * -det_w;
+      g += v[i] * v[j];
+      g += v[i] * v[j];
+      o->G[(size_t)j * m + i] = g;
+    }
+  for (int i = 0; i < m; i++) {
+    o->AW[i] = v[i];
+    o->AQc[i] = det_w * (dotn((size_t)n, o->A + (size_t)i * len + 1, QC1) - o->A[(size_t)i * len] * C0);
+  }
+  o->ip_cQc = det_w * (dotn((size_t)n, C1, QC1) - C0 * C0);
+  const double scale = dotn((size_t)n, QW1, C1) + C0 * W0; /* (Q = I: W1 . C1 + C0 W0, the same value) */
+  for (int i = 0; i < m; i++) o->AQc[i] += 2 * v[i] * scale;
+  o->ip_cQc += 2 * (c_dot_x + C0 * W0) * scale;
+  o->ip_wc = scale;
+  /* "Account for Jordan inner-product <x, y> := 2 x^T y" */
+  for (int i = 0; i < m; i++) {
+    o->AQc[i] *= 2;
+    o->AW[i] *= 2;
+  }
+  o->ip_cQc *= 2;
+  o->ip_wc *= 2;
+  for (size_t q = 0; q < (size_t)m * m; q++) o->G[q] *= 2;
+}
+/* PrepareStep(QuadraticConstraintBase*) :176-214.  wsqrt_q0 is a REFERENCE to *W0: the scalar part of
+ * w^{1/2} overwrites W0 here (W1 stays), TakeStep reads it from there. */
+static void quad_prepare_step(cxo_constraint* o, double c_weight, const double* y, double* normsqrd, double* norminfd) {
+  const int n = o->n;
+  double* ms1 = (double*)malloc(sizeof(double) * (size_t)n);
+  double ms0;
+  quad_negative_slack(o, c_weight, y, &ms0, ms1);
+  double* wsq1 = o->temp2;
+  memcpy(wsq1, o->W + 1, sizeof(double) * (size_t)n);
+  quad_sqrt(n, quad_norm(o, wsq1), &o->W[0], wsq1);
+  o->wsq_norm_sqr = quad_ip(o, wsq1, wsq1);
+  double* d1 = o->temp1;
+  quad_quadrep(n, o->wsq_norm_sqr, quad_ip(o, wsq1, ms1), o->W[0], wsq1, ms0, ms1, &o->d0, d1);
+  o->d0 += 1;
+  const double nd = quad_norm(o, d1);
+  const double e0 = o->d0 + nd, e1 = o->d0 - nd;
+  *norminfd = fabs(e0);
+  if (*norminfd < fabs(e1)) *norminfd = fabs(e1);
+  *normsqrd = e0 * e0 + e1 * e1;
+  free(ms1);
+}
+/* TakeStep(QuadraticConstraintBase*) :221-243 */
+static void quad_take_step(cxo_constraint* o, double step_size) {
+  const int n = o->n;
+  double* d1 = o->temp1;
+  if (step_size != 1) {
+    o->d0 = step_size * o->d0;
+    for (int i = 0; i < n; i++) d1[i] = step_size * d1[i];
+  }
+  quad_exp(n, quad_norm(o, d1), &o->d0, d1);
+  const double* wsq1 = o->temp2;
+  const double ip = quad_ip(o, wsq1, d1);
+  double w0;
+  double* w1 = (double*)malloc(sizeof(double) * (size_t)n);
+  quad_quadrep(n, o->wsq_norm_sqr, ip, o->W[0], wsq1, o->d0, d1, &w0, w1);
+  o->W[0] = w0;
+  memcpy(o->W + 1, w1, sizeof(double) * (size_t)n);
+  free(w1);
+}
+/* GetWeightedSlackEigenvalues(QuadraticConstraintBase*) :142-174 */
+static void quad_weighted_eigs(cxo_constraint* o, const double* y, double c_weight, double* lmin, double* lmax,
+                               double* frob, double* tr) {
+  const int n = o->n;
+  double* ms1 = (double*)malloc(sizeof(double) * (size_t)n);
+  double* wsq1 = (double*)malloc(sizeof(double) * (size_t)n);
+  double* Ws1 = (double*)malloc(sizeof(double) * (size_t)n);
+  double ms0, wsq0 = o->W[0], Ws0;
+  quad_negative_slack(o, c_weight, y, &ms0, ms1);
+  memcpy(wsq1, o->W + 1, sizeof(double) * (size_t)n);
+  quad_sqrt(n, quad_norm(o, wsq1), &wsq0, wsq1);
+  quad_quadrep(n, quad_ip(o, wsq1, wsq1), quad_ip(o, wsq1, ms1), wsq0, wsq1, ms0, ms1, &Ws0, Ws1);
+  const double nq = quad_norm(o, Ws1);
+  const double e0 = Ws0 + nq, e1 = Ws0 - nq;
+  const double mn = e0 < e1 ? e0 : e1, mx = e0 < e1 ? e1 : e0;
+  *lmax = -mn;
+  *lmin = -mx;
+  *frob = (*lmax) * (*lmax) + (*lmin) * (*lmin);
+  *tr = (*lmax) + (*lmin);
+  free(ms1);
+  free(wsq1);
+  free(Ws1);
+}
+
 static void schur_static(cxo_constraint* o) { /* supernodal_assembler.h:127 G = A_ */
   memcpy(o->G, o->A, sizeof(double) * (size_t)o->m * o->m);
   memset(o->AW, 0, sizeof(double) * (size_t)o->m);
@@ -575,6 +770,7 @@ static void set_dense_data(cxo_constraint* o) {
     case CXO_EQUALITY: schur_equality(o); break;
     case CXO_LINEAR: schur_linear(o); break;
     case CXO_SOC: schur_soc(o); break;
+    case CXO_QUADRATIC: schur_quadratic(o); break;
     case CXO_STATIC: schur_static(o); break;
   }
 }
@@ -1169,6 +1365,7 @@ void cxo_prepare_step(cxo_program* p, int affine, double c_weight, double e_weig
         break;
       case CXO_LINEAR: lin_prepare_step(c, affine, c_weight, e_weight, 1.0, z, &ni_sq, &ni_inf); break;
       case CXO_SOC: soc_prepare_step(c, c_weight, z, &ni_sq, &ni_inf); break;
+      case CXO_QUADRATIC: quad_prepare_step(c, c_weight, z, &ni_sq, &ni_inf); break;
       case CXO_EQUALITY: /* equality_constraint.cc:32-37: lambda_ = y.tail(rows) */
         for (int q = 0; q < c->n; q++) c->W[q] = z[c->m - c->n + q];
         ni_sq = 0;
@@ -1193,6 +1390,7 @@ void cxo_take_step(cxo_program* p, int affine, double e_weight, double step_size
       case CXO_HERMITIAN: herm_take_step(c, e_weight, step_size); break;
       case CXO_LINEAR: lin_take_step(c, affine, step_size); break;
       case CXO_SOC: soc_take_step(c, step_size); break;
+      case CXO_QUADRATIC: quad_take_step(c, step_size); break;
       default: break;
     }
   }
@@ -1217,6 +1415,7 @@ void cxo_weighted_slack_eigenvalues(cxo_program* p, const double* y, double c_we
         break;
       case CXO_LINEAR: lin_weighted_eigs(c, z, c_weight, &t_min, &t_max, &t_frob, &t_tr); break;
       case CXO_SOC: soc_weighted_eigs(c, z, c_weight, &t_min, &t_max, &t_frob, &t_tr); break;
+      case CXO_QUADRATIC: quad_weighted_eigs(c, z, c_weight, &t_min, &t_max, &t_frob, &t_tr); break;
       default: break;
     }
     if (lmax < t_max) lmax = t_max;
@@ -1305,6 +1504,7 @@ static int rank_of(const cxo_constraint* c) {
     case CXO_EQUALITY: return 0;
     case CXO_LINEAR: return c->n;
     case CXO_SOC: return 2;
+    case CXO_QUADRATIC: return 2; /* quadratic_cone_constraint.h:38 */
     default: return 0;
   }
 }

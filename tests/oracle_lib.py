@@ -62,6 +62,7 @@ def lib():
         "cxo_add_lmi": (C.c_int, [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
         "cxo_add_linear": (C.c_int, [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
         "cxo_add_soc": (C.c_int, [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
+        "cxo_add_quadratic": (C.c_int, [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p]),
         "cxo_add_static": (C.c_int, [vp, C.c_int, c_double_p, c_int_p]),
         "cxo_add_equality": (C.c_int, [vp, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p]),
         "cxo_add_hermitian": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p,
@@ -260,6 +261,18 @@ class Program:
         r = self.L.cxo_add_soc(self.h, n1 - 1, m, dp(a), dp(cc), vp_)
         if r >= 0:
             self.cons.append(("soc", n1 - 1, m))
+        return r
+
+    def add_quadratic(self, Q, A, c, vars_=None):
+        A = np.asarray(A, dtype=np.float64)
+        n1, m = A.shape
+        a = colmajor(A)
+        cc = f64(np.asarray(c).ravel())
+        q = None if Q is None else colmajor(np.asarray(Q, dtype=np.float64))
+        v, vp_ = self._vars(vars_)
+        r = self.L.cxo_add_quadratic(self.h, n1 - 1, m, None if q is None else dp(q), dp(a), dp(cc), vp_)
+        if r >= 0:
+            self.cons.append(("quad", n1 - 1, m))
         return r
 
     def add_static(self, G, vars_):
