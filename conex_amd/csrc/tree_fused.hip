@@ -145,10 +145,23 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   // where this supernode's values go: lane t of round r publishes value number t + 64 r (the
   // s (s + 1) / 2 Schur updates in the reference's S_S enumeration, then the s forward values);
   // lanes 0 .. 7: the arrival words of the supernodes that consume them
-  int pd[PR > 0 ? PR : 1];
-  pd[0] = 0;
+  int pd[PR > 0 ? PR : 1], prd[PR > 0 ? PR : 1];
+  pd[0] = prd[0] = 0;
 #pragma unroll
-  for (int r = 0; r < PR; r++) pd[r] = A.pub[pub_beg + (lane + 64 * r < nv ? lane + 64 * r : 0)];
+  for (int r = 0; r < PR; r++) {
+    const int t = lane + 64 * r;
+    pd[r] = A.pub[pub_beg + (t < nv ? t : 0)];
+    // where value t will sit in the scratch image the separator lanes write after the elimination
+    // (lane l's registers a[NSMAX ..] and its right-hand side at my[(SMAX + 1) l + c]): Schur update
+    // t = (k, c) of the S_S enumeration, or forward value k
+    int k = 0, rem = t < npairs ? t : 0;
+    while (rem >= s - k && k < s) {
+      rem -= s - k;
+      k++;
+    }
+    const int kk = t < npairs ? k : t - npairs, cc = t < npairs ? k + rem : SMAX;
+    prd[r] = (SMAX + 1) * (NSMAX + (t < nv ? kk : 0)) + (t < nv ? cc : 0);
+  }
   const int ppr = A.pprobe[(size_t)blockIdx.x * 8 + (lane & 7)];
   const int ntg = R.tg_end - R.tg_beg;
   int ploc0 = 0, ploc1 = 0;
@@ -353,18 +366,15 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   // store instruction carries 64 of them (a store costs a lone wavefront ~70 cycles of issue)
   if constexpr (SMAX > 0) {
     if (s > 0) {
-      if (is_sep) {
-        const int t0 = sc * s - sc * (sc - 1) / 2 - sc;  // value (k, c) is number t0 + c
+      // (every lane writes, no predicates: SMAX + 1 LDS stores, one read, one global store)
 #pragma unroll
-        for (int c = 0; c < SMAX; c++)
-          if (c >= sc && c < s) my[t0 + c] = -a[NSMAX + c];
-        my[npairs + sc] = -a[RB];
-      }
+      for (int c = 0; c < SMAX; c++) my[(SMAX + 1) * lane + c] = a[NSMAX + c];
+      my[(SMAX + 1) * lane + SMAX] = a[RB];
       WaveSync();
 #pragma unroll
       for (int r = 0; r < PR; r++) {
-        const int t = lane + 64 * r;
-        if (t < nv) StoreAgent(handG + pd[r], my[t]);
+        const double v = -my[prd[r]];
+        if (lane + 64 * r < nv) StoreAgent(handG + pd[r], v);
       }
       if (lane < 8 && ppr >= 0) StoreAgent(handG + ppr, 1.0);
       WaveSync();
@@ -392,14 +402,46 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   double dg = my[66 * li];
   FT_STAMP(9);  // columns of L back from the image
   constexpr int QN = SMAX < 8 ? SMAX : 8;
-  double bv[QN > 0 ? QN : 1], yv[QN > 0 ? QN : 1];
-  bv[0] = yv[0] = 0.0;
+  double bv[QN > 0 ? QN : 1], yv[QN > 0 ? QN : 1], Mb[QN > 0 ? QN : 1];
+  bv[0] = yv[0] = Mb[0] = 0.0;
   if constexpr (QN > 0) {
 #pragma unroll
     for (int qq = 0; qq < QN; qq++) {
       const unsigned sw = qq < cnt ? (unsigned)R.sep[qq] : 0u;
       bv[qq] = my[65 * li + NSMAX + (int)(sw >> 26)];
     }
+  }
+  // While the ancestors are still at work: the back substitution is linear in the separator's
+  // solution, y = L^-T z - (L^-T B) y_sep, so u = L^-T z and the columns M = L^-T B are solved for
+  // now (one sweep, 1 + cnt right-hand sides) and the arrival of y_sep is followed by cnt
+  // multiply-adds instead of the NSMAX dependent steps of the sweep.  (Same solution to rounding;
+  // BackwardSupernodeLean subtracts B y_sep first and sweeps once.)
+#pragma unroll
+  for (int k = 0; k < NSMAX; k++) col[k] = (active && k > lane && k < ns) ? col[k] : 0.0;
+  dg = active ? dg : 1.0;
+  double ub = active ? a[RB] : 0.0;
+  if constexpr (QN > 0) {
+#pragma unroll
+    for (int qq = 0; qq < QN; qq++) Mb[qq] = (qq < cnt && active) ? bv[qq] : 0.0;
+  }
+  {
+    const double dinv = 1.0 / dg;
+#pragma unroll
+    for (int k = NSMAX - 1; k >= 0; k--) {
+      if (lane == k) ub *= dinv;
+      ub = fma(-col[k], ReadLane(ub, k), ub);  // col[k] is zero for lanes >= k
+      if constexpr (QN > 0) {
+        if (cnt > 0) {
+#pragma unroll
+          for (int qq = 0; qq < QN; qq++) {
+            if (lane == k) Mb[qq] *= dinv;
+            Mb[qq] = fma(-col[k], ReadLane(Mb[qq], k), Mb[qq]);
+          }
+        }
+      }
+    }
+  }
+  if constexpr (QN > 0) {
     if (cnt > 0) {
       // lane qq < cnt polls the solution entry of separator variable qq
       const int sepw = __builtin_amdgcn_ds_bpermute(4 * (24 + (lane < 8 ? lane : 0)), w);
@@ -422,19 +464,10 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     }
   }
   FT_STAMP(5);  // the separator's solution is in
-#pragma unroll
-  for (int k = 0; k < NSMAX; k++) col[k] = (active && k > lane && k < ns) ? col[k] : 0.0;
-  dg = active ? dg : 1.0;
-  double acc = active ? a[RB] : 0.0;
+  double acc = ub;
   if constexpr (QN > 0) {
 #pragma unroll
-    for (int qq = 0; qq < QN; qq++) acc -= ((qq < cnt && active) ? bv[qq] : 0.0) * (qq < cnt ? yv[qq] : 0.0);
-  }
-  const double dinv = 1.0 / dg;
-#pragma unroll
-  for (int k = NSMAX - 1; k >= 0; k--) {
-    if (lane == k) acc *= dinv;
-    acc = fma(-col[k], ReadLane(acc, k), acc);  // col[k] is zero for lanes >= k
+    for (int qq = 0; qq < QN; qq++) acc = fma(-Mb[qq], qq < cnt ? yv[qq] : 0.0, acc);
   }
   if (active) StoreAgent(ysG + R.start + lane, acc);
   FT_STAMP(6);
@@ -703,19 +736,21 @@ __global__ void __launch_bounds__(64) tree_fused_solve1(FusedTreeArgs A) {
 }
 
 namespace {
+// doubles of LDS one wavefront needs: the transposed image of L (65 NSMAX) / the publish scratch (64 (SMAX + 1))
+constexpr int FusedImage(int nsmax, int smax) { return 65 * nsmax > 64 * (smax + 1) ? 65 * nsmax : 64 * (smax + 1); }
 template <typename F>
 bool ForPair(int sa, int sb, F&& fn) {
 #define CXK_FUSED_ONE(NA_, SA_)                                                     \
   if (sa == ((NA_) << 8 | (SA_)) && sb == sa) {                                     \
     fn(reinterpret_cast<const void*>(&tree_fused1<NA_, SA_>),                       \
-       reinterpret_cast<const void*>(&tree_fused_solve1<NA_, SA_>), 65 * (NA_));    \
+       reinterpret_cast<const void*>(&tree_fused_solve1<NA_, SA_>), FusedImage(NA_, SA_)); \
     return true;                                                                    \
   }
 #define CXK_FUSED_PAIR(NA_, SA_, NB_, SB_)                                                          \
   if (sa == ((NA_) << 8 | (SA_)) && sb == ((NB_) << 8 | (SB_))) {                                   \
     fn(reinterpret_cast<const void*>(&tree_fused<NA_, SA_, NB_, SB_>),                              \
        reinterpret_cast<const void*>(&tree_fused_solve<NA_, SA_, NB_, SB_>),                        \
-       65 * ((NA_) > (NB_) ? (NA_) : (NB_)));                                                       \
+       FusedImage(NA_, SA_) > FusedImage(NB_, SB_) ? FusedImage(NA_, SA_) : FusedImage(NB_, SB_));   \
     return true;                                                                                    \
   }
   CXK_FUSED_ONE(8, 8)
