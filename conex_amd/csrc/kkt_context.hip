@@ -237,6 +237,7 @@ struct cxk_context {
   // several sources, the two sets of hand-off slots and their initial images (re-uploaded after a
   // wait ran out), the run counter whose parity picks the set
   bool fused_tree = false;
+  bool fused_split = false;  // more supernodes than resident wavefronts: the way up and the way down are two launches
   bool fused_sweep = false;  // solve-only sweeps in one launch too (CXK_NO_FUSED_SWEEP=1 turns this part off)
   int fused_sa = 0, fused_sb = 0;
   DevBuf<int> fx_rec, fx_xreg;
@@ -1361,22 +1362,42 @@ int BuildPlans(cxk_context* ctx) {
   if (!sharded && !ctx->use_ldlt && !ctx->no_lean && !getenv("CXK_NO_FUSED_TREE") && nlev >= 1 && N < (1 << 26)) {
     const int cnt_all = (int)ctx->level_sn.size();
     bool ok = cnt_all > 0 && cnt_all == ctx->level_ptr[nlev];
+    const char* why = ok ? nullptr : "a supernode without columns / beyond LDS";
+    auto note = [&](const char* msg) {
+      if (!ok && !why) why = msg;
+    };
     int sa = 0, sb = 0;
-    for (int l = 0; l < nlev && ok; l++) {
-      ok = ctx->level_lean[l] && !ctx->level_big[l] && ctx->level_nh[l] == ctx->level_ptr[l + 1] - ctx->level_ptr[l];
-      for (auto& sg : ctx->level_segs[l]) {
-        if (sa == 0 || sg.shape == sa) {
-          sa = sg.shape;
-        } else if (sb == 0 || sg.shape == sb) {
-          sb = sg.shape;
-        } else {
-          ok = false;
-        }
+    {
+      // at most two register shapes; a shape without separator columns <N, 0> runs on <N, S> where
+      // the tree has one (same rows per lane: the pull locations tg_reg are the same)
+      std::vector<int> shapes;
+      for (int l = 0; l < nlev && ok; l++) {
+        ok = ctx->level_lean[l] && !ctx->level_big[l] && ctx->level_nh[l] == ctx->level_ptr[l + 1] - ctx->level_ptr[l];
+        for (auto& sg : ctx->level_segs[l])
+          if (std::find(shapes.begin(), shapes.end(), sg.shape) == shapes.end()) shapes.push_back(sg.shape);
+      }
+      for (size_t i = 0; i < shapes.size(); i++)
+        if ((shapes[i] & 255) == 0)
+          for (size_t j = 0; j < shapes.size(); j++)
+            if (j != i && shapes[i] >= 0 && (shapes[j] >> 8) == (shapes[i] >> 8) && (shapes[j] & 255) > 0) {
+              shapes[i] = -1;
+              break;
+            }
+      shapes.erase(std::remove(shapes.begin(), shapes.end(), -1), shapes.end());
+      std::sort(shapes.begin(), shapes.end());
+      note("a level without lean kernels");
+      ok = ok && !shapes.empty() && shapes.size() <= 2;
+      note("more than two register shapes");
+      if (ok) {
+        sa = shapes[0];
+        sb = shapes.back();
       }
     }
-    if (sb != 0 && sb < sa) std::swap(sa, sb);
-    if (sb == 0) sb = sa;
+    // (a tree that is one long chain keeps the chain kernel: one wavefront, no hand-offs)
+    ok = ok && (nlev <= 64 || cnt_all >= 4 * nlev);
+    note("a long chain");
     ok = ok && FusedTreeCompiled(sa, sb);
+    note("no instance for the pair of shapes");
     std::vector<int> recs((size_t)cnt_all * kFusedRecWords, 0), xreg;
     std::vector<long long> xsrc, rsrc;
     for (int pos = 0; pos < cnt_all && ok; pos++) {
@@ -1388,6 +1409,7 @@ int BuildPlans(cxk_context* ctx) {
       const int nse = (int)r.size(), nsp = (int)sp.size();
       const int nsm = RegisterShape(ns[e], nsep[e]) >> 8;
       ok = nse == ns[e] && nsp == nsep[e] && nse + nsp <= 72 && m <= 255 && ctx->owned[i] && nsm > 0;
+      note("a supernode that is not its constraint's own block");
       if (!ok) break;
       int* w = recs.data() + (size_t)pos * kFusedRecWords;
       memcpy(w, &h_recs[pos], sizeof(SnRec));
@@ -1404,6 +1426,7 @@ int BuildPlans(cxk_context* ctx) {
         ok = sp[a] >= 0 && sp[a] < m;
         ar.pos[nse + a] = (unsigned char)sp[a];
       }
+      note("a fill-in row (position -1)");
       if (!ok) break;
       memcpy(w + 32, &ar, sizeof(AsmRec));
       // entries with further sources, in the order of the panel (columns of the diagonal block, then
@@ -1424,9 +1447,11 @@ int BuildPlans(cxk_context* ctx) {
         for (int i2 = j; i2 < nse && ok; i2++) ok = visit(L.diag_off[e] + (int64_t)j * nse + i2, r[i2], r[j], 64 * j + i2);
       for (int j = 0; j < nsp && ok; j++)
         for (int i2 = 0; i2 < nse && ok; i2++) ok = visit(L.offd_off[e] + (int64_t)j * nse + i2, r[i2], sp[j], 64 * i2 + nsm + j);
+      note("an entry whose first source is not the own block");
       size_t mx = 0;
       for (auto& x : extra) mx = std::max(mx, x.second.size());
-      ok = ok && extra.size() <= (size_t)kFusedExtraTargets && mx <= (size_t)kFusedExtraSlots;
+      ok = ok && extra.size() <= (size_t)kFusedExtraTargets && mx <= (size_t)kFusedExtraMax;
+      note("too many entries with further sources / too many sources");
       // variables that several constraints share: all their sources, in the gather's order
       size_t mr = 0;
       for (int a = 0; a < nse && ok; a++) {
@@ -1437,7 +1462,9 @@ int BuildPlans(cxk_context* ctx) {
           ok = !lst.empty() && std::find(lst.begin(), lst.end(), ar.r_off + r[a]) != lst.end();
         if (lst.size() > 1) mr = std::max(mr, lst.size());
       }
-      ok = ok && mr <= (size_t)kFusedExtraSlots;
+      note("a variable whose sources do not include the own constraint");
+      ok = ok && mr <= (size_t)kFusedExtraMax;
+      note("a variable shared by more than 64 constraints");
       if (!ok) break;
       const int64_t xbase = (int64_t)xsrc.size();
       w[56] = (int)xreg.size();
@@ -1478,7 +1505,9 @@ int BuildPlans(cxk_context* ctx) {
           }
           ok = ok && pos_of[p] > pos;  // (waits go to lower positions on the way up)
         }
+        note("a consumer at a lower position");
         ok = ok && cons_of[e].size() <= 8;
+        note("a supernode with more than 8 consumers");
       }
       std::vector<int> pbase(K, 0);
       for (int pos = 0; pos < cnt_all && ok; pos++) {
@@ -1486,6 +1515,7 @@ int BuildPlans(cxk_context* ctx) {
         pbase[e] = (int)(us + ubs + nprobe);
         nprobe += kids[e].size();
         ok = kids[e].size() <= 64;
+        note("a supernode with more than 64 publishers");
       }
       ok = ok && us + ubs + nprobe + 8 < (size_t)INT32_MAX;
       for (int pos = 0; pos < cnt_all && ok; pos++) {
@@ -1503,16 +1533,20 @@ int BuildPlans(cxk_context* ctx) {
         }
       }
     }
+    bool split = false;
     if (ok) {
       // residency: every workgroup (one wavefront each, one more for the scalars) at once, with a
-      // CU's worth of margin per slot count the occupancy query may overstate
+      // CU's worth of margin per slot count the occupancy query may overstate; a larger tree takes
+      // the way up and the way down as two launches (tree_fused.h, FusedTreeMode)
       const int occ = FusedTreeOccupancy(sa, sb);
-      ok = occ >= 2 && (int64_t)cnt_all + 1 <= (int64_t)(occ - 1) * ctx->cus;
+      ok = occ >= 2;
+      note("occupancy query failed");
+      split = (int64_t)cnt_all + 1 > (int64_t)(occ - 1) * ctx->cus || getenv("CXK_FUSED_SPLIT") != nullptr;
     }
     if (ok) {
       xreg.resize(xreg.size() + kPullPad, 0);
-      xsrc.resize(xsrc.size() + kPullPad * kFusedExtraSlots, -1ll);
-      rsrc.resize(rsrc.size() + 64 * kFusedExtraSlots, -1ll);
+      xsrc.resize(xsrc.size() + kPullPad * kFusedExtraMax, -1ll);
+      rsrc.resize(rsrc.size() + 64 * kFusedExtraMax, -1ll);
       pub.resize(pub.size() + 64, (int)slots);
       // hand-off slots: every slot with a producer starts as the sentinel in BOTH sets, the rest 0.0
       const double sent = [] {
@@ -1545,10 +1579,14 @@ int BuildPlans(cxk_context* ctx) {
       ctx->fused_sb = sb;
       ctx->fused_gen = 0;
       ctx->fused_tree = true;
+      ctx->fused_split = split;
       ctx->fused_sweep = getenv("CXK_NO_FUSED_SWEEP") == nullptr;
       if (getenv("CXK_DEBUG_LEVELS"))
-        fprintf(stderr, "whole tree in one launch: %d supernodes, shapes <%d,%d> <%d,%d>, %zu entries / %zu variables with further sources\n",
-                cnt_all, sa >> 8, sa & 255, sb >> 8, sb & 255, xreg.size() - kPullPad, rsrc.size());
+        fprintf(stderr, "whole tree in %s: %d supernodes, shapes <%d,%d> <%d,%d>, %zu entries / %zu variables with further sources\n",
+                split ? "two launches (up, down)" : "one launch", cnt_all, sa >> 8, sa & 255, sb >> 8, sb & 255,
+                xreg.size() - kPullPad, rsrc.size());
+    } else if (getenv("CXK_DEBUG_LEVELS")) {
+      fprintf(stderr, "whole-tree launch not taken: %s\n", why ? why : "(unnamed check)");
     }
   }
   // ---- the top as one dense T x T factorization (single GPU, Cholesky): tables for
@@ -2567,7 +2605,12 @@ int LaunchFusedTreeSolve(cxk_context* ctx) {
   a.cq = ap.cq;
   a.cw = ap.cw;
   a.comb = ap.with_rhs == 2;
-  CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, false, ctx->stream));
+  if (ctx->fused_split) {
+    CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedUp, ctx->stream));
+    CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedDown, ctx->stream));
+  } else {
+    CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedFull, ctx->stream));
+  }
   return CXK_SUCCESS;
 }
 
@@ -2584,7 +2627,12 @@ int LaunchFusedTreeSweep(cxk_context* ctx) {
   a.cb = ri.cb;
   a.cq = ri.cq;
   a.cw = ri.cw;
-  CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, true, ctx->stream));
+  if (ctx->fused_split) {
+    CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedForward, ctx->stream));
+    CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedDown, ctx->stream));
+  } else {
+    CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedSolve, ctx->stream));
+  }
   return CXK_SUCCESS;
 }
 

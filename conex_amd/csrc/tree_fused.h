@@ -18,7 +18,8 @@ constexpr unsigned long long kFusedSentinel = 0x7FF4C0DEC0DE5EEDull;
 
 constexpr int kFusedRecWords = 64;   // one record per supernode: 256 bytes, one dword per lane
 constexpr int kFusedExtraTargets = 128;  // panel entries with more than one source (two per lane)
-constexpr int kFusedExtraSlots = 8;      // further sources per such entry / sources per shared variable
+constexpr int kFusedExtraSlots = 8;      // further sources per such entry / sources per shared variable fetched at once
+constexpr int kFusedExtraMax = 64;       // ... at most (longer lists: the level kernels)
 
 // Words of a record (position = dependency order: a supernode only waits for lower positions):
 //   [0, 32)   SnRec (kernels_kkt.hip.h); its spare words: 21 first arrival word of this supernode's
@@ -64,14 +65,18 @@ struct FusedTreeArgs {
   double* host_flag;  // pinned host word: set to 1.0 when a wait ran out (the sets are then rebuilt)
 };
 
-// Register shapes (NSMAX << 8 | SMAX) of the tree's supernodes: at most two.  False when no
-// instance is compiled for the pair.
+// What a launch does.  A tree whose supernodes are all resident at once takes kFusedFull (assembly,
+// factorization with the first right-hand side, back substitution) and kFusedSolve (forward + back
+// substitution on the stored factor); a larger one the same work as two launches each -- kFusedUp
+// then kFusedDown, kFusedForward then kFusedDown -- because a wavefront that waits for its
+// ANCESTORS while it holds a slot could keep them from ever starting.
+enum FusedTreeMode { kFusedFull = 0, kFusedSolve = 1, kFusedUp = 2, kFusedForward = 3, kFusedDown = 4 };
+
+// Register shapes (NSMAX << 8 | SMAX) of the tree's supernodes: at most two (shape_b == shape_a for
+// one).  False when no instance is compiled for the pair.
 bool FusedTreeCompiled(int shape_a, int shape_b);
-size_t FusedTreeLds(int shape_a, int shape_b);
 // Workgroups per CU the hardware can hold of the instance (0 on error).
 int FusedTreeOccupancy(int shape_a, int shape_b);
-// solve_only: forward and back substitution on the stored factor (FusedTreeArgs::form picks the
-// right-hand side) instead of assembly + factorization + solve.
-hipError_t LaunchFusedTree(const FusedTreeArgs& a, int shape_a, int shape_b, bool solve_only, hipStream_t stream);
+hipError_t LaunchFusedTree(const FusedTreeArgs& a, int shape_a, int shape_b, int mode, hipStream_t stream);
 
 }  // namespace cxk

@@ -86,7 +86,11 @@ __device__ __forceinline__ void ReportTimeout(const FusedTreeArgs& A) {
 }
 
 // One supernode: w = this lane's word of its record (kFusedRecWords dwords, one per lane).
-template <int NSMAX, int SMAX>
+// UP_ONLY: the first of two launches (trees with more supernodes than the chip holds wavefronts: a
+// supernode that waited for its ANCESTORS' solution while holding its slot could keep them from ever
+// starting): stops after publishing, leaves the factor and the forward-solved right-hand side in
+// memory; the back substitution is tree_fused_down's.
+template <int NSMAX, int SMAX, bool UP_ONLY = false>
 __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int w, double* __restrict__ my) {
   static_assert(NSMAX + SMAX <= 64, "one lane per panel row");
   constexpr int RB = NSMAX + SMAX, MMAX = kFastSlots, MFMAX = kFastSlots, XMAX = kFusedExtraSlots;
@@ -232,6 +236,22 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
         awv += ax[i];
         aqv += qx[i];
       }
+    // (a variable more than XMAX constraints share: the rest of its list, XMAX at a time)
+    for (int c0 = XMAX; c0 < mr; c0 += XMAX) {
+#pragma unroll
+      for (int i = 0; i < XMAX; i++) rs[i] = A.rsrc[rbase + (is_row ? lane : 0) * mr + (c0 + i < mr ? c0 + i : mrl)];
+#pragma unroll
+      for (int i = 0; i < XMAX; i++) {
+        ax[i] = A.AWc[rs[i] >= 0 ? rs[i] : 0];
+        qx[i] = A.AQcc[rs[i] >= 0 ? rs[i] : 0];
+      }
+#pragma unroll
+      for (int i = 0; i < XMAX; i++)
+        if (c0 + i < mr && rs[i] >= 0) {
+          awv += ax[i];
+          aqv += qx[i];
+        }
+    }
   }
   // the expressions of build_rhs / build_rhs_comb, term for term
   if (A.comb)
@@ -265,6 +285,23 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
         for (int i = 0; i < XMAX; i++) acc += gx1[i];
         my[xloc1] = acc;
       }
+      // (an entry with more than XMAX further sources: the rest of its list, XMAX at a time)
+      for (int c0 = XMAX; c0 < mx; c0 += XMAX)
+        for (int half = 0; half < 2 && 64 * half < nxt; half++) {
+          const int t = lane + 64 * half;
+          const int ts = t < nxt ? t : 0;
+          long long xs[XMAX];
+          double gv[XMAX];
+#pragma unroll
+          for (int i = 0; i < XMAX; i++) xs[i] = A.xsrc[xbase + (int64_t)ts * mx + (c0 + i < mx ? c0 + i : mx - 1)];
+#pragma unroll
+          for (int i = 0; i < XMAX; i++) gv[i] = A.G[xs[i] >= 0 ? xs[i] : 0];
+          const int xloc = half ? xloc1 : xloc0;
+          double acc = my[xloc];
+#pragma unroll
+          for (int i = 0; i < XMAX; i++) acc += (c0 + i < mx && xs[i] >= 0) ? gv[i] : 0.0;
+          if (t < nxt) my[xloc] = acc;
+        }
       WaveSync();
     }
   }
@@ -381,6 +418,25 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     }
   }
   FT_STAMP(7);  // published
+  if constexpr (UP_ONLY) {
+#pragma unroll
+    for (int j = 0; j < NSMAX; j++)
+      if (j < lim) base[o0 + j * st] = a[j];
+    if (is_row) {
+      A.y[R.start + lane] = a[RB];
+      A.AW[R.start + lane] = awv;
+      A.AQc[R.start + lane] = aqv;
+    }
+    if constexpr (SMAX > 0) {
+      if (s > 0) {
+#pragma unroll
+        for (int r = 0; r < PR; r++)
+          if (lane + 64 * r < nv) StoreAgent(handO + pd[r], SentinelValue());
+        if (lane < 8 && ppr >= 0) StoreAgent(handO + ppr, SentinelValue());
+      }
+    }
+    return;
+  }
   // ---- the way back down: rows of L become columns through an LDS image with an odd stride
   // (RootBackward's), lane i owns y_i; the separator's solution comes from the ancestors
   const int cnt = R.bs_end - R.bs_beg;
@@ -500,7 +556,10 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
 // the same hand-off slots (forward values, arrival words, solution entries).  Arithmetic and its
 // order are ForwardSupernodeLean's and BackwardSupernodeLean's.  The rows of L (forward) and its
 // columns (backward) both come straight from the slab.
-template <int NSMAX, int SMAX>
+// PHASE 0: forward and back substitution; 1: forward only (the forward-solved right-hand side goes
+// to y); 2: back substitution only (reads it from there): the two launches of a tree too large to
+// be resident at once, see FusedSupernode.
+template <int NSMAX, int SMAX, int PHASE = 0>
 __device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, const int w) {
   static_assert(NSMAX + SMAX <= 64, "one lane per panel row");
   constexpr int MFMAX = kFastSlots;
@@ -533,7 +592,7 @@ __device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, cons
   double dg = base[is_row ? (unsigned)lane * (unsigned)(ns + 1) : 0u];
   const int p = R.start + (is_row ? lane : 0);
   double b;
-  if (A.form == 0) {
+  if (PHASE == 2 || A.form == 0) {
     b = A.y[p];
   } else {
     const double bp = A.b[p], aq = A.AQc[p], aw = A.AW[p];
@@ -561,7 +620,7 @@ __device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, cons
   double pb[MFMAX];
 #pragma unroll
   for (int i = 0; i < MFMAX; i++) pb[i] = 0.0;
-  if (R.mf > 0) {
+  if (PHASE != 2 && R.mf > 0) {
     {
       const double* src = handG + probe_base + (lane < nch ? lane : 0);
       for (int spin = 0;; spin++) {
@@ -591,6 +650,7 @@ __device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, cons
     }
   }
   // ---- forward substitution (ForwardSupernodeLean)
+  if constexpr (PHASE != 2) {
 #pragma unroll
   for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? a[j] : 0.0;
   b = is_row ? b : 0.0;
@@ -614,7 +674,12 @@ __device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, cons
       if (lane < 8 && ppr >= 0) StoreAgent(handG + ppr, 1.0);
     }
   }
+  }  // PHASE != 2
+  if constexpr (PHASE == 1) {
+    if (is_row) A.y[R.start + lane] = b;
+  }
   // ---- back substitution (BackwardSupernodeLean)
+  if constexpr (PHASE != 1) {
   if constexpr (QN > 0) {
     if (cnt > 0) {
       const int sepw = __builtin_amdgcn_ds_bpermute(4 * (24 + (lane < 8 ? lane : 0)), w);
@@ -652,9 +717,10 @@ __device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, cons
     A.y[R.start + lane] = acc;
     StoreAgent(ysO + R.start + lane, SentinelValue());
   }
+  }  // PHASE != 1
   // re-arm the other set: ALL of this supernode's slots, the Schur-update ones too (a factor sweep
   // may be the next run)
-  if constexpr (SMAX > 0) {
+  if constexpr (SMAX > 0 && PHASE != 2) {
     if (s > 0) {
 #pragma unroll
       for (int r = 0; r < PR; r++) {
@@ -689,7 +755,9 @@ __device__ __forceinline__ void FusedScalars(const FusedTreeArgs& A) {
   }
 }
 
-template <int NA, int SA, int NB, int SB>
+// MODE 0: the whole sweep (assembly + factor + solve); 1: its upward half only (two launches: trees
+// too large to be resident at once)
+template <int NA, int SA, int NB, int SB, int MODE>
 __global__ void __launch_bounds__(64) tree_fused(FusedTreeArgs A) {
   extern __shared__ double lds[];
   const int pos = blockIdx.x;
@@ -699,110 +767,98 @@ __global__ void __launch_bounds__(64) tree_fused(FusedTreeArgs A) {
   }
   const int w = A.rec[(size_t)pos * kFusedRecWords + (threadIdx.x & 63)];
   const int ns = __builtin_amdgcn_readlane(w, 1), s = __builtin_amdgcn_readlane(w, 2);
-  if (RegisterShape(ns, s) == (NA << 8 | SA))
-    FusedSupernode<NA, SA>(A, w, lds);
-  else
-    FusedSupernode<NB, SB>(A, w, lds);
-}
-
-template <int NA, int SA>
-__global__ void __launch_bounds__(64) tree_fused1(FusedTreeArgs A) {
-  extern __shared__ double lds[];
-  const int pos = blockIdx.x;
-  if (pos >= A.count) {
-    FusedScalars(A);
-    return;
+  if (NA == NB && SA == SB) {
+    FusedSupernode<NA, SA, MODE == 1>(A, w, lds);
+  } else if (RegisterShape(ns, s) == (NA << 8 | SA)) {
+    FusedSupernode<NA, SA, MODE == 1>(A, w, lds);
+  } else {
+    FusedSupernode<NB, SB, MODE == 1>(A, w, lds);
   }
-  const int w = A.rec[(size_t)pos * kFusedRecWords + (threadIdx.x & 63)];
-  FusedSupernode<NA, SA>(A, w, lds);
 }
 
-template <int NA, int SA, int NB, int SB>
+// PHASE 0: forward + back substitution in one launch; 1: forward only; 2: back substitution only,
+// workgroups in REVERSE position order (the root first: a supernode waits for its ancestors)
+template <int NA, int SA, int NB, int SB, int PHASE>
 __global__ void __launch_bounds__(64) tree_fused_solve(FusedTreeArgs A) {
-  const int pos = blockIdx.x;
+  const int pos = PHASE == 2 ? A.count - 1 - (int)blockIdx.x : (int)blockIdx.x;
   const int w = A.rec[(size_t)pos * kFusedRecWords + (threadIdx.x & 63)];
   const int ns = __builtin_amdgcn_readlane(w, 1), s = __builtin_amdgcn_readlane(w, 2);
-  if (RegisterShape(ns, s) == (NA << 8 | SA))
-    FusedSolveSupernode<NA, SA>(A, w);
-  else
-    FusedSolveSupernode<NB, SB>(A, w);
-}
-
-template <int NA, int SA>
-__global__ void __launch_bounds__(64) tree_fused_solve1(FusedTreeArgs A) {
-  const int pos = blockIdx.x;
-  const int w = A.rec[(size_t)pos * kFusedRecWords + (threadIdx.x & 63)];
-  FusedSolveSupernode<NA, SA>(A, w);
+  if (NA == NB && SA == SB) {
+    FusedSolveSupernode<NA, SA, PHASE>(A, w);
+  } else if (RegisterShape(ns, s) == (NA << 8 | SA)) {
+    FusedSolveSupernode<NA, SA, PHASE>(A, w);
+  } else {
+    FusedSolveSupernode<NB, SB, PHASE>(A, w);
+  }
 }
 
 namespace {
 // doubles of LDS one wavefront needs: the transposed image of L (65 NSMAX) / the publish scratch (64 (SMAX + 1))
 constexpr int FusedImage(int nsmax, int smax) { return 65 * nsmax > 64 * (smax + 1) ? 65 * nsmax : 64 * (smax + 1); }
-template <typename F>
-bool ForPair(int sa, int sb, F&& fn) {
-#define CXK_FUSED_ONE(NA_, SA_)                                                     \
-  if (sa == ((NA_) << 8 | (SA_)) && sb == sa) {                                     \
-    fn(reinterpret_cast<const void*>(&tree_fused1<NA_, SA_>),                       \
-       reinterpret_cast<const void*>(&tree_fused_solve1<NA_, SA_>), FusedImage(NA_, SA_)); \
-    return true;                                                                    \
+
+struct FusedKernels {
+  const void* k[5];  // FusedTreeMode order
+  int image;         // doubles of LDS of the factor sweeps
+};
+
+template <int NA, int SA, int NB, int SB>
+FusedKernels KernelsOf() {
+  FusedKernels f;
+  f.k[kFusedFull] = reinterpret_cast<const void*>(&tree_fused<NA, SA, NB, SB, 0>);
+  f.k[kFusedSolve] = reinterpret_cast<const void*>(&tree_fused_solve<NA, SA, NB, SB, 0>);
+  f.k[kFusedUp] = reinterpret_cast<const void*>(&tree_fused<NA, SA, NB, SB, 1>);
+  f.k[kFusedForward] = reinterpret_cast<const void*>(&tree_fused_solve<NA, SA, NB, SB, 1>);
+  f.k[kFusedDown] = reinterpret_cast<const void*>(&tree_fused_solve<NA, SA, NB, SB, 2>);
+  f.image = FusedImage(NA, SA) > FusedImage(NB, SB) ? FusedImage(NA, SA) : FusedImage(NB, SB);
+  return f;
+}
+
+bool ForPair(int sa, int sb, FusedKernels* out) {
+#define CXK_FUSED_PAIR(NA_, SA_, NB_, SB_)                          \
+  if (sa == ((NA_) << 8 | (SA_)) && sb == ((NB_) << 8 | (SB_))) {   \
+    if (out) *out = KernelsOf<NA_, SA_, NB_, SB_>();                \
+    return true;                                                    \
   }
-#define CXK_FUSED_PAIR(NA_, SA_, NB_, SB_)                                                          \
-  if (sa == ((NA_) << 8 | (SA_)) && sb == ((NB_) << 8 | (SB_))) {                                   \
-    fn(reinterpret_cast<const void*>(&tree_fused<NA_, SA_, NB_, SB_>),                              \
-       reinterpret_cast<const void*>(&tree_fused_solve<NA_, SA_, NB_, SB_>),                        \
-       FusedImage(NA_, SA_) > FusedImage(NB_, SB_) ? FusedImage(NA_, SA_) : FusedImage(NB_, SB_));   \
-    return true;                                                                                    \
-  }
-  CXK_FUSED_ONE(8, 8)
-  CXK_FUSED_ONE(16, 8)
-  CXK_FUSED_ONE(24, 0)
-  CXK_FUSED_ONE(24, 8)
-  CXK_FUSED_ONE(32, 16)
+  CXK_FUSED_PAIR(8, 8, 8, 8)
+  CXK_FUSED_PAIR(16, 8, 16, 8)
+  CXK_FUSED_PAIR(24, 0, 24, 0)
+  CXK_FUSED_PAIR(24, 8, 24, 8)
+  CXK_FUSED_PAIR(32, 16, 32, 16)
   CXK_FUSED_PAIR(8, 8, 16, 8)
   CXK_FUSED_PAIR(8, 8, 24, 0)
+  CXK_FUSED_PAIR(8, 8, 24, 8)
+  CXK_FUSED_PAIR(8, 8, 32, 16)
   CXK_FUSED_PAIR(16, 8, 24, 0)
   CXK_FUSED_PAIR(16, 8, 24, 8)
+  CXK_FUSED_PAIR(16, 8, 32, 16)
   CXK_FUSED_PAIR(24, 0, 24, 8)
   CXK_FUSED_PAIR(24, 0, 32, 16)
-#undef CXK_FUSED_ONE
+  CXK_FUSED_PAIR(24, 8, 32, 16)
 #undef CXK_FUSED_PAIR
   return false;
 }
 }  // namespace
 
-bool FusedTreeCompiled(int sa, int sb) {
-  return ForPair(sa, sb, [](const void*, const void*, int) {});
-}
-
-size_t FusedTreeLds(int sa, int sb) {
-  size_t lds = 0;
-  ForPair(sa, sb, [&](const void*, const void*, int doubles) { lds = sizeof(double) * (size_t)doubles; });
-  return lds;
-}
+bool FusedTreeCompiled(int sa, int sb) { return ForPair(sa, sb, nullptr); }
 
 int FusedTreeOccupancy(int sa, int sb) {
-  int nb = 0;
-  ForPair(sa, sb, [&](const void* k, const void* ks, int doubles) {
-    int nbs = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 64, sizeof(double) * (size_t)doubles) != hipSuccess) nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, ks, 64, 0) != hipSuccess) nbs = 0;
-    nb = nb < nbs ? nb : nbs;
-  });
-  return nb;
+  FusedKernels f;
+  if (!ForPair(sa, sb, &f)) return 0;
+  int nb = 0, nbs = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f.k[kFusedFull], 64, sizeof(double) * (size_t)f.image) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, f.k[kFusedSolve], 64, 0) != hipSuccess) return 0;
+  return nb < nbs ? nb : nbs;
 }
 
-hipError_t LaunchFusedTree(const FusedTreeArgs& a, int sa, int sb, bool solve_only, hipStream_t stream) {
-  const void* kern = nullptr;
-  size_t lds = 0;
-  if (!ForPair(sa, sb, [&](const void* k, const void* ks, int doubles) {
-        kern = solve_only ? ks : k;
-        lds = solve_only ? 0 : sizeof(double) * (size_t)doubles;
-      }))
-    return hipErrorInvalidValue;
+hipError_t LaunchFusedTree(const FusedTreeArgs& a, int sa, int sb, int mode, hipStream_t stream) {
+  FusedKernels f;
+  if (mode < 0 || mode > kFusedDown || !ForPair(sa, sb, &f)) return hipErrorInvalidValue;
+  const bool factor = mode == kFusedFull || mode == kFusedUp;
   FusedTreeArgs args = a;
   void* params[] = {&args};
-  // (the factor sweep's extra workgroup sums the two scalars)
-  return hipLaunchKernel(kern, dim3(a.count + (solve_only ? 0 : 1)), dim3(64), params, lds, stream);
+  // (the factor sweeps' extra workgroup sums the two scalars)
+  return hipLaunchKernel(f.k[mode], dim3(a.count + (factor ? 1 : 0)), dim3(64), params,
+                         factor ? sizeof(double) * (size_t)f.image : 0, stream);
 }
 
 }  // namespace cxk

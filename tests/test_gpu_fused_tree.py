@@ -77,6 +77,38 @@ def test_fused_tree_equals_level_kernels(K, n, branching, overlap):
     assert np.array_equal(fused.get_y(), levels.get_y())
 
 
+@pytest.mark.parametrize("K,n,branching,overlap", [(100, 20, 8, 5), (41, 12, 2, 7)])
+def test_fused_tree_as_two_launches_equals_level_kernels(K, n, branching, overlap):
+    """A tree with more supernodes than the chip holds wavefronts takes the way up and the way down
+    as two launches (CXK_FUSED_SPLIT=1 forces that on a small tree): same results."""
+    prob = syn.lmi_problem(K=K, n=n, m=20, branching=branching, overlap=overlap, seed=41)
+    W = syn.scaling_points(K, n, seed=42)
+
+    def make():
+        k = syn.build(KktContext, prob, "lmi", device=0)
+        for i in range(k.K):
+            k.set_W(i, W[i])
+        k.set_cost(prob["b"])
+        return k
+
+    os.environ["CXK_FUSED_SPLIT"] = "1"
+    try:
+        fused, levels = both_paths(make)
+    finally:
+        os.environ.pop("CXK_FUSED_SPLIT", None)
+    for mu in (0.7, 0.4, 0.9):
+        for k in (fused, levels):
+            k.kkt_solve_async(mu, 0.9, 0.8)
+            assert k.sync()
+        a, b = snapshot(fused), snapshot(levels)
+        for x, y in zip(a, b):     # (the two-launch form sweeps back down as the level kernels do: same bits)
+            assert np.array_equal(x, y, equal_nan=True)
+        for k in (fused, levels):
+            k.solve_rhs(0.3, -0.2, 1.5)
+            assert k.sync()
+        assert np.array_equal(fused.get_y(), levels.get_y())
+
+
 def test_fused_tree_against_the_oracle_and_two_runs_agree():
     prob = syn.lmi_problem(K=150, n=20, m=20, branching=8, overlap=5, seed=5)
     W = syn.scaling_points(150, 20, seed=6)
@@ -126,8 +158,7 @@ def test_fused_tree_on_the_mixed_program_shapes():
 
     os.environ.pop("CXK_NO_FUSED_TREE", None)
     fused = make()
-    if not fused.fused_tree():
-        pytest.skip("no whole-tree instance for this program's shapes")
+    assert fused.fused_tree()
     os.environ["CXK_NO_FUSED_TREE"] = "1"
     try:
         levels = make()
