@@ -16,6 +16,15 @@ from test_gpu_random_structures import random_program
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def level_kernels_only():
+    """This module is about the LEVEL kernels: the whole-tree launch, which takes over where a tree
+    allows it, has its own comparison against them (test_gpu_fused_tree.py)."""
+    os.environ["CXK_NO_FUSED_TREE"] = "1"
+    yield
+    os.environ.pop("CXK_NO_FUSED_TREE", None)
+
+
 def both_paths(make):
     """-> (lean context, generic context), same program."""
     os.environ.pop("CXK_NO_LEAN", None)
