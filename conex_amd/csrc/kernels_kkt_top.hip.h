@@ -45,10 +45,18 @@ struct TopDenseArgs {
                                      // with a slot that is always 0.0)
 };
 
+struct ElimNoSink {
+  __device__ __forceinline__ void operator()(int, double) const {}
+};
+
+// sink(j, column): called with column j of L as soon as it is final (lane r holds L[r][j]): a caller
+// that stores the factor does it there, where the store's issue time hides behind the next pivot's
+// dependent chain (tree_fused.hip).
 template <int TM, int J>
 struct ElimWide {
   static constexpr int LEN = TM + 1;
-  static __device__ __forceinline__ void run(double (&a)[LEN], int lane, int T, bool& bad) {
+  template <typename Sink = ElimNoSink>
+  static __device__ __forceinline__ void run(double (&a)[LEN], int lane, int T, bool& bad, Sink sink = Sink()) {
     if constexpr (J < TM) {
       if (J < T) {  // wave-uniform: columns >= T are padding
         const double d = ReadLane(a[J], J);
@@ -56,6 +64,7 @@ struct ElimWide {
         double root, inv;
         SqrtAndInverse(d, root, inv);
         a[J] = (lane == J) ? root : a[J] * inv;
+        sink(J, a[J]);
         // column J of L, DPP row k mirrored into every row: m[k]
         const RowPair p16 = Swap16(a[J]);  // a = [r0 r0 r2 r2], b = [r1 r1 r3 r3]
         double m0 = p16.a, m1 = p16.b, m2 = 0.0, m3 = 0.0;
@@ -83,7 +92,7 @@ struct ElimWide {
         else if (lane == J)
           a[TM] = yj;
       }
-      ElimWide<TM, J + 1>::run(a, lane, T, bad);
+      ElimWide<TM, J + 1>::run(a, lane, T, bad, sink);
     }
   }
 };

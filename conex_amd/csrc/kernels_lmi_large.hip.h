@@ -630,19 +630,21 @@ inline hipError_t LmiLargeSchur(const LmiGroup& g, const Arena& ar, const LmiLar
   const int64_t nn = (int64_t)n * n;
   hipError_t e;
   {  // PT[c,i] = W[c] A[c,i] (= P[c,i]^T, both factors symmetric), P = its transposed copy: ONE
-     // n x (n m) GEMM per constraint against the matrices side by side, [A_1 ... A_m] (contiguous,
-     // leading dimension n), instead of m GEMMs of n^3 -- at n = 200 the 64-wide tiles are 78 %
-     // full instead of 61 %.  Same products in the same k order as A_i W: same bits.
+     // n x (n (m + 1)) GEMM per constraint against the matrices side by side, [A_1 ... A_m C] (the
+     // host stores C behind the A_i: contiguous, leading dimension n), instead of m + 1 GEMMs of n^3
+     // -- at n = 200 the 64-wide tiles are 78 % full instead of 61 %, and the affine term no longer
+     // costs a launch of its own (a lone 200^3 product: 16 workgroups, 17 us of latency).  Same
+     // products in the same k order as A_i W: same bits.
     GemmArgs a{};
     a.M = n;
-    a.N = n * m;
+    a.N = n * m1;
     a.K = n;
     a.A = g.W;
     a.lda = n;
     a.sA1 = nn;
     a.B = g.A;
     a.ldb = n;
-    a.sB1 = m * nn;
+    a.sB1 = g.a_stride;
     a.C = ws.PT;
     a.ldc = n;
     a.sC1 = m1 * nn;
@@ -655,13 +657,6 @@ inline hipError_t LmiLargeSchur(const LmiGroup& g, const Arena& ar, const LmiLar
     a.alpha = 1.0;
     a.beta = 0.0;
     a.splits = 1;
-    if (m > 0 && (e = LaunchGemm(a, false, false, g.count, st)) != hipSuccess) return e;
-  }
-  {  // P[c,m] = C[c] W[c]
-    GemmArgs a = SquareGemm(n, g.C, nn, g.W, nn, ws.P + m * nn, m1 * nn);
-    a.Ct = ws.PT + m * nn;
-    a.ldct = n;
-    a.sT1 = m1 * nn;
     if ((e = LaunchGemm(a, false, false, g.count, st)) != hipSuccess) return e;
   }
   {  // Gf[c] = X^T Y, X = P[c] (n^2 x m1), Y = PT[c]

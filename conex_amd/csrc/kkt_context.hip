@@ -393,7 +393,7 @@ LmiGroup MakeLmi(Group& g) {
   d.m = g.m;
   d.count = static_cast<int>(g.ids.size());
   d.A = g.A.p;
-  d.a_stride = (long long)(g.mfma ? g.m + 1 : g.m) * g.n * g.n;
+  d.a_stride = (long long)((g.mfma || g.schur_gemm) ? g.m + 1 : g.m) * g.n * g.n;
   d.C = g.C.p;
   d.W = g.W.p;
   d.T1 = g.T1.p;
@@ -1367,7 +1367,13 @@ int BuildPlans(cxk_context* ctx) {
       if (!ok && !why) why = msg;
     };
     int sa = 0, sb = 0;
-    {
+    // a program that is ONE dense supernode of 33 .. 64 columns (BASELINE config 2: 50): the wide
+    // instances of the same launch (tree_fused.hip, ElimWide)
+    const bool wide_single = ok && cnt_all == 1 && K >= 1 && ns[ctx->level_sn[0]] > 32 && ns[ctx->level_sn[0]] <= 64 &&
+                             nsep[ctx->level_sn[0]] == 0 && !getenv("CXK_NO_FUSED_WIDE");
+    if (wide_single) {
+      sa = sb = ((ns[ctx->level_sn[0]] + 7) / 8 * 8) << 8;
+    } else {
       // at most two register shapes; a shape without separator columns <N, 0> runs on <N, S> where
       // the tree has one (same rows per lane: the pull locations tg_reg are the same)
       std::vector<int> shapes;
@@ -1407,7 +1413,7 @@ int BuildPlans(cxk_context* ctx) {
       const IntList& r = md.supernodes_pos[e];
       const IntList& sp = md.separators_pos[e];
       const int nse = (int)r.size(), nsp = (int)sp.size();
-      const int nsm = RegisterShape(ns[e], nsep[e]) >> 8;
+      const int nsm = wide_single ? sa >> 8 : RegisterShape(ns[e], nsep[e]) >> 8;
       ok = nse == ns[e] && nsp == nsep[e] && nse + nsp <= 72 && m <= 255 && ctx->owned[i] && nsm > 0;
       note("a supernode that is not its constraint's own block");
       if (!ok) break;
@@ -3418,7 +3424,7 @@ static int FinalizeImpl(cxk_context* ctx) {
     }
     // lmi_schur_mfma reads [A_1 .. A_m | C] of a constraint as one contiguous array of stacked
     // rows: such groups keep a copy of C right behind the A_i (LmiGroup::a_stride)
-    const size_t a_blk = a_sz + (g.type == CXK_LMI && g.mfma ? c_sz : 0);
+    const size_t a_blk = a_sz + (g.type == CXK_LMI && (g.mfma || g.schur_gemm) ? c_sz : 0);
     std::vector<double> hA(a_blk * cnt), hC(c_sz * cnt);
     for (size_t k = 0; k < cnt; k++) {
       const ConstraintRec& c = ctx->cons[g.ids[k]];
@@ -3484,7 +3490,10 @@ static int FinalizeImpl(cxk_context* ctx) {
       // split-K of the contraction: enough workgroups to fill the chip, at most one K step each
       const int ksteps = (int)((nn + kGemmBK - 1) / kGemmBK);
       const int tiles = (int)(((m1 + 63) / 64) * ((m1 + 63) / 64));
-      g.splits = std::max(1, std::min(std::max(1, ksteps / 8), (int)((512 + cnt * tiles - 1) / (cnt * tiles))));
+      // (measured on BASELINE config 2, one constraint, K = 40 000: 39 / 78 / 156 / 312 / 512 / 768 / 1024
+      // splits -> 115 / 93 / 82 / 81 / 76 / 80 / 82 us per KKT solve)
+      g.splits = std::max(1, std::min(std::max(1, ksteps / 4), (int)((512 + cnt * tiles - 1) / (cnt * tiles))));
+      if (getenv("CXK_GRAM_SPLITS")) g.splits = std::max(1, atoi(getenv("CXK_GRAM_SPLITS")));  // (comparison runs)
       CXK_TRY(g.ws_main.alloc(cnt * std::max(2 * m1 * nn, 8 * nn)));
       CXK_TRY(g.ws_gf.alloc(cnt * m1 * m1));
       CXK_TRY(g.ws_piv.alloc(cnt * (size_t)g.n));

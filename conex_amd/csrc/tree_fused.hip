@@ -37,6 +37,7 @@
 
 #define CXK_DEVICE_FUNCTIONS_ONLY
 #include "kernels_kkt.hip.h"
+#include "kernels_kkt_top.hip.h"  // ElimWide: the elimination over four mirrored DPP rows (33 .. 64 columns)
 #include "tree_fused.h"
 
 namespace cxk {
@@ -395,7 +396,19 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     if (j >= ns && lane == j) a[j] = 1.0;
   FT_STAMP(3);  // descendants' values are in
   bool bad = false;
-  ElimSteps<NSMAX, SMAX, 0>::run(a, lane, bad, ns);
+  if constexpr (NSMAX > 32) {
+    // a supernode of 33 .. 64 columns without separator (the one dense block of a single-constraint
+    // program: BASELINE config 2's 50 x 50): a column of L spans four 16-lane DPP rows
+    static_assert(SMAX == 0, "the wide elimination has no separator rows");
+    // every finished column goes to the slab and to the transposed LDS image at once: the issue time
+    // of those stores hides behind the next pivot's dependent chain (after the loop they cost ~6 us)
+    ElimWide<NSMAX, 0>::run(a, lane, ns, bad, [&](int j, double colj) {
+      if (j < lim) base[o0 + j * st] = colj;
+      my[65 * j + lane] = colj;
+    });
+  } else {
+    ElimSteps<NSMAX, SMAX, 0>::run(a, lane, bad, ns);
+  }
   FT_STAMP(4);  // eliminated
   if (bad && lane == 0) atomicExch(A.fail + 1, A.tag);  // (carries on: everybody above must still drain)
   // ---- publish (the ancestors are waiting): the values sit in the separator lanes' registers --
@@ -441,8 +454,10 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   // (RootBackward's), lane i owns y_i; the separator's solution comes from the ancestors
   const int cnt = R.bs_end - R.bs_beg;
   const bool active = is_row;
+  if constexpr (NSMAX <= 32) {
 #pragma unroll
-  for (int j = 0; j < NSMAX; j++) my[65 * j + lane] = a[j];
+    for (int j = 0; j < NSMAX; j++) my[65 * j + lane] = a[j];
+  }
   WaveSync();
   if (cnt > 0) {
     // (the root keeps its factor for after its back substitution: everybody waits for that)
@@ -535,7 +550,7 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     A.AQc[R.start + lane] = aqv;
     StoreAgent(ysO + R.start + lane, SentinelValue());
   }
-  if (cnt == 0) {
+  if (NSMAX <= 32 && cnt == 0) {
 #pragma unroll
     for (int j = 0; j < NSMAX; j++)
       if (j < lim) base[o0 + j * st] = a[j];
@@ -834,6 +849,10 @@ bool ForPair(int sa, int sb, FusedKernels* out) {
   CXK_FUSED_PAIR(24, 0, 24, 8)
   CXK_FUSED_PAIR(24, 0, 32, 16)
   CXK_FUSED_PAIR(24, 8, 32, 16)
+  CXK_FUSED_PAIR(40, 0, 40, 0)
+  CXK_FUSED_PAIR(48, 0, 48, 0)
+  CXK_FUSED_PAIR(56, 0, 56, 0)
+  CXK_FUSED_PAIR(64, 0, 64, 0)
 #undef CXK_FUSED_PAIR
   return false;
 }

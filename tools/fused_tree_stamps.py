@@ -3,7 +3,7 @@
 Every wavefront (= supernode) stamps s_memrealtime (100 MHz, chip-wide) at: 0 entry, 1 record
 decoded, 2 own panel assembled, 3 descendants' values in, 4 eliminated, 5 separator's solution in,
 6 done.  Printed per tree level: median / max of each stamp in microseconds since the first entry.
-Run on the GPU box:  python tools/fused_tree_stamps.py [K]
+Run on the GPU box:  python tools/fused_tree_stamps.py [K [n [m]]]
 """
 import ctypes as C
 import os
@@ -18,9 +18,11 @@ kk.LIB_PATH = os.path.join(os.path.dirname(kk.LIB_PATH), os.environ.get("CXK_DBG
 from conex_amd import KktContext, synthetic as syn
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+n_ = int(sys.argv[2]) if len(sys.argv) > 2 else 20      # order of the LMIs
+m_ = int(sys.argv[3]) if len(sys.argv) > 3 else 20      # variables per LMI (python tools/fused_tree_stamps.py 1 200 50: config 2)
 L = kk.load_library()
-prob = syn.lmi_problem(K=K, n=20, m=20, branching=8, overlap=5)
-W = syn.scaling_points(K, 20)
+prob = syn.lmi_problem(K=K, n=n_, m=m_, branching=8 if K > 1 else 2, overlap=5 if K > 1 else 1)
+W = syn.scaling_points(K, n_)
 ctx = syn.build(KktContext, prob, "lmi", device=0)
 assert ctx.fused_tree()
 for i in range(ctx.K):
