@@ -16,8 +16,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench --
 python3 "$ROOT/bench.py" --workload c2 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -o bench -- \
   python3 "$ROOT/bench.py" --workload c2 --no-cpu --steps 50 > "$OUT/bench_c2_under_rocprof.log" 2>&1
-# timeline of one steady-state step; the interior-point loop through conex.h, wall and per kernel
+# timeline of one steady-state step; the in-kernel timeline of the whole-tree launch (diagnostic
+# library: make -C conex_amd/csrc dbg); the interior-point loop through conex.h, wall and per kernel
 "$ROOT/tools/step_timeline.sh" c4 > "$OUT/step_timeline.txt" 2>&1
+CXK_NO_FUSED_TREE=1 "$ROOT/tools/step_timeline.sh" c4_levels > "$OUT/step_timeline_level_kernels.txt" 2>&1
+python3 "$ROOT/tools/fused_tree_stamps.py" > "$OUT/fused_tree_stamps.txt" 2>&1
+python3 "$ROOT/tools/fused_tree_stamps.py" 1 200 50 > "$OUT/fused_tree_stamps_c2.txt" 2>&1
 python3 "$ROOT/tools/ipm_iteration.py" --timers > "$OUT/ipm_iteration.txt" 2>&1
 "$ROOT/tools/ipm_rocprof.sh" 2>&1 | grep -v "^[EW]20" > "$OUT/ipm_kernels.txt"
 cd /tmp

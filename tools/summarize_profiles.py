@@ -24,7 +24,8 @@ def main():
     dst = os.path.join(ROOT, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
     for name in ["bench_default.json", "bench_default_under_rocprof.log", "bench_c2.json",
-                 "bench_c2_under_rocprof.log", "step_timeline.txt", "ipm_iteration.txt", "ipm_kernels.txt"]:
+                 "bench_c2_under_rocprof.log", "step_timeline.txt", "step_timeline_level_kernels.txt",
+                 "fused_tree_stamps.txt", "fused_tree_stamps_c2.txt", "ipm_iteration.txt", "ipm_kernels.txt"]:
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, name))
     for sub, out in [("stats", "bench_default_kernel_stats.csv"), ("stats_c2", "bench_c2_kernel_stats.csv")]:
