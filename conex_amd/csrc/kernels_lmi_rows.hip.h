@@ -43,15 +43,52 @@ struct RowDotSteps {  // acc += sum_{j >= J} M[j][c] row[j]
   }
 };
 
-// out[c] = sum_j row[j] * M[j][c], M[j][c] = lane j's mat[c]; columns C .. N-1
+// The same for W columns at once, term j of every column before term j + 1 of any: each column's sum
+// is one dependent chain (an fp64 fma can issue every 4 cycles, its result is back after ~8), so one
+// column at a time leaves every other issue slot empty.  Same chains, same bits.
+template <int N, int W, int J>
+struct RowDotStepsWide {
+  static __device__ __forceinline__ void run(double (&acc)[W], const double (&m0)[W], const double (&m1)[W],
+                                             const double (&row)[N]) {
+    if constexpr (J < N) {
+#pragma unroll
+      for (int q = 0; q < W; q++) {
+        if constexpr (J < 16)
+          FmaBcast<J>(acc[q], m0[q], row[J]);
+        else
+          FmaBcast<J - 16>(acc[q], m1[q], row[J]);
+      }
+      RowDotStepsWide<N, W, J + 1>::run(acc, m0, m1, row);
+    }
+  }
+};
+
+// out[c] = sum_j row[j] * M[j][c], M[j][c] = lane j's mat[c]; columns C .. N-1, kRowColumns at a time
+constexpr int kRowColumns = 4;
 template <int N, int C>
 struct RowTimesMatrix {
   static __device__ __forceinline__ void run(const double (&row)[N], const double (&mat)[N], double (&out)[N]) {
-    if constexpr (C < N) {
-      const RowPair mp = Swap16(mat[C]);  // a: DPP rows 0/2 everywhere, b: rows 1/3
+    if constexpr (C + kRowColumns <= N) {
+      constexpr int W = kRowColumns;
+      double m0[W], m1[W], acc[W];
+#pragma unroll
+      for (int q = 0; q < W; q++) {
+        const RowPair mp = Swap16(mat[C + q]);  // a: DPP rows 0/2 everywhere, b: rows 1/3
+        m0[q] = mp.a;
+        m1[q] = mp.b;
+        acc[q] = 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < W; q++) DppOperandFence(m0[q], m1[q], acc[q]);
+      RowDotStepsWide<N, W, 0>::run(acc, m0, m1, row);  // rows / columns beyond the order hold zeros
+#pragma unroll
+      for (int q = 0; q < W; q++) out[C + q] = acc[q];
+      RowTimesMatrix<N, C + W>::run(row, mat, out);
+    } else if constexpr (C < N) {
+      const RowPair mp = Swap16(mat[C]);
       double m0 = mp.a, m1 = mp.b, acc = 0.0;
       DppOperandFence(m0, m1, acc);
-      RowDotSteps<N, 0>::run(acc, m0, m1, row);  // rows / columns beyond the order hold zeros
+      RowDotSteps<N, 0>::run(acc, m0, m1, row);
       out[C] = acc;
       RowTimesMatrix<N, C + 1>::run(row, mat, out);
     }
