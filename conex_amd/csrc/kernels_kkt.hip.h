@@ -1840,13 +1840,20 @@ tree_sweep_block(FactorPlan P, int base0, double* __restrict__ slab, double* __r
 //   U[k][j] = sum_r (D_r off[r][k]) off[r][j]   with off = D^-1 L^-1 P off
 //   t[c]    = sum_r off[r][c] b_r               with b = L^-1 P b (D^-1 is applied afterwards)
 // ---------------------------------------------------------------------------------------
-template <int MODE>
-__global__ void __launch_bounds__(256)
+// HBM: the panel image lives in `ws` (global memory) instead of LDS -- supernodes beyond LDS, one
+// workgroup of 1024 threads each, the same operations in the same order (a workgroup barrier orders
+// its threads' global accesses as it orders their LDS accesses); the extra columns (off block,
+// right-hand side) are then swept by all threads together, column step by column step, instead of
+// one thread per column.  Slow (every step is a round trip to L2) but complete: the blocked LDLT with
+// the reference's pivot rule needs the whole trailing diagonal at every step.
+template <int MODE, bool HBM = false>
+__global__ void __launch_bounds__(HBM ? 1024 : 256)
 tree_sweep_block_ldlt(FactorPlan P, int base0, double* __restrict__ slab, double* __restrict__ rhs,
-                      int* __restrict__ tr_all, int* __restrict__ regularized) {
-  extern __shared__ double lds[];
-  __shared__ double s_val[4];
-  __shared__ int s_idx[4];
+                      int* __restrict__ tr_all, int* __restrict__ regularized, double* __restrict__ ws = nullptr) {
+  extern __shared__ double lds_dyn[];
+  double* lds = HBM ? ws : lds_dyn;
+  __shared__ double s_val[16];
+  __shared__ int s_idx[16];
   __shared__ int s_piv;
   const SnRec R = LoadRec(P.rec, base0 + blockIdx.x);
   const int ns = R.ns, s = R.nsep, tid = threadIdx.x, nt = blockDim.x;
@@ -2007,6 +2014,32 @@ tree_sweep_block_ldlt(FactorPlan P, int base0, double* __restrict__ slab, double
   // extra columns: off block (factor sweep only) and rhs.  One thread per column:
   // P, then the unit-lower solve; off additionally scaled by D^-1.
   const int ext = s + (with_rhs ? 1 : 0), c0 = with_matrix ? 0 : s;
+  if constexpr (HBM) {
+    for (int c = c0 + tid; c < ext; c += nt) {
+      double* col = c < s ? sB + (size_t)c * ns : sb;
+      for (int k = 0; k < ns; k++) {
+        const int t = str[k];
+        if (t != k) {
+          const double v = col[k];
+          col[k] = col[t];
+          col[t] = v;
+        }
+      }
+    }
+    __syncthreads();
+    const int ncol = ext - c0;
+    for (int j = 0; j + 1 < ns; j++) {  // every entry takes its terms in the order of the one-thread sweep
+      const int below = ns - j - 1;
+      for (int q = tid; q < below * ncol; q += nt) {
+        const int c = c0 + q / below, i = j + 1 + q % below;
+        double* col = c < s ? sB + (size_t)c * ns : sb;
+        col[i] -= sD[i + (size_t)j * ns] * col[j];
+      }
+      __syncthreads();
+    }
+    if (with_matrix)
+      for (int q = tid; q < ns * s; q += nt) sB[q] = (1.0 / sD[(q % ns) * (size_t)(ns + 1)]) * sB[q];
+  } else
   for (int c = c0 + tid; c < ext; c += nt) {
     double* col = c < s ? sB + c * ns : sb;
     for (int k = 0; k < ns; k++) {

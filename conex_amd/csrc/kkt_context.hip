@@ -529,8 +529,21 @@ int LaunchGather(cxk_context* ctx, bool with_rhs, double k, double bs, double cs
 int LaunchHuge(cxk_context* ctx, int l, int mode, bool with_rhs) {
   const int first = ctx->level_ptr[l] + ctx->level_nh[l], last = ctx->level_ptr[l + 1];
   if (first == last) return CXK_SUCCESS;
-  CXK_DEMAND(!ctx->use_ldlt, "equality constraints with supernodes beyond LDS: blocked LDLT is not built");
   double* rhs = (with_rhs || mode != 0) ? ctx->y.p : nullptr;
+  if (ctx->use_ldlt) {
+    // the LDLT kernel of the LDS-sized supernodes with its panel image in HBM (same pivot rule, same
+    // operations: RLDLT.h:298-431 picks every pivot from the whole trailing diagonal)
+    for (int pos = first; pos < last; pos++) {
+      if (mode == 0)
+        tree_sweep_block_ldlt<0, true><<<1, 1024, 0, ctx->stream>>>(ctx->plan, pos, ctx->slab.p, rhs, ctx->d_tr.p, ctx->d_reg.p, ctx->big_ws.p);
+      else if (mode == 1)
+        tree_sweep_block_ldlt<1, true><<<1, 1024, 0, ctx->stream>>>(ctx->plan, pos, ctx->slab.p, rhs, ctx->d_tr.p, ctx->d_reg.p, ctx->big_ws.p);
+      else
+        tree_sweep_block_ldlt<2, true><<<1, 1024, 0, ctx->stream>>>(ctx->plan, pos, ctx->slab.p, rhs, ctx->d_tr.p, ctx->d_reg.p, ctx->big_ws.p);
+      CXK_TRY(hipGetLastError());
+    }
+    return CXK_SUCCESS;
+  }
   for (int pos = first; pos < last; pos++)
     CXK_TRY(BigSupernodeSweep(ctx->plan, ctx->h_recs[pos], mode, ctx->slab.p, rhs, ctx->d_fail.p,
                               ctx->big_ws.p, ctx->stream));

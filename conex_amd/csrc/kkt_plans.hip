@@ -540,6 +540,7 @@ int BuildPlans(cxk_context* ctx) {
         if (panel_bytes(e) > kLdsLimit) {
           huge.push_back(e);
           big_ws = std::max(big_ws, (size_t)nsep[e] * nsep[e] + nsep[e] + 1);
+          if (ctx->use_ldlt) big_ws = std::max(big_ws, panel_bytes(e) / sizeof(double) + 2);  // the panel image of the LDLT kernel
           continue;
         }
         ctx->level_sn.push_back(e);

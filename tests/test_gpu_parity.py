@@ -399,6 +399,52 @@ def test_equality_constraints_ldlt_newton_step(kind, seed):
     assert k.factor_regularized() == 0
 
 
+@pytest.mark.parametrize("kind", ["lp", "lmi"])
+def test_equality_constraints_with_supernodes_beyond_lds(kind):
+    """Equality blocks on supernodes whose panel exceeds LDS (> ~140 columns): the LDLT kernel with
+    its panel image in HBM -- same pivot rule (the largest |diagonal| of the whole trailing part,
+    RLDLT.h:298-431), same operations as the LDS-resident one -- against the oracle."""
+    rng = np.random.default_rng(77)
+    if kind == "lp":
+        nv = 180
+        A = rng.uniform(-1, 1, (260, nv))
+        c = np.abs(rng.uniform(0.5, 1.5, 260))
+        eqs = [(rng.uniform(-1, 1, (4, nv)), rng.uniform(-1, 1, 4), None)]
+        b = rng.uniform(-1, 1, nv)
+
+        def build(cls, **kw):
+            p = cls(nv, **kw)
+            p.add_linear(A, c)
+            for Ae, be, v in eqs:
+                p.add_equality(Ae, be, v)
+            p.initialize()
+            return p
+        W = None
+    else:
+        prob = syn.lmi_problem(K=3, n=24, m=170, branching=2, overlap=21, seed=170)
+        nv, b = prob["num_vars"], prob["b"]
+        eqs = [(rng.uniform(-1, 1, (2, 170)), rng.uniform(-0.1, 0.1, 2), prob["cliques"][0]),
+               (rng.uniform(-1, 1, (1, 30)), rng.uniform(-0.1, 0.1, 1), prob["cliques"][2][-30:])]
+
+        def build(cls, **kw):
+            p = cls(nv, **kw)
+            for ci, cl in enumerate(prob["cliques"]):
+                p.add_lmi(prob["A"][ci], prob["C"][ci], cl)
+            for Ae, be, v in eqs:
+                p.add_equality(Ae, be, v)
+            p.initialize()
+            return p
+        W = syn.scaling_points(3, 24, seed=5)
+    o, k = build(ol.Program), build(KktContext, device=0)
+    if W is not None:
+        for i in range(len(W)):
+            o.set_W(i, W[i])
+            k.set_W(i, W[i])
+    assert max(o.supernode_sizes()) > 140 and k.N == o.N > len(b)
+    check_newton_step(o, k, b, check_update=False, inv_sqrt_mu=0.4 if kind == "lp" else 1.0)
+    assert k.factor_regularized() == 0
+
+
 @pytest.mark.parametrize("N", [2, 40])
 def test_lqr_literal_through_the_hip_ldlt_path(N):
     """The reference's LQR KKT literals (assembly_test.cc:67-106 BuildLQRProblem, :108-169
