@@ -12,6 +12,8 @@
 //     U = off^T off, t = off^T b   (GEMM TN), scattered to the consumer slots
 // Storage is the slab itself: diag block ns x ns column-major, off block ns x s column-major.
 #pragma once
+#include "big_chol.h"
+#include "big_panel_solve.hip.h"
 #include "kernels_gemm.hip.h"
 #include "kernels_kkt.hip.h"
 
@@ -43,28 +45,6 @@ __global__ void __launch_bounds__(256) big_pull(FactorPlan P, SnRec R, double* _
       rhs[R.start + i] = acc;
     }
 }
-
-// Steps I .. NB-1 of the register forward substitution of big_panel (compile-time recursion:
-// register indices and DPP controls are immediates).
-template <int NB, int I>
-struct BigPanelSolve {
-  static __device__ __forceinline__ void run(const double (&a)[NB + 1], double (&x)[NB], double dinv) {
-    if constexpr (I < NB) {
-      x[I] *= ReadLane(dinv, I);
-      if constexpr (I + 1 < NB) {
-        const RowPair cp = Swap16(a[I]);  // a = rows 0/2 everywhere (L[0..15][I]), b = rows 1/3 (L[16..31][I])
-        double c0 = cp.a, c1 = cp.b;
-        double nx = -x[I];
-        DppOperandFence(c0, c1, nx);
-        constexpr int kLo0 = (I + 1 < 16) ? I + 1 : 16;
-        constexpr int kHi0 = (I + 1 > 16) ? I + 1 : 16;
-        DppColumns<NB, kLo0, 16, 0>::run(x, c0, nx);
-        DppColumns<NB, kHi0, NB, 16>::run(x, c1, nx);
-      }
-      BigPanelSolve<NB, I + 1>::run(a, x, dinv);
-    }
-  }
-};
 
 // Panel step of the blocked factorization; one WAVEFRONT per workgroup, one work item per lane.
 // Every wavefront factors the nb x nb diagonal block at (k0, k0) itself -- row per lane, the
@@ -192,55 +172,118 @@ __global__ void __launch_bounds__(1024) big_solve_fwd(const double* __restrict__
   for (int i = threadIdx.x; i < ns; i += blockDim.x) b[i] = sb[i];
 }
 
-// b <- L^-T b, panels from the last to the first: the 32 dot products L21^T x_below are split
-// over the 1024 threads (32 consecutive rows per column group: coalesced), reduced in a fixed
-// order, then wavefront 0 solves the transposed 32 x 32 block (column per lane in registers).
-__global__ void __launch_bounds__(1024) big_solve_bwd(const double* __restrict__ D, double* __restrict__ b,
-                                                      int ns) {
-  constexpr int NB = kBigNB;
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads()
+// also waits for every outstanding global load (vmcnt(0)), i.e. for the operands requested a phase
+// ahead below -- which is the round trip the request was issued early to hide.
+__device__ __forceinline__ void BigLdsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// b <- L^-T b, panels from the last to the first.  Wavefront 0 solves the transposed 32 x 32 blocks
+// (column per lane in registers); wavefronts 1 .. 8 form the 32 dot products L21^T x_below, sixteen
+// lanes per column (16 consecutive rows per load instruction), reduced in a fixed order.
+// Two things keep a panel at "its own arithmetic plus two barriers":
+//  * L does not depend on b, so every operand is requested a whole panel ahead, and the barriers
+//    order LDS traffic only (BigLdsBarrier: __syncthreads() would wait for those requests);
+//  * of a panel's dot products only the terms of the 32 rows solved LAST are on the dependent chain:
+//    the terms of all earlier-solved rows are summed while wavefront 0 solves the panel in between.
+constexpr int kBigBwdThreads = 64 + 32 * 16, kBigBwdU = 28, kBigBwdRows = 32 + 16 * kBigBwdU;
+__global__ void __launch_bounds__(kBigBwdThreads) big_solve_bwd(const double* __restrict__ D,
+                                                                double* __restrict__ b, int ns) {
+  constexpr int NB = kBigNB, U = kBigBwdU;
   extern __shared__ double sb[];  // ns
   __shared__ double part[NB];
   const int lane = threadIdx.x & 63;
+  const bool solver = threadIdx.x < 64;
+  const int j = ((int)threadIdx.x - 64) >> 4, sub = ((int)threadIdx.x - 64) & 15;  // column j of a panel, 16 lanes each
   for (int i = threadIdx.x; i < ns; i += blockDim.x) sb[i] = b[i];
-  __syncthreads();
   const int nblk = (ns + NB - 1) / NB;
+  // solver: c[k] = L[k0 + k][k0 + lane].  Others, for the panel whose dot products they are forming:
+  // w[.][h] = L[k0 + nb + sub + 16 h][k0 + j], h = 0, 1 (the 32 rows right below the panel: solved last),
+  // v[u] = the rows 32 + sub + 16 u below it
+  // one register array for both roles: c = rg; v[u] = rg[u], w of this panel rg[U + h], of the next rg[U + 2 + h]
+  double rg[NB];
+  static_assert(kBigBwdU + 4 == kBigNB, "v and w fill the array");
+#define c rg
+#define v rg
+#define w_cur(h_) rg[U + (h_)]
+#define w_next(h_) rg[U + 2 + (h_)]
+  double old_part = 0.0;  // the dot product over the rows 32 .. below - 1 of the panel coming next
+  auto request_block = [&](int kb) {
+    if (kb < 0) return;
+    const int k0 = kb * NB, nb = ns - k0 < NB ? ns - k0 : NB;
+    const double* src = D + k0 + (size_t)(k0 + (lane < nb ? lane : 0)) * ns;
+#pragma unroll
+    for (int k = 0; k < NB; k++) c[k] = src[k < nb ? k : 0];
+  };
+  auto request_rows = [&](int kb) {  // (never the last panel: nb = 32)
+    if (kb < 0) return;
+    const int k0 = kb * NB, below = ns - k0 - NB;
+    const double* colp = D + (k0 + NB) + (size_t)(k0 + j) * ns;
+#pragma unroll
+    for (int h = 0; h < 2; h++) w_next(h) = colp[sub + 16 * h < below ? sub + 16 * h : 0];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = colp[32 + sub + 16 * u < below ? 32 + sub + 16 * u : 0];
+  };
+  if (solver)
+    request_block(nblk - 1);
+  else
+    request_rows(nblk - 2);
+  BigLdsBarrier();
   for (int kb = nblk - 1; kb >= 0; kb--) {
     const int k0 = kb * NB, nb = ns - k0 < NB ? ns - k0 : NB, below = ns - k0 - nb;
-    {
-      const int j = threadIdx.x >> 5, sub = threadIdx.x & 31;  // 32 column groups of 32 lanes
-      double acc = 0.0;
-      if (j < nb) {
-        const double* colp = D + (k0 + nb) + (size_t)(k0 + j) * ns;
-        for (int r = sub; r < below; r += 32) acc = fma(colp[r], sb[k0 + nb + r], acc);
+    if (!solver) {
+      // the panel's dot products: what was summed during the previous solve plus the rows solved by it
+      double acc = old_part;
+      if (below > 0) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+          if (sub + 16 * h < below) acc = fma(w_cur(h), sb[k0 + nb + sub + 16 * h], acc);
       }
 #pragma unroll
-      for (int d = 16; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+      for (int h = 0; h < 2; h++) w_cur(h) = w_next(h);  // (requested a panel ago; the next request overwrites w_next)
+#pragma unroll
+      for (int d = 8; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
       if (sub == 0) part[j] = acc;
     }
-    __syncthreads();
-    if (threadIdx.x < 64) {
+    BigLdsBarrier();
+    if (solver) {
       const bool colv = lane < nb;
-      double c[NB];  // c[k] = L[k0+k][k0+lane], k >= lane
-      const double* src = D + k0 + (size_t)(k0 + (colv ? lane : 0)) * ns;
 #pragma unroll
-      for (int k = 0; k < NB; k++) c[k] = (colv && k >= lane && k < nb) ? src[k] : (k == lane ? 1.0 : 0.0);
-      double v = colv ? sb[k0 + lane] - part[lane] : 0.0;
+      for (int k = 0; k < NB; k++) c[k] = (colv && k >= lane && k < nb) ? c[k] : (k == lane ? 1.0 : 0.0);
+      double x = colv ? sb[k0 + lane] - (below > 0 ? part[lane] : 0.0) : 0.0;
       double diag = 1.0;
 #pragma unroll
       for (int k = 0; k < NB; k++) diag = (lane == k) ? c[k] : diag;
       const double dinv = 1.0 / diag;
 #pragma unroll
       for (int k = NB - 1; k >= 0; k--) {
-        const double xk = ReadLane(v, k) * ReadLane(dinv, k);
+        const double xk = ReadLane(x, k) * ReadLane(dinv, k);
         if (lane == k)
-          v = xk;
+          x = xk;
         else if (lane < k)
-          v = fma(-c[k], xk, v);
+          x = fma(-c[k], xk, x);
       }
-      if (colv) sb[k0 + lane] = v;
+      if (colv) sb[k0 + lane] = x;
+      request_block(kb - 1);
+    } else if (kb >= 1) {
+      // meanwhile, for the NEXT panel (kb - 1): its rows from 32 on, whose unknowns are all solved
+      const int k1 = k0 - NB, below1 = ns - k1 - NB;
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (32 + sub + 16 * u < below1) acc = fma(v[u], sb[k1 + NB + 32 + sub + 16 * u], acc);
+      if (below1 > kBigBwdRows) {  // (very tall blocks: the rest is loaded here)
+        const double* colp = D + (k1 + NB) + (size_t)(k1 + j) * ns;
+        for (int r = kBigBwdRows + sub; r < below1; r += 16) acc = fma(colp[r], sb[k1 + NB + r], acc);
+      }
+      old_part = acc;
+      request_rows(kb - 2);
     }
-    __syncthreads();
+    BigLdsBarrier();
   }
+#undef c
+#undef v
+#undef w_cur
+#undef w_next
   for (int i = threadIdx.x; i < ns; i += blockDim.x) b[i] = sb[i];
 }
 
@@ -302,8 +345,11 @@ inline GemmArgs BigGemm(int M, int N, int K, const double* A, int64_t lda, const
 
 // mode 0: factor (+ forward when rhs), mode 1: forward only, mode 2: backward.
 // ws: at least s*s + s doubles.
+// df_flags != nullptr: the factor sweep of a supernode that fits big_chol_dataflow (big_chol.h) takes
+// that ONE launch for the panel loop and the forward substitution; *df_gen counts its launches.
 inline hipError_t BigSupernodeSweep(const FactorPlan& P, const SnRec& R, int mode, double* slab, double* rhs,
-                                    int* fail, double* ws, hipStream_t st) {
+                                    int* fail, double* ws, hipStream_t st, int* df_flags = nullptr,
+                                    int* df_gen = nullptr) {
   const int ns = R.ns, s = R.nsep;
   double* D = slab + R.diag_off;
   double* B = slab + R.offd_off;
@@ -322,13 +368,25 @@ inline hipError_t BigSupernodeSweep(const FactorPlan& P, const SnRec& R, int mod
   });
   if (e != hipSuccess) return e;
   if (mode == 2) {
-    big_backsep<<<(ns + 255) / 256, 256, 0, st>>>(P, R, slab, rhs);
-    big_solve_bwd<<<1, 1024, solve_lds, st>>>(D, b, ns);
+    if (R.bs_end > R.bs_beg) big_backsep<<<(ns + 255) / 256, 256, 0, st>>>(P, R, slab, rhs);
+    big_solve_bwd<<<1, kBigBwdThreads, solve_lds, st>>>(D, b, ns);
     return hipGetLastError();
   }
   const int with_matrix = mode == 0;
-  if (R.tg_end > R.tg_beg || rhs) big_pull<<<64, 256, 0, st>>>(P, R, slab, rhs, with_matrix);
-  if (with_matrix)
+  if ((with_matrix && R.tg_end > R.tg_beg) || (rhs && R.mf > 0)) big_pull<<<64, 256, 0, st>>>(P, R, slab, rhs, with_matrix);
+  const bool dataflow = with_matrix && df_flags && df_gen && BigCholSupports(ns, s);
+  if (dataflow) {
+    BigCholArgs ca;
+    ca.D = D;
+    ca.B = B;
+    ca.b = b;
+    ca.ns = ns;
+    ca.s = s;
+    ca.flags = df_flags;
+    ca.gen = *df_gen = (*df_gen >= (1 << 30)) ? 1 : *df_gen + 1;
+    ca.fail = fail;
+    if ((e = LaunchBigChol(ca, st)) != hipSuccess) return e;
+  } else if (with_matrix)
     for (int k0 = 0; k0 < ns; k0 += kBigNB) {
       const int nb = std::min(kBigNB, ns - k0), below = ns - k0 - nb;
       const int items = below + s;
@@ -344,7 +402,7 @@ inline hipError_t BigSupernodeSweep(const FactorPlan& P, const SnRec& R, int mod
         }
       }
     }
-  if (rhs) big_solve_fwd<<<1, 1024, solve_lds, st>>>(D, b, ns);
+  if (rhs && !dataflow) big_solve_fwd<<<1, 1024, solve_lds, st>>>(D, b, ns);
   if (s > 0) {
     double* U = ws;
     double* t = ws + (size_t)s * s;

@@ -546,7 +546,7 @@ int LaunchHuge(cxk_context* ctx, int l, int mode, bool with_rhs) {
   }
   for (int pos = first; pos < last; pos++)
     CXK_TRY(BigSupernodeSweep(ctx->plan, ctx->h_recs[pos], mode, ctx->slab.p, rhs, ctx->d_fail.p,
-                              ctx->big_ws.p, ctx->stream));
+                              ctx->big_ws.p, ctx->stream, ctx->big_flags.p, &ctx->big_gen));
   return CXK_SUCCESS;
 }
 

@@ -183,6 +183,8 @@ struct cxk_context {
   std::vector<int> level_nh;
   std::vector<SnRec> h_recs;  // host copy of the level-ordered records
   DevBuf<double> big_ws;
+  DevBuf<int> big_flags;  // big_chol_dataflow's per-block-column words (null: the host-driven panel loop)
+  int big_gen = 0;
   // Level ranges below the top that are swept by one launch each: workgroup g of range r sweeps
   // one connected piece of the elimination forest restricted to levels [lo, hi)
   struct SweepRange {

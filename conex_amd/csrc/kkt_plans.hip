@@ -4,6 +4,7 @@
 // records of the whole-tree launch, the dense top.  Split off kkt_context.hip (launches + C-ABI).
 #define CXK_DEVICE_FUNCTIONS_ONLY  // kernels_kkt.hip.h: types and templates only (the plain kernels live in kkt_context.hip)
 #include "kkt_internal.h"
+#include "big_chol.h"
 
 namespace cxk_host {
 
@@ -579,6 +580,8 @@ int BuildPlans(cxk_context* ctx) {
   if (big_ws > 0) {
     CXK_DEMAND(!sharded, "supernodes beyond LDS are single-GPU for now");
     CXK_TRY(ctx->big_ws.alloc(big_ws));
+    // (CXK_NO_BIG_DATAFLOW=1: the host-driven panel loop, for comparison)
+    if (!getenv("CXK_NO_BIG_DATAFLOW")) CXK_TRY(ctx->big_flags.alloc(2 * kBigCholMaxBlocks, true));
   }
   CXK_DEMAND(ctx->chol_lds <= kLdsLimit,
              "internal error: a supernode routed to the LDS kernels does not fit LDS");

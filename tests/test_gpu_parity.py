@@ -263,6 +263,33 @@ def test_big_supernode_odd_sizes(num_vars, rows):
     check_newton_step(o, k, prob["b"], inv_sqrt_mu=0.4)
 
 
+@pytest.mark.parametrize("num_vars,rows", [(500, 640), (960, 1100)])
+def test_big_supernode_one_launch_and_host_driven_loop_agree(num_vars, rows, monkeypatch):
+    """big_chol_dataflow (one launch: a workgroup per 32-column block column, block columns handed
+    on through flags) against the host-driven panel loop it replaces up to 927 rows
+    (CXK_NO_BIG_DATAFLOW=1; 960 variables take the host-driven loop either way) and the oracle."""
+    prob = syn.lp_problem(rows=rows, num_vars=num_vars, seed=num_vars)
+    o, k = make_pair(prob, "lp")
+    check_newton_step(o, k, prob["b"], inv_sqrt_mu=0.4)
+    k1 = syn.build(KktContext, prob, "lp", device=0)
+    monkeypatch.setenv("CXK_NO_BIG_DATAFLOW", "1")
+    k2 = syn.build(KktContext, prob, "lp", device=0)
+    monkeypatch.delenv("CXK_NO_BIG_DATAFLOW")
+    ys = []
+    for kk in (k1, k2):
+        ok, y = kk.kkt_solve(prob["b"], 0.4, 0.9, 0.8)
+        assert ok == 1
+        ys.append(y)
+        ok, y = kk.kkt_solve(prob["b"], 0.4, 0.9, 0.8)     # a second launch on the same flag words
+        assert ok == 1 and np.array_equal(y, ys[-1])
+    assert rel(ys[0], ys[1]) <= 1e-11
+    # a pivot that is not positive is reported by either path
+    for kk in (k1, k2):
+        kk.set_W(0, np.zeros(rows))                        # G = 0
+        ok, _ = kk.kkt_solve(prob["b"], 0.4, 0.9, 0.8)
+        assert ok == 0
+
+
 @pytest.mark.parametrize("m,overlap", [(170, 21), (230, 45)])
 def test_big_supernodes_with_separators(m, overlap):
     """Big leaves (m - overlap columns, `overlap` separator columns: the off block rides through

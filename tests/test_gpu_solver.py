@@ -181,6 +181,32 @@ def test_linear_inequalities_with_equality_rows_take_the_ldlt_path():
     L.CONEX_DeleteConeProgram(p)
 
 
+def test_equality_rows_on_a_supernode_beyond_lds_through_conex_h():
+    """The same with 170 variables: ONE 170-column supernode plus multipliers, i.e. the LDLT kernel
+    with its panel in HBM, solved through CONEX_Maximize to the known optimum."""
+    rng = np.random.default_rng(22)
+    nv, nin, neq = 170, 260, 3
+    A = rng.uniform(-1, 1, (nin + neq, nv))
+    y_opt = rng.uniform(-1, 1, nv)
+    act = nin - 90            # nv - neq active inequalities and strictly complementary: the optimum is unique
+    slack = np.r_[np.zeros(act), np.ones(nin - act)]
+    dual = np.r_[np.ones(act), np.zeros(nin - act)]
+    ub = np.r_[slack + A[:nin] @ y_opt, A[nin:] @ y_opt]
+    lb = np.r_[np.full(nin, -1e9), A[nin:] @ y_opt]
+    cost = A[:nin].T @ dual
+    L = ca.api()
+    p = L.CONEX_CreateConeProgram()
+    assert L.CONEX_SetNumberOfVariables(p, nv) == 0
+    assert L.CONEX_AddLinearInequalities(p, ca.dp(ca.colmajor(A)), nin + neq, nv, ca.dp(lb), nin + neq,
+                                         ca.dp(ub), nin + neq) == -1
+    ok, y = _maximize(L, p, cost)
+    assert ok == 1
+    assert np.linalg.norm(A[nin:] @ y - ub[nin:]) <= 1e-5
+    assert np.all(A[:nin] @ y <= ub[:nin] + 1e-6)
+    assert abs(cost @ y - cost @ y_opt) <= 1e-4 * max(1.0, abs(cost @ y_opt))
+    L.CONEX_DeleteConeProgram(p)
+
+
 @pytest.mark.parametrize("n,num_ineqs", [(5, 10), (10, 20), (50, 70)])
 def test_random_qp_with_line_search_through_conex_h(n, num_ineqs):
     """quadratic_objective_test.cc:142-175 (RandomQP Small / Medium / Large): quadratic cost +
