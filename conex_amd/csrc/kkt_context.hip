@@ -7,6 +7,7 @@
 #include "kernels_cone.hip.h"
 #include "kernels_gemm.hip.h"
 #include "kernels_kkt_big.hip.h"
+#include "kernels_oct.hip.h"
 #include "kernels_lmi.hip.h"
 #include "lmi_fused_mfma.h"
 #include "kernels_lmi_sparse.hip.h"
@@ -94,6 +95,18 @@ QuadGroup MakeQuad(Group& g) {
   d.W = g.W.p;
   d.D = g.T1.p;
   d.S = g.qS.p;
+  d.ids = g.dids.p;
+  return d;
+}
+OctGroup MakeOct(Group& g) {
+  OctGroup d;
+  d.n = g.n;
+  d.m = g.m;
+  d.count = static_cast<int>(g.ids.size());
+  d.A = g.A.p;
+  d.C = g.C.p;
+  d.W = g.W.p;
+  d.S = g.T1.p;
   d.ids = g.dids.p;
   return d;
 }
@@ -446,6 +459,9 @@ int LaunchSchur(cxk_context* ctx) {
         break;
       case CXK_QUAD:
         quad_schur<<<count, 64, sizeof(double) * (size_t)(2 * g.n + g.m + 4), ctx->stream>>>(MakeQuad(g), ar);
+        break;
+      case CXK_OCT:
+        oct_schur<<<count, 64, 0, ctx->stream>>>(MakeOct(g), ar);
         break;
     }
   }
@@ -1421,9 +1437,24 @@ void ExtractPlanes(int d, int n, const double* emb, double* planes) {
 int cxk_add_hermitian(cxk_context* ctx, int n, int d, int m, const double* A, const double* C,
                       const int* vars) {
   if (!ctx || n < 1 || m < 0 || !A || !C) return -1;
+  if (d == 8) {
+    // Hermitian matrices over the octonions: no real representation (the algebra is not
+    // associative): a cone type of its own, planes as they come (kernels_oct.hip.h)
+    if (n > 3) {
+      fprintf(stderr, "cxk_add_hermitian: order of octonion algebra cannot be greater than 3 (interfaces/conex.cc:310-311)\n");
+      return -1;
+    }
+    ConstraintRec r;
+    r.type = CXK_OCT;
+    r.n = n;
+    r.m = m;
+    const size_t sz = (size_t)8 * n * n;
+    r.A.assign(A, A + (size_t)m * sz);
+    r.C.assign(C, C + sz);
+    return AddConstraint(ctx, std::move(r), vars);
+  }
   if (d != 1 && d != 2 && d != 4) {
-    fprintf(stderr, "cxk_add_hermitian: hyper-complex dimension %d not supported (octonions take a "
-                    "separate heuristic path in the reference, hermitian_psd.cc:108-168)\n", d);
+    fprintf(stderr, "cxk_add_hermitian: hyper-complex dimension %d is not 1, 2, 4 or 8\n", d);
     return -1;
   }
   ConstraintRec r;
@@ -1774,6 +1805,10 @@ static int FinalizeImpl(cxk_context* ctx) {
         a_sz = (size_t)(g.n + 1) * g.m;
         c_sz = w_sz = (size_t)(g.n + 1);
         break;
+      case CXK_OCT:
+        a_sz = (size_t)g.m * 8 * g.n * g.n;
+        c_sz = w_sz = (size_t)8 * g.n * g.n;
+        break;
     }
     if (g.type == CXK_LMI && g.sparse) {
       if (UploadSparseLmi(ctx, g)) return CXK_FAILURE;
@@ -1957,6 +1992,7 @@ int cxk_dual_size(const cxk_context* ctx, int i) {
     case CXK_LINEAR: return c.n;
     case CXK_SOC: return c.n + 1;
     case CXK_QUAD: return c.n + 1;
+    case CXK_OCT: return 8 * c.n * c.n;
     case CXK_STATIC: return c.eq_rows;  // lambda_ of an equality block; 0 for a quadratic cost
     default: return 0;
   }
@@ -1972,6 +2008,8 @@ int cxk_set_identity(cxk_context* ctx) {
     else if (g.type == CXK_LINEAR || g.type == CXK_SOC || g.type == CXK_QUAD)
       vec_set_identity<<<GridFor(cnt * (g.n + 1), 256), 256, 0, ctx->stream>>>(MakeVec(g),
                                                                                g.type != CXK_LINEAR);
+    else if (g.type == CXK_OCT)
+      oct_set_identity<<<GridFor(cnt * 8 * g.n * g.n, 256), 256, 0, ctx->stream>>>(MakeOct(g));
   }
   CXK_TRY(hipGetLastError());
   return CXK_SUCCESS;
@@ -2495,6 +2533,8 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
           MakeVec(g), sa);
     else if (g.type == CXK_QUAD)
       quad_prepare<0><<<cnt, 64, sizeof(double) * (size_t)(g.m + 4 * (g.n + 1)), ctx->stream>>>(MakeQuad(g), sa);
+    else if (g.type == CXK_OCT)
+      oct_prepare<0><<<cnt, 64, sizeof(double) * (size_t)g.m, ctx->stream>>>(MakeOct(g), sa);
   }
   CXK_TRY(hipGetLastError());
   if (ctx->use_ldlt) {  // lambda_ = y.tail(rows) (equality_constraint.cc:32-37)
@@ -2558,6 +2598,8 @@ static int LaunchTakeStep(cxk_context* ctx, double e_weight, double step_size, c
       soc_take_step<<<cnt, 64, sizeof(double) * (size_t)(4 * (g.n + 1)), ctx->stream>>>(MakeVec(g), sa);
     else if (g.type == CXK_QUAD)
       quad_take_step<<<cnt, 64, sizeof(double) * (size_t)(3 * (g.n + 1)), ctx->stream>>>(MakeQuad(g), sa);
+    else if (g.type == CXK_OCT)
+      oct_take_step<<<cnt, 64, 0, ctx->stream>>>(MakeOct(g), sa);
   }
   CXK_TRY(hipGetLastError());
   return CXK_SUCCESS;
@@ -2588,6 +2630,8 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
           MakeVec(g), sa);
     else if (g.type == CXK_QUAD)
       quad_prepare<1><<<cnt, 64, sizeof(double) * (size_t)(g.m + 4 * (g.n + 1)), ctx->stream>>>(MakeQuad(g), sa);
+    else if (g.type == CXK_OCT)
+      oct_prepare<1><<<cnt, 64, sizeof(double) * (size_t)g.m, ctx->stream>>>(MakeOct(g), sa);
   }
   CXK_TRY(hipGetLastError());
   if (ReduceStepInfoAndSync(ctx, 1, ctx->info4.p)) return CXK_FAILURE;

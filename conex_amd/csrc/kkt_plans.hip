@@ -46,6 +46,7 @@ double ConstraintWork(const ConstraintRec& c) {
     case CXK_LINEAR: return n * m * m;
     case CXK_SOC: return (n + 1) * m * m;
     case CXK_QUAD: return (n + 1) * m * m;
+    case CXK_OCT: return 8 * 64 * 8 * n * n * n * (m + 1) + 8 * n * n * m * m;
     default: return m * m;
   }
 }

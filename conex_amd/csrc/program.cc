@@ -189,7 +189,6 @@ int BuildContext(Program* p) {
     switch (c.kind) {
       case kLmi: {
         if (c.hermitian) {
-          CONEX_DEMAND(c.hyper != 8, "octonion LMIs are not on the device (see DESIGN.md)");
           const size_t sz = (size_t)c.order * c.order * c.hyper;
           std::vector<double> A((size_t)m * sz, 0.0), C(sz, 0.0);
           for (int v = 0; v < m && v < (int)c.mats.size(); v++)
@@ -815,11 +814,8 @@ CONEX_STATUS CONEX_NewLinearMatrixInequality(void* x, int order, int hyper_compl
   CAST_PROGRAM(x, p);
   if (hyper_complex_dim == 8)
     CONEX_DEMAND(order <= 3, "Order of octonion algebra cannot be greater than 3.");
-  // The octonion algebra is not associative and has no real matrix representation: the reference
-  // itself runs it on heuristics (hermitian_psd.cc:108-168).  Not on the device: refused HERE, when
-  // the constraint is created, not when the program is solved.
-  CONEX_DEMAND(hyper_complex_dim != 8,
-               "Octonion LMIs are not supported by the HIP build (hypercomplex dimension 1, 2 or 4 only).");
+  // (octonions: no real matrix representation -- a cone type of its own on the device, with the
+  // reference's rules for it, hermitian_psd.cc:108-168: kernels_oct.hip.h)
   Cone k;
   k.kind = kLmi;
   k.order = order;
@@ -873,7 +869,8 @@ CONEX_STATUS CONEX_UpdateLinearOperator(void* x, int constraint, double value, i
       CONEX_DEMAND(!(value != 0 && row == col && dim > 0),
                    "Imaginary components must be skew-symmetric.");
       CONEX_DEMAND(variable >= 0, "Indices cannot be negative.");
-      if (k.hyper == 8 && dim >= 3) return 0;  // reference returns false (= success) here
+      // (hermitian_psd.cc:257-262 means to refuse dim >= 3 of an octonion matrix, but tests
+      //  is_same<HermitianPsdConstraint<H>, Octonions>, which never holds: every plane is accepted)
       const size_t nn = (size_t)k.order * k.order;
       if ((int)k.mats.size() <= variable) k.mats.resize(variable + 1);
       if (k.mats[variable].empty()) k.mats[variable].assign(nn * k.hyper, 0.0);
@@ -925,7 +922,6 @@ CONEX_STATUS CONEX_UpdateAffineTerm(void* x, int constraint, double value, int r
                    "Matrix dimension out of bounds.");
       CONEX_DEMAND(!(value != 0 && row == col && dim > 0),
                    "Imaginary components must be skew-symmetric.");
-      if (k.hyper == 8 && dim >= 3) return 0;
       const size_t nn = (size_t)k.order * k.order;
       if (k.affine.empty()) k.affine.assign(nn * k.hyper, 0.0);
       double* M = k.affine.data() + nn * dim;

@@ -205,7 +205,8 @@ class KktContext:
         return r
 
     def add_hermitian(self, A, Cm, vars_=None):
-        """Hermitian PSD over R/C/H: A (m, d, n, n) real planes, Cm (d, n, n); d in {1, 2, 4}."""
+        """Hermitian PSD over R / C / H / O: A (m, d, n, n) real planes, Cm (d, n, n); d in {1, 2, 4, 8}
+        (octonions, d = 8: order at most 3)."""
         A = np.asarray(A, dtype=np.float64)
         m, d, n = A.shape[0], A.shape[1], A.shape[2]
         a = np.ascontiguousarray(np.swapaxes(A, -1, -2)).ravel()

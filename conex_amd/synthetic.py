@@ -190,9 +190,11 @@ def hermitian_scaling_points(K, n, d, seed=SEED + 3, scale=0.2):
     return W
 
 
-# sign table of the reference's hyper-complex product (jordan_matrix_algebra.cc:103-124, 4x4
-# corner): plane (i ^ j) receives  sign[i][j] * X_i Y_j
-HC_SIGN = np.array([[1, 1, 1, 1], [1, -1, -1, 1], [1, 1, -1, -1], [1, -1, 1, -1]])
+# sign table of the reference's hyper-complex product (jordan_matrix_algebra.cc:103-124; the algebra
+# of dimension d uses the top-left d x d corner): plane (i ^ j) receives  sign[i][j] * X_i Y_j
+HC_SIGN = np.array([[1, 1, 1, 1, 1, 1, 1, 1], [1, -1, -1, 1, -1, 1, 1, -1], [1, 1, -1, -1, -1, -1, 1, 1],
+                    [1, -1, 1, -1, -1, 1, -1, 1], [1, 1, 1, 1, -1, -1, -1, -1], [1, -1, 1, -1, 1, -1, 1, -1],
+                    [1, -1, -1, 1, 1, -1, -1, 1], [1, 1, -1, -1, 1, 1, -1, -1]])
 
 
 def hc_multiply(X, Y):

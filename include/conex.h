@@ -116,7 +116,7 @@ int CONEX_AddSparseLMIConstraint(void* program,
  * interfaces/conex.cc:287-397 */
 
 /* Hermitian PSD cone over R / C / H / O: hyper_complex_dim in {1, 2, 4, 8}
- * (octonions are accepted here and refused at solve time) */
+ * (octonions, hyper_complex_dim = 8: order at most 3, interfaces/conex.cc:310-311) */
 CONEX_STATUS CONEX_NewLinearMatrixInequality(void* program, int order, int hyper_complex_dim,
                                              int* constraint_id);
 CONEX_STATUS CONEX_NewLorentzConeConstraint(void* program, int order, int* constraint_id);

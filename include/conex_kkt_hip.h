@@ -35,8 +35,10 @@ enum {
   CXK_SOC = 2,    /* SOCConstraint       soc_constraint.h:6-54 */
   CXK_STATIC = 3, /* constant Schur block: QuadraticFunction quadratic_cost.cc:18-69,
                      SupernodalAssemblerStatic supernodal_assembler.h:122-129 */
-  CXK_QUAD = 4    /* QuadraticConstraint quadratic_cone_constraint.h:11-86: Lorentz cone
+  CXK_QUAD = 4,   /* QuadraticConstraint quadratic_cone_constraint.h:11-86: Lorentz cone
                      x0 >= sqrt(x1' Q x1) with an inner-product matrix Q on the vector part */
+  CXK_OCT = 5     /* HermitianPsdConstraint<Octonions> hermitian_psd.cc:116-168, 171-230: Hermitian
+                     matrices of order <= 3 over the octonions (cxk_add_hermitian with d = 8) */
 };
 
 /* ---- lifetime --------------------------------------------------------- */
@@ -58,7 +60,9 @@ int cxk_add_lmi(cxk_context* ctx, int n, int m, const double* A /* m x (n x n) *
  * C = d planes.  W / dual variables are exchanged as d planes (cxk_dual_size = d n^2).  On the
  * device the cone is held through its real representation of order d n and runs on the LMI
  * kernels with the reference's Hermitian step rules (Taylor-squaring exponential, random-start
- * Lanczos, hermitian_psd.cc:10-91).  d = 8 (octonions) is rejected. */
+ * Lanczos, hermitian_psd.cc:10-91).  d = 8 (octonions, n <= 3): no real representation exists --
+ * a cone type of its own (CXK_OCT) with the reference's octonion rules (hermitian_psd.cc:108-168:
+ * quadratic representations in place of W A W, its heuristic step norms, GeodesicUpdateScaled). */
 int cxk_add_hermitian(cxk_context* ctx, int n, int d, int m, const double* A, const double* C,
                       const int* vars);
 /* Program::AddConstraint(EqualityConstraints{A, b}, vars) -> ConstraintManager::

@@ -7,9 +7,9 @@
  *          conex/exponential_map.cc:15-43 (DoExponentialMap: degree-2 Taylor, two squarings),
  *          conex/hermitian_psd.cc:10-91, 171-230 and hermitian_psd.h:103-115.
  *
- * A hyper-complex matrix is d real planes (d in {1,2,4}); plane p of an r x c matrix starts at
- * p*r*c, column-major.  Octonions (d = 8) take a different, heuristic path in the reference
- * (hermitian_psd.cc:108-168) and are not restated.
+ * A hyper-complex matrix is d real planes (d in {1,2,4,8}); plane p of an r x c matrix starts at
+ * p*r*c, column-major.  Octonions (d = 8, order <= 3) use the same tables; their cone follows the
+ * reference's separate, heuristic rules (hermitian_psd.cc:108-168, restated in cxo_program.c).
  *
  * The reference draws the Lanczos start vector with T::Random (libc rand(), unseeded): that is
  * unpinned, so the restatement and the product share the stateless generator cxo_hc_random()
@@ -23,7 +23,12 @@
 #include "cxo_internal.h"
 
 /* jordan_matrix_algebra.cc:103-124, upper-left 4x4 corner; target plane indx(i,j) = i ^ j */
-static const int kSign[4][4] = {{1, 1, 1, 1}, {1, -1, -1, 1}, {1, 1, -1, -1}, {1, -1, 1, -1}};
+/* the sign table M of jordan_matrix_algebra.cc:104-111 (the algebra of dimension d uses its top-left
+ * d x d corner; the product index is i ^ j: the table indx of :113-120) */
+static const int kSign[8][8] = {{1, 1, 1, 1, 1, 1, 1, 1},     {1, -1, -1, 1, -1, 1, 1, -1},
+                                {1, 1, -1, -1, -1, -1, 1, 1}, {1, -1, 1, -1, -1, 1, -1, 1},
+                                {1, 1, 1, 1, -1, -1, -1, -1}, {1, -1, 1, -1, 1, -1, 1, -1},
+                                {1, -1, -1, 1, 1, -1, -1, 1}, {1, 1, -1, -1, 1, 1, -1, -1}};
 
 double cxo_hc_random(uint64_t id, uint64_t call, uint64_t idx) {
   uint64_t z = 0x243F6A8885A308D3ull + id * 0x9E3779B97F4A7C15ull + call * 0xD1B54A32D192ED03ull +
@@ -116,6 +121,26 @@ void cxo_hc_quadratic_representation(int d, int n, const double* x, const double
   free(t1);
   free(t2);
   free(t3);
+}
+
+/* DoGeodesicUpdateScaled exponential_map.cc:131-144:
+ *   herm(c^2 w + 2 c k Q(w) s + k^2 Q(w) (Q(s) w)),  c = 1.5, k = 0.5
+ * (the octonion cone's TakeStep, hermitian_psd.cc:116-127; out must not alias w or s) */
+void cxo_hc_geodesic_update_scaled(int d, int n, const double* w, const double* s, double* out) {
+  size_t sz = (size_t)n * n * d;
+  const double c = 1.5, k = 1.0 / 2.0;
+  double* q1 = (double*)malloc(sizeof(double) * sz);
+  double* q2 = (double*)malloc(sizeof(double) * sz);
+  double* q3 = (double*)malloc(sizeof(double) * sz);
+  cxo_hc_quadratic_representation(d, n, w, s, q1);
+  cxo_hc_quadratic_representation(d, n, s, w, q2);
+  cxo_hc_quadratic_representation(d, n, w, q2, q3);
+  for (size_t q = 0; q < sz; q++) q1[q] = (w[q] * (c * c) + q1[q] * (2 * k * c)) + q3[q] * (k * k);
+  cxo_hc_conj_transpose(d, n, n, q1, q2);
+  for (size_t q = 0; q < sz; q++) out[q] = (q1[q] + q2[q]) * .5;
+  free(q1);
+  free(q2);
+  free(q3);
 }
 
 /* inner_product<d>(V, U) = (V.col(0)^* U.col(1)).at(0)(0,0)  :379-384.  V, U are n x 2. */

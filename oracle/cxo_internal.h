@@ -150,6 +150,7 @@ void cxo_hc_multiply(int d, int r, int k, int c, const double* X, const double* 
 void cxo_hc_conj_transpose(int d, int r, int c, const double* X, double* Z);
 double cxo_hc_trace_inner_product(int d, int n, const double* X, const double* Y);
 void cxo_hc_quadratic_representation(int d, int n, const double* x, const double* y, double* out);
+void cxo_hc_geodesic_update_scaled(int d, int n, const double* w, const double* s, double* out);
 int cxo_hc_approximate_eigenvalues(int d, int n, const double* WS, const double* W, const double* r,
                                    int num_iter, double* eigs);
 void cxo_hc_exponential_map(int d, int n, const double* x, double* y);

@@ -256,7 +256,8 @@ int cxo_add_lmi(cxo_program* p, int n, int m, const double* A, const double* C, 
 int cxo_add_hermitian(cxo_program* p, int n, int d, int m, const double* A, const double* C,
                       const int* vars) {
   if (!vars && m != p->num_vars) return -1;
-  if (d != 1 && d != 2 && d != 4) return -1; /* octonions: different (heuristic) reference path */
+  if (d != 1 && d != 2 && d != 4 && d != 8) return -1;
+  if (d == 8 && n > 3) return -1; /* interfaces/conex.cc:310-311: "Order of octonion algebra cannot be greater than 3." */
   cxo_constraint* c = new_constraint(p, m, vars);
   if (!c) return -1;
   size_t sz = (size_t)n * n * d;
@@ -1222,11 +1223,15 @@ static void schur_hermitian(cxo_constraint* o) {
   double* AW = (double*)malloc(sizeof(double) * sz);
   double* WAW = (double*)malloc(sizeof(double) * sz);
   for (int i = 0; i < m; i++) {
-    cxo_hc_multiply(d, n, n, n, o->A + (size_t)i * sz, o->W, AW);
-    cxo_hc_multiply(d, n, n, n, o->W, AW, WAW);
+    if (d == 8) { /* octonions are not associative: W A W is Q(W) A, <A, W> stands in for tr(A W)  :181-196 */
+      cxo_hc_quadratic_representation(d, n, o->W, o->A + (size_t)i * sz, WAW);
+    } else {
+      cxo_hc_multiply(d, n, n, n, o->A + (size_t)i * sz, o->W, AW);
+      cxo_hc_multiply(d, n, n, n, o->W, AW, WAW);
+    }
     for (int j = i; j < m; j++)
       o->G[(size_t)i * m + j] = cxo_hc_trace_inner_product(d, n, o->A + (size_t)j * sz, WAW);
-    o->AW[i] = trace_n(n, AW); /* AW.at(0).trace() */
+    o->AW[i] = d == 8 ? cxo_hc_trace_inner_product(d, n, o->A + (size_t)i * sz, o->W) : trace_n(n, AW); /* AW.at(0).trace() */
     o->AQc[i] = cxo_hc_trace_inner_product(d, n, o->C, WAW);
   }
   o->ip_wc = 0;
@@ -1260,6 +1265,14 @@ static void herm_prepare_step(cxo_constraint* o, int id, unsigned long call, int
   double* WS = o->temp1;
   double* minus_s = o->temp2;
   herm_negative_slack(o, c_weight, y, minus_s);
+  if (d == 8) { /* PrepareStep(HermitianPsdConstraint<Octonions>*) hermitian_psd.cc:129-145: no affine branch,
+                   no e_weight; the infinity norm is the reference's "heuristic approximation" */
+    const double trace_ws = cxo_hc_trace_inner_product(d, n, o->W, minus_s);
+    cxo_hc_quadratic_representation(d, n, o->W, minus_s, WS);
+    *normsqrd = cxo_hc_trace_inner_product(d, n, WS, minus_s) + 2 * trace_ws + n;
+    *norminfd = 1.0 / 3.0 * (trace_ws + n);
+    return;
+  }
   cxo_hc_multiply(d, n, n, n, o->W, minus_s, WS);
   if (affine) {
     double* WSW = (double*)malloc(sizeof(double) * sz);
@@ -1296,6 +1309,18 @@ static void herm_take_step(cxo_constraint* o, double e_weight, double step_size)
   int n = o->n, d = o->hd;
   size_t nn = (size_t)n * n, sz = nn * d;
   double* WS = o->temp1;
+  if (d == 8) { /* TakeStep(HermitianPsdConstraint<Octonions>*) hermitian_psd.cc:116-127 with
+                   DoGeodesicUpdateScaled exponential_map.cc:131-144:
+                   W <- herm(c^2 W + 2 c k Q(W) s + k^2 Q(W) (Q(s) W)), c = 1.5, k = 0.5 */
+    double* ms = o->temp2;
+    if (step_size != 1)
+      for (size_t q = 0; q < sz; q++) ms[q] = ms[q] * step_size;
+    double* wn = (double*)malloc(sizeof(double) * sz);
+    cxo_hc_geodesic_update_scaled(d, n, o->W, ms, wn);
+    memcpy(o->W, wn, sizeof(double) * sz);
+    free(wn);
+    return;
+  }
   for (int i = 0; i < n; i++) WS[(size_t)i * n + i] += e_weight;
   if (step_size != 1.0)
     for (size_t q = 0; q < sz; q++) WS[q] = WS[q] * step_size;
@@ -1322,6 +1347,21 @@ static void herm_weighted_eigs(cxo_constraint* o, int id, unsigned long call, co
   double* r = (double*)malloc(sizeof(double) * (size_t)n * d);
   double* eigs = (double*)malloc(sizeof(double) * (size_t)(n + 2));
   herm_negative_slack(o, c_weight, y, minus_s);
+  if (d == 8) { /* GetWeightedSlackEigenvalues(HermitianPsdConstraint<Octonions>*) hermitian_psd.cc:147-168 */
+    cxo_hc_quadratic_representation(d, n, o->W, minus_s, WS);
+    const double normsqrd = cxo_hc_trace_inner_product(d, n, WS, minus_s);
+    const double tws = cxo_hc_trace_inner_product(d, n, o->W, minus_s);
+    *lmax = fabs(normsqrd) / (1e-15 + fabs(tws));
+    *lmin = *lmax * .01;
+    *tr = -tws;
+    *frob = normsqrd;
+    free(minus_s);
+    free(WS);
+    free(WSWS);
+    free(r);
+    free(eigs);
+    return;
+  }
   cxo_hc_multiply(d, n, n, n, o->W, minus_s, WS);
   herm_start_vector(o, id, call, r);
   int ne = cxo_hc_approximate_eigenvalues(d, n, WS, o->W, r, n / 2 + 1, eigs);

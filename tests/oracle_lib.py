@@ -70,6 +70,9 @@ def lib():
         "cxo_hc_multiply": (None, [C.c_int, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p,
                                    c_double_p]),
         "cxo_hc_exponential_map": (None, [C.c_int, C.c_int, c_double_p, c_double_p]),
+        "cxo_hc_quadratic_representation": (None, [C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
+        "cxo_hc_trace_inner_product": (C.c_double, [C.c_int, C.c_int, c_double_p, c_double_p]),
+        "cxo_hc_geodesic_update_scaled": (None, [C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
         "cxo_hc_approximate_eigenvalues": (C.c_int, [C.c_int, C.c_int, c_double_p, c_double_p,
                                                      c_double_p, C.c_int, c_double_p]),
         "cxo_hc_random": (C.c_double, [C.c_ulong, C.c_ulong, C.c_ulong]),

@@ -63,7 +63,7 @@ def test_add_lmi_status_codes():  # interface_test.cc:5-33
     assert L.CONEX_NewLinearMatrixInequality(p, 2, 3, C.byref(cid)) == FAILURE
     assert L.CONEX_NewLinearMatrixInequality(p, 0, 2, C.byref(cid)) == FAILURE
     assert L.CONEX_NewLinearMatrixInequality(p, 4, 8, C.byref(cid)) == FAILURE  # octonion order <= 3
-    assert L.CONEX_NewLinearMatrixInequality(p, 3, 8, C.byref(cid)) == FAILURE  # octonions: refused at creation
+    assert L.CONEX_NewLinearMatrixInequality(p, 3, 8, C.byref(cid)) == SUCCESS  # octonions: order <= 3
     L.CONEX_DeleteConeProgram(p)
 
 

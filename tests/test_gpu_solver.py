@@ -135,16 +135,29 @@ def test_complex_and_quaternion_lmi_solve_matches_oracle(d, order, m):
     L.CONEX_DeleteConeProgram(p)
 
 
-def test_octonion_lmi_is_rejected_when_it_is_created():
-    """Octonion LMIs (the reference's heuristic path, hermitian_psd.cc:108-168) are not built:
-    CONEX_NewLinearMatrixInequality refuses them with CONEX_FAILURE -- not the solve, later."""
+@pytest.mark.parametrize("m", [2, 5, 8])
+def test_octonion_lmi_solve_matches_oracle(m):
+    """hermitian_psd_test.cc:69-107 (TestCases<Octonions>::SolveRandomInstances: order 3, m = 2, 5, 8)
+    through conex.h -- CONEX_NewLinearMatrixInequality(.., hyper_complex_dim = 8) -- against the
+    oracle's restatement of the reference's octonion rules (hermitian_psd.cc:108-168)."""
+    from conex_amd import synthetic as syn
     L = ca.api()
+    prob = syn.hermitian_problem(K=1, n=3, d=8, m=m, seed=190 + m)
+    cfg = ca.default_config()
+    cfg.inv_sqrt_mu_max = 1000
+    cfg.final_centering_steps = 4
+    cfg.max_iterations = 100
     p = L.CONEX_CreateConeProgram()
-    assert L.CONEX_SetNumberOfVariables(p, 1) == 0
+    assert L.CONEX_SetNumberOfVariables(p, m) == 0
     cid = C.c_int(-7)
-    assert L.CONEX_NewLinearMatrixInequality(p, 3, 8, C.byref(cid)) == 1
-    assert cid.value == -7                                                  # no constraint was added
-    assert L.CONEX_NewLinearMatrixInequality(p, 3, 4, C.byref(cid)) == 0 and cid.value == 0
+    assert L.CONEX_NewLinearMatrixInequality(p, 4, 8, C.byref(cid)) == 1 and cid.value == -7   # conex.cc:310-311
+    _new_hermitian(L, p, 3, 8, prob["A"][0], prob["C"][0])
+    ok, y = _maximize(L, p, prob["b"], cfg)
+    o = ol.Program(m)
+    assert o.add_hermitian(prob["A"][0], prob["C"][0]) == 0
+    oko, yo = o.solve(prob["b"], _sync_cfg(cfg))
+    assert ok == oko == 1                       # EXPECT_TRUE(Solve(..)) is all the reference asks
+    assert np.allclose(y, yo, rtol=1e-7, atol=1e-9)
     L.CONEX_DeleteConeProgram(p)
 
 
