@@ -17,7 +17,8 @@
 // Hand-off without flags or fences.  A published value is its own "ready" flag: every slot a
 // consumer reads starts as kFusedSentinel (a signalling-NaN bit pattern no arithmetic produces),
 // the producer overwrites it with ONE 8-byte write-through store (sc1: agent scope), the consumer
-// polls with sc1 loads until no slot of its own shows the sentinel.  An aligned 8-byte store is
+// polls with sc1 loads -- two rounds of them in flight, so that a value is in registers one memory
+// latency after it became visible -- until no slot of its own shows the sentinel.  An aligned 8-byte store is
 // not torn, and each value is waited for individually, so no ordering between values is needed
 // (MI355X_MICROARCH.md, "data-tagged granules").  Slots come in TWO sets used by alternate runs:
 // run g publishes into set g & 1 and re-arms the same slot of the other set, which nobody reads
@@ -34,6 +35,8 @@
 // order): the factor, the direction and AW / AQc / <w,c> / <c,Qc> are the bits the level kernels
 // with the separate gather produce.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #define CXK_DEVICE_FUNCTIONS_ONLY
 #include "kernels_kkt.hip.h"
@@ -117,7 +120,6 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   double* handO = A.hand + (int64_t)(gen ^ 1) * A.hand_stride;  // the other one: re-armed at the end
   double* ysG = A.ysig + (int64_t)gen * A.ysig_stride;
   double* ysO = A.ysig + (int64_t)(gen ^ 1) * A.ysig_stride;
-  const int probe_base = __builtin_amdgcn_readlane(w, 21), nch = __builtin_amdgcn_readlane(w, 22);
   const int pub_beg = __builtin_amdgcn_readlane(w, 23);
   const int npairs = s * (s + 1) / 2, nv = npairs + s;
 
@@ -148,8 +150,7 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   double aqv = A.AQcc[roff + pr];
   double rb = A.b[R.start + (is_row ? lane : 0)];
   // where this supernode's values go: lane t of round r publishes value number t + 64 r (the
-  // s (s + 1) / 2 Schur updates in the reference's S_S enumeration, then the s forward values);
-  // lanes 0 .. 7: the arrival words of the supernodes that consume them
+  // s (s + 1) / 2 Schur updates in the reference's S_S enumeration, then the s forward values)
   int pd[PR > 0 ? PR : 1], prd[PR > 0 ? PR : 1];
   pd[0] = prd[0] = 0;
 #pragma unroll
@@ -167,7 +168,6 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     const int kk = t < npairs ? k : t - npairs, cc = t < npairs ? k + rem : SMAX;
     prd[r] = (SMAX + 1) * (NSMAX + (t < nv ? kk : 0)) + (t < nv ? cc : 0);
   }
-  const int ppr = A.pprobe[(size_t)blockIdx.x * 8 + (lane & 7)];
   const int ntg = R.tg_end - R.tg_beg;
   int ploc0 = 0, ploc1 = 0;
   if (ntg > 0) {
@@ -307,16 +307,82 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     }
   }
   if (pulls) {
-    // ---- wait for the descendants.  Stage 1: one arrival word per publishing supernode (ONE load
-    // per poll: a poll of every value took 1 - 2 us).  Stage 2: the values themselves, each checked
-    // against the sentinel (an arrival word says its supernode has ISSUED its values, not that they
-    // are visible), again until none is missing.
-    {
-      const double* src = handG + probe_base + (lane < nch ? lane : 0);
+    // ---- wait for the descendants: the values themselves are polled, each checked against the
+    // sentinel, with TWO rounds of loads in flight (every load unconditional, unused slots re-read slot
+    // 0 and are masked: the number of loads per round is static, so the compiler's waits are exact
+    // and a round is examined while the next is on its way).  A value is then in registers one
+    // memory latency after it became visible -- the earlier form (one arrival word per publisher
+    // polled first, then the values) paid two dependent round trips behind every level of the tree.
+    double pv0[MMAX], pv1[MMAX], pb[MFMAX];
+    const double* src0 = handG + R.ubase + (int64_t)(lane < ntg ? lane : 0) * R.m;
+    const double* src1 = handG + R.ubase + (int64_t)(lane + 64 < ntg ? lane + 64 : 0) * R.m;
+    const double* srcb = handG + A.updb_base + R.fbase + (is_row ? lane : 0) * R.mf;
+#pragma unroll
+    for (int i = 0; i < MMAX; i++) pv1[i] = 0.0;
+    if (ntg <= 64) {
+      double q0[MMAX], qb[MFMAX];  // the second round in flight (the first one lands in pv0 / pb)
+      auto arrived = [&](const double (&v0)[MMAX], const double (&vb)[MFMAX]) {
+        bool pending = false;
+#pragma unroll
+        for (int i = 0; i < MMAX; i++) pending = pending || (i < R.m && lane < ntg && IsSentinel(v0[i]));
+#pragma unroll
+        for (int i = 0; i < MFMAX; i++) pending = pending || (i < R.mf && is_row && IsSentinel(vb[i]));
+        return __ballot(pending) == 0;
+      };
+#define CXK_FUSED_ISSUE(V0, VB)                                                          \
+  do {                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < MMAX; i_++) V0[i_] = LoadAgent(src0 + (i_ < R.m ? i_ : 0));   \
+    _Pragma("unroll") for (int i_ = 0; i_ < MFMAX; i_++) VB[i_] = LoadAgent(srcb + (i_ < R.mf ? i_ : 0)); \
+  } while (0)
+      CXK_FUSED_ISSUE(pv0, pb);
       for (int spin = 0;; spin++) {
-        const double v = LoadAgent(src);
-        if (__ballot(lane < nch && IsSentinel(v)) == 0) {
-          FT_COUNT(13, spin);
+        CXK_FUSED_ISSUE(q0, qb);
+        if (arrived(pv0, pb)) {
+          FT_COUNT(12, 2 * spin);
+          break;
+        }
+        CXK_FUSED_ISSUE(pv0, pb);
+        if (arrived(q0, qb) || 2 * spin >= kFusedSpinLimit) {
+          if (2 * spin >= kFusedSpinLimit) ReportTimeout(A);
+#pragma unroll
+          for (int i = 0; i < MMAX; i++) pv0[i] = q0[i];
+#pragma unroll
+          for (int i = 0; i < MFMAX; i++) pb[i] = qb[i];
+          FT_COUNT(12, 2 * spin + 1);
+          break;
+        }
+      }
+#undef CXK_FUSED_ISSUE
+#pragma unroll
+      for (int i = 0; i < MMAX; i++) pv0[i] = i < R.m ? pv0[i] : 0.0;
+#pragma unroll
+      for (int i = 0; i < MFMAX; i++) pb[i] = i < R.mf ? pb[i] : 0.0;
+    } else {
+      // (more than 64 pulled entries: one round at a time)
+      for (int spin = 0;; spin++) {
+        bool pending = false;
+#pragma unroll
+        for (int i = 0; i < MMAX; i++) pv0[i] = pv1[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < MFMAX; i++) pb[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < MMAX; i++)
+          if (i < R.m) {
+            pv0[i] = LoadAgent(src0 + i);
+            pv1[i] = LoadAgent(src1 + i);
+          }
+#pragma unroll
+        for (int i = 0; i < MFMAX; i++)
+          if (i < R.mf) pb[i] = LoadAgent(srcb + i);
+#pragma unroll
+        for (int i = 0; i < MMAX; i++) {
+          pending = pending || (lane < ntg && IsSentinel(pv0[i]));
+          pending = pending || (lane + 64 < ntg && IsSentinel(pv1[i]));
+        }
+#pragma unroll
+        for (int i = 0; i < MFMAX; i++) pending = pending || (is_row && IsSentinel(pb[i]));
+        if (__ballot(pending) == 0) {
+          FT_COUNT(12, spin);
           break;
         }
         if (spin >= kFusedSpinLimit) {
@@ -325,47 +391,6 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
         }
         __builtin_amdgcn_s_sleep(1);
       }
-    }
-    double pv0[MMAX], pv1[MMAX], pb[MFMAX];
-    const double* src0 = handG + R.ubase + (int64_t)(lane < ntg ? lane : 0) * R.m;
-    const double* src1 = handG + R.ubase + (int64_t)(lane + 64 < ntg ? lane + 64 : 0) * R.m;
-    const double* srcb = handG + A.updb_base + R.fbase + (is_row ? lane : 0) * R.mf;
-    for (int spin = 0;; spin++) {
-      bool pending = false;
-#pragma unroll
-      for (int i = 0; i < MMAX; i++) pv0[i] = pv1[i] = 0.0;
-#pragma unroll
-      for (int i = 0; i < MFMAX; i++) pb[i] = 0.0;
-      // (wave-uniform guards: only the slots in use are loaded)
-      if (ntg > 0) {
-#pragma unroll
-        for (int i = 0; i < MMAX; i++)
-          if (i < R.m) pv0[i] = LoadAgent(src0 + i);
-      }
-      if (ntg > 64) {
-#pragma unroll
-        for (int i = 0; i < MMAX; i++)
-          if (i < R.m) pv1[i] = LoadAgent(src1 + i);
-      }
-#pragma unroll
-      for (int i = 0; i < MFMAX; i++)
-        if (i < R.mf) pb[i] = LoadAgent(srcb + i);
-#pragma unroll
-      for (int i = 0; i < MMAX; i++) {
-        pending = pending || (lane < ntg && IsSentinel(pv0[i]));
-        pending = pending || (lane + 64 < ntg && IsSentinel(pv1[i]));
-      }
-#pragma unroll
-      for (int i = 0; i < MFMAX; i++) pending = pending || (is_row && IsSentinel(pb[i]));
-      if (__ballot(pending) == 0) {
-        FT_COUNT(12, spin);
-        break;
-      }
-      if (spin >= kFusedSpinLimit) {
-        ReportTimeout(A);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
     }
     if (ntg > 0) {
       if (lane < ntg) {
@@ -426,7 +451,6 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
         const double v = -my[prd[r]];
         if (lane + 64 * r < nv) StoreAgent(handG + pd[r], v);
       }
-      if (lane < 8 && ppr >= 0) StoreAgent(handG + ppr, 1.0);
       WaveSync();
     }
   }
@@ -445,7 +469,6 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
 #pragma unroll
         for (int r = 0; r < PR; r++)
           if (lane + 64 * r < nv) StoreAgent(handO + pd[r], SentinelValue());
-        if (lane < 8 && ppr >= 0) StoreAgent(handO + ppr, SentinelValue());
       }
     }
     return;
@@ -560,7 +583,6 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
 #pragma unroll
       for (int r = 0; r < PR; r++)
         if (lane + 64 * r < nv) StoreAgent(handO + pd[r], SentinelValue());
-      if (lane < 8 && ppr >= 0) StoreAgent(handO + ppr, SentinelValue());
     }
   }
   FT_STAMP_FLUSH(f(31));
@@ -596,7 +618,6 @@ __device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, cons
   double* handO = A.hand + (int64_t)(gen ^ 1) * A.hand_stride;
   double* ysG = A.ysig + (int64_t)gen * A.ysig_stride;
   double* ysO = A.ysig + (int64_t)(gen ^ 1) * A.ysig_stride;
-  const int probe_base = __builtin_amdgcn_readlane(w, 21), nch = __builtin_amdgcn_readlane(w, 22);
   const int pub_beg = __builtin_amdgcn_readlane(w, 23);
   const int npairs = s * (s + 1) / 2, nv = npairs + s;
   const int cnt = R.bs_end - R.bs_beg;
@@ -630,39 +651,35 @@ __device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, cons
   }
   int pdb = 0;
   if constexpr (SMAX > 0) pdb = A.pub[pub_beg + npairs + (is_sep ? sc : 0)];
-  const int ppr = A.pprobe[(size_t)blockIdx.x * 8 + (lane & 7)];
   // ---- wait for the descendants' forward values (arrival words, then the values, as in the factor sweep)
   double pb[MFMAX];
 #pragma unroll
   for (int i = 0; i < MFMAX; i++) pb[i] = 0.0;
   if (PHASE != 2 && R.mf > 0) {
-    {
-      const double* src = handG + probe_base + (lane < nch ? lane : 0);
-      for (int spin = 0;; spin++) {
-        const double v = LoadAgent(src);
-        if (__ballot(lane < nch && IsSentinel(v)) == 0) break;
-        if (spin >= kFusedSpinLimit) {
-          ReportTimeout(A);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
+    // (two rounds of loads in flight, every load unconditional: see the factor sweep)
     const double* srcb = handG + A.updb_base + R.fbase + (is_row ? lane : 0) * R.mf;
-    for (int spin = 0;; spin++) {
+    double qb[MFMAX];
+    auto arrived = [&](const double (&vb)[MFMAX]) {
       bool pending = false;
 #pragma unroll
-      for (int i = 0; i < MFMAX; i++)
-        if (i < R.mf) pb[i] = LoadAgent(srcb + i);
+      for (int i = 0; i < MFMAX; i++) pending = pending || (i < R.mf && is_row && IsSentinel(vb[i]));
+      return __ballot(pending) == 0;
+    };
+#define CXK_FUSED_ISSUE(VB) \
+  _Pragma("unroll") for (int i_ = 0; i_ < MFMAX; i_++) VB[i_] = LoadAgent(srcb + (i_ < R.mf ? i_ : 0))
+    CXK_FUSED_ISSUE(pb);
+    for (int spin = 0;; spin++) {
+      CXK_FUSED_ISSUE(qb);
+      if (arrived(pb)) break;
+      CXK_FUSED_ISSUE(pb);
+      if (arrived(qb) || 2 * spin >= kFusedSpinLimit) {
+        if (2 * spin >= kFusedSpinLimit) ReportTimeout(A);
 #pragma unroll
-      for (int i = 0; i < MFMAX; i++) pending = pending || (is_row && IsSentinel(pb[i]));
-      if (__ballot(pending) == 0) break;
-      if (spin >= kFusedSpinLimit) {
-        ReportTimeout(A);
+        for (int i = 0; i < MFMAX; i++) pb[i] = qb[i];
         break;
       }
-      __builtin_amdgcn_s_sleep(1);
     }
+#undef CXK_FUSED_ISSUE
   }
   // ---- forward substitution (ForwardSupernodeLean)
   if constexpr (PHASE != 2) {
@@ -685,8 +702,6 @@ __device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, cons
   if constexpr (SMAX > 0) {
     if (s > 0) {
       if (is_sep) StoreAgent(handG + pdb, dot);
-      // (issued behind the values, not ordered with them: the consumer checks every value it reads)
-      if (lane < 8 && ppr >= 0) StoreAgent(handG + ppr, 1.0);
     }
   }
   }  // PHASE != 2
@@ -743,7 +758,6 @@ __device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, cons
         const int d = A.pub[pub_beg + (t < nv ? t : 0)];
         if (t < nv) StoreAgent(handO + d, SentinelValue());
       }
-      if (lane < 8 && ppr >= 0) StoreAgent(handO + ppr, SentinelValue());
     }
   }
 }
