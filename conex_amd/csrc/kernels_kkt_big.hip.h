@@ -117,25 +117,77 @@ __global__ void __launch_bounds__(64) big_panel(double* __restrict__ D, double* 
   BPSTAMP(5);
 }
 
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads()
+// also waits for every outstanding global load (vmcnt(0)), i.e. for the operands requested a phase
+// ahead below -- which is the round trip the request was issued early to hide.
+__device__ __forceinline__ void BigLdsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // b <- L^-1 b for the factored diagonal block of a big supernode: ONE workgroup streams L once,
-// panel by panel (b lives in LDS): wavefront 0 solves the 32 x 32 block (row per lane in
-// registers), then every thread updates its rows below with the panel's 32 solved values.
-__global__ void __launch_bounds__(1024) big_solve_fwd(const double* __restrict__ D, double* __restrict__ b,
-                                                      int ns) {
+// panel by panel (b lives in LDS), the mirror image of big_solve_bwd below.  Wavefront 0 solves the
+// 32 x 32 blocks (row per lane in registers).  Of the update  b_below -= L21 y_k  only the 32 rows of
+// the NEXT panel are on the dependent chain: wavefronts 1 .. 8 form them as 32 dot products (sixteen
+// lanes per row) between two solves, and apply the rest of the update (one row per thread, 32
+// multiply-adds) while wavefront 0 solves the next block.  L does not depend on b: operands are
+// requested a panel ahead, the barriers order LDS traffic only.
+constexpr int kBigFwdThreads = 64 + 32 * 16, kBigFwdRows = 32 * 16;
+__global__ void __launch_bounds__(kBigFwdThreads) big_solve_fwd(const double* __restrict__ D,
+                                                                double* __restrict__ b, int ns) {
   constexpr int NB = kBigNB;
   extern __shared__ double sb[];  // ns
   __shared__ double yk[NB];
   const int lane = threadIdx.x & 63;
+  const bool solver = threadIdx.x < 64;
+  const int ut = (int)threadIdx.x - 64, g = ut >> 4, sub = ut & 15;  // row g of the next panel, 16 lanes each
   for (int i = threadIdx.x; i < ns; i += blockDim.x) sb[i] = b[i];
-  __syncthreads();
+  // solver: rg[j] = L[k0 + lane][k0 + j].  Others, for panel k's columns: rg[j] = L[k0 + 64 + ut][k0 + j]
+  // (a row beyond the next panel), near[h] = L[k0 + 32 + g][k0 + sub + 16 h] (a row of the next panel)
+  double rg[NB], near_cur[2], near_next[2];
+  near_cur[0] = near_cur[1] = near_next[0] = near_next[1] = 0.0;
+  auto request_block = [&](int k0) {
+    if (k0 >= ns) return;
+    const int nb = ns - k0 < NB ? ns - k0 : NB;
+    const double* src = D + (k0 + (lane < nb ? lane : 0)) + (size_t)k0 * ns;
+#pragma unroll
+    for (int j = 0; j < NB; j++) rg[j] = src[(size_t)(j < nb ? j : 0) * ns];
+  };
+  // near_next <- the rows of the panel behind columns c0 .. c0 + 31 (used two phases 1 later)
+  auto request_near = [&](int c0) {
+    if (c0 + NB >= ns) return;
+    const int below = ns - c0 - NB;
+    const double* nrow = D + (c0 + NB + (g < below ? g : 0)) + (size_t)c0 * ns;
+#pragma unroll
+    for (int h = 0; h < 2; h++) near_next[h] = nrow[(size_t)(sub + 16 * h) * ns];
+  };
+  // rg <- this thread's row beyond the next panel, columns k0 .. k0 + 31 (used while the next block is solved)
+  auto request_far = [&](int k0) {
+    if (k0 + NB >= ns) return;
+    const int below = ns - k0 - NB;
+    const double* frow = D + (k0 + NB + (32 + ut < below ? 32 + ut : 0)) + (size_t)k0 * ns;
+#pragma unroll
+    for (int j = 0; j < NB; j++) rg[j] = frow[(size_t)j * ns];
+  };
+  if (solver)
+    request_block(0);
+  else
+    request_near(0);
+  BigLdsBarrier();
   for (int k0 = 0; k0 < ns; k0 += NB) {
-    const int nb = ns - k0 < NB ? ns - k0 : NB, below = ns - k0 - nb;
-    if (threadIdx.x < 64) {
+    const int nb = ns - k0 < NB ? ns - k0 : NB;
+    if (!solver && k0 > 0) {
+      // the rows of THIS panel take the term of the panel solved last (everything older is in already)
+      double acc = 0.0;
+#pragma unroll
+      for (int h = 0; h < 2; h++) acc = fma(near_cur[h], yk[sub + 16 * h], acc);
+#pragma unroll
+      for (int d = 8; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+      if (sub == 0 && g < nb) sb[k0 + g] -= acc;
+    }
+    BigLdsBarrier();
+    if (solver) {
       const bool row = lane < nb;
       double l[NB];
-      const double* src = D + (k0 + (row ? lane : 0)) + (size_t)k0 * ns;
 #pragma unroll
-      for (int j = 0; j < NB; j++) l[j] = (row && j <= lane) ? src[(size_t)(j < nb ? j : 0) * ns] : (j == lane ? 1.0 : 0.0);
+      for (int j = 0; j < NB; j++) l[j] = (row && j <= lane && j < nb) ? rg[j] : (j == lane ? 1.0 : 0.0);
       double v = row ? sb[k0 + lane] : 0.0;
       double diag = 1.0;
 #pragma unroll
@@ -149,33 +201,43 @@ __global__ void __launch_bounds__(1024) big_solve_fwd(const double* __restrict__
         else if (lane > j)
           v = fma(-l[j], yj, v);
       }
+      // (yk of the previous panel is still being read by the others in this phase: written after the barrier)
+      BigLdsBarrier();
       if (row) {
         sb[k0 + lane] = v;
         yk[lane] = v;
       } else if (lane < NB) {
         yk[lane] = 0.0;
       }
-    }
-    __syncthreads();
-    for (int r = threadIdx.x; r < below; r += blockDim.x) {
-      const double* rowp = D + (k0 + nb + r) + (size_t)k0 * ns;
-      double v[NB];
+      request_block(k0 + NB);
+    } else {
+      if (k0 > 0) {
+        // meanwhile: the previous panel's term for the rows beyond this panel
+        const int kp = k0 - NB, belowp = ns - kp - NB;
+        if (32 + ut < belowp) {
+          double acc = sb[kp + NB + 32 + ut];
 #pragma unroll
-      for (int j = 0; j < NB; j++) v[j] = rowp[(size_t)(j < nb ? j : 0) * ns];
-      double acc = sb[k0 + nb + r];
+          for (int j = 0; j < NB; j++) acc = fma(-rg[j], yk[j], acc);
+          sb[kp + NB + 32 + ut] = acc;
+        }
+        for (int r = 32 + ut + kBigFwdRows; r < belowp; r += kBigFwdRows) {  // (very tall blocks: loaded here)
+          const double* frow = D + (kp + NB + r) + (size_t)kp * ns;
+          double acc = sb[kp + NB + r];
+#pragma unroll 8
+          for (int j = 0; j < NB; j++) acc = fma(-frow[(size_t)j * ns], yk[j], acc);
+          sb[kp + NB + r] = acc;
+        }
+      }
+      BigLdsBarrier();
 #pragma unroll
-      for (int j = 0; j < NB; j++) acc = fma(-v[j], yk[j], acc);  // yk is zero beyond nb
-      sb[k0 + nb + r] = acc;
+      for (int h = 0; h < 2; h++) near_cur[h] = near_next[h];  // (requested a panel ago)
+      request_near(k0 + NB);
+      request_far(k0);  // this panel's columns: used once it is solved, behind the next solve
     }
-    __syncthreads();
+    BigLdsBarrier();
   }
   for (int i = threadIdx.x; i < ns; i += blockDim.x) b[i] = sb[i];
 }
-
-// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  __syncthreads()
-// also waits for every outstanding global load (vmcnt(0)), i.e. for the operands requested a phase
-// ahead below -- which is the round trip the request was issued early to hide.
-__device__ __forceinline__ void BigLdsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // b <- L^-T b, panels from the last to the first.  Wavefront 0 solves the transposed 32 x 32 blocks
 // (column per lane in registers); wavefronts 1 .. 8 form the 32 dot products L21^T x_below, sixteen
@@ -402,7 +464,7 @@ inline hipError_t BigSupernodeSweep(const FactorPlan& P, const SnRec& R, int mod
         }
       }
     }
-  if (rhs && !dataflow) big_solve_fwd<<<1, 1024, solve_lds, st>>>(D, b, ns);
+  if (rhs && !dataflow) big_solve_fwd<<<1, kBigFwdThreads, solve_lds, st>>>(D, b, ns);
   if (s > 0) {
     double* U = ws;
     double* t = ws + (size_t)s * s;
