@@ -1088,10 +1088,12 @@ int LaunchTreeCore(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
 constexpr int kQrMaxOrder = 1500;
 
 // Column-pivoted Householder QR, A P = Q R, of the n x n column-major matrix `a` (overwritten:
-// R on and above the diagonal, the essential parts of the reflectors below).  Pivot rule, rank
-// threshold and the solve are those of Eigen::ColPivHouseholderQR (largest remaining column norm
-// first; rank = number of pivots above epsilon * n * largest pivot; solve() applies Q^T, solves
-// with the leading rank x rank triangle and leaves the remaining unknowns zero).
+// R on and above the diagonal, the essential parts of the reflectors below).  Pivot rule and solve
+// are those of Eigen::ColPivHouseholderQR: largest remaining column norm first; solve() works with
+// nonzeroPivots() -- NOT rank(): the factorization stops counting pivots at the first step k whose
+// largest remaining squared column norm is below (eps * largest initial column norm)^2 / n * (n - k)
+// -- applies that many reflectors, solves with the leading triangle of that size and leaves the
+// remaining unknowns zero.  `rank` returns that count.
 void DenseQrFactor(int n, std::vector<double>& a, std::vector<double>& tau, std::vector<int>& piv, int* rank) {
   tau.assign(n, 0.0);
   piv.resize(n);
@@ -1102,8 +1104,10 @@ void DenseQrFactor(int n, std::vector<double>& a, std::vector<double>& tau, std:
     for (int i = 0; i < n; i++) t += a[i + (size_t)j * n] * a[i + (size_t)j * n];
     norm2[j] = t;
   }
-  double maxpivot = 0;
-  int r = 0;
+  double maxnorm2 = 0;
+  for (int j = 0; j < n; j++) maxnorm2 = std::max(maxnorm2, norm2[j]);
+  const double threshold_helper = maxnorm2 * DBL_EPSILON * DBL_EPSILON / n;  // abs2(max col norm * eps) / rows
+  int nonzero = n;
   for (int k = 0; k < n; k++) {
     int best = k;
     for (int j = k; j < n; j++) {  // column norms of the trailing block, recomputed (n is small)
@@ -1112,6 +1116,7 @@ void DenseQrFactor(int n, std::vector<double>& a, std::vector<double>& tau, std:
       norm2[j] = t;
       if (t > norm2[best]) best = j;
     }
+    if (nonzero == n && norm2[best] < threshold_helper * (n - k)) nonzero = k;
     if (best != k) {
       for (int i = 0; i < n; i++) std::swap(a[i + (size_t)k * n], a[i + (size_t)best * n]);
       std::swap(piv[k], piv[best]);
@@ -1138,18 +1143,14 @@ void DenseQrFactor(int n, std::vector<double>& a, std::vector<double>& tau, std:
         for (int i = k + 1; i < n; i++) cj[i] -= w * col[i];
       }
     }
-    maxpivot = std::max(maxpivot, std::fabs(beta));
   }
-  const double thresh = DBL_EPSILON * n * maxpivot;
-  for (int k = 0; k < n; k++)
-    if (std::fabs(a[k + (size_t)k * n]) > thresh) r++;
-  *rank = r;
+  *rank = nonzero;
 }
 
 void DenseQrSolve(const cxk_context::DenseQr& Q, std::vector<double>& b) {
   const int n = Q.n;
   const std::vector<double>& a = Q.qr;
-  for (int k = 0; k < n; k++) {  // c = Q^T b
+  for (int k = 0; k < Q.rank; k++) {  // c = Q^T b, the first nonzeroPivots() reflectors (householderQ().setLength)
     if (Q.tau[k] == 0.0) continue;
     double w = b[k];
     for (int i = k + 1; i < n; i++) w += a[i + (size_t)k * n] * b[i];

@@ -404,6 +404,52 @@ def test_qr_solver_mode_matches_the_supernodal_solve():
     assert np.linalg.norm(q.solve_inplace(r2) - y_ldlt) <= 1e-9 * np.linalg.norm(y_ldlt)
 
 
+def test_qr_solver_mode_on_a_rank_deficient_system_follows_eigen():
+    """Two variables with the same matrices: the KKT matrix is singular.  Eigen's
+    ColPivHouseholderQR::solve works with nonzeroPivots() (pivots until the largest remaining squared
+    column norm falls under (eps * max column norm)^2 / n * (n - k)), applies that many reflectors,
+    solves the leading triangle and leaves the other unknowns zero (kkt_solver.cc:227-231 calls
+    exactly that): restated here with scipy's pivoted QR."""
+    import scipy.linalg
+    from conex_amd import KktContext, synthetic as syn
+    prob = syn.lmi_problem(K=1, n=7, m=6, branching=2, overlap=1, seed=43)
+    A = prob["A"][0].copy()
+    A[4] = A[1]                                   # a repeated variable: rank 5 of 6
+    W = syn.scaling_points(1, 7, seed=3)
+    o, k = ol.Program(6), KktContext(6, device=0)
+    for p in (o, k):
+        p.add_lmi(A, prob["C"][0], list(range(6)))
+        p.initialize()
+        p.set_W(0, W[0])
+        p.assemble()
+    T = o.kkt_matrix()
+    T = np.tril(T) + np.tril(T, -1).T
+    assert np.linalg.matrix_rank(T) == 5
+    k.set_solver_mode(2)
+    assert k.factor() == 1                        # Factor() returns true in QR mode (kkt_solver.cc:197)
+    rhs = np.random.default_rng(1).uniform(-1, 1, 6)
+    y = k.solve_inplace(rhs)
+    # Eigen's rule
+    Q, R, piv = scipy.linalg.qr(T, pivoting=True)
+    n = 6
+    helper = (np.sqrt((T * T).sum(axis=0).max()) * np.finfo(float).eps) ** 2 / n
+    nz = n
+    Tk = T[:, piv].copy()
+    for kk in range(n):                           # largest remaining squared column norm at step kk
+        rem = (Q.T @ T[:, piv])[kk:, kk:]
+        if (rem * rem).sum(axis=0).max() < helper * (n - kk):
+            nz = kk
+            break
+    assert nz == 5
+    c = (Q.T @ rhs)[:nz]
+    z = np.zeros(n)
+    z[:nz] = scipy.linalg.solve_triangular(R[:nz, :nz], c)
+    ref = np.zeros(n)
+    ref[piv] = z
+    assert np.linalg.norm(y - ref) <= 1e-8 * np.linalg.norm(ref)
+    assert np.count_nonzero(y == 0.0) == 1        # the dropped unknown is exactly zero
+
+
 def test_qr_solver_mode_refuses_large_systems():
     from conex_amd import KktContext, synthetic as syn
     prob = syn.lmi_problem(K=120, n=4, m=20, branching=8, overlap=5, seed=4)   # N = 1805
