@@ -335,8 +335,62 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa)
   const double* Cm = g.C + (size_t)mem * NN;
   const double* Wg = g.W + (size_t)mem * NN;
   double* M = sM[wave];
-  // minus_s = sum_i y_i A_i - k C (dense_lmi_constraint.cc:8-27): lane l owns the 16-byte chunks l, l + 64, ..
+  // minus_s = sum_i y_i A_i - k C (dense_lmi_constraint.cc:8-27)
   const double yv = lane < m ? sa.y[sa.cl_perm[sa.cl_ptr[id] + lane]] : 0.0;
+  if (g.Apk) {
+    // from the packed lower triangles (exactly symmetric data: the mirrored entry is the same sum of
+    // the same terms): 105 16-byte chunks per matrix instead of 200, lane l owns chunks l and l + 64,
+    // twenty matrices per batch -- the whole constraint behind ONE round trip at m <= 20
+    constexpr int PK = N * (N + 1) / 2, PH = PK / 2, CP = (PH + 63) / 64, PB = 20;
+    static_assert(PK % 2 == 0, "16-byte chunks");
+    double2 acc[CP];
+    int eo[CP];
+#pragma unroll
+    for (int u = 0; u < CP; u++) {
+      acc[u] = make_double2(0.0, 0.0);
+      eo[u] = lane + 64 * u < PH ? lane + 64 * u : PH - 1;
+    }
+    const double2* base = reinterpret_cast<const double2*>(g.Apk + (size_t)mem * m * PK);
+    for (int i0 = 0; i0 < m; i0 += PB) {
+      double2 v[PB][CP];
+#pragma unroll
+      for (int b = 0; b < PB; b++) {
+        const int i = i0 + b < m ? i0 + b : m - 1;
+#pragma unroll
+        for (int u = 0; u < CP; u++) v[b][u] = base[(size_t)i * PH + eo[u]];
+      }
+#pragma unroll
+      for (int b = 0; b < PB; b++) {
+        if (i0 + b < m) {  // wave-uniform
+          const double yi = ReadLaneUniform(yv, i0 + b);
+#pragma unroll
+          for (int u = 0; u < CP; u++) {
+            acc[u].x += yi * v[b][u].x;
+            acc[u].y += yi * v[b][u].y;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CP; u++) {
+      const int e2 = lane + 64 * u;
+      if (e2 < PH) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          int c = 0, rem = 2 * e2 + h;  // packed position -> (row, column), column by column
+          while (rem >= N - c) {
+            rem -= N - c;
+            c++;
+          }
+          const int r = c + rem;
+          const double a = h == 0 ? acc[u].x : acc[u].y;
+          M[r + c * N] = a - sa.c_weight * Cm[r + c * N];
+          if (r != c) M[c + r * N] = a - sa.c_weight * Cm[c + r * N];
+        }
+      }
+    }
+  } else {
+  // lane l owns the 16-byte chunks l, l + 64, ..
   double2 acc[CH];
 #pragma unroll
   for (int u = 0; u < CH; u++) acc[u] = make_double2(0.0, 0.0);
@@ -377,6 +431,7 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa)
       M[2 * e] = acc[u].x - sa.c_weight * Cm[2 * e];
       M[2 * e + 1] = acc[u].y - sa.c_weight * Cm[2 * e + 1];
     }
+  }
   }
   WaveSync();
   const bool row = lane < N;

@@ -74,6 +74,7 @@ LmiGroup MakeLmi(Group& g) {
   d.W = g.W.p;
   d.T1 = g.T1.p;
   d.ids = g.dids.p;
+  d.Apk = g.Apk.n ? g.Apk.p : nullptr;
   d.herm_d = g.herm_d;
   d.sp_eptr = g.sparse ? g.sp_eptr.p : nullptr;
   d.sp_erc = g.sparse ? g.sp_erc.p : nullptr;
@@ -1840,6 +1841,23 @@ static int FinalizeImpl(cxk_context* ctx) {
         }
       }
       CXK_TRY(g.Apad.upload(hp));
+    }
+    if (g.type == CXK_LMI && !g.literal && !getenv("CXK_NO_PACKED_SLACK") &&
+        LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse)) {
+      // the slack pass of PrepareStep / the eigenvalue query streams every A_i once more per call: a
+      // packed copy of the lower triangles (the data is exactly symmetric) halves those bytes
+      const int n = g.n, pk = n * (n + 1) / 2;
+      std::vector<double> hp((size_t)pk * g.m * cnt);
+      for (size_t k = 0; k < cnt; k++) {
+        const ConstraintRec& c = ctx->cons[g.ids[k]];
+        for (int i = 0; i < g.m; i++) {
+          const double* src = c.A.data() + (size_t)i * n * n;
+          double* dst = hp.data() + (k * g.m + i) * (size_t)pk;
+          for (int col = 0; col < n; col++)
+            for (int row = col; row < n; row++) *dst++ = src[row + (size_t)col * n];
+        }
+      }
+      CXK_TRY(g.Apk.upload(hp));
     }
     if (g.type == CXK_QUAD) {
       // A_gram = A1' (Q A1), made once (QuadraticConstraintBase::Initialize, quadratic_cone_constraint.cc:216-219)

@@ -17,6 +17,10 @@ struct LmiGroup {
   double* W;        // count x (n*n)
   double* T1;       // count x (n*n)   temp_1 of WorkspaceDensePSD (WS between Prepare/TakeStep)
   const int* ids;   // member -> constraint id
+  // lower triangles of the A_i, packed column by column (n (n + 1) / 2 doubles each, count x m of them),
+  // for the kernels that only need sum_i y_i A_i of symmetric data (the slack of lmi_prepare_rows:
+  // half the bytes of the full matrices); nullptr where no such copy is kept
+  const double* Apk;
   // 0: DenseLMIConstraint semantics.  d in {1,2,4}: HermitianPsdConstraint over R / C / H stored
   // through its real representation (order n = d * hyper-complex order): outputs carry the
   // factor 1/d (tr over the representation = d * Re tr), TakeStep uses the reference's
