@@ -166,6 +166,9 @@ __global__ void __launch_bounds__(256) lmi_schur_generic(LmiGroup g, Arena ar) {
 // on one lane); the reference only consumes min / max of
 // SelfAdjointEigenSolver::computeFromTridiagonal (approximate_eigenvalues.cc:232-238), and both
 // methods are accurate to a few ulps of the matrix norm.  d, e are read-only (LDS).
+// MAXN > 0: n <= MAXN, the matrix is copied into registers once (a lone wavefront pays ~50 cycles per
+// LDS read: two per step of every count, ten counts).
+template <int MAXN = 0>
 __device__ __forceinline__ void TridiagMinMaxWave(int n, const double* d, const double* e, double* mn, double* mx) {
   const int lane = threadIdx.x & 63;
   if (n == 1) {
@@ -184,19 +187,43 @@ __device__ __forceinline__ void TridiagMinMaxWave(int n, const double* d, const 
   double a = glo - pad, b = ghi + pad;
   const int half = lane >> 5, sub = lane & 31;
   const int target = half == 0 ? 1 : n;
+  double dd[MAXN > 0 ? MAXN : 1], e2[MAXN > 0 ? MAXN : 1];
+  if constexpr (MAXN > 0) {
+#pragma unroll
+    for (int i = 0; i < MAXN; i++) {
+      dd[i] = d[i < n ? i : 0];
+      const double ev = e[(i >= 1 && i < n) ? i - 1 : 0];
+      e2[i] = ev * ev;
+    }
+  }
   for (int round = 0; round < 10; round++) {
     const double w = b - a;
     const double x = a + w * ((sub + 1) * (1.0 / 33.0));
-    int c = 0;
-    double q = d[0] - x;
-    c += q < 0.0;
+    // Sturm count as sign changes of the leading principal minors p_0 = 1, p_1 = d_0 - x,
+    // p_{i+1} = (d_i - x) p_i - e_{i-1}^2 p_{i-1} (the pivot of the LDL^T recurrence is their ratio):
+    // two dependent fmas per step where the pivot recurrence waits for a reciprocal and its Newton
+    // step (~70 cycles a step on a lone wavefront; the ten rounds took 7 of PrepareStep's 24 us).
+    // Rescaled when it leaves [1e-150, 1e150]; an exact zero keeps the sign of its predecessor.
+    double pm = 1.0, p = (MAXN > 0 ? dd[0] : d[0]) - x;
+    bool neg = p < 0.0;
+    int c = neg;
+    auto step = [&](double di, double ee) {
+      double pn = fma(di - x, p, -(ee * pm));
+      const double mag = fabs(pn);
+      const double sc = mag > 1e150 ? 1e-150 : ((mag < 1e-150 && mag > 0.0) ? 1e150 : 1.0);
+      pm = p * sc;
+      p = pn * sc;
+      const bool ng = p < 0.0;
+      c += (p != 0.0 && ng != neg);
+      neg = p != 0.0 ? ng : neg;
+    };
+    if constexpr (MAXN > 0) {
+#pragma unroll
+      for (int i = 1; i < MAXN; i++)
+        if (i < n) step(dd[i], e2[i]);  // wave-uniform
+    } else {
 #pragma unroll 4
-    for (int i = 1; i < n; i++) {
-      if (fabs(q) < 1e-290) q = q < 0.0 ? -1e-290 : 1e-290;
-      double r = __builtin_amdgcn_rcp(q);
-      r = fma(fma(-q, r, 1.0), r, r);  // one Newton step: only the sign of the pivot matters
-      q = (d[i] - x) - e[i - 1] * e[i - 1] * r;
-      c += q < 0.0;
+      for (int i = 1; i < n; i++) step(d[i], e[i - 1] * e[i - 1]);
     }
     const unsigned long long m = __ballot(c >= target);
     const unsigned int mh = half ? (unsigned int)(m >> 32) : (unsigned int)(m & 0xffffffffull);

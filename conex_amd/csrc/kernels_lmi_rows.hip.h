@@ -318,7 +318,7 @@ __device__ __forceinline__ void LanczosRows(const double (&ws)[N], const double 
     }
   }
   WaveSync();  // alpha / beta were written by lane 0
-  TridiagMinMaxWave(cnt + 1, alpha, beta, &out[0], &out[1]);
+  TridiagMinMaxWave<N / 2 + 1>(cnt + 1, alpha, beta, &out[0], &out[1]);  // (at most num_iter = N / 2 steps)
 }
 
 template <int MODE, int N>
