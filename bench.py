@@ -73,6 +73,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--preheat", type=int, default=200,
+                    help="untimed steps BEFORE the --warmup steps: a freshly started process finds the GPU at "
+                         "its idle clocks, and --warmup 5 --steps 20 (1.3 ms of work) would time the ramp, not "
+                         "the steady state the metric is about; reported as config.preheat_steps (0 disables)")
     ap.add_argument("--K", type=int, default=1000)
     ap.add_argument("--workload", choices=["c4", "c2", "c3", "c5", "c4s", "maxcut"], default="c4",
                     help="c4 (default, the metric's config): 1000 LMIs n=20; extras, single GPU: "
@@ -233,9 +237,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(max(0, args.preheat)):   # clocks up (see --preheat); not part of the contract's W + K steps
+        step()
+    ok0 = ctx.sync()
     for _ in range(args.warmup):
         step()
-    ok = ctx.sync()
+    ok = ctx.sync() and ok0
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):      # the timed region carries no instrumentation
@@ -301,6 +308,7 @@ def main():
                        if sharded
                        else "single GPU",
                        "n_ranks_seen": ctx.comm_count() if sharded else 1,
+                       "preheat_steps": max(0, args.preheat),
                        "factor_ok": bool(ok)},
         }
         if nsamp > 0 and kern_ms > 0:
