@@ -11,6 +11,8 @@ OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python3 "$ROOT/bench.py" > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+# (the driver's command line: 5 + 20 steps behind the untimed preheat)
+python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_settings.json" 2> "$OUT/bench_driver_settings.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
   python3 "$ROOT/bench.py" --no-cpu > "$OUT/bench_default_under_rocprof.log" 2>&1
 python3 "$ROOT/bench.py" --workload c2 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
@@ -22,6 +24,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -o bench
 CXK_NO_FUSED_TREE=1 "$ROOT/tools/step_timeline.sh" c4_levels > "$OUT/step_timeline_level_kernels.txt" 2>&1
 python3 "$ROOT/tools/fused_tree_stamps.py" > "$OUT/fused_tree_stamps.txt" 2>&1
 python3 "$ROOT/tools/fused_tree_stamps.py" 1 200 50 > "$OUT/fused_tree_stamps_c2.txt" 2>&1
+# big supernodes: in-kernel timeline of big_chol_dataflow at 500 columns, kernel statistics of the max-cut step
+python3 "$ROOT/tools/big_chol_stamps.py" 500 > "$OUT/big_chol_stamps.txt" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_maxcut500" -o bench -- \
+  python3 "$ROOT/bench.py" --workload maxcut --maxcut-n 500 --no-cpu --steps 100 > "$OUT/bench_maxcut500_under_rocprof.log" 2>&1
 python3 "$ROOT/tools/ipm_iteration.py" --timers > "$OUT/ipm_iteration.txt" 2>&1
 "$ROOT/tools/ipm_rocprof.sh" 2>&1 | grep -v "^[EW]20" > "$OUT/ipm_kernels.txt"
 cd /tmp

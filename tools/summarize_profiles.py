@@ -25,10 +25,12 @@ def main():
     os.makedirs(dst, exist_ok=True)
     for name in ["bench_default.json", "bench_default_under_rocprof.log", "bench_c2.json",
                  "bench_c2_under_rocprof.log", "step_timeline.txt", "step_timeline_level_kernels.txt",
-                 "fused_tree_stamps.txt", "fused_tree_stamps_c2.txt", "ipm_iteration.txt", "ipm_kernels.txt"]:
+                 "fused_tree_stamps.txt", "fused_tree_stamps_c2.txt", "ipm_iteration.txt", "ipm_kernels.txt",
+                 "bench_driver_settings.json", "big_chol_stamps.txt"]:
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, name))
-    for sub, out in [("stats", "bench_default_kernel_stats.csv"), ("stats_c2", "bench_c2_kernel_stats.csv")]:
+    for sub, out in [("stats", "bench_default_kernel_stats.csv"), ("stats_c2", "bench_c2_kernel_stats.csv"),
+                     ("stats_maxcut500", "bench_maxcut500_kernel_stats.csv")]:
         files = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
         if files:
             shutil.copy(files[0], os.path.join(dst, out))
