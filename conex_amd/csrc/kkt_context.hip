@@ -946,7 +946,6 @@ int MakeFusedTreeArgs(cxk_context* ctx, FusedTreeArgs* out) {
   a.slab = ctx->slab.p;
   a.y = ctx->y.p;
   a.pub = ctx->fx_pub.p;
-  a.pprobe = ctx->fx_pprobe.p;
   a.tg_reg = ctx->tg_reg.p;
   a.xreg = ctx->fx_xreg.p;
   a.xsrc = ctx->fx_xsrc.p;

@@ -239,7 +239,7 @@ struct cxk_context {
   int fused_sa = 0, fused_sb = 0;
   DevBuf<int> fx_rec, fx_xreg;
   DevBuf<long long> fx_xsrc, fx_rsrc;
-  DevBuf<int> fx_pub, fx_pprobe;
+  DevBuf<int> fx_pub;
   DevBuf<double> fx_hand, fx_ysig;
   std::vector<double> fx_hand_init;
   long long fx_updb_base = 0;

@@ -1011,51 +1011,26 @@ int BuildPlans(cxk_context* ctx) {
         }
       ok = rsrc.size() < (size_t)INT32_MAX && xreg.size() < (size_t)INT32_MAX;
     }
-    // who consumes a supernode's published values: the supernodes that own its separator variables
-    // (at most 8).  Every (publisher, consumer) pair gets an arrival word; a consumer's are consecutive.
-    std::vector<int> pub, pprobe((size_t)cnt_all * 8, -1);
+    // a supernode's published values go to the supernodes that own its separator variables: all of
+    // them must sit at higher positions (waits go to lower positions on the way up)
+    std::vector<int> pub;
     const size_t us = (size_t)slots + 1 + kPullPad, ubs = (size_t)slotsb + 2 + kPullPad;
-    size_t nprobe = 0;
     if (ok) {
       std::vector<int> pos_of(K, -1);
       for (int pos = 0; pos < cnt_all; pos++) pos_of[ctx->level_sn[pos]] = pos;
-      std::vector<std::vector<int>> cons_of(K), kids(K);
       for (int pos = 0; pos < cnt_all && ok; pos++) {
         const int e = ctx->level_sn[pos];
-        for (int v : L.separators[e]) {
-          const int p = L.var_to_sn[v];
-          if (std::find(cons_of[e].begin(), cons_of[e].end(), p) == cons_of[e].end()) {
-            cons_of[e].push_back(p);
-            kids[p].push_back(e);
-          }
-          ok = ok && pos_of[p] > pos;  // (waits go to lower positions on the way up)
-        }
+        for (int v : L.separators[e]) ok = ok && pos_of[L.var_to_sn[v]] > pos;
         note("a consumer at a lower position");
-        ok = ok && cons_of[e].size() <= 8;
-        note("a supernode with more than 8 consumers");
       }
-      std::vector<int> pbase(K, 0);
-      for (int pos = 0; pos < cnt_all && ok; pos++) {
-        const int e = ctx->level_sn[pos];
-        pbase[e] = (int)(us + ubs + nprobe);
-        nprobe += kids[e].size();
-        ok = kids[e].size() <= 64;
-        note("a supernode with more than 64 publishers");
-      }
-      ok = ok && us + ubs + nprobe + 8 < (size_t)INT32_MAX;
+      ok = ok && us + ubs + 8 < (size_t)INT32_MAX;
       for (int pos = 0; pos < cnt_all && ok; pos++) {
         const int e = ctx->level_sn[pos];
         int* w = recs.data() + (size_t)pos * kFusedRecWords;
-        w[21] = pbase[e];
-        w[22] = (int)kids[e].size();
+        w[21] = w[22] = 0;
         w[23] = (int)pub.size();
         for (int64_t t = 0; t < (int64_t)nsep[e] * (nsep[e] + 1) / 2; t++) pub.push_back(pub_dst[(size_t)(upd_off[e] + t)]);
         for (int c = 0; c < nsep[e]; c++) pub.push_back((int)us + pubb_dst[(size_t)(updb_off[e] + c)]);
-        for (size_t q2 = 0; q2 < cons_of[e].size(); q2++) {
-          const int p = cons_of[e][q2];
-          const int idx = (int)(std::find(kids[p].begin(), kids[p].end(), e) - kids[p].begin());
-          pprobe[(size_t)pos * 8 + q2] = pbase[p] + idx;
-        }
       }
     }
     bool split = false;
@@ -1080,20 +1055,18 @@ int BuildPlans(cxk_context* ctx) {
         memcpy(&d, &bits, sizeof(d));
         return d;
       }();
-      const size_t hs = us + ubs + nprobe + 8;
+      const size_t hs = us + ubs + 8;
       ctx->fx_updb_base = (long long)us;
       ctx->fx_hand_init.assign(2 * hs, 0.0);
       for (size_t t = 0; t + 64 < pub.size(); t++) {
         const int d = pub[t];
         if (d != (int)slots && d != (int)us + slotsb) ctx->fx_hand_init[d] = ctx->fx_hand_init[hs + d] = sent;
       }
-      for (size_t t = 0; t < nprobe; t++) ctx->fx_hand_init[us + ubs + t] = ctx->fx_hand_init[hs + us + ubs + t] = sent;
       CXK_TRY(ctx->fx_rec.upload(recs));
       CXK_TRY(ctx->fx_xreg.upload(xreg));
       CXK_TRY(ctx->fx_xsrc.upload(xsrc));
       CXK_TRY(ctx->fx_rsrc.upload(rsrc));
       CXK_TRY(ctx->fx_pub.upload(pub));
-      CXK_TRY(ctx->fx_pprobe.upload(pprobe));
       CXK_TRY(ctx->fx_hand.upload(ctx->fx_hand_init));
       CXK_TRY(ctx->fx_ysig.upload(std::vector<double>(2 * (size_t)N, sent)));
       if (!ctx->fx_flag) {

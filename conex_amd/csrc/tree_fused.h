@@ -22,8 +22,7 @@ constexpr int kFusedExtraSlots = 8;      // further sources per such entry / sou
 constexpr int kFusedExtraMax = 64;       // ... at most (longer lists: the level kernels)
 
 // Words of a record (position = dependency order: a supernode only waits for lower positions):
-//   [0, 32)   SnRec (kernels_kkt.hip.h); its spare words: 21 first arrival word of this supernode's
-//             publishers (consecutive), 22 their number, 23 pub_beg
+//   [0, 32)   SnRec (kernels_kkt.hip.h); its spare word 23: pub_beg
 //   [32, 56)  AsmRec: the Schur block of the supernode's own constraint and the position of every
 //             panel row in it
 //   56 xt_beg  57 nxt  58 mx   panel entries with further sources: image location xreg[xt_beg + t],
@@ -39,14 +38,13 @@ struct FusedTreeArgs {
   double* slab;
   double* y;
   const int* pub;      // pub[pub_beg + t]: hand-off slot of a supernode's published value number t
-  const int* pprobe;   // pprobe[8 position + q]: arrival word of the q-th consumer of its values, -1 none
   const int* tg_reg;
   const int* xreg;
   const long long* xsrc;
   const long long* rsrc;
   // Hand-off slots, two sets (run parity, see tree_fused.hip): [0, updb_base) the consumer-ordered
-  // Schur-update slots of BuildPlans, then the forward-value slots, then one arrival word per
-  // (publisher, consumer) pair; and the solution entries a descendant's back substitution reads.
+  // Schur-update slots of BuildPlans, then the forward-value slots; and the solution entries a
+  // descendant's back substitution reads.
   double* hand;
   long long hand_stride;
   long long updb_base;
