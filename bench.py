@@ -13,7 +13,10 @@ plainly (`python bench.py --gpus N`) it launches torch.distributed.run on itself
 process BEFORE anything touches a GPU, relays the ranks' output and exits with their status.
 The constraints of the ONE program are sharded across ranks (strong scaling); the only
 thing that touches the GPUs' links is the library's own RCCL communicator (a `gloo` group on the
-CPU ships its 128-byte id and carries the timing barrier).  Prints one JSON line on rank 0.
+CPU ships its 128-byte id and carries the timing barrier).  Before the warmup the sharded step and
+the same step unsharded on every rank are both timed for 40 steps, and the faster layout is the one
+measured (`config.layout_trial`, `config.parallelism`; `--force-shard` keeps the sharded one): a step
+as short as config 4's does not pay for its exchange.  Prints one JSON line on rank 0.
 """
 import argparse
 import json
@@ -99,6 +102,9 @@ def main():
     ap.add_argument("--cold-copies", type=int, default=5,
                     help="c4, one GPU: also time the step cycling this many copies of the program "
                          "(5 x 64 MB of A > the 256 MiB Infinity Cache), reported as \"cold_cache\"; 0/1 = off")
+    ap.add_argument("--force-shard", action="store_true",
+                    help="N > 1: time the sharded step even where the unsharded one is faster (default: both "
+                         "layouts are timed for a few steps before the warmup and the faster one is measured)")
     ap.add_argument("--event-samples", type=int, default=20,
                     help="launches of the dominant kernel timed with a hipEvent pair in a separate pass "
                          "AFTER the timed region (at most --steps)")
@@ -226,6 +232,44 @@ def main():
 
     exch_bytes = 8 * ctx.shard_info()[2] if sharded else 0
 
+    # N > 1: the library shards ONE program's constraints and elimination subtrees (strong scaling).
+    # Whether that pays depends on the program: a step as short as config 4's (two launches, ~50 us,
+    # of which only the 22 us assembly parallelises) is LONGER sharded -- level-by-level tree kernels,
+    # pack / all-reduce / unpack -- than on one GPU.  So both layouts of the same job are timed here,
+    # before the contract's warmup, and the faster one is measured: "replicated" = every rank runs the
+    # whole step (the job's rate is one rank's rate: `value` is NOT multiplied by N).
+    use_shard = sharded
+    trial = None
+    ctx_sharded = ctx
+    if sharded and not args.force_shard:
+        rep = build_context("")
+        for i in range(rep.K):
+            rep.set_W(i, W[i])
+        rep.set_cost(prob["b"])
+
+        def trial_us(c, n=40, pre=60):
+            for _ in range(pre):
+                c.kkt_solve_async(0.7, 0.9, 0.8)
+            okc = c.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0_ = time.perf_counter()
+            for _ in range(n):
+                c.kkt_solve_async(0.7, 0.9, 0.8)
+            okc = c.sync() and okc
+            torch.cuda.synchronize()
+            t_ = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)     # every rank sees the same number: same choice
+            return 1e6 * float(t_.item()) / n, okc
+
+        t_sh, ok_sh = trial_us(ctx)
+        t_rep, ok_rep = trial_us(rep)
+        trial = {"sharded_us_per_step": t_sh, "replicated_us_per_step": t_rep, "steps": 40}
+        if t_rep < t_sh:
+            ctx, use_shard = rep, False
+        else:
+            del rep
+
     def step():
         # sharded contexts: own constraints + own subtrees, ONE ncclAllReduce(sum) of the packed top
         # (a few KB) issued by the library, replicated top, own back-substitution
@@ -266,7 +310,7 @@ def main():
     ctx.enable_timing(False)
     nsamp, kern_ms = ctx.kernel_time(reset=True)
     abytes, aflops = ctx.assembly_work()
-    y = ctx.get_y() if not sharded else None
+    y = ctx.get_y() if not use_shard else None
 
     if rank == 0:
         out = {
@@ -305,9 +349,14 @@ def main():
                                        "per solve, " + ("RCCL, issued by libconex.so" if collective == "rccl" else
                                                         "torch.distributed through the all-reduce callback (FALLBACK)"
                                                         if collective == "torch" else "one-rank RCCL communicator (single-GPU plumbing run)"))
-                       if sharded
-                       else "single GPU",
-                       "n_ranks_seen": ctx.comm_count() if sharded else 1,
+                       if use_shard
+                       else (f"replicated on {world} GPUs: the sharded step took {trial['sharded_us_per_step']:.1f} us "
+                             f"against {trial['replicated_us_per_step']:.1f} us unsharded (one all-reduce of {exch_bytes} B "
+                             "per solve plus level-by-level tree launches cost more than sharding the assembly saves); "
+                             "value = one rank's rate, --force-shard times the sharded layout"
+                             if sharded else "single GPU"),
+                       "layout_trial": trial,
+                       "n_ranks_seen": ctx_sharded.comm_count() if sharded else 1,
                        "preheat_steps": max(0, args.preheat),
                        "factor_ok": bool(ok)},
         }
