@@ -490,6 +490,38 @@ __device__ __forceinline__ void MailboxPack(const MailboxArgs& m) {
   if (t == 0) m.mb[11] = m.seq;
 }
 
+// Sharded contexts: the ranks' partial step results meet in ONE sum all-reduce.  Rank r writes its
+// (up to four) values into slot r of a world x 4 buffer and zeros the other slots (step_slots_fill);
+// after the sum every rank holds every rank's values and combines them in RANK ORDER
+// (step_slots_reduce): min / max / sum as the mode asks, the sums in one fixed order on every rank.
+// mode 0: {sum normsqrd, max norminfd}; mode 1: {min lambda_min, max lambda_max, sum frob, sum trace}.
+__global__ void step_slots_fill(int rank, int world, const double* __restrict__ red, double* __restrict__ slots) {
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < 4 * world; q += gridDim.x * blockDim.x)
+    slots[q] = (q >> 2) == rank ? red[q & 3] : 0.0;
+}
+__global__ void step_slots_reduce(int mode, int world, const double* __restrict__ slots, double* __restrict__ red) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double v0 = slots[0], v1 = slots[1], v2 = slots[2], v3 = slots[3];
+  for (int r = 1; r < world; r++) {
+    const double* s = slots + 4 * r;
+    if (mode == 0) {
+      v0 += s[0];
+      v1 = fmax(v1, s[1]);
+    } else {
+      v0 = fmin(v0, s[0]);
+      v1 = fmax(v1, s[1]);
+      v2 += s[2];
+      v3 += s[3];
+    }
+  }
+  red[0] = v0;
+  red[1] = v1;
+  if (mode != 0) {
+    red[2] = v2;
+    red[3] = v3;
+  }
+}
+
 // Fixed-order reduction of the per-constraint step outputs on one workgroup.
 // mode 0: info2 -> {sum normsqrd, max norminfd (init -1)}
 // mode 1: info4 -> {min lambda_min (init 30000), max lambda_max (init -30000), sum frob, sum trace}

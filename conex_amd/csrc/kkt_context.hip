@@ -2202,16 +2202,15 @@ int ReduceStepInfoAndSync(cxk_context* ctx, int mode, const double* info, const 
     if (took) *took = 1;
   }
   if (fold) return WaitMailbox(ctx, want);
-  if (mode == 0) {
-    // sharded: sum of normsqrd, max of norminfd over the ranks (each reduced its own constraints)
-    if (ShardAllReduce(ctx, ctx->red_out.p, 1, kOpSum) || ShardAllReduce(ctx, ctx->red_out.p + 1, 1, kOpMax))
-      return CXK_FAILURE;
-  } else {
-    // sharded: {min lambda_min, max lambda_max, sum frob, sum trace} over the ranks
-    if (ShardAllReduce(ctx, ctx->red_out.p, 1, kOpMin) || ShardAllReduce(ctx, ctx->red_out.p + 1, 1, kOpMax) ||
-        ShardAllReduce(ctx, ctx->red_out.p + 2, 2, kOpSum))
-      return CXK_FAILURE;
-  }
+  // sharded: every rank reduced its own constraints; ONE sum all-reduce of a (world x 4)-slot buffer
+  // brings all partial results to every rank, which combines them in rank order (kernels_cone.hip.h:
+  // sum / max for mode 0, min / max / sum / sum for mode 1 -- two or three collectives before)
+  if (ctx->step_slots.n != (size_t)4 * ctx->world) CXK_TRY(ctx->step_slots.alloc((size_t)4 * ctx->world));
+  step_slots_fill<<<1, 64, 0, ctx->stream>>>(ctx->rank, ctx->world, ctx->red_out.p, ctx->step_slots.p);
+  CXK_TRY(hipGetLastError());
+  if (ShardAllReduce(ctx, ctx->step_slots.p, (size_t)4 * ctx->world, kOpSum)) return CXK_FAILURE;
+  step_slots_reduce<<<1, 64, 0, ctx->stream>>>(mode, ctx->world, ctx->step_slots.p, ctx->red_out.p);
+  CXK_TRY(hipGetLastError());
   ctx->seq++;
   return SyncMailbox(ctx);
 }

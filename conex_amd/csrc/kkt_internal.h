@@ -183,6 +183,7 @@ struct cxk_context {
   // one through the blocked HBM path (kernels_kkt_big.hip.h); level_nh = count of the others
   std::vector<int> level_nh;
   std::vector<SnRec> h_recs;  // host copy of the level-ordered records
+  DevBuf<double> step_slots;  // sharded: world x 4 partial step results behind one sum all-reduce
   DevBuf<double> big_ws;
   DevBuf<int> big_flags;  // big_chol_dataflow's per-block-column words (null: the host-driven panel loop)
   int big_gen = 0;
