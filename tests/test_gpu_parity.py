@@ -263,11 +263,12 @@ def test_big_supernode_odd_sizes(num_vars, rows):
     check_newton_step(o, k, prob["b"], inv_sqrt_mu=0.4)
 
 
-@pytest.mark.parametrize("num_vars,rows", [(500, 640), (960, 1100)])
+@pytest.mark.parametrize("num_vars,rows", [(500, 640), (896, 1000), (926, 1030), (960, 1100)])
 def test_big_supernode_one_launch_and_host_driven_loop_agree(num_vars, rows, monkeypatch):
     """big_chol_dataflow (one launch: a workgroup per 32-column block column, block columns handed
     on through flags) against the host-driven panel loop it replaces up to 927 rows
-    (CXK_NO_BIG_DATAFLOW=1; 960 variables take the host-driven loop either way) and the oracle."""
+    (CXK_NO_BIG_DATAFLOW=1; 926 variables + the right-hand side are the last size the one launch takes,
+    960 variables take the host-driven loop either way) and the oracle."""
     prob = syn.lp_problem(rows=rows, num_vars=num_vars, seed=num_vars)
     o, k = make_pair(prob, "lp")
     check_newton_step(o, k, prob["b"], inv_sqrt_mu=0.4)
