@@ -27,6 +27,10 @@ struct LmiLargeWs {
   double* tmp;   // count x 8 x n^2       step temporaries (aliases P: never live together)
   int* piv;      // count x n             pivot rows of the Pade LU
   int splits;
+  // Hermitian cones over C / H (herm_d = 2 / 4), folded form: fold = n / herm_d > 0, Aleft = the first
+  // `fold` columns of every [A_1 .. A_m C], side by side (count x n x fold (m+1), leading dimension n)
+  int fold;
+  const double* Aleft;
 };
 
 // ---- assembly ---------------------------------------------------------------------------
@@ -42,7 +46,8 @@ lmi_large_reduce_finalize(LmiGroup g, Arena ar, LmiLargeWs ws, const double* __r
   const int mem = blockIdx.y, id = g.ids[mem];
   const int lane = threadIdx.x & 63;
   int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const double osc = g.herm_d > 1 ? 1.0 / g.herm_d : 1.0;  // exact (power of two)
+  // (folded Hermitian form: the contraction already is tr / herm_d, see LmiLargeSchurFolded)
+  const double osc = (g.herm_d > 1 && !ws.fold) ? 1.0 / g.herm_d : 1.0;  // exact (power of two)
   if (splits <= 1) {
     // nothing to reduce: a THREAD per output element (waves [0, ew)), then a wave per trace.  (The
     // wave-per-element form below would return the same bits -- one addend and 63 zeros -- at
@@ -79,9 +84,12 @@ lmi_large_reduce_finalize(LmiGroup g, Arena ar, LmiLargeWs ws, const double* __r
     }
   } else if (w < m1 * m1 + m1) {
     const int i = w - m1 * m1;
-    const double* Pi = ws.P + ((size_t)mem * m1 + i) * nn;
+    // (folded: P_i is its top `fold` rows, fold x n with leading dimension fold; tr / herm_d = the trace
+    //  of its first block)
+    const int nr = ws.fold ? ws.fold : n;
+    const double* Pi = ws.P + (size_t)mem * m1 * nn + (size_t)i * nr * n;
     double t = 0;
-    for (int r = lane; r < n; r += 64) t += Pi[r + (size_t)r * n];
+    for (int r = lane; r < nr; r += 64) t += Pi[r + (size_t)r * nr];
     t = WaveSum(t) * osc;
     if (lane == 0) {
       if (i < m)
@@ -625,7 +633,98 @@ inline GemmArgs SquareGemm(int n, const double* A, int64_t sA, const double* B, 
   return a;
 }
 
+// Hermitian cones over C / H through their real representation L(X) of order n = d n0 (block (k, j) =
+// +- X_{k ^ j}; block row 0 = (X_0, -X_1, .., -X_{d-1}), block column 0 = (X_0, X_1, ..)^T): products of
+// such matrices have the same form, so a product is known from its top n0 rows, and
+//     tr(P_x P_y) = d sum_C s_C tr(T_x[:, C] T_y[:, C]),   T = top n0 rows, s = (+, -, .., -),
+// because block (C, 0) of P_y is -(block (0, C)) for C >= 1.  So only  T_i^T = W A_i[:, 0 .. n0)  is
+// formed (ONE GEMM against the first n0 columns of all matrices side by side: 1 / d of the
+// multiply-adds, full 64-row tiles), and the contraction runs over n0 n entries instead of n^2
+// against the partner image  Z_y[r, C n0 + k] = s_C T_y^T[C n0 + r, k]  -- the reference computes
+// plane by plane (jordan_matrix_algebra.cc:101-138); this is the same saving on the matrix pipe.
+__global__ void __launch_bounds__(256)
+lmi_large_herm_partner(int n, int n0, int m1, int64_t stride, const double* __restrict__ PTl, double* __restrict__ Z) {
+  const int mem = blockIdx.y;
+  const double* src = PTl + (size_t)mem * stride;
+  double* dst = Z + (size_t)mem * stride;
+  const int per = n0 * n, total = per * m1;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+    const int i = q / per, e = q - i * per, r = e % n0, col = e / n0, C = col / n0, k = col - C * n0;
+    const double v = src[(size_t)(i * n0 + k) * n + C * n0 + r];
+    dst[(size_t)i * per + e] = C == 0 ? v : -v;
+  }
+}
+
+inline hipError_t LmiLargeReduceFinalizeLaunch(const LmiGroup& g, const Arena& ar, const LmiLargeWs& ws, const GemmArgs& a,
+                                               hipStream_t st) {
+  const int m1 = g.m + 1;
+  const bool split = a.splits > 1;
+  const int waves = (split ? m1 * m1 : (m1 * m1 + 63) / 64) + m1;
+  lmi_large_reduce_finalize<<<dim3((waves + 3) / 4, g.count), 256, 0, st>>>(g, ar, ws, split ? ws.part : ws.Gf, a.splits,
+                                                                          a.sCs);
+  return hipGetLastError();
+}
+
+inline hipError_t LmiLargeSchurFolded(const LmiGroup& g, const Arena& ar, const LmiLargeWs& ws, hipStream_t st) {
+  const int n = g.n, m1 = g.m + 1, n0 = ws.fold;
+  const int64_t nn = (int64_t)n * n, per = (int64_t)n0 * n, stride = m1 * nn;
+  double* PTl = ws.PT;               // T_i^T side by side: n x (n0 m1), leading dimension n
+  double* Z = ws.PT + stride / 2;    // partner images, n0 x n each (per m1 <= stride / 2: herm_d >= 2)
+  hipError_t e;
+  {
+    GemmArgs a{};
+    a.M = n;
+    a.N = n0 * m1;
+    a.K = n;
+    a.A = g.W;
+    a.lda = n;
+    a.sA1 = nn;
+    a.B = ws.Aleft;
+    a.ldb = n;
+    a.sB1 = per * m1;
+    a.C = PTl;
+    a.ldc = n;
+    a.sC1 = stride;
+    a.Ct = ws.P;  // T_i (n0 x n, leading dimension n0), matrix i at i * per
+    a.ldct = n0;
+    a.sT1 = stride;
+    a.ctb = n0;
+    a.sTb = per - n0;
+    a.inner = 1;
+    a.alpha = 1.0;
+    a.beta = 0.0;
+    a.splits = 1;
+    if ((e = LaunchGemm(a, false, false, g.count, st)) != hipSuccess) return e;
+  }
+  {
+    const int blocks = (int)std::min<int64_t>((per * m1 + 255) / 256, 256);
+    lmi_large_herm_partner<<<dim3(blocks, g.count), 256, 0, st>>>(n, n0, m1, stride, PTl, Z);
+  }
+  GemmArgs a{};
+  a.M = a.N = m1;
+  a.K = (int)per;
+  a.A = ws.P;
+  a.lda = per;
+  a.sA1 = stride;
+  a.B = Z;
+  a.ldb = per;
+  a.sB1 = stride;
+  a.C = ws.Gf;
+  a.ldc = m1;
+  a.sC1 = (int64_t)m1 * m1;
+  a.inner = 1;
+  a.alpha = 1.0;
+  a.beta = 0.0;
+  a.lower_only = 1;
+  a.splits = std::max(1, std::min(ws.splits, (int)((per + kGemmBK - 1) / kGemmBK)));
+  a.sCs = (int64_t)g.count * m1 * m1;
+  if (a.splits > 1) a.C = ws.part;
+  if ((e = LaunchGemm(a, true, false, g.count, st)) != hipSuccess) return e;
+  return LmiLargeReduceFinalizeLaunch(g, ar, ws, a, st);
+}
+
 inline hipError_t LmiLargeSchur(const LmiGroup& g, const Arena& ar, const LmiLargeWs& ws, hipStream_t st) {
+  if (ws.fold) return LmiLargeSchurFolded(g, ar, ws, st);
   const int n = g.n, m = g.m, m1 = m + 1;
   const int64_t nn = (int64_t)n * n;
   hipError_t e;

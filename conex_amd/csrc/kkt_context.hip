@@ -169,6 +169,8 @@ LmiLargeWs MakeLargeWs(Group& g) {
   w.part = g.ws_part.p;
   w.piv = g.ws_piv.p;
   w.splits = g.splits;
+  w.fold = g.Aleft.n ? g.n / g.herm_d : 0;
+  w.Aleft = g.Aleft.p;
   return w;
 }
 
@@ -1840,6 +1842,21 @@ static int FinalizeImpl(cxk_context* ctx) {
         }
       }
       CXK_TRY(g.Apad.upload(hp));
+    }
+    if (g.type == CXK_LMI && g.herm_d > 1 && g.schur_gemm && !g.literal && !getenv("CXK_NO_HERM_FOLD")) {
+      // Hermitian cones over C / H on the batched-GEMM assembly: the folded form needs only the first
+      // n / herm_d columns of every matrix of the real representation (kernels_lmi_large.hip.h)
+      const int n = g.n, n0 = g.n / g.herm_d;
+      const size_t per = (size_t)n * n0, m1 = (size_t)g.m + 1;
+      std::vector<double> hl(per * m1 * cnt);
+      for (size_t k = 0; k < cnt; k++) {
+        const ConstraintRec& c = ctx->cons[g.ids[k]];
+        for (size_t i = 0; i < m1; i++) {
+          const double* src = i < (size_t)g.m ? c.A.data() + i * (size_t)n * n : c.C.data();
+          std::copy(src, src + per, hl.begin() + (k * m1 + i) * per);
+        }
+      }
+      CXK_TRY(g.Aleft.upload(hl));
     }
     if (g.type == CXK_LMI && !g.literal && !getenv("CXK_NO_PACKED_SLACK") &&
         LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse)) {

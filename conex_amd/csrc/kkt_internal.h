@@ -91,6 +91,7 @@ struct Group {
   DevBuf<double> Apad;  // lmi_schur_mfma at a padded order: [A_1 .. A_m | C] per member, zero-padded (LmiMfmaPaddedOrder)
   DevBuf<int> dids;
   bool has_q = false;             // CXK_QUAD: the members carry an inner-product matrix Q
+  DevBuf<double> Aleft;           // Hermitian C / H groups on the GEMM assembly: first n / herm_d columns of [A_i | C]
   DevBuf<double> Apk;             // CXK_LMI: packed lower triangles of the A_i (LmiGroup::Apk), may be empty
   DevBuf<double> qQ, qGram, qS;   // CXK_QUAD: Q, A1' Q A1, the state kept between PrepareStep and TakeStep
   int herm_d = 0;
