@@ -455,9 +455,9 @@ __global__ void static_schur(StaticGroup g, Arena ar) {
   }
 }
 
-// What the host reads after a round trip, written into its pinned mailbox by the first 64 threads
-// of a workgroup (all of them must call): the four reduction outputs, the six step scalars, the
-// factorization flag, then -- after a system-scope fence -- the sequence number the host spins on.
+// What the host reads after a round trip, written into its pinned mailbox by the first wavefront
+// of a workgroup: the four reduction outputs, the six step scalars, the factorization flag, the
+// sequence number the host spins on and a checksum (MailboxWrite).
 struct MailboxArgs {
   const double* red;   // [4]
   const double* scal;  // [6]
@@ -466,28 +466,42 @@ struct MailboxArgs {
   double seq;
   double* mb;          // pinned host memory, 16 doubles; nullptr: no mailbox write
 };
+// v: this thread's slot value (threads 0 .. 10; anything elsewhere).  The eleven values, the sequence
+// number the host spins on (slot 11) and a checksum (slot 12) leave in ONE store instruction, no
+// fence in between: the host does not rely on the order in which the bytes arrive (they cross PCIe
+// as posted writes; with a system-scope fence between data and sequence number -- 2 us per round
+// trip -- the sequence number was still seen ahead of the data about once in a thousand round trips
+// on a cold box).  It accepts a mailbox only when slot 12 equals the XOR of the sequence number's
+// bit pattern and the eleven values', each rotated by its own amount (kMailboxRot: stale slots
+// cannot cancel each other the way equal changes of two slots would under a plain XOR).
+__host__ __device__ constexpr int MailboxRot(int slot) { return (7 * slot + 1) & 63; }
+__device__ __forceinline__ void MailboxWrite(const MailboxArgs& m, double v) {
+  const int t = threadIdx.x;
+  if (t >= 64) return;
+  unsigned long long x = 0ull;
+  if (t <= 10) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const int r = MailboxRot(t);
+    x = r ? (bits << r) | (bits >> (64 - r)) : bits;
+  }
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) x ^= (unsigned long long)__shfl_xor((long long)x, d, 64);
+  double out = v;
+  if (t == 11) out = m.seq;
+  if (t == 12) out = __longlong_as_double((long long)(x ^ (unsigned long long)__double_as_longlong(m.seq)));
+  if (t <= 12) __hip_atomic_store(m.mb + t, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// fail[1] == tag: a pivot failed in the first factor level of the latest fused launch
+__device__ __forceinline__ double MailboxFailValue(const MailboxArgs& m) {
+  return (m.fail[0] != 0 || (m.tag != 0 && m.fail[1] == m.tag)) ? 1.0 : 0.0;
+}
 __device__ __forceinline__ void MailboxPack(const MailboxArgs& m) {
   const int t = threadIdx.x;
   double v = 0.0;
   if (t < 4) v = m.red[t];
   if (t >= 4 && t < 10) v = m.scal[t - 4];
-  // fail[1] == tag: a pivot failed in the first factor level of the latest fused launch
-  if (t == 10) v = (m.fail[0] != 0 || (m.tag != 0 && m.fail[1] == m.tag)) ? 1.0 : 0.0;
-  if (t <= 10) m.mb[t] = v;
-  // The host must not trust the ORDER in which these writes and the sequence number below arrive
-  // (they cross PCIe as posted writes; on a cold box the sequence number was seen ahead of the
-  // data about once in a thousand round trips): slot 12 carries the XOR of the eleven bit patterns
-  // and the sequence number's, which the host checks before it accepts the mailbox.
-  if (t < 64) {
-    unsigned long long x = t <= 10 ? (unsigned long long)__double_as_longlong(v) : 0ull;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) x ^= (unsigned long long)__shfl_xor((long long)x, d, 64);
-    if (t == 0)
-      reinterpret_cast<unsigned long long*>(m.mb)[12] = x ^ (unsigned long long)__double_as_longlong(m.seq);
-  }
-  __threadfence_system();
-  __syncthreads();
-  if (t == 0) m.mb[11] = m.seq;
+  if (t == 10) v = MailboxFailValue(m);
+  MailboxWrite(m, v);
 }
 
 // Sharded contexts: the ranks' partial step results meet in ONE sum all-reduce.  Rank r writes its
@@ -522,14 +536,76 @@ __global__ void step_slots_reduce(int mode, int world, const double* __restrict_
   }
 }
 
+// The end of the fixed-order reduction below: the 256 threads' partial results -> out[], and with a
+// mailbox the results travel to the host from here (no separate mailbox_pack).
+// LOCAL (the tail workgroup): the mailbox takes the reduced values from LDS, the step scalars from
+// `scal_lds` (this workgroup formed them) or, like the failure flag, from `pre_value` (threads 4 .. 10:
+// their slot's value, read before the wait) -- no memory round trip between the last result and the
+// host write.
+template <bool LOCAL = false>
+__device__ __forceinline__ void ReduceStepFinish(int mode, double a, double b, double c, double d,
+                                                 double* __restrict__ out, const MailboxArgs& mbx,
+                                                 const double* scal_lds = nullptr, double pre_value = 0.0) {
+  __shared__ double red[8], red2[8], red3[8], red4[8], res[4];
+  // the two BlockSums (wave sum, wave totals added in wave order) and the max / min reductions
+  // behind ONE barrier
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+  a = WaveSum(a);
+  d = WaveSum(d);
+  const double bm = (mode == 0) ? WaveMax(b) : -WaveMax(-b);
+  const double cm = WaveMax(c);
+  if (lane == 0) {
+    red[wave] = bm;
+    red2[wave] = cm;
+    red3[wave] = a;
+    red4[wave] = d;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double B = red[0], C = red2[0], A = 0, D = 0;
+    for (int w = 1; w < nw; w++) {
+      B = (mode == 0) ? fmax(B, red[w]) : fmin(B, red[w]);
+      C = fmax(C, red2[w]);
+    }
+    for (int w = 0; w < nw; w++) {
+      A += red3[w];
+      D += red4[w];
+    }
+    if (mode == 0) {
+      out[0] = A;
+      out[1] = B;
+      if (LOCAL) res[0] = A, res[1] = B;
+    } else {
+      out[0] = B;
+      out[1] = C;
+      out[2] = A;
+      out[3] = D;
+      if (LOCAL) res[0] = B, res[1] = C, res[2] = A, res[3] = D;
+    }
+  }
+  if (!mbx.mb) return;
+  if (LOCAL) {
+    __syncthreads();
+    const int t = threadIdx.x;
+    double v = 0.0;
+    // (the separate launches send out[2], out[3] as the last mode-1 call left them: nobody reads them in mode 0)
+    if (t < (mode == 0 ? 2 : 4)) v = res[t];
+    if (t >= 4 && t < 10) v = scal_lds ? scal_lds[t - 4] : pre_value;
+    if (t == 10) v = pre_value;
+    MailboxWrite(mbx, v);
+  } else {
+    __threadfence();  // out[] is read back below by other threads of this workgroup
+    __syncthreads();
+    MailboxPack(mbx);
+  }
+}
+
 // Fixed-order reduction of the per-constraint step outputs on one workgroup.
 // mode 0: info2 -> {sum normsqrd, max norminfd (init -1)}
 // mode 1: info4 -> {min lambda_min (init 30000), max lambda_max (init -30000), sum frob, sum trace}
-// With a mailbox the results travel to the host from this launch (no separate mailbox_pack).
 __global__ void __launch_bounds__(256)
 reduce_step_info(int K, int mode, const double* __restrict__ info, const unsigned char* __restrict__ mask,
                  double* __restrict__ out, MailboxArgs mbx) {
-  __shared__ double red[8], red2[8], red3[8], red4[8];
   double a = 0, b = (mode == 0) ? -1.0 : 30000.0, c = -30000.0, d = 0;
   // eight strided constraints per trip, loads issued together (a plain loop pays two dependent
   // round trips -- mask, values -- per element); accumulation order unchanged
@@ -565,45 +641,156 @@ reduce_step_info(int K, int mode, const double* __restrict__ info, const unsigne
       }
     }
   }
-  // the two BlockSums (wave sum, wave totals added in wave order) and the max / min reductions
-  // behind ONE barrier
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
-  a = WaveSum(a);
-  d = WaveSum(d);
-  const double bm = (mode == 0) ? WaveMax(b) : -WaveMax(-b);
-  const double cm = WaveMax(c);
-  if (lane == 0) {
-    red[wave] = bm;
-    red2[wave] = cm;
-    red3[wave] = a;
-    red4[wave] = d;
+  ReduceStepFinish(mode, a, b, c, d, out, mbx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The tail workgroup of a PrepareStep / eigenvalue-query launch (lmi_prepare_rows: one workgroup
+// more than the constraints need): what reduce_step_info and step_scalars do in launches of their
+// own behind it.  The constraints' wavefronts hand their results over through `slots` (four doubles
+// per constraint, data-as-flag: armed with kTailSentinel, written with write-through stores, polled
+// here with sc1 loads -- MI355X_MICROARCH.md's hand-off rules, as in tree_fused); this workgroup
+// first forms the step scalars (they need y only), then takes the results as they arrive, reduces
+// them in reduce_step_info's order (the same bits), writes the mailbox and re-arms the slots.
+constexpr unsigned long long kTailSentinel = 0x7FF4C0DEC0DE7A11ull;
+constexpr int kTailSpin = 1 << 20;  // polls before the workgroup gives up (NaNs go out: the solve fails loudly)
+struct StepTail {
+  double* slots;  // nullptr: no tail workgroup in this launch
+  int K, mode;
+  const unsigned char* mask;
+  double* red_out;
+  int scal, N;    // scal != 0: the step scalars as well
+  const double *b, *AQc, *y, *sys_sc;
+  double* scal_out;
+  MailboxArgs mbx;
+};
+typedef unsigned int TailU4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double AgentLoad(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void AgentStore(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// step_scalars (kernels_kkt.hip.h, 1024 threads) on 256: thread r plays threads r, r + 256, r + 512,
+// r + 768 -- the same fma chains, the same wave sums (wave (r >> 6) + 4 q of the 1024), the sixteen
+// wave totals added in the same order: the same bits.
+__device__ inline void StepScalarsOn256(int N, const double* __restrict__ b, const double* __restrict__ AQc,
+                                        const double* __restrict__ y, const double* __restrict__ sys_sc,
+                                        double* __restrict__ out, double* lds_out) {
+  __shared__ double red[4][16];
+  double s[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) s[q][k] = 0.0;
+  constexpr int U = 4;
+  for (int base = 0; base < N; base += 1024 * U) {
+    double vb[4][U], vq[4][U], vy[4][U];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int p = base + 1024 * u + 256 * q + (int)threadIdx.x;
+        const bool on = p < N;
+        vb[q][u] = on ? b[p] : 0.0;
+        vq[q][u] = on ? AQc[p] : 0.0;
+        vy[q][u] = on ? y[p] : 0.0;
+      }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        s[q][0] = fma(vb[q][u], vy[q][u], s[q][0]);
+        s[q][1] = fma(vq[q][u], vy[q][u], s[q][1]);
+        s[q][2] = fma(vb[q][u], vb[q][u], s[q][2]);
+        s[q][3] = fma(vq[q][u], vq[q][u], s[q][3]);
+      }
   }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const double t = WaveSum(s[q][k]);
+      if (lane == 0) red[k][wave + 4 * q] = t;
+    }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double B = red[0], C = red2[0], A = 0, D = 0;
-    for (int w = 1; w < nw; w++) {
-      B = (mode == 0) ? fmax(B, red[w]) : fmin(B, red[w]);
-      C = fmax(C, red2[w]);
+  if (threadIdx.x < 4) {
+    double t = 0;
+    for (int w = 0; w < 16; w++) t += red[threadIdx.x][w];
+    out[threadIdx.x] = lds_out[threadIdx.x] = t;
+  }
+  if (threadIdx.x == 4) out[4] = lds_out[4] = sys_sc[0];
+  if (threadIdx.x == 5) out[5] = lds_out[5] = sys_sc[1];
+}
+
+__device__ inline void PrepareTailBlock(const StepTail& T) {
+  __shared__ double s_scal[6];
+  if (T.scal) StepScalarsOn256(T.N, T.b, T.AQc, T.y, T.sys_sc, T.scal_out, s_scal);
+  const int K = T.K, mode = T.mode, nq = mode == 0 ? 2 : 4, t = threadIdx.x;
+  // what the mailbox carries besides this launch's results: final before the launch
+  double pre = 0.0;
+  if (T.mbx.mb) {
+    if (t >= 4 && t < 10 && !T.scal) pre = T.mbx.scal[t - 4];
+    if (t == 10) pre = MailboxFailValue(T.mbx);
+  }
+  const double armed = __longlong_as_double((long long)kTailSentinel);
+  double a = 0, b = (mode == 0) ? -1.0 : 30000.0, c = -30000.0, d = 0;
+  // A polling round is one or two 16-byte sc1 loads per constraint (8-byte loads of the four values
+  // one by one made a round of 1000 constraints cost several microseconds of address processing on
+  // this one CU -- more than the launch it replaces); offsets past the buffer return zeros without
+  // a memory request.
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(T.slots, 0, K * 32, 0x00020000);
+  constexpr int U = 4;
+  for (int i0 = t; i0 < K; i0 += U * 256) {
+    double v[U][4];
+    bool on[U];
+    int off[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = i0 + u * 256;
+      on[u] = i < K && T.mask[i < K ? i : 0] != 0;
+      off[u] = i < K ? 32 * i : 0x7ffffff0;
     }
-    for (int w = 0; w < nw; w++) {
-      A += red3[w];
-      D += red4[w];
+    for (int spin = 0; spin < kTailSpin; spin++) {
+      bool pending = false;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        TailU4 lo = {0u, 0u, 0u, 0u}, hi = {0u, 0u, 0u, 0u};
+        lo = __builtin_amdgcn_raw_buffer_load_b128(rs, off[u], 0, 16);  // (aux 16: sc1)
+        if (mode != 0) hi = __builtin_amdgcn_raw_buffer_load_b128(rs, off[u] + 16, 0, 16);
+        const unsigned long long w0 = ((unsigned long long)lo.y << 32) | lo.x, w1 = ((unsigned long long)lo.w << 32) | lo.z;
+        const unsigned long long w2 = ((unsigned long long)hi.y << 32) | hi.x, w3 = ((unsigned long long)hi.w << 32) | hi.z;
+        pending = pending || w0 == kTailSentinel || w1 == kTailSentinel || w2 == kTailSentinel || w3 == kTailSentinel;
+        v[u][0] = __longlong_as_double((long long)w0);
+        v[u][1] = __longlong_as_double((long long)w1);
+        v[u][2] = __longlong_as_double((long long)w2);
+        v[u][3] = __longlong_as_double((long long)w3);
+      }
+      if (!pending) break;
+      __builtin_amdgcn_s_sleep(2);
     }
-    if (mode == 0) {
-      out[0] = A;
-      out[1] = B;
-    } else {
-      out[0] = B;
-      out[1] = C;
-      out[2] = A;
-      out[3] = D;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (!on[u]) continue;
+      if (mode == 0) {
+        a += v[u][0];
+        b = fmax(b, v[u][1]);
+      } else {
+        b = fmin(b, v[u][0]);
+        c = fmax(c, v[u][1]);
+        a += v[u][2];
+        d += v[u][3];
+      }
     }
   }
-  if (mbx.mb) {
-    __threadfence();  // out[] is read back below by other threads of this workgroup
-    __syncthreads();
-    MailboxPack(mbx);
-  }
+  ReduceStepFinish<true>(mode, a, b, c, d, T.red_out, T.mbx, T.scal ? s_scal : nullptr, pre);
+  // re-arm the slots for the next launch (everything has been taken: every thread is past its loop)
+  for (int i = t; i < K; i += 256)
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (q < nq) AgentStore(T.slots + 4 * i + q, armed);
 }
 
 }  // namespace cxk

@@ -16,6 +16,7 @@
 // the elimination order differs from an LU + triangular solves, so W agrees with the oracle to
 // rounding (tests/test_gpu_parity.py, <= 1e-11).
 #pragma once
+#include "kernels_cone.hip.h"
 #include "kernels_kkt.hip.h"
 #include "kernels_lmi.hip.h"
 
@@ -322,12 +323,17 @@ __device__ __forceinline__ void LanczosRows(const double (&ws)[N], const double 
 }
 
 template <int MODE, int N>
-__global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa) {
+__global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa, StepTail tail) {
   static_assert(N > 16 && N <= 32 && (N * N) % 2 == 0, "two DPP rows; 16-byte chunks");
   constexpr int NN = N * N, HALF = NN / 2, CH = (HALF + 63) / 64, ITERS = N / 2;
   __shared__ double sM[4][NN];
   __shared__ double sAB[4][2 * (ITERS + 2)];
   __shared__ double sOut[4][2];
+  // with a tail the launch has one workgroup more: it reduces what the others produce and talks to the host
+  if (tail.slots && blockIdx.x == gridDim.x - 1) {
+    PrepareTailBlock(tail);
+    return;
+  }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mem = blockIdx.x * 4 + wave;
   if (mem >= g.count) return;  // wave-uniform; no workgroup barrier below
@@ -491,13 +497,24 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa)
     if (!sa.no_clamp) ClampToSpectrumBound(N, t1, t2, &mn, &mx);
     if (MODE == 0) {
       const double l1 = fabs(sa.e_weight + mn), l2 = fabs(sa.e_weight + mx);
-      sa.info[2 * id] = t2 + 2 * t1 + N;
-      sa.info[2 * id + 1] = l1 < l2 ? l2 : l1;
+      const double v0 = t2 + 2 * t1 + N, v1 = l1 < l2 ? l2 : l1;
+      sa.info[2 * id] = v0;
+      sa.info[2 * id + 1] = v1;
+      if (tail.slots) {
+        AgentStore(tail.slots + 4 * id, v0);
+        AgentStore(tail.slots + 4 * id + 1, v1);
+      }
     } else {
       sa.info[4 * id] = -mx;      // lambda_min
       sa.info[4 * id + 1] = -mn;  // lambda_max
       sa.info[4 * id + 2] = t2;
       sa.info[4 * id + 3] = -t1;
+      if (tail.slots) {
+        AgentStore(tail.slots + 4 * id, -mx);
+        AgentStore(tail.slots + 4 * id + 1, -mn);
+        AgentStore(tail.slots + 4 * id + 2, t2);
+        AgentStore(tail.slots + 4 * id + 3, -t1);
+      }
     }
   }
 }

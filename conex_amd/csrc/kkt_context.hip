@@ -1337,10 +1337,32 @@ bool FusedAssembly(const cxk_context* ctx) {
 }
 // cxk_assemble leaves the gather to the factorization that normally follows; any other entry point
 // that runs first gets the assembled system by the separate launch.
-int FlushDeferred(cxk_context* ctx) {
-  if (!ctx->asm_deferred) return CXK_SUCCESS;
-  ctx->asm_deferred = false;
-  return LaunchGather(ctx, false, 0, 0, 0);
+int LaunchStepScalars(cxk_context* ctx) {
+  if (ctx->world > 1) {
+    // every rank sums over its own share of the variables, the four dot products are then summed
+    step_scalars_masked<<<1, 1024, 0, ctx->stream>>>(ctx->md.N, ctx->d_count_mask.p, ctx->b.p, ctx->AQc.p, ctx->y.p,
+                                                     ctx->sys_sc.p, ctx->scal_out.p);
+    CXK_TRY(hipGetLastError());
+    if (ShardAllReduce(ctx, ctx->scal_out.p, 4, kOpSum)) return CXK_FAILURE;
+  } else {
+    step_scalars<<<1, 1024, 0, ctx->stream>>>(ctx->md.N, ctx->b.p, ctx->AQc.p, ctx->y.p,
+                                              ctx->sys_sc.p, ctx->scal_out.p);
+  }
+  CXK_TRY(hipGetLastError());
+  ctx->scal_seq = ++ctx->seq;
+  return CXK_SUCCESS;
+}
+
+int FlushDeferred(cxk_context* ctx, bool keep_scalars = false) {
+  if (ctx->asm_deferred) {
+    ctx->asm_deferred = false;
+    if (LaunchGather(ctx, false, 0, 0, 0)) return CXK_FAILURE;
+  }
+  if (ctx->scal_deferred && !keep_scalars) {
+    ctx->scal_deferred = false;
+    if (LaunchStepScalars(ctx)) return CXK_FAILURE;
+  }
+  return CXK_SUCCESS;
 }
 #define CXK_ENTER_KEEP(ctx)                     \
   if (CheckReady(ctx)) return CXK_FAILURE;      \
@@ -1360,6 +1382,7 @@ int cxk_create(int num_vars, int device, void* stream, cxk_context** out) {
   ctx->num_vars = num_vars;
   ctx->device = device;
   ctx->stream = static_cast<hipStream_t>(stream);
+  ctx->no_step_tail = getenv("CXK_NO_STEP_TAIL") != nullptr || getenv("CXK_PREPARE_LDS") != nullptr;
   if (device >= 0) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -2143,8 +2166,8 @@ int NextMailbox(cxk_context* ctx, MailboxArgs* m) {
 int WaitMailbox(cxk_context* ctx, long long want) {
   // spin on the sequence number (a stream synchronisation costs tens of microseconds of driver
   // wake-up); the stream is polled now and then so that a failed launch cannot hang the host.
-  // The data slots are accepted only with a matching checksum (MailboxPack): their writes and the
-  // sequence number's are separate posted writes to host memory and have been observed out of order.
+  // The data slots are accepted only with a matching checksum (MailboxWrite): the bytes cross PCIe
+  // as posted writes whose order of arrival is not relied upon.
   volatile double* flag = ctx->mb + 11;
   volatile unsigned long long* raw = reinterpret_cast<volatile unsigned long long*>(ctx->mb);
   static const bool no_spin = getenv("CXK_NO_SPIN") != nullptr;
@@ -2158,7 +2181,8 @@ int WaitMailbox(cxk_context* ctx, long long want) {
       unsigned long long snap[13], x = wbits;
       for (int i = 0; i <= 10; i++) {
         snap[i] = raw[i];
-        x ^= snap[i];
+        const int r = MailboxRot(i);
+        x ^= r ? (snap[i] << r) | (snap[i] >> (64 - r)) : snap[i];
       }
       snap[12] = raw[12];
       if (x == snap[12] || synced) {
@@ -2206,14 +2230,16 @@ bool TakeStepFromDeviceOk(const cxk_context* ctx) {
 // take_e_weight != nullptr (mode 0): TakeStep with the step length of cone_program.cc:417-418 taken
 // from the reduced norms ON THE DEVICE is enqueued before the host waits, *took reports it.
 int ReduceStepInfoAndSync(cxk_context* ctx, int mode, const double* info, const double* take_e_weight = nullptr,
-                          int* took = nullptr) {
+                          int* took = nullptr, bool tail_done = false) {
   MailboxArgs m;
   m.mb = nullptr;
   const bool fold = ctx->world <= 1;
-  if (fold && NextMailbox(ctx, &m)) return CXK_FAILURE;
+  if (fold && !tail_done && NextMailbox(ctx, &m)) return CXK_FAILURE;
   const long long want = ctx->seq;
-  reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), mode, info, ctx->d_mask.p, ctx->red_out.p, m);
-  CXK_TRY(hipGetLastError());
+  if (!tail_done) {  // (else the launch's tail workgroup has reduced and written the mailbox: StepTail)
+    reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), mode, info, ctx->d_mask.p, ctx->red_out.p, m);
+    CXK_TRY(hipGetLastError());
+  }
   if (fold && take_e_weight && TakeStepFromDeviceOk(ctx)) {
     if (LaunchTakeStep(ctx, *take_e_weight, 1.0, ctx->red_out.p)) return CXK_FAILURE;
     if (took) *took = 1;
@@ -2250,21 +2276,59 @@ int cxk_factor_status(cxk_context* ctx, int* ok) {
   return CXK_SUCCESS;
 }
 
+}  // extern "C"
+namespace {
+// The tail workgroup (StepTail) serves a PrepareStep / eigenvalue query whose constraints ALL go
+// through lmi_prepare_rows on one GPU: then the reduction, the step scalars and the mailbox write
+// ride in that launch.  CXK_NO_STEP_TAIL=1 keeps the separate launches (tests compare both).
+bool StepTailOk(const cxk_context* ctx, int affine) {
+  if (ctx->no_step_tail || affine || ctx->world > 1 || ctx->use_ldlt) return false;
+  const Group* only = nullptr;
+  for (const Group& g : ctx->groups) {
+    if (g.ids.empty()) continue;
+    if (only) return false;
+    only = &g;
+  }
+  return only && only->type == CXK_LMI && !only->large && !only->literal && only->ids.size() == ctx->cons.size() &&
+         LmiPrepareRowsSupports(only->n, only->m, only->herm_d, only->sparse);
+}
+int MakeStepTail(cxk_context* ctx, int mode, StepTail* t) {
+  const size_t K = ctx->cons.size();
+  if (ctx->tail_slots.n != 4 * K) {
+    double armed;
+    const unsigned long long bits = kTailSentinel;
+    memcpy(&armed, &bits, sizeof(armed));
+    CXK_TRY(ctx->tail_slots.upload(std::vector<double>(4 * K, armed)));
+  }
+  t->slots = ctx->tail_slots.p;
+  t->K = (int)K;
+  t->mode = mode;
+  t->mask = ctx->d_mask.p;
+  t->red_out = ctx->red_out.p;
+  t->scal = (mode == 0 && ctx->scal_deferred) ? 1 : 0;
+  t->N = ctx->md.N;
+  t->b = ctx->b.p;
+  t->AQc = ctx->AQc.p;
+  t->y = ctx->y.p;
+  t->sys_sc = ctx->sys_sc.p;
+  t->scal_out = ctx->scal_out.p;
+  if (NextMailbox(ctx, &t->mbx)) return CXK_FAILURE;
+  if (t->scal) {  // the scalars travel in this launch's mailbox
+    ctx->scal_deferred = false;
+    ctx->scal_seq = ctx->seq;
+  }
+  return CXK_SUCCESS;
+}
+}  // namespace
+extern "C" {
+
 int cxk_step_scalars_async(cxk_context* ctx) {
   CXK_ENTER(ctx);
-  if (ctx->world > 1) {
-    // every rank sums over its own share of the variables, the four dot products are then summed
-    step_scalars_masked<<<1, 1024, 0, ctx->stream>>>(ctx->md.N, ctx->d_count_mask.p, ctx->b.p, ctx->AQc.p, ctx->y.p,
-                                                     ctx->sys_sc.p, ctx->scal_out.p);
-    CXK_TRY(hipGetLastError());
-    if (ShardAllReduce(ctx, ctx->scal_out.p, 4, kOpSum)) return CXK_FAILURE;
-  } else {
-    step_scalars<<<1, 1024, 0, ctx->stream>>>(ctx->md.N, ctx->b.p, ctx->AQc.p, ctx->y.p,
-                                              ctx->sys_sc.p, ctx->scal_out.p);
+  if (StepTailOk(ctx, 0)) {
+    ctx->scal_deferred = true;  // normally picked up by the PrepareStep that follows
+    return CXK_SUCCESS;
   }
-  CXK_TRY(hipGetLastError());
-  ctx->scal_seq = ++ctx->seq;
-  return CXK_SUCCESS;
+  return LaunchStepScalars(ctx);
 }
 
 // Factor and solve in one sweep (the forward substitution rides in the elimination as in
@@ -2462,8 +2526,8 @@ int cxk_line_search(cxk_context* ctx, double dinf_upper_bound, double b_scaling,
 }
 
 int cxk_step_scalars(cxk_context* ctx, double* out6) {
-  CXK_ENTER(ctx);
-  if (ctx->scal_seq < 0 && cxk_step_scalars_async(ctx)) return CXK_FAILURE;  // not enqueued yet
+  CXK_ENTER(ctx);  // (a deferred launch has gone out here)
+  if (ctx->scal_seq < 0 && LaunchStepScalars(ctx)) return CXK_FAILURE;  // not enqueued yet
   if (ctx->mb_seen < ctx->scal_seq && SyncMailbox(ctx)) return CXK_FAILURE;
   for (int i = 0; i < 6; i++) out6[i] = ctx->mbv[4 + i];
   ctx->scal_seq = -1;  // consumed: the next call computes them afresh
@@ -2543,8 +2607,13 @@ int cxk_prepare_take_step(cxk_context* ctx, double c_weight, double e_weight, do
 }
 static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double e_weight, double* info, bool take,
                            int* took) {
-  CXK_ENTER(ctx);
+  CXK_ENTER_KEEP(ctx);
+  const bool with_tail = StepTailOk(ctx, affine);
+  if (FlushDeferred(ctx, with_tail)) return CXK_FAILURE;
   StepArgs sa = MakeStep(ctx, ctx->info2.p, affine, c_weight, e_weight, 1.0);
+  StepTail tail;
+  tail.slots = nullptr;
+  if (with_tail && MakeStepTail(ctx, 0, &tail)) return CXK_FAILURE;
   ctx->lanczos_calls++;
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
@@ -2554,7 +2623,7 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
     else if (g.type == CXK_LMI) {
       static const bool lds_kernel = getenv("CXK_PREPARE_LDS") != nullptr;  // A/B switch (tests, timing)
       if (!affine && !lds_kernel && !g.literal && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse))
-        lmi_prepare_rows<0, 20><<<(cnt + 3) / 4, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+        lmi_prepare_rows<0, 20><<<(cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, 0, ctx->stream>>>(MakeLmi(g), sa, tail);
       else if (g.n == 20)
         lmi_prepare_generic<0, 20><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
       else
@@ -2577,7 +2646,7 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
     CXK_TRY(hipMemcpy(ctx->y_at_prepare.data(), ctx->y.p, sizeof(double) * ctx->md.N, hipMemcpyDeviceToHost));
   }
   if (affine) return CXK_SUCCESS;
-  if (ReduceStepInfoAndSync(ctx, 0, ctx->info2.p, take ? &e_weight : nullptr, took)) return CXK_FAILURE;
+  if (ReduceStepInfoAndSync(ctx, 0, ctx->info2.p, take ? &e_weight : nullptr, took, with_tail)) return CXK_FAILURE;
   info[0] = ctx->mbv[0];
   info[1] = ctx->mbv[1];
   return CXK_SUCCESS;
@@ -2642,6 +2711,10 @@ static int LaunchTakeStep(cxk_context* ctx, double e_weight, double step_size, c
 int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* out) {
   CXK_ENTER(ctx);
   StepArgs sa = MakeStep(ctx, ctx->info4.p, 0, c_weight, 0.0, 1.0);
+  const bool with_tail = StepTailOk(ctx, 0);
+  StepTail tail;
+  tail.slots = nullptr;
+  if (with_tail && MakeStepTail(ctx, 1, &tail)) return CXK_FAILURE;
   ctx->lanczos_calls++;
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
@@ -2651,7 +2724,7 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
     else if (g.type == CXK_LMI) {
       static const bool lds_kernel = getenv("CXK_PREPARE_LDS") != nullptr;
       if (!lds_kernel && !g.literal && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse))
-        lmi_prepare_rows<1, 20><<<(cnt + 3) / 4, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+        lmi_prepare_rows<1, 20><<<(cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, 0, ctx->stream>>>(MakeLmi(g), sa, tail);
       else if (g.n == 20)
         lmi_prepare_generic<1, 20><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
       else
@@ -2668,7 +2741,7 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
       oct_prepare<1><<<cnt, 64, sizeof(double) * (size_t)g.m, ctx->stream>>>(MakeOct(g), sa);
   }
   CXK_TRY(hipGetLastError());
-  if (ReduceStepInfoAndSync(ctx, 1, ctx->info4.p)) return CXK_FAILURE;
+  if (ReduceStepInfoAndSync(ctx, 1, ctx->info4.p, nullptr, nullptr, with_tail)) return CXK_FAILURE;
   for (int i = 0; i < 4; i++) out[i] = ctx->mbv[i];
   return CXK_SUCCESS;
 }

@@ -318,6 +318,11 @@ struct cxk_context {
   double mbv[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // the last validated snapshot of the mailbox (WaitMailbox)
   double* pin_y = nullptr;  // pinned staging of y for cxk_get_y
   long long seq = 0, mb_seen = -1, factor_seq = -1, scal_seq = -1;
+  // cxk_step_scalars_async leaves its launch to the tail workgroup of the PrepareStep that normally
+  // follows (StepTail, kernels_cone.hip.h); any other entry point runs it first (FlushDeferred)
+  bool scal_deferred = false;
+  bool no_step_tail = false;  // CXK_NO_STEP_TAIL / CXK_PREPARE_LDS in the environment at cxk_create
+  DevBuf<double> tail_slots;  // 4 per constraint, armed with kTailSentinel
 };
 
 #define CXK_TRY(expr)                                                                       \
