@@ -11,6 +11,7 @@
 #pragma once
 #include "device_utils.h"
 #include "kernels_lmi.hip.h"
+#include "mu_rule.h"
 
 namespace cxk {
 
@@ -465,21 +466,22 @@ struct MailboxArgs {
   int tag;
   double seq;
   double* mb;          // pinned host memory, 16 doubles; nullptr: no mailbox write
+  const double* mu;    // [1] inv_sqrt_mu as the device last selected it (MuRuleArgs), slot 13; may be null
 };
-// v: this thread's slot value (threads 0 .. 10; anything elsewhere).  The eleven values, the sequence
+// v: this thread's slot value (threads 0 .. 10 and 13; anything elsewhere).  The twelve values, the sequence
 // number the host spins on (slot 11) and a checksum (slot 12) leave in ONE store instruction, no
 // fence in between: the host does not rely on the order in which the bytes arrive (they cross PCIe
 // as posted writes; with a system-scope fence between data and sequence number -- 2 us per round
 // trip -- the sequence number was still seen ahead of the data about once in a thousand round trips
 // on a cold box).  It accepts a mailbox only when slot 12 equals the XOR of the sequence number's
-// bit pattern and the eleven values', each rotated by its own amount (kMailboxRot: stale slots
+// bit pattern and the twelve values', each rotated by its own amount (kMailboxRot: stale slots
 // cannot cancel each other the way equal changes of two slots would under a plain XOR).
 __host__ __device__ constexpr int MailboxRot(int slot) { return (7 * slot + 1) & 63; }
 __device__ __forceinline__ void MailboxWrite(const MailboxArgs& m, double v) {
   const int t = threadIdx.x;
   if (t >= 64) return;
   unsigned long long x = 0ull;
-  if (t <= 10) {
+  if (t <= 10 || t == 13) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
     const int r = MailboxRot(t);
     x = r ? (bits << r) | (bits >> (64 - r)) : bits;
@@ -489,7 +491,7 @@ __device__ __forceinline__ void MailboxWrite(const MailboxArgs& m, double v) {
   double out = v;
   if (t == 11) out = m.seq;
   if (t == 12) out = __longlong_as_double((long long)(x ^ (unsigned long long)__double_as_longlong(m.seq)));
-  if (t <= 12) __hip_atomic_store(m.mb + t, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (t <= 13) __hip_atomic_store(m.mb + t, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // fail[1] == tag: a pivot failed in the first factor level of the latest fused launch
 __device__ __forceinline__ double MailboxFailValue(const MailboxArgs& m) {
@@ -501,6 +503,7 @@ __device__ __forceinline__ void MailboxPack(const MailboxArgs& m) {
   if (t < 4) v = m.red[t];
   if (t >= 4 && t < 10) v = m.scal[t - 4];
   if (t == 10) v = MailboxFailValue(m);
+  if (t == 13 && m.mu) v = *m.mu;
   MailboxWrite(m, v);
 }
 
@@ -542,11 +545,19 @@ __global__ void step_slots_reduce(int mode, int world, const double* __restrict_
 // `scal_lds` (this workgroup formed them) or, like the failure flag, from `pre_value` (threads 4 .. 10:
 // their slot's value, read before the wait) -- no memory round trip between the last result and the
 // host write.
+// The barrier-parameter selection evaluated where its inputs appear (mode 1, the tail workgroup):
+// out[0] <- NextInvSqrtMu(u, the reduced eigenvalue bounds), mu_rule.h.
+struct MuRuleArgs {
+  int on;
+  cxk_mu::Update u;
+  double* out;
+};
 template <bool LOCAL = false>
 __device__ __forceinline__ void ReduceStepFinish(int mode, double a, double b, double c, double d,
                                                  double* __restrict__ out, const MailboxArgs& mbx,
-                                                 const double* scal_lds = nullptr, double pre_value = 0.0) {
-  __shared__ double red[8], red2[8], red3[8], red4[8], res[4];
+                                                 const double* scal_lds = nullptr, double pre_value = 0.0,
+                                                 const MuRuleArgs* rule = nullptr) {
+  __shared__ double red[8], red2[8], red3[8], red4[8], res[5];
   // the two BlockSums (wave sum, wave totals added in wave order) and the max / min reductions
   // behind ONE barrier
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
@@ -581,6 +592,16 @@ __device__ __forceinline__ void ReduceStepFinish(int mode, double a, double b, d
       out[2] = A;
       out[3] = D;
       if (LOCAL) res[0] = B, res[1] = C, res[2] = A, res[3] = D;
+      if (LOCAL && rule && rule->on) {
+        cxk_mu::Wse e;
+        e.lmin = B;
+        e.lmax = C;
+        e.frob = A;
+        e.trace = D;
+        const double v = cxk_mu::NextInvSqrtMu(rule->u, e);
+        rule->out[0] = v;
+        res[4] = v;
+      }
     }
   }
   if (!mbx.mb) return;
@@ -592,6 +613,7 @@ __device__ __forceinline__ void ReduceStepFinish(int mode, double a, double b, d
     if (t < (mode == 0 ? 2 : 4)) v = res[t];
     if (t >= 4 && t < 10) v = scal_lds ? scal_lds[t - 4] : pre_value;
     if (t == 10) v = pre_value;
+    if (t == 13) v = (mode != 0 && rule && rule->on) ? res[4] : pre_value;
     MailboxWrite(mbx, v);
   } else {
     __threadfence();  // out[] is read back below by other threads of this workgroup
@@ -663,6 +685,7 @@ struct StepTail {
   const double *b, *AQc, *y, *sys_sc;
   double* scal_out;
   MailboxArgs mbx;
+  MuRuleArgs rule;  // mode 1: the selection of inv_sqrt_mu on the device
 };
 typedef unsigned int TailU4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double AgentLoad(const double* p) {
@@ -734,6 +757,7 @@ __device__ inline void PrepareTailBlock(const StepTail& T) {
   if (T.mbx.mb) {
     if (t >= 4 && t < 10 && !T.scal) pre = T.mbx.scal[t - 4];
     if (t == 10) pre = MailboxFailValue(T.mbx);
+    if (t == 13 && T.mbx.mu) pre = *T.mbx.mu;
   }
   const double armed = __longlong_as_double((long long)kTailSentinel);
   double a = 0, b = (mode == 0) ? -1.0 : 30000.0, c = -30000.0, d = 0;
@@ -785,7 +809,7 @@ __device__ inline void PrepareTailBlock(const StepTail& T) {
       }
     }
   }
-  ReduceStepFinish<true>(mode, a, b, c, d, T.red_out, T.mbx, T.scal ? s_scal : nullptr, pre);
+  ReduceStepFinish<true>(mode, a, b, c, d, T.red_out, T.mbx, T.scal ? s_scal : nullptr, pre, &T.rule);
   // re-arm the slots for the next launch (everything has been taken: every thread is past its loop)
   for (int i = t; i < K; i += 256)
 #pragma unroll

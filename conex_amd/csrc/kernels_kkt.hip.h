@@ -996,6 +996,7 @@ struct RhsIn {
   const double *b, *AQc, *AW;
   double k, bs, cs;    // form 1: k (b bs + AQc cs) - 2 AW   (cone_program.cc:409-411)
   double cb, cq, cw;   // form 2: cb b + cq AQc + cw AW      (cone_program.cc:181, 504)
+  const double* k_from;  // form 1 on the whole-tree launch only: k read from the device (FusedTreeArgs::k_from)
 };
 __device__ __forceinline__ double RhsValue(const RhsIn& ri, const double* __restrict__ rhs, int p) {
   if (ri.form == 0) return rhs[p];

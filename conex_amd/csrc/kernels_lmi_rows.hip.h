@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) lmi_take_step_rows(LmiGroup g, StepArgs s
   __shared__ double sT[4][N * N];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mem = blockIdx.x * 4 + wave;
-  if (mem >= g.count) return;  // wave-uniform; no workgroup barrier below
+  if (mem >= g.count || StepSkipped(sa)) return;  // wave-uniform; no workgroup barrier below
   const int n = g.n, nn = n * n;
   double* Wg = g.W + (size_t)mem * nn;
   const double* T1 = g.T1 + (size_t)mem * nn;
@@ -338,6 +338,7 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
   const int mem = blockIdx.x * 4 + wave;
   if (mem >= g.count) return;  // wave-uniform; no workgroup barrier below
   const int id = g.ids[mem], m = g.m;
+  const double c_weight = sa.cw_from ? sa.cw_from[0] * sa.cw_scale : sa.c_weight;
   const double* Cm = g.C + (size_t)mem * NN;
   const double* Wg = g.W + (size_t)mem * NN;
   double* M = sM[wave];
@@ -390,8 +391,8 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
           }
           const int r = c + rem;
           const double a = h == 0 ? acc[u].x : acc[u].y;
-          M[r + c * N] = a - sa.c_weight * Cm[r + c * N];
-          if (r != c) M[c + r * N] = a - sa.c_weight * Cm[c + r * N];
+          M[r + c * N] = a - c_weight * Cm[r + c * N];
+          if (r != c) M[c + r * N] = a - c_weight * Cm[c + r * N];
         }
       }
     }
@@ -434,8 +435,8 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
   for (int u = 0; u < CH; u++) {
     const int e = lane + 64 * u;
     if (e < HALF) {
-      M[2 * e] = acc[u].x - sa.c_weight * Cm[2 * e];
-      M[2 * e + 1] = acc[u].y - sa.c_weight * Cm[2 * e + 1];
+      M[2 * e] = acc[u].x - c_weight * Cm[2 * e];
+      M[2 * e + 1] = acc[u].y - c_weight * Cm[2 * e + 1];
     }
   }
   }

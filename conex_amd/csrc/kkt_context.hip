@@ -154,6 +154,10 @@ StepArgs MakeStep(cxk_context* ctx, double* info, int affine, double cw, double 
   s.e_weight = ew;
   s.step_size = ss;
   s.step_from = nullptr;
+  s.cw_from = nullptr;
+  s.cw_scale = 1.0;
+  s.skip_if = nullptr;
+  s.skip_tag = 0;
   s.call = ctx->lanczos_calls;
   s.no_clamp = ctx->reference_identity > 0;
   return s;
@@ -961,6 +965,7 @@ int MakeFusedTreeArgs(cxk_context* ctx, FusedTreeArgs* out) {
   a.fail = ctx->d_fail.p;
   a.tag = ctx->fail_tag;
   a.k = a.bs = a.cs = a.cb = a.cq = a.cw = 0;
+  a.k_from = nullptr;
   a.comb = 0;
   a.form = 0;
   a.sc = ctx->sc.p;
@@ -1003,6 +1008,7 @@ int LaunchFusedTreeSweep(cxk_context* ctx) {
   const RhsIn& ri = ctx->rhs_in;
   a.form = ri.form;
   a.k = ri.k;
+  a.k_from = ri.k_from;
   a.bs = ri.bs;
   a.cs = ri.cs;
   a.cb = ri.cb;
@@ -2159,6 +2165,7 @@ int NextMailbox(cxk_context* ctx, MailboxArgs* m) {
   m->tag = ctx->fail_tag;
   m->seq = (double)(++ctx->seq);
   m->mb = ctx->mb;
+  m->mu = ctx->mu_dev.p;  // (null until the device has selected a barrier parameter)
   return CXK_SUCCESS;
 }
 
@@ -2178,23 +2185,25 @@ int WaitMailbox(cxk_context* ctx, long long want) {
   bool synced = no_spin;
   for (unsigned spins = 1;; spins++) {
     if (*flag == dw) {
-      unsigned long long snap[13], x = wbits;
-      for (int i = 0; i <= 10; i++) {
+      unsigned long long snap[14], x = wbits;
+      for (int i = 0; i <= 13; i++) {
         snap[i] = raw[i];
+        if (i == 11 || i == 12) continue;  // sequence number, checksum
         const int r = MailboxRot(i);
         x ^= r ? (snap[i] << r) | (snap[i] >> (64 - r)) : snap[i];
       }
-      snap[12] = raw[12];
       if (x == snap[12] || synced) {
-        memcpy(ctx->mbv, snap, sizeof(double) * 11);
+        memcpy(ctx->mbv, snap, sizeof(double) * 14);
         break;
       }
     }
-    if ((spins & 0xfff) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) {
+    // (rarely: a stream query enqueues a marker behind the last command, and the next launch then
+    // starts ~5.7 us late -- with a query every few thousand spins every iteration of conex::Solve paid that)
+    if ((spins & 0xfffff) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady) {
       CXK_TRY(hipStreamSynchronize(ctx->stream));  // everything has run: whatever is there now is final
       synced = true;
       if (*flag != dw) {  // (a launch failed: report what the mailbox holds)
-        for (int i = 0; i <= 10; i++) ctx->mbv[i] = ctx->mb[i];
+        for (int i = 0; i <= 13; i++) ctx->mbv[i] = ctx->mb[i];
         break;
       }
     }
@@ -2215,7 +2224,8 @@ int SyncMailbox(cxk_context* ctx) {
 
 // TakeStep of every cone; step_from != nullptr: step length from the device (StepArgs::step_from).
 extern "C" {
-static int LaunchTakeStep(cxk_context* ctx, double e_weight, double step_size, const double* step_from);
+static int LaunchTakeStep(cxk_context* ctx, double e_weight, double step_size, const double* step_from,
+                          bool skip_on_fail = false);
 }
 // Whether TakeStep can read its step length from the device (every kernel of this program does).
 bool TakeStepFromDeviceOk(const cxk_context* ctx) {
@@ -2230,7 +2240,7 @@ bool TakeStepFromDeviceOk(const cxk_context* ctx) {
 // take_e_weight != nullptr (mode 0): TakeStep with the step length of cone_program.cc:417-418 taken
 // from the reduced norms ON THE DEVICE is enqueued before the host waits, *took reports it.
 int ReduceStepInfoAndSync(cxk_context* ctx, int mode, const double* info, const double* take_e_weight = nullptr,
-                          int* took = nullptr, bool tail_done = false) {
+                          int* took = nullptr, bool tail_done = false, bool skip_on_fail = false, bool wait = true) {
   MailboxArgs m;
   m.mb = nullptr;
   const bool fold = ctx->world <= 1;
@@ -2241,9 +2251,10 @@ int ReduceStepInfoAndSync(cxk_context* ctx, int mode, const double* info, const 
     CXK_TRY(hipGetLastError());
   }
   if (fold && take_e_weight && TakeStepFromDeviceOk(ctx)) {
-    if (LaunchTakeStep(ctx, *take_e_weight, 1.0, ctx->red_out.p)) return CXK_FAILURE;
+    if (LaunchTakeStep(ctx, *take_e_weight, 1.0, ctx->red_out.p, skip_on_fail)) return CXK_FAILURE;
     if (took) *took = 1;
   }
+  if (fold && !wait) return CXK_SUCCESS;  // (the results come back with a later mailbox)
   if (fold) return WaitMailbox(ctx, want);
   // sharded: every rank reduced its own constraints; ONE sum all-reduce of a (world x 4)-slot buffer
   // brings all partial results to every rank, which combines them in rank order (kernels_cone.hip.h:
@@ -2312,6 +2323,7 @@ int MakeStepTail(cxk_context* ctx, int mode, StepTail* t) {
   t->y = ctx->y.p;
   t->sys_sc = ctx->sys_sc.p;
   t->scal_out = ctx->scal_out.p;
+  t->rule.on = 0;
   if (NextMailbox(ctx, &t->mbx)) return CXK_FAILURE;
   if (t->scal) {  // the scalars travel in this launch's mailbox
     ctx->scal_deferred = false;
@@ -2597,7 +2609,7 @@ int cxk_set_y(cxk_context* ctx, const double* yh) {
 }
 
 static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double e_weight, double* info, bool take,
-                           int* took);
+                           int* took, const double* cw_from = nullptr, double cw_scale = 1.0);
 int cxk_prepare_step(cxk_context* ctx, int affine, double c_weight, double e_weight, double* info) {
   return PrepareStepImpl(ctx, affine, c_weight, e_weight, info, false, nullptr);
 }
@@ -2606,11 +2618,13 @@ int cxk_prepare_take_step(cxk_context* ctx, double c_weight, double e_weight, do
   return PrepareStepImpl(ctx, 0, c_weight, e_weight, info, true, took);
 }
 static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double e_weight, double* info, bool take,
-                           int* took) {
+                           int* took, const double* cw_from, double cw_scale) {
   CXK_ENTER_KEEP(ctx);
   const bool with_tail = StepTailOk(ctx, affine);
   if (FlushDeferred(ctx, with_tail)) return CXK_FAILURE;
   StepArgs sa = MakeStep(ctx, ctx->info2.p, affine, c_weight, e_weight, 1.0);
+  sa.cw_from = cw_from;  // (lmi_prepare_rows: the only kernel of a program that gets here with it, DeviceMuOk)
+  sa.cw_scale = cw_scale;
   StepTail tail;
   tail.slots = nullptr;
   if (with_tail && MakeStepTail(ctx, 0, &tail)) return CXK_FAILURE;
@@ -2646,7 +2660,8 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
     CXK_TRY(hipMemcpy(ctx->y_at_prepare.data(), ctx->y.p, sizeof(double) * ctx->md.N, hipMemcpyDeviceToHost));
   }
   if (affine) return CXK_SUCCESS;
-  if (ReduceStepInfoAndSync(ctx, 0, ctx->info2.p, take ? &e_weight : nullptr, took, with_tail)) return CXK_FAILURE;
+  if (ReduceStepInfoAndSync(ctx, 0, ctx->info2.p, take ? &e_weight : nullptr, took, with_tail, cw_from != nullptr))
+    return CXK_FAILURE;
   info[0] = ctx->mbv[0];
   info[1] = ctx->mbv[1];
   return CXK_SUCCESS;
@@ -2666,9 +2681,14 @@ int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_siz
   return LaunchTakeStep(ctx, e_weight, step_size, nullptr);
 }
 
-static int LaunchTakeStep(cxk_context* ctx, double e_weight, double step_size, const double* step_from) {
+static int LaunchTakeStep(cxk_context* ctx, double e_weight, double step_size, const double* step_from,
+                          bool skip_on_fail) {
   StepArgs sa = MakeStep(ctx, ctx->info2.p, 0, 0.0, e_weight, step_size);
   sa.step_from = step_from;
+  if (skip_on_fail) {  // (lmi_take_step_rows: the only kernel of a program that gets here, DeviceMuOk)
+    sa.skip_if = ctx->d_fail.p;
+    sa.skip_tag = ctx->fail_tag;
+  }
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
     if (cnt == 0) continue;
@@ -2708,13 +2728,22 @@ static int LaunchTakeStep(cxk_context* ctx, double e_weight, double step_size, c
   return CXK_SUCCESS;
 }
 
+static int SlackEigenvaluesImpl(cxk_context* ctx, double c_weight, double* out, const MuRuleArgs* rule);
 int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* out) {
+  return SlackEigenvaluesImpl(ctx, c_weight, out, nullptr);
+}
+// rule != nullptr: the selection of the barrier parameter rides in the launch's tail workgroup and
+// nobody waits (cxk_select_mu_async)
+static int SlackEigenvaluesImpl(cxk_context* ctx, double c_weight, double* out, const MuRuleArgs* rule) {
   CXK_ENTER(ctx);
   StepArgs sa = MakeStep(ctx, ctx->info4.p, 0, c_weight, 0.0, 1.0);
   const bool with_tail = StepTailOk(ctx, 0);
+  CXK_DEMAND(with_tail || !rule, "the barrier parameter is selected on the device only behind cxk_device_mu_supported");
   StepTail tail;
   tail.slots = nullptr;
+  tail.rule.on = 0;
   if (with_tail && MakeStepTail(ctx, 1, &tail)) return CXK_FAILURE;
+  if (rule) tail.rule = *rule;
   ctx->lanczos_calls++;
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
@@ -2741,8 +2770,61 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
       oct_prepare<1><<<cnt, 64, sizeof(double) * (size_t)g.m, ctx->stream>>>(MakeOct(g), sa);
   }
   CXK_TRY(hipGetLastError());
-  if (ReduceStepInfoAndSync(ctx, 1, ctx->info4.p, nullptr, nullptr, with_tail)) return CXK_FAILURE;
-  for (int i = 0; i < 4; i++) out[i] = ctx->mbv[i];
+  if (ReduceStepInfoAndSync(ctx, 1, ctx->info4.p, nullptr, nullptr, with_tail, false, rule == nullptr)) return CXK_FAILURE;
+  if (out && !rule)
+    for (int i = 0; i < 4; i++) out[i] = ctx->mbv[i];
+  return CXK_SUCCESS;
+}
+
+// ---- the barrier parameter selected on the device: conex::Solve's iteration without the host round
+// trip between the eigenvalue query and the Newton direction (cone_program.cc:366-413).
+static bool DeviceMuOk(const cxk_context* ctx) {
+  static const bool off = getenv("CXK_NO_DEVICE_MU") != nullptr || getenv("CXK_TAKE_STEP_LDS") != nullptr;
+  if (off || !StepTailOk(ctx, 0) || !TakeStepFromDeviceOk(ctx)) return false;
+  // the Newton direction's right-hand side is formed inside the whole-tree solve launch
+  return ctx->fused_tree && ctx->fused_sweep && ctx->world == 1 && ctx->solver_mode != 2 && ctx->refine_iters <= 0 &&
+         !ctx->no_lean;
+}
+int cxk_device_mu_supported(cxk_context* ctx) {
+  if (!ctx || CheckReady(ctx)) return 0;
+  return DeviceMuOk(ctx) ? 1 : 0;
+}
+int cxk_select_mu_async(cxk_context* ctx, double c_weight, double divergence_upper_bound, int rank, double prev,
+                        double lb, double ub) {
+  if (!ctx || CheckReady(ctx)) return CXK_FAILURE;
+  CXK_DEMAND(DeviceMuOk(ctx), "cxk_select_mu_async: not supported by this program (cxk_device_mu_supported)");
+  if (ctx->mu_dev.n != 1) CXK_TRY(ctx->mu_dev.alloc(1, true));
+  MuRuleArgs r;
+  r.on = 1;
+  r.u.divergence_upper_bound = divergence_upper_bound;
+  r.u.rankK = rank;
+  r.u.prev = prev;
+  r.u.lb = lb;
+  r.u.ub = ub;
+  r.out = ctx->mu_dev.p;
+  return SlackEigenvaluesImpl(ctx, c_weight, nullptr, &r);
+}
+int cxk_newton_direction_device_mu(cxk_context* ctx, double bs, double cs) {
+  CXK_ENTER(ctx);
+  CXK_DEMAND(DeviceMuOk(ctx) && ctx->mu_dev.n == 1, "cxk_newton_direction_device_mu: no barrier parameter on the device");
+  RhsIn f{};
+  f.form = 1;
+  f.b = ctx->b.p;
+  f.AQc = ctx->AQc.p;
+  f.AW = ctx->AW.p;
+  f.k = 0.0;
+  f.k_from = ctx->mu_dev.p;
+  f.bs = bs;
+  f.cs = cs;
+  return SolveWithRhs(ctx, f);
+}
+int cxk_prepare_take_step_device_mu(cxk_context* ctx, double c_scaling, double e_weight, double* info, int* took,
+                                    double* inv_sqrt_mu) {
+  if (took) *took = 0;
+  if (!ctx || CheckReady(ctx)) return CXK_FAILURE;
+  CXK_DEMAND(DeviceMuOk(ctx) && ctx->mu_dev.n == 1, "cxk_prepare_take_step_device_mu: no barrier parameter on the device");
+  if (PrepareStepImpl(ctx, 0, 0.0, e_weight, info, true, took, ctx->mu_dev.p, c_scaling)) return CXK_FAILURE;
+  if (inv_sqrt_mu) *inv_sqrt_mu = ctx->mbv[13];
   return CXK_SUCCESS;
 }
 

@@ -315,7 +315,7 @@ struct cxk_context {
   // picked up by the host without a D2H copy.  seq counts enqueued producers; mb_seen is the
   // value the mailbox carried when the host last waited for it.
   double* mb = nullptr;
-  double mbv[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // the last validated snapshot of the mailbox (WaitMailbox)
+  double mbv[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // the last validated snapshot of the mailbox (WaitMailbox)
   double* pin_y = nullptr;  // pinned staging of y for cxk_get_y
   long long seq = 0, mb_seen = -1, factor_seq = -1, scal_seq = -1;
   // cxk_step_scalars_async leaves its launch to the tail workgroup of the PrepareStep that normally
@@ -323,6 +323,7 @@ struct cxk_context {
   bool scal_deferred = false;
   bool no_step_tail = false;  // CXK_NO_STEP_TAIL / CXK_PREPARE_LDS in the environment at cxk_create
   DevBuf<double> tail_slots;  // 4 per constraint, armed with kTailSentinel
+  DevBuf<double> mu_dev;      // [1] inv_sqrt_mu as selected on the device (cxk_select_mu_async)
 };
 
 #define CXK_TRY(expr)                                                                       \

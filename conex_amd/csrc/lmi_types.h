@@ -61,6 +61,14 @@ struct StepArgs {
   // just before, step = min(1, 2 / norminfd^2) with norminfd = step_from[1] (cone_program.cc:417-418),
   // so that TakeStep can be enqueued without a host round trip in between
   const double* step_from;
+  // not null: c_weight = cw_from[0] * cw_scale, the barrier parameter the device selected
+  // (cxk_select_mu_async) times c_scaling (cone_program.cc:413), read by lmi_prepare_rows
+  const double* cw_from;
+  double cw_scale;
+  // not null (TakeStep enqueued before the host has seen the factorization's outcome): leave W alone
+  // when the factorization failed -- skip_if[0] != 0, or skip_if[1] == skip_tag != 0 (MailboxFailValue)
+  const int* skip_if;
+  int skip_tag;
   unsigned long long call;  // index of this PrepareStep / eigenvalue query (Hermitian start vectors)
   // reference identity (cxk_set_reference_identity / CXK_REFERENCE_QUIRKS=1): the Ritz values go
   // out exactly as approximate_eigenvalues.cc:178-239 produces them, without the Samuelson clamp
@@ -68,6 +76,9 @@ struct StepArgs {
 };
 
 #ifdef __HIPCC__
+__device__ __forceinline__ bool StepSkipped(const StepArgs& sa) {
+  return sa.skip_if && (sa.skip_if[0] != 0 || (sa.skip_tag != 0 && sa.skip_if[1] == sa.skip_tag));
+}
 __device__ __forceinline__ double StepSizeOf(const StepArgs& sa) {
   if (!sa.step_from) return sa.step_size;
   const double v = sa.step_from[1];

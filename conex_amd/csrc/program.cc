@@ -26,6 +26,7 @@
 
 #include "../../include/conex.h"
 #include "../../include/conex_kkt_hip.h"
+#include "mu_rule.h"
 
 namespace {
 
@@ -110,46 +111,8 @@ int AddCone(Program* p, Cone&& c) {
   return static_cast<int>(p->cones.size()) - 1;
 }
 
-// ---------------------------------------------------------------- divergence.cc
-struct Wse {
-  double frob = 0, trace = 0, lmin = 0, lmax = 0, rank = 0;
-};
-
-double SolveRational(double a, double b, double c, double d, double k) {
-  const double ur = b * b - 4 * a * c + 8 * a * k + 2 * b * d * k + std::pow(d * k, 2);
-  return -(b + d * k - std::sqrt(ur)) / (2 * a);
-}
-bool InLimits(double x, double lo, double hi) { return x >= lo && x <= hi; }
-double InverseLambdaMaxBranch(double bound, const Wse& p) {
-  const double x = SolveRational(p.frob, -2 * p.trace, p.rank, p.lmax, bound);
-  const double lower = 2.0 / (p.lmax + p.lmin);
-  return x >= lower ? x : -1;
-}
-double InverseLambdaMinBranch(double bound, const Wse& p) {
-  const double upper = 2.0 / (p.lmax + p.lmin);
-  const double a = p.frob / p.lmin, b = 2 * p.trace / p.lmin, n = p.rank / p.lmin, c = bound;
-  const double ur = b * b + 2 * b * c + c * c - 4 * a * n;
-  const double f = (b + c + std::sqrt(ur)) / (2 * a), s = (b + c - std::sqrt(ur)) / (2 * a);
-  double k = -1;
-  if (!(ur < 0)) {
-    if (InLimits(f, 0, upper)) k = f;
-    if (InLimits(s, 0, upper) && s > k) k = s;
-  }
-  return k;
-}
-bool BoundIsFinite(double k, const Wse& p) {
-  double ni = std::fabs(k * p.lmax - 1);
-  if (ni < std::fabs(k * p.lmin - 1)) ni = std::fabs(k * p.lmin - 1);
-  return ni < 1;
-}
-double DivergenceUpperBoundInverse(double bound, const Wse& p) {
-  double k = -1;
-  const double k1 = InverseLambdaMinBranch(bound, p);
-  const double k2 = InverseLambdaMaxBranch(bound, p);
-  if (BoundIsFinite(k1, p)) k = k1;
-  if (k2 > k && BoundIsFinite(k2, p)) k = k2;
-  return k;
-}
+// ---------------------------------------------------------------- divergence.cc: mu_rule.h
+using cxk_mu::Wse;
 
 int RankOf(const Cone& c) {
   switch (c.kind) {
@@ -246,10 +209,7 @@ int BuildContext(Program* p) {
   return 0;
 }
 
-void ApplyLimits(double* x, double lb, double ub) {
-  if (*x > ub) *x = ub;
-  if (*x < lb) *x = lb;
-}
+using cxk_mu::ApplyLimits;
 
 #define REPORT(name, val) \
   if (Verbose()) printf(#name ": %.2e, ", (double)(val));
@@ -307,23 +267,7 @@ int MuFromDivergence(Program* p, const Config& cfg, int rankK, double* out, bool
   mp.lmax = e4[1];
   mp.frob = e4[2];
   mp.trace = e4[3];
-  mp.rank = rankK;
-  const double bound = cfg.divergence_upper_bound * rankK;
-  double inv = DivergenceUpperBoundInverse(bound, mp);
-  if (inv == -1) {  // MinimizeNormInf :166-172
-    inv = -1;
-    if (mp.lmin > 0) inv = 2.0 / (mp.lmin + mp.lmax);
-  }
-  if (inv < 0 && mp.trace > 1e-12) {
-    const double kstar = mp.trace / mp.frob;
-    double nb = 1.5 * (mp.frob * kstar * kstar - 2 * mp.trace * kstar + rankK);
-    if (nb > rankK * .7) nb = rankK * .7;
-    const double a = mp.frob, b = -2 * mp.trace, c = rankK - nb;
-    if (b * b - 4 * a * c < 0)
-      inv = mp.trace / mp.frob;
-    else
-      inv = (-b + std::sqrt(b * b - 4 * a * c)) / (2 * a);
-  }
+  const double inv = cxk_mu::SelectFromDivergence(cfg.divergence_upper_bound, rankK, mp);
   *out = inv;
   return 0;
 }
@@ -483,7 +427,18 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
       PRINTSTATUS("Factorization failed.");
       return kFailed;
     };
-    if (update_mu) {
+    // The selection of mu on the device (cxk_select_mu_async): the eigenvalue query's launch evaluates
+    // the rule below itself, the Newton direction and PrepareStep read inv_sqrt_mu from device memory,
+    // and the host learns it, with everything else, from the one mailbox at the end of the iteration.
+    const bool mu_on_device = fuse_mu_solve && !p->contains_quadratic_costs && !timers &&
+                              !(i == 0 && cfg.initialization_mode == 1) && cxk_device_mu_supported(ctx) == 1;
+    const double mu_lb = std::sqrt(1.0 / (1e-15 + cfg.maximum_mu));
+    if (mu_on_device) {
+      cxk_phase_mark(ctx, CXK_PHASE_OTHER);
+      if (TIMED(2, cxk_select_mu_async(ctx, c_scaling, cfg.divergence_upper_bound, rankK, inv_sqrt_mu, mu_lb,
+                                       inv_sqrt_mu_max)))
+        return 0;
+    } else if (update_mu) {
       cxk_phase_mark(ctx, CXK_PHASE_OTHER);  // mu selection: untimed in the reference
       double temp = -1;
       if (cfg.enable_line_search) {  // cone_program.cc:376-384
@@ -508,10 +463,14 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
       else
         inv_sqrt_mu *= .5;
     }
-    ApplyLimits(&inv_sqrt_mu, std::sqrt(1.0 / (1e-15 + cfg.maximum_mu)), inv_sqrt_mu_max);
+    if (!mu_on_device) ApplyLimits(&inv_sqrt_mu, mu_lb, inv_sqrt_mu_max);  // (on the device: part of the rule)
 
     cxk_phase_mark(ctx, CXK_PHASE_SOLVE);
-    if (!fuse_direction && TIMED(4, cxk_newton_direction(ctx, inv_sqrt_mu, b_scaling, c_scaling))) return 0;
+    if (mu_on_device) {
+      if (TIMED(4, cxk_newton_direction_device_mu(ctx, b_scaling, c_scaling))) return 0;
+    } else if (!fuse_direction && TIMED(4, cxk_newton_direction(ctx, inv_sqrt_mu, b_scaling, c_scaling))) {
+      return 0;
+    }
     if (TIMED(6, cxk_step_scalars_async(ctx))) return 0;  // by / cx of :439-446 need y only: same round trip
     e_weight = 1;
     c_weight = inv_sqrt_mu * c_scaling;
@@ -522,7 +481,15 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     // the step rule below evaluated on the device: the host round trip no longer separates them.
     int took_step = 0;
     const bool step_on_device = update_mu && !(i == 0 && cfg.initialization_mode == 1);
-    if (step_on_device) {
+    if (mu_on_device) {
+      // (the first host round trip of this iteration: the factorization's outcome arrives with it)
+      if (TIMED(5, cxk_prepare_take_step_device_mu(ctx, c_scaling, e_weight, info, &took_step, &inv_sqrt_mu)))
+        return 0;
+      c_weight = inv_sqrt_mu * c_scaling;
+      const int fo = factor_outcome();
+      if (fo == kRetry) continue;
+      if (fo == kFailed) return 0;
+    } else if (step_on_device) {
       if (TIMED(5, cxk_prepare_take_step(ctx, c_weight, e_weight, info, &took_step))) return 0;
     } else if (TIMED(5, cxk_prepare_step(ctx, 0, c_weight, e_weight, info))) {
       return 0;

@@ -57,6 +57,7 @@ struct FusedTreeArgs {
   double cb, cq, cw;  // or (comb != 0) y = cb b + cq AQc + cw AW  (cone_program.cc:181, 504)
   int comb;
   int form;  // solve-only sweeps: 0 the right-hand side is in y, 1 k (b bs + AQc cs) - 2 AW, 2 cb b + cq AQc + cw AW
+  const double* k_from;  // form 1, not null: k = k_from[0], the barrier parameter the device selected (cxk_select_mu_async)
   const double* sc;  // per-constraint <w,c>, <c,Qc>
   double* sys_sc;
   int K;

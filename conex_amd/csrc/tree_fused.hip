@@ -632,7 +632,8 @@ __device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, cons
     b = A.y[p];
   } else {
     const double bp = A.b[p], aq = A.AQc[p], aw = A.AW[p];
-    b = A.form == 1 ? A.k * (bp * A.bs + aq * A.cs) - 2 * aw : A.cb * bp + A.cq * aq + A.cw * aw;
+    const double kk = (A.form == 1 && A.k_from) ? A.k_from[0] : A.k;
+    b = A.form == 1 ? kk * (bp * A.bs + aq * A.cs) - 2 * aw : A.cb * bp + A.cq * aq + A.cw * aw;
   }
   const bool active = is_row;
   const double* D = A.slab + R.diag_off + (size_t)(active ? lane : 0) * ns;  // column `lane`

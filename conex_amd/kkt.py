@@ -109,6 +109,12 @@ _SIGNATURES = {
     "cxk_factor_direction_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
     "cxk_factor_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "cxk_step_scalars_async": (C.c_int, [C.c_void_p]),
+    "cxk_device_mu_supported": (C.c_int, [C.c_void_p]),
+    "cxk_select_mu_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
+                                      C.c_double]),
+    "cxk_newton_direction_device_mu": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "cxk_prepare_take_step_device_mu": (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_double_p,
+                                                  C.POINTER(C.c_int), c_double_p]),
     "cxk_kernel_time": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     "cxk_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_set_iterative_refinement": (C.c_int, [C.c_void_p, C.c_int]),

@@ -199,6 +199,30 @@ int cxk_take_step(cxk_context* ctx, int affine, double e_weight, double step_siz
  * out = {lambda_min, lambda_max, frobenius_norm_squared, trace} */
 int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* out);
 
+/* ---- The barrier parameter selected on the device: one iteration of conex::Solve without the host
+ * round trip between the eigenvalue query and the Newton direction (cone_program.cc:366-413).
+ * The eigenvalue query's launch evaluates ComputeMuFromDivergence's rule and the update of
+ * inv_sqrt_mu that Solve makes with it (cone_program.cc:166-224, :386-392, divergence.cc:17-110;
+ * the same source as the host loop compiles: csrc/mu_rule.h -- the same IEEE operations, the same
+ * bits) where the four reduced eigenvalue bounds appear; the Newton direction's right-hand side
+ * (:409-411) and PrepareStep's c_weight (:413) then read inv_sqrt_mu from device memory, and the
+ * host learns it -- with the factorization flag, the step norms and the by / cx scalars -- from the
+ * ONE mailbox at the end of the iteration.  TakeStep, enqueued before the host has seen the
+ * factorization's outcome, leaves W alone when the factorization failed.
+ * cxk_device_mu_supported: 1 when this program can run that way (one GPU, Cholesky, every
+ * constraint on the register LMI kernels, the whole-tree solve launch), else 0. */
+int cxk_device_mu_supported(cxk_context* ctx);
+/* GetWeightedSlackEigenvalues(c_weight) on the device-resident y, then
+ * inv_sqrt_mu <- limits(selection > 0 ? selection : prev / 2, lb, ub) on the device.  Does not wait. */
+int cxk_select_mu_async(cxk_context* ctx, double c_weight, double divergence_upper_bound, int rank,
+                        double prev, double lb, double ub);
+/* cxk_newton_direction with k = the device's inv_sqrt_mu */
+int cxk_newton_direction_device_mu(cxk_context* ctx, double b_scaling, double c_scaling);
+/* cxk_prepare_take_step with c_weight = the device's inv_sqrt_mu * c_scaling; waits, and returns
+ * the selected inv_sqrt_mu as well */
+int cxk_prepare_take_step_device_mu(cxk_context* ctx, double c_scaling, double e_weight, double* info,
+                                    int* took, double* inv_sqrt_mu);
+
 /* ---- inspection (tests, KKTMatrix() kkt_solver.cc:265-269) ------------- */
 int cxk_get_slab(cxk_context* ctx, double* out);
 int cxk_set_slab(cxk_context* ctx, const double* in);
