@@ -94,3 +94,109 @@ def test_prepare_step_results_match_the_oracle_with_the_tail(monkeypatch):
     assert np.allclose(ik, io, rtol=1e-9)
     eo, ek = o.weighted_slack_eigenvalues(yo, 0.8), k.weighted_slack_eigenvalues(yo, 0.8)
     assert np.allclose(ek, eo, rtol=1e-9)
+
+
+# ------------------------------------------------------------------ the barrier parameter on the device
+def _host_rule(dub, rankK, e4, prev, lb, ub):
+    """ComputeMuFromDivergence's rule and Solve's update of inv_sqrt_mu (cone_program.cc:166-224,
+    :386-392), restated over the oracle's DivergenceUpperBoundInverse -- plain IEEE doubles in the
+    reference's order of operations."""
+    import ctypes as C
+    lmin, lmax, frob, trace = (float(v) for v in e4)
+    p5 = np.array([frob, trace, lmin, lmax, float(rankK)])
+    bound = dub * rankK
+    inv = ol.lib().cxo_divergence_upper_bound_inverse(bound, ol.dp(p5))
+    if inv == -1:
+        inv = -1.0
+        if lmin > 0:
+            inv = 2.0 / (lmin + lmax)
+    if inv < 0 and trace > 1e-12:
+        kstar = trace / frob
+        nb = 1.5 * (frob * kstar * kstar - 2 * trace * kstar + rankK)
+        if nb > rankK * .7:
+            nb = rankK * .7
+        a, b, c = frob, -2 * trace, rankK - nb
+        if b * b - 4 * a * c < 0:
+            inv = trace / frob
+        else:
+            inv = (-b + np.sqrt(b * b - 4 * a * c)) / (2 * a)
+    out = inv if inv > 0 else prev * .5
+    out = min(out, ub)
+    out = max(out, lb)
+    return float(out)
+
+
+@pytest.mark.parametrize("dub,prev,lb,ub", [(1.0, 0.0, 1e-8, 1e9), (1e-9, 0.3, 1e-8, 1e9), (50.0, 0.3, 1e-8, 1e9),
+                                            (1.0, 0.3, 1e-8, 0.01), (1.0, 0.3, 5.0, 1e9)])
+def test_mu_selected_on_the_device_is_the_host_rule_bit_for_bit(dub, prev, lb, ub, monkeypatch):
+    import ctypes as C
+    K = 48
+    prob = syn.lmi_problem(K=K, n=20, m=20, branching=4, overlap=5, seed=19)
+    a, b = _contexts(prob, monkeypatch)   # a: tail + device mu, b: separate launches, host rule
+    assert a.L.cxk_device_mu_supported(a.h) == 1 and b.L.cxk_device_mu_supported(b.h) == 0
+    W = syn.scaling_points(K, 20, seed=6)
+    bs, cs, rankK = 0.9, 0.8, 20 * K
+    for k in (a, b):
+        for i in range(K):
+            k.set_W(i, W[i])
+        k.set_cost(prob["b"])
+        k.assemble()
+        k.factor_solve_async(-bs, cs, 0.0)          # the mu-selection solve rides in the factorization
+    # host path
+    e4 = b.weighted_slack_eigenvalues(None, cs)
+    inv_host = _host_rule(dub, rankK, e4, prev, lb, ub)
+    b._check(b.L.cxk_newton_direction(b.h, inv_host, bs, cs), "cxk_newton_direction")
+    assert b.L.cxk_step_scalars_async(b.h) == 0
+    n2b, ninfb, tookb = b.prepare_take_step(None, inv_host * cs)
+    scb = b.step_scalars()
+    # device path: nothing waits until the last call
+    a._check(a.L.cxk_select_mu_async(a.h, cs, dub, rankK, prev, lb, ub), "cxk_select_mu_async")
+    a._check(a.L.cxk_newton_direction_device_mu(a.h, bs, cs), "cxk_newton_direction_device_mu")
+    assert a.L.cxk_step_scalars_async(a.h) == 0
+    info, took, inv_dev = np.zeros(2), C.c_int(0), C.c_double(0)
+    a._check(a.L.cxk_prepare_take_step_device_mu(a.h, cs, 1.0, ol.dp(info), C.byref(took), C.byref(inv_dev)),
+             "cxk_prepare_take_step_device_mu")
+    sca = a.step_scalars()
+    assert inv_dev.value == inv_host, (inv_dev.value, inv_host)
+    assert took.value == 1 and tookb
+    assert info[0] == n2b and info[1] == ninfb
+    assert np.array_equal(sca, scb)
+    assert np.array_equal(a.get_y(), b.get_y())
+    for i in (0, K // 2, K - 1):
+        assert np.array_equal(a.get_W(i), b.get_W(i))
+
+
+def test_take_step_behind_a_failed_factorization_leaves_w_alone(monkeypatch):
+    """With mu selected on the device TakeStep is enqueued before the host has seen the LLT flag: it
+    must not touch W when the factorization failed (the reference returns before it, cone_program.cc:360-365)."""
+    import ctypes as C
+    K = 24
+    prob = syn.lmi_problem(K=K, n=20, m=20, branching=4, overlap=5, seed=23)
+    from conex_amd import KktContext
+    k = syn.build(KktContext, prob, "lmi", device=0)
+    W = syn.scaling_points(K, 20, seed=7)
+    for i in range(K):
+        k.set_W(i, W[i])
+    k.set_cost(prob["b"])
+    k.assemble()
+    k.set_slab(-k.slab())                                   # negative definite: the first pivot fails
+    k._check(k.L.cxk_factor_async(k.h), "cxk_factor_async")
+    k._check(k.L.cxk_select_mu_async(k.h, 0.8, 1.0, 20 * K, 0.3, 1e-8, 1e9), "cxk_select_mu_async")
+    k._check(k.L.cxk_newton_direction_device_mu(k.h, 0.9, 0.8), "cxk_newton_direction_device_mu")
+    info, took, inv = np.zeros(2), C.c_int(0), C.c_double(0)
+    k._check(k.L.cxk_prepare_take_step_device_mu(k.h, 0.8, 1.0, ol.dp(info), C.byref(took), C.byref(inv)),
+             "cxk_prepare_take_step_device_mu")
+    ok = C.c_int(1)
+    k._check(k.L.cxk_factor_status(k.h, C.byref(ok)), "cxk_factor_status")
+    assert ok.value == 0 and took.value == 1
+    for i in range(K):
+        assert np.array_equal(np.asarray(k.get_W(i)).ravel(), W[i].ravel())   # (symmetric: either layout)
+
+
+def test_device_mu_is_not_offered_where_a_kernel_needs_the_value_from_the_host():
+    from conex_amd import KktContext
+    k = syn.build(KktContext, syn.soc_problem(K=10, dim=6, m=5, overlap=2), "soc", device=0)
+    assert k.L.cxk_device_mu_supported(k.h) == 0
+    p2 = syn.lmi_problem(K=12, n=12, m=6, branching=3, overlap=2, seed=4)   # order 12: the workgroup kernels
+    k2 = syn.build(KktContext, p2, "lmi", device=0)
+    assert k2.L.cxk_device_mu_supported(k2.h) == 0
