@@ -673,11 +673,12 @@ reduce_step_info(int K, int mode, const double* __restrict__ info, const unsigne
 // per constraint, data-as-flag: armed with kTailSentinel, written with write-through stores, polled
 // here with sc1 loads -- MI355X_MICROARCH.md's hand-off rules, as in tree_fused); this workgroup
 // first forms the step scalars (they need y only), then takes the results as they arrive, reduces
-// them in reduce_step_info's order (the same bits), writes the mailbox and re-arms the slots.
+// them in reduce_step_info's order (the same bits) and writes the mailbox.
 constexpr unsigned long long kTailSentinel = 0x7FF4C0DEC0DE7A11ull;
 constexpr int kTailSpin = 1 << 20;  // polls before the workgroup gives up (NaNs go out: the solve fails loudly)
 struct StepTail {
   double* slots;  // nullptr: no tail workgroup in this launch
+  double* rearm;  // the other slot set: consumed by the launch before, armed again by this one while it waits
   int K, mode;
   const unsigned char* mask;
   double* red_out;
@@ -751,7 +752,7 @@ __device__ inline void StepScalarsOn256(int N, const double* __restrict__ b, con
 __device__ inline void PrepareTailBlock(const StepTail& T) {
   __shared__ double s_scal[6];
   if (T.scal) StepScalarsOn256(T.N, T.b, T.AQc, T.y, T.sys_sc, T.scal_out, s_scal);
-  const int K = T.K, mode = T.mode, nq = mode == 0 ? 2 : 4, t = threadIdx.x;
+  const int K = T.K, mode = T.mode, t = threadIdx.x;
   // what the mailbox carries besides this launch's results: final before the launch
   double pre = 0.0;
   if (T.mbx.mb) {
@@ -759,7 +760,10 @@ __device__ inline void PrepareTailBlock(const StepTail& T) {
     if (t == 10) pre = MailboxFailValue(T.mbx);
     if (t == 13 && T.mbx.mu) pre = *T.mbx.mu;
   }
+  // (two slot sets, used in turn: the stores that arm a set again are long complete when the launch
+  // that uses it next begins, and none of them sits between this launch's last result and its end)
   const double armed = __longlong_as_double((long long)kTailSentinel);
+  for (int i = t; i < 4 * K; i += 256) AgentStore(T.rearm + i, armed);
   double a = 0, b = (mode == 0) ? -1.0 : 30000.0, c = -30000.0, d = 0;
   // A polling round is one or two 16-byte sc1 loads per constraint (8-byte loads of the four values
   // one by one made a round of 1000 constraints cost several microseconds of address processing on
@@ -810,11 +814,6 @@ __device__ inline void PrepareTailBlock(const StepTail& T) {
     }
   }
   ReduceStepFinish<true>(mode, a, b, c, d, T.red_out, T.mbx, T.scal ? s_scal : nullptr, pre, &T.rule);
-  // re-arm the slots for the next launch (everything has been taken: every thread is past its loop)
-  for (int i = t; i < K; i += 256)
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (q < nq) AgentStore(T.slots + 4 * i + q, armed);
 }
 
 }  // namespace cxk

@@ -2305,13 +2305,16 @@ bool StepTailOk(const cxk_context* ctx, int affine) {
 }
 int MakeStepTail(cxk_context* ctx, int mode, StepTail* t) {
   const size_t K = ctx->cons.size();
-  if (ctx->tail_slots.n != 4 * K) {
+  if (ctx->tail_slots.n != 8 * K) {  // two sets, used in turn
     double armed;
     const unsigned long long bits = kTailSentinel;
     memcpy(&armed, &bits, sizeof(armed));
-    CXK_TRY(ctx->tail_slots.upload(std::vector<double>(4 * K, armed)));
+    CXK_TRY(ctx->tail_slots.upload(std::vector<double>(8 * K, armed)));
+    ctx->tail_parity = 0;
   }
-  t->slots = ctx->tail_slots.p;
+  t->slots = ctx->tail_slots.p + (size_t)ctx->tail_parity * 4 * K;
+  t->rearm = ctx->tail_slots.p + (size_t)(ctx->tail_parity ^ 1) * 4 * K;
+  ctx->tail_parity ^= 1;
   t->K = (int)K;
   t->mode = mode;
   t->mask = ctx->d_mask.p;
