@@ -29,6 +29,8 @@ python3 "$ROOT/tools/big_chol_stamps.py" 500 > "$OUT/big_chol_stamps.txt" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_maxcut500" -o bench -- \
   python3 "$ROOT/bench.py" --workload maxcut --maxcut-n 500 --no-cpu --steps 100 > "$OUT/bench_maxcut500_under_rocprof.log" 2>&1
 python3 "$ROOT/tools/ipm_iteration.py" --timers > "$OUT/ipm_iteration.txt" 2>&1
+# (the timed run takes the path with a host round trip per phase; this one is the product's)
+python3 "$ROOT/tools/ipm_iteration.py" > "$OUT/ipm_iteration_wall.txt" 2>&1
 "$ROOT/tools/ipm_rocprof.sh" 2>&1 | grep -v "^[EW]20" > "$OUT/ipm_kernels.txt"
 cd /tmp
 i=0

@@ -25,7 +25,7 @@ def main():
     os.makedirs(dst, exist_ok=True)
     for name in ["bench_default.json", "bench_default_under_rocprof.log", "bench_c2.json",
                  "bench_c2_under_rocprof.log", "step_timeline.txt", "step_timeline_level_kernels.txt",
-                 "fused_tree_stamps.txt", "fused_tree_stamps_c2.txt", "ipm_iteration.txt", "ipm_kernels.txt",
+                 "fused_tree_stamps.txt", "fused_tree_stamps_c2.txt", "ipm_iteration.txt", "ipm_iteration_wall.txt", "ipm_kernels.txt",
                  "bench_driver_settings.json", "big_chol_stamps.txt"]:
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, name))
