@@ -1389,6 +1389,7 @@ int cxk_create(int num_vars, int device, void* stream, cxk_context** out) {
   ctx->device = device;
   ctx->stream = static_cast<hipStream_t>(stream);
   ctx->no_step_tail = getenv("CXK_NO_STEP_TAIL") != nullptr || getenv("CXK_PREPARE_LDS") != nullptr;
+  ctx->no_device_mu = getenv("CXK_NO_DEVICE_MU") != nullptr || getenv("CXK_TAKE_STEP_LDS") != nullptr;
   if (device >= 0) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -2782,8 +2783,7 @@ static int SlackEigenvaluesImpl(cxk_context* ctx, double c_weight, double* out, 
 // ---- the barrier parameter selected on the device: conex::Solve's iteration without the host round
 // trip between the eigenvalue query and the Newton direction (cone_program.cc:366-413).
 static bool DeviceMuOk(const cxk_context* ctx) {
-  static const bool off = getenv("CXK_NO_DEVICE_MU") != nullptr || getenv("CXK_TAKE_STEP_LDS") != nullptr;
-  if (off || !StepTailOk(ctx, 0) || !TakeStepFromDeviceOk(ctx)) return false;
+  if (ctx->no_device_mu || !StepTailOk(ctx, 0) || !TakeStepFromDeviceOk(ctx)) return false;
   // the Newton direction's right-hand side is formed inside the whole-tree solve launch
   return ctx->fused_tree && ctx->fused_sweep && ctx->world == 1 && ctx->solver_mode != 2 && ctx->refine_iters <= 0 &&
          !ctx->no_lean;

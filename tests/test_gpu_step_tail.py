@@ -200,3 +200,44 @@ def test_device_mu_is_not_offered_where_a_kernel_needs_the_value_from_the_host()
     p2 = syn.lmi_problem(K=12, n=12, m=6, branching=3, overlap=2, seed=4)   # order 12: the workgroup kernels
     k2 = syn.build(KktContext, p2, "lmi", device=0)
     assert k2.L.cxk_device_mu_supported(k2.h) == 0
+
+
+def test_conex_maximize_is_the_same_solve_with_mu_on_the_device_and_on_the_host(monkeypatch):
+    """CONEX_Maximize on a C4-shaped program three ways -- the one-round-trip iteration (default), the
+    host-side selection (CXK_NO_DEVICE_MU=1) and the separate reduction launches as well
+    (CXK_NO_STEP_TAIL=1): the same iterate, the same mu at every iteration, bit for bit."""
+    import ctypes as C
+    from conex_amd import capi as ca
+    prob = syn.lmi_problem(K=120, n=20, m=20, branching=4, overlap=5, seed=41)
+    L = ca.api()
+    b = np.ascontiguousarray(prob["b"], dtype=np.float64)
+
+    def solve():
+        p = L.CONEX_CreateConeProgram()
+        assert L.CONEX_SetNumberOfVariables(p, prob["num_vars"]) == 0
+        for c, cl in enumerate(prob["cliques"]):
+            a, cm = ca.colmajor(prob["A"][c]), ca.colmajor(prob["C"][c])
+            v = np.ascontiguousarray(cl, dtype=np.int64)
+            assert L.CONEX_AddSparseLMIConstraint(p, ca.dp(a), 20, 20, len(cl), ca.dp(cm), 20, 20,
+                                                  v.ctypes.data_as(C.POINTER(C.c_long)), len(cl)) == c
+        cfg = ca.default_config()
+        y = np.zeros(len(b))
+        ok = L.CONEX_Maximize(p, ca.dp(b), len(b), C.byref(cfg), ca.dp(y), len(b))
+        st = ca.IterationStats()
+        L.CONEX_GetIterationStats(p, C.byref(st), -1)
+        n_it = st.iteration_number + 1
+        mus = []
+        for i in range(n_it):
+            L.CONEX_GetIterationStats(p, C.byref(st), i)
+            mus.append(st.mu)
+        L.CONEX_DeleteConeProgram(p)
+        return ok, y, np.array(mus)
+
+    ok0, y0, mu0 = solve()
+    monkeypatch.setenv("CXK_NO_DEVICE_MU", "1")
+    ok1, y1, mu1 = solve()
+    monkeypatch.setenv("CXK_NO_STEP_TAIL", "1")
+    ok2, y2, mu2 = solve()
+    assert ok0 == ok1 == ok2 == 1 and len(mu0) > 5
+    assert np.array_equal(mu0, mu1) and np.array_equal(mu0, mu2)
+    assert np.array_equal(y0, y1) and np.array_equal(y0, y2)
