@@ -145,7 +145,9 @@ __global__ void __launch_bounds__(256) lmi_take_step_rows(LmiGroup g, StepArgs s
   __shared__ double sT[4][N * N];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mem = blockIdx.x * 4 + wave;
-  if (mem >= g.count || StepSkipped(sa)) return;  // wave-uniform; no workgroup barrier below
+  if (mem >= g.count) return;  // wave-uniform; no workgroup barrier below
+  // (asked for here, looked at in front of the store: the flags' round trip stays off the chain)
+  const int skip0 = sa.skip_if ? sa.skip_if[0] : 0, skip1 = sa.skip_if ? sa.skip_if[1] : 0;
   const int n = g.n, nn = n * n;
   double* Wg = g.W + (size_t)mem * nn;
   const double* T1 = g.T1 + (size_t)mem * nn;
@@ -192,7 +194,8 @@ __global__ void __launch_bounds__(256) lmi_take_step_rows(LmiGroup g, StepArgs s
       if (c < n) T[myk + c * n] = ew[c];
   }
   WaveSync();
-  if (row) {
+  const bool skipped = skip0 != 0 || (sa.skip_tag != 0 && skip1 == sa.skip_tag);  // StepSkipped
+  if (row && !skipped) {
 #pragma unroll
     for (int c = 0; c < N; c++)
       if (c < n) Wg[r + c * n] = (T[r + c * n] + T[c + r * n]) * 0.5;
