@@ -689,9 +689,6 @@ struct StepTail {
   MuRuleArgs rule;  // mode 1: the selection of inv_sqrt_mu on the device
 };
 typedef unsigned int TailU4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ double AgentLoad(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ void AgentStore(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
