@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(256) linear_line_search(VecGroup g, LineSearch
 // mode 0 PrepareStep, mode 1 GetWeightedSlackEigenvalues
 template <int MODE>
 __global__ void __launch_bounds__(256) linear_prepare(VecGroup g, StepArgs sa) {
+  sa.c_weight = CWeightOf(sa);  // (the barrier parameter may live on the device: cxk_select_mu_async)
   extern __shared__ double lds[];
   __shared__ double red[8];
   const int r = g.len, m = g.m;
@@ -220,6 +221,7 @@ __global__ void __launch_bounds__(256) linear_prepare(VecGroup g, StepArgs sa) {
 }
 
 __global__ void linear_take_step(VecGroup g, StepArgs sa) {
+  if (StepSkipped(sa)) return;  // (enqueued before the host saw the factorization fail: leave W alone)
   const size_t total = (size_t)g.count * g.len;
   for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < total;
        q += (size_t)gridDim.x * blockDim.x) {
@@ -357,6 +359,7 @@ __global__ void __launch_bounds__(256) soc_schur(VecGroup g, Arena ar) {
 
 template <int MODE>
 __global__ void __launch_bounds__(64) soc_prepare(VecGroup g, StepArgs sa) {
+  sa.c_weight = CWeightOf(sa);  // (the barrier parameter may live on the device: cxk_select_mu_async)
   extern __shared__ double lds[];
   const int len = g.len, n = len - 1, m = g.m;
   const int mem = blockIdx.x, id = g.ids[mem];
@@ -407,6 +410,7 @@ __global__ void __launch_bounds__(64) soc_prepare(VecGroup g, StepArgs sa) {
 }
 
 __global__ void __launch_bounds__(64) soc_take_step(VecGroup g, StepArgs sa) {
+  if (StepSkipped(sa)) return;  // (enqueued before the host saw the factorization fail: leave W alone)
   extern __shared__ double lds[];
   const int len = g.len, n = len - 1;
   const int mem = blockIdx.x;
@@ -592,7 +596,7 @@ __device__ __forceinline__ void ReduceStepFinish(int mode, double a, double b, d
       out[2] = A;
       out[3] = D;
       if (LOCAL) res[0] = B, res[1] = C, res[2] = A, res[3] = D;
-      if (LOCAL && rule && rule->on) {
+      if (rule && rule->on) {  // (not LOCAL: the mailbox reads it back from rule->out behind the fence below)
         cxk_mu::Wse e;
         e.lmin = B;
         e.lmax = C;
@@ -600,7 +604,7 @@ __device__ __forceinline__ void ReduceStepFinish(int mode, double a, double b, d
         e.trace = D;
         const double v = cxk_mu::NextInvSqrtMu(rule->u, e);
         rule->out[0] = v;
-        res[4] = v;
+        if (LOCAL) res[4] = v;
       }
     }
   }
@@ -627,7 +631,7 @@ __device__ __forceinline__ void ReduceStepFinish(int mode, double a, double b, d
 // mode 1: info4 -> {min lambda_min (init 30000), max lambda_max (init -30000), sum frob, sum trace}
 __global__ void __launch_bounds__(256)
 reduce_step_info(int K, int mode, const double* __restrict__ info, const unsigned char* __restrict__ mask,
-                 double* __restrict__ out, MailboxArgs mbx) {
+                 double* __restrict__ out, MailboxArgs mbx, MuRuleArgs rule) {
   double a = 0, b = (mode == 0) ? -1.0 : 30000.0, c = -30000.0, d = 0;
   // eight strided constraints per trip, loads issued together (a plain loop pays two dependent
   // round trips -- mask, values -- per element); accumulation order unchanged
@@ -663,7 +667,7 @@ reduce_step_info(int K, int mode, const double* __restrict__ info, const unsigne
       }
     }
   }
-  ReduceStepFinish(mode, a, b, c, d, out, mbx);
+  ReduceStepFinish(mode, a, b, c, d, out, mbx, nullptr, 0.0, &rule);
 }
 
 // ---------------------------------------------------------------------------------------------

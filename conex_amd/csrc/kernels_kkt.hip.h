@@ -122,8 +122,10 @@ __global__ void __launch_bounds__(256) assemble_gather(GatherArgs a) { GatherBod
 // (reset: when not null, the factorization-failure flag cleared here instead of by a memset launch)
 __global__ void build_rhs(int N, double k, double bs, double cs, const double* __restrict__ b,
                           const double* __restrict__ AQc, const double* __restrict__ AW,
-                          double* __restrict__ y, int* __restrict__ reset = nullptr) {
+                          double* __restrict__ y, int* __restrict__ reset = nullptr,
+                          const double* __restrict__ k_from = nullptr) {
   if (reset && blockIdx.x == 0 && threadIdx.x == 0) *reset = 0;
+  if (k_from) k = k_from[0];  // the barrier parameter the device selected (cxk_select_mu_async)
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < N; p += gridDim.x * blockDim.x)
     y[p] = k * (b[p] * bs + AQc[p] * cs) - 2 * AW[p];
 }
@@ -996,12 +998,13 @@ struct RhsIn {
   const double *b, *AQc, *AW;
   double k, bs, cs;    // form 1: k (b bs + AQc cs) - 2 AW   (cone_program.cc:409-411)
   double cb, cq, cw;   // form 2: cb b + cq AQc + cw AW      (cone_program.cc:181, 504)
-  const double* k_from;  // form 1 on the whole-tree launch only: k read from the device (FusedTreeArgs::k_from)
+  const double* k_from;  // form 1, not null: k = k_from[0], the barrier parameter the device selected
 };
 __device__ __forceinline__ double RhsValue(const RhsIn& ri, const double* __restrict__ rhs, int p) {
   if (ri.form == 0) return rhs[p];
   const double bp = ri.b[p], aq = ri.AQc[p], aw = ri.AW[p];
-  return ri.form == 1 ? ri.k * (bp * ri.bs + aq * ri.cs) - 2 * aw : ri.cb * bp + ri.cq * aq + ri.cw * aw;
+  const double kk = (ri.form == 1 && ri.k_from) ? ri.k_from[0] : ri.k;
+  return ri.form == 1 ? kk * (bp * ri.bs + aq * ri.cs) - 2 * aw : ri.cb * bp + ri.cq * aq + ri.cw * aw;
 }
 
 // ForwardSupernodeWave (b_j <- L_j^{-1} (b_j - pulled forward updates), publish t[c] = off[:,c].b)

@@ -335,6 +335,7 @@ __device__ __forceinline__ void LanczosWave0(int n, const double* sWS, const dou
 // lone wavefront issues one dependent instruction per ~8 cycles, instruction count is latency).
 template <int MODE, int NF = 0>
 __global__ void __launch_bounds__(256) lmi_prepare_generic(LmiGroup g, StepArgs sa) {
+  sa.c_weight = CWeightOf(sa);  // (the barrier parameter may live on the device: cxk_select_mu_async)
   extern __shared__ double lds[];
   const int n = NF > 0 ? NF : g.n, m = g.m, nn = n * n;
   double* sW = lds;
@@ -465,6 +466,7 @@ __global__ void __launch_bounds__(256) lmi_prepare_generic(LmiGroup g, StepArgs 
 // W <- sym( pade33( (WS + e I) * alpha ) * W )
 template <int NF = 0>
 __global__ void __launch_bounds__(256) lmi_take_step_generic(LmiGroup g, StepArgs sa) {
+  if (StepSkipped(sa)) return;  // (enqueued before the host saw the factorization fail: leave W alone)
   extern __shared__ double lds[];
   const int n = NF > 0 ? NF : g.n, nn = n * n;
   double* sW = lds;

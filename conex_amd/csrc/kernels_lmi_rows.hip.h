@@ -208,6 +208,7 @@ __global__ void __launch_bounds__(256) lmi_take_step_rows(LmiGroup g, StepArgs s
 // every product is the same fma chain as in lmi_take_step_generic's Hermitian branch.
 template <int N>
 __global__ void __launch_bounds__(256) lmi_take_step_rows_taylor(LmiGroup g, StepArgs sa) {
+  if (StepSkipped(sa)) return;  // (enqueued before the host saw the factorization fail: leave W alone)
   static_assert(N <= 32, "a column spans DPP rows 0 and 1");
   __shared__ double sT[4][N * N];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

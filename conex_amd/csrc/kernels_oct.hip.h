@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(64) oct_schur(OctGroup g, Arena ar) {
 // MODE 0: PrepareStep (:129-145); MODE 1: GetWeightedSlackEigenvalues (:147-168)
 template <int MODE>
 __global__ void __launch_bounds__(64) oct_prepare(OctGroup g, StepArgs sa) {
+  sa.c_weight = CWeightOf(sa);  // (the barrier parameter may live on the device: cxk_select_mu_async)
   extern __shared__ double sy[];  // m
   __shared__ double sW[kOctMax], sS[kOctMax], sQ[kOctMax], t1[kOctMax], t2[kOctMax], t3[kOctMax], ta[kOctMax],
       tb[kOctMax];
@@ -165,6 +166,7 @@ __global__ void __launch_bounds__(64) oct_prepare(OctGroup g, StepArgs sa) {
 
 // TakeStep (:116-127) with GeodesicUpdateScaled: W <- herm(c^2 W + 2 c k Q(W) s + k^2 Q(W) (Q(s) W)), c = 1.5, k = 0.5
 __global__ void __launch_bounds__(64) oct_take_step(OctGroup g, StepArgs sa) {
+  if (StepSkipped(sa)) return;  // (enqueued before the host saw the factorization fail: leave W alone)
   __shared__ double sW[kOctMax], sS[kOctMax], q1[kOctMax], q2[kOctMax], q3[kOctMax], t1[kOctMax], t2[kOctMax],
       t3[kOctMax], ta[kOctMax], tb[kOctMax];
   const int n = g.n, nn = n * n, sz = 8 * nn, mem = blockIdx.x;

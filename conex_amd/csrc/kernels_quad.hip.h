@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(64) quad_schur(QuadGroup g, Arena ar) {
 // MODE 0: PrepareStep :176-214; MODE 1: GetWeightedSlackEigenvalues :142-174
 template <int MODE>
 __global__ void __launch_bounds__(64) quad_prepare(QuadGroup g, StepArgs sa) {
+  sa.c_weight = CWeightOf(sa);  // (the barrier parameter may live on the device: cxk_select_mu_async)
   extern __shared__ double lds[];
   const int n = g.n, m = g.m, len = n + 1, mem = blockIdx.x, id = g.ids[mem];
   const double* A = g.A + (size_t)mem * len * m;
@@ -169,6 +170,7 @@ __global__ void __launch_bounds__(64) quad_prepare(QuadGroup g, StepArgs sa) {
 
 // TakeStep :221-243
 __global__ void __launch_bounds__(64) quad_take_step(QuadGroup g, StepArgs sa) {
+  if (StepSkipped(sa)) return;  // (enqueued before the host saw the factorization fail: leave W alone)
   extern __shared__ double lds[];
   const int n = g.n, len = n + 1, mem = blockIdx.x;
   const double* Q = g.Q ? g.Q + (size_t)mem * n * n : nullptr;

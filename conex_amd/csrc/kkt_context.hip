@@ -1389,7 +1389,7 @@ int cxk_create(int num_vars, int device, void* stream, cxk_context** out) {
   ctx->device = device;
   ctx->stream = static_cast<hipStream_t>(stream);
   ctx->no_step_tail = getenv("CXK_NO_STEP_TAIL") != nullptr || getenv("CXK_PREPARE_LDS") != nullptr;
-  ctx->no_device_mu = getenv("CXK_NO_DEVICE_MU") != nullptr || getenv("CXK_TAKE_STEP_LDS") != nullptr;
+  ctx->no_device_mu = getenv("CXK_NO_DEVICE_MU") != nullptr;
   if (device >= 0) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -2241,14 +2241,18 @@ bool TakeStepFromDeviceOk(const cxk_context* ctx) {
 // take_e_weight != nullptr (mode 0): TakeStep with the step length of cone_program.cc:417-418 taken
 // from the reduced norms ON THE DEVICE is enqueued before the host waits, *took reports it.
 int ReduceStepInfoAndSync(cxk_context* ctx, int mode, const double* info, const double* take_e_weight = nullptr,
-                          int* took = nullptr, bool tail_done = false, bool skip_on_fail = false, bool wait = true) {
+                          int* took = nullptr, bool tail_done = false, bool skip_on_fail = false, bool wait = true,
+                          const MuRuleArgs* rule = nullptr) {
   MailboxArgs m;
   m.mb = nullptr;
   const bool fold = ctx->world <= 1;
   if (fold && !tail_done && NextMailbox(ctx, &m)) return CXK_FAILURE;
   const long long want = ctx->seq;
   if (!tail_done) {  // (else the launch's tail workgroup has reduced and written the mailbox: StepTail)
-    reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), mode, info, ctx->d_mask.p, ctx->red_out.p, m);
+    MuRuleArgs r;
+    r.on = 0;
+    if (rule && mode == 1) r = *rule;  // (the selection of the barrier parameter rides in the reduction)
+    reduce_step_info<<<1, 256, 0, ctx->stream>>>((int)ctx->cons.size(), mode, info, ctx->d_mask.p, ctx->red_out.p, m, r);
     CXK_TRY(hipGetLastError());
   }
   if (fold && take_e_weight && TakeStepFromDeviceOk(ctx)) {
@@ -2448,7 +2452,7 @@ static int SolveWithRhs(cxk_context* ctx, const RhsIn& form) {
     ctx->rhs_in = form;
   } else if (form.form == 1) {
     build_rhs<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, form.k, form.bs, form.cs, ctx->b.p, ctx->AQc.p, ctx->AW.p,
-                                                        ctx->y.p);
+                                                        ctx->y.p, nullptr, form.k_from);
   } else {
     build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, form.cb, form.cq, form.cw, ctx->b.p, ctx->AQc.p,
                                                              ctx->AW.p, ctx->y.p);
@@ -2627,7 +2631,7 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
   const bool with_tail = StepTailOk(ctx, affine);
   if (FlushDeferred(ctx, with_tail)) return CXK_FAILURE;
   StepArgs sa = MakeStep(ctx, ctx->info2.p, affine, c_weight, e_weight, 1.0);
-  sa.cw_from = cw_from;  // (lmi_prepare_rows: the only kernel of a program that gets here with it, DeviceMuOk)
+  sa.cw_from = cw_from;  // (CWeightOf in every PrepareStep kernel)
   sa.cw_scale = cw_scale;
   StepTail tail;
   tail.slots = nullptr;
@@ -2689,7 +2693,7 @@ static int LaunchTakeStep(cxk_context* ctx, double e_weight, double step_size, c
                           bool skip_on_fail) {
   StepArgs sa = MakeStep(ctx, ctx->info2.p, 0, 0.0, e_weight, step_size);
   sa.step_from = step_from;
-  if (skip_on_fail) {  // (lmi_take_step_rows: the only kernel of a program that gets here, DeviceMuOk)
+  if (skip_on_fail) {  // (TakeStep enqueued before the host has seen the factorization's outcome)
     sa.skip_if = ctx->d_fail.p;
     sa.skip_tag = ctx->fail_tag;
   }
@@ -2742,7 +2746,6 @@ static int SlackEigenvaluesImpl(cxk_context* ctx, double c_weight, double* out, 
   CXK_ENTER(ctx);
   StepArgs sa = MakeStep(ctx, ctx->info4.p, 0, c_weight, 0.0, 1.0);
   const bool with_tail = StepTailOk(ctx, 0);
-  CXK_DEMAND(with_tail || !rule, "the barrier parameter is selected on the device only behind cxk_device_mu_supported");
   StepTail tail;
   tail.slots = nullptr;
   tail.rule.on = 0;
@@ -2774,7 +2777,8 @@ static int SlackEigenvaluesImpl(cxk_context* ctx, double c_weight, double* out, 
       oct_prepare<1><<<cnt, 64, sizeof(double) * (size_t)g.m, ctx->stream>>>(MakeOct(g), sa);
   }
   CXK_TRY(hipGetLastError());
-  if (ReduceStepInfoAndSync(ctx, 1, ctx->info4.p, nullptr, nullptr, with_tail, false, rule == nullptr)) return CXK_FAILURE;
+  if (ReduceStepInfoAndSync(ctx, 1, ctx->info4.p, nullptr, nullptr, with_tail, false, rule == nullptr, rule))
+    return CXK_FAILURE;
   if (out && !rule)
     for (int i = 0; i < 4; i++) out[i] = ctx->mbv[i];
   return CXK_SUCCESS;
@@ -2783,10 +2787,9 @@ static int SlackEigenvaluesImpl(cxk_context* ctx, double c_weight, double* out, 
 // ---- the barrier parameter selected on the device: conex::Solve's iteration without the host round
 // trip between the eigenvalue query and the Newton direction (cone_program.cc:366-413).
 static bool DeviceMuOk(const cxk_context* ctx) {
-  if (ctx->no_device_mu || !StepTailOk(ctx, 0) || !TakeStepFromDeviceOk(ctx)) return false;
-  // the Newton direction's right-hand side is formed inside the whole-tree solve launch
-  return ctx->fused_tree && ctx->fused_sweep && ctx->world == 1 && ctx->solver_mode != 2 && ctx->refine_iters <= 0 &&
-         !ctx->no_lean;
+  // one GPU, Cholesky on the device (the QR mode solves on the host), every TakeStep kernel able to
+  // take its step length from the device (TakeStepFromDeviceOk: no equality rows, no LMI beyond LDS)
+  return !ctx->no_device_mu && ctx->world <= 1 && ctx->solver_mode != 2 && TakeStepFromDeviceOk(ctx);
 }
 int cxk_device_mu_supported(cxk_context* ctx) {
   if (!ctx || CheckReady(ctx)) return 0;

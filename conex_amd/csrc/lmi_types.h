@@ -62,7 +62,7 @@ struct StepArgs {
   // so that TakeStep can be enqueued without a host round trip in between
   const double* step_from;
   // not null: c_weight = cw_from[0] * cw_scale, the barrier parameter the device selected
-  // (cxk_select_mu_async) times c_scaling (cone_program.cc:413), read by lmi_prepare_rows
+  // (cxk_select_mu_async) times c_scaling (cone_program.cc:413): CWeightOf, every PrepareStep kernel
   const double* cw_from;
   double cw_scale;
   // not null (TakeStep enqueued before the host has seen the factorization's outcome): leave W alone
@@ -78,6 +78,9 @@ struct StepArgs {
 #ifdef __HIPCC__
 __device__ __forceinline__ bool StepSkipped(const StepArgs& sa) {
   return sa.skip_if && (sa.skip_if[0] != 0 || (sa.skip_tag != 0 && sa.skip_if[1] == sa.skip_tag));
+}
+__device__ __forceinline__ double CWeightOf(const StepArgs& sa) {
+  return sa.cw_from ? sa.cw_from[0] * sa.cw_scale : sa.c_weight;
 }
 __device__ __forceinline__ double StepSizeOf(const StepArgs& sa) {
   if (!sa.step_from) return sa.step_size;

@@ -209,8 +209,11 @@ int cxk_weighted_slack_eigenvalues(cxk_context* ctx, double c_weight, double* ou
  * host learns it -- with the factorization flag, the step norms and the by / cx scalars -- from the
  * ONE mailbox at the end of the iteration.  TakeStep, enqueued before the host has seen the
  * factorization's outcome, leaves W alone when the factorization failed.
- * cxk_device_mu_supported: 1 when this program can run that way (one GPU, Cholesky, every
- * constraint on the register LMI kernels, the whole-tree solve launch), else 0. */
+ * cxk_device_mu_supported: 1 when this program can run that way -- one GPU, Cholesky on the device
+ * (not the QR mode, no equality rows), no LMI beyond LDS (its TakeStep takes the step length from the
+ * host) -- else 0.  Every cone type takes part: the selection rides in the tail workgroup of the
+ * eigenvalue query where all constraints run on the register LMI kernels, in its reduction launch
+ * otherwise. */
 int cxk_device_mu_supported(cxk_context* ctx);
 /* GetWeightedSlackEigenvalues(c_weight) on the device-resident y, then
  * inv_sqrt_mu <- limits(selection > 0 ? selection : prev / 2, lb, ub) on the device.  Does not wait. */

@@ -132,8 +132,8 @@ def test_mu_selected_on_the_device_is_the_host_rule_bit_for_bit(dub, prev, lb, u
     import ctypes as C
     K = 48
     prob = syn.lmi_problem(K=K, n=20, m=20, branching=4, overlap=5, seed=19)
-    a, b = _contexts(prob, monkeypatch)   # a: tail + device mu, b: separate launches, host rule
-    assert a.L.cxk_device_mu_supported(a.h) == 1 and b.L.cxk_device_mu_supported(b.h) == 0
+    a, b = _contexts(prob, monkeypatch)   # a: tail + device mu, b: separate launches, driven through the host rule
+    assert a.L.cxk_device_mu_supported(a.h) == 1
     W = syn.scaling_points(K, 20, seed=6)
     bs, cs, rankK = 0.9, 0.8, 20 * K
     for k in (a, b):
@@ -193,13 +193,70 @@ def test_take_step_behind_a_failed_factorization_leaves_w_alone(monkeypatch):
         assert np.array_equal(np.asarray(k.get_W(i)).ravel(), W[i].ravel())   # (symmetric: either layout)
 
 
-def test_device_mu_is_not_offered_where_a_kernel_needs_the_value_from_the_host():
+def _problem(kind):
+    if kind == "soc":
+        return syn.soc_problem(K=60, dim=6, m=5, overlap=2, tree=4), "soc", 120
+    if kind == "mixed":
+        return syn.mixed_problem(K=46, herm_every=(4, 7), branching=4, overlap=3), "mixed", 300
+    if kind == "lmi12":
+        return syn.lmi_problem(K=30, n=12, m=6, branching=3, overlap=2, seed=4), "lmi", 360
+    if kind == "lp":
+        return syn.lp_problem(rows=30, num_vars=8), "lp", 30
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["soc", "mixed", "lmi12", "lp"])
+def test_device_mu_on_every_cone_type_is_the_host_path_bit_for_bit(kind, monkeypatch):
+    """Programs whose constraints do not take the register LMI kernels have no tail workgroup, but the
+    selection still rides in the eigenvalue query's reduction launch, the right-hand side and every
+    PrepareStep kernel read inv_sqrt_mu from the device (CWeightOf) and TakeStep follows without the
+    host: two rounds (the second from the W the first produced) against the host-side sequence."""
+    import ctypes as C
     from conex_amd import KktContext
-    k = syn.build(KktContext, syn.soc_problem(K=10, dim=6, m=5, overlap=2), "soc", device=0)
+    prob, build_kind, rankK = _problem(kind)
+    a = syn.build(KktContext, prob, build_kind, device=0)
+    monkeypatch.setenv("CXK_NO_DEVICE_MU", "1")
+    b = syn.build(KktContext, prob, build_kind, device=0)
+    monkeypatch.delenv("CXK_NO_DEVICE_MU")
+    assert a.L.cxk_device_mu_supported(a.h) == 1 and b.L.cxk_device_mu_supported(b.h) == 0
+    cost = prob["b"]
+    bs, cs, prev = 0.9, 0.8, 0.0
+    for k in (a, b):
+        k.set_cost(cost)
+    for rnd in range(2):
+        for k in (a, b):
+            k.assemble()
+            k.factor_solve_async(-bs, cs, 0.0)
+        e4 = b.weighted_slack_eigenvalues(None, cs)
+        inv_host = _host_rule(1.0, rankK, e4, prev, 1e-8, 1e9)
+        b._check(b.L.cxk_newton_direction(b.h, inv_host, bs, cs), "cxk_newton_direction")
+        assert b.L.cxk_step_scalars_async(b.h) == 0
+        n2b, ninfb, tookb = b.prepare_take_step(None, inv_host * cs)
+        scb = b.step_scalars()
+        a._check(a.L.cxk_select_mu_async(a.h, cs, 1.0, rankK, prev, 1e-8, 1e9), "cxk_select_mu_async")
+        a._check(a.L.cxk_newton_direction_device_mu(a.h, bs, cs), "cxk_newton_direction_device_mu")
+        assert a.L.cxk_step_scalars_async(a.h) == 0
+        info, took, inv_dev = np.zeros(2), C.c_int(0), C.c_double(0)
+        a._check(a.L.cxk_prepare_take_step_device_mu(a.h, cs, 1.0, ol.dp(info), C.byref(took), C.byref(inv_dev)),
+                 "cxk_prepare_take_step_device_mu")
+        sca = a.step_scalars()
+        assert inv_dev.value == inv_host, (rnd, inv_dev.value, inv_host)
+        assert took.value == 1 and tookb
+        assert info[0] == n2b and info[1] == ninfb
+        assert np.array_equal(sca, scb)
+        assert np.array_equal(a.get_y(), b.get_y())
+        prev = inv_host
+    for i in range(len(a.cons)):
+        assert np.array_equal(np.asarray(a.get_W(i)), np.asarray(b.get_W(i)))
+
+
+def test_device_mu_is_not_offered_where_the_host_is_needed():
+    """An LMI beyond LDS takes its step length from the host (its exponential is a chain of GEMM
+    launches), equality rows are solved through the host-paced LDLT: the loop keeps the host round trip."""
+    from conex_amd import KktContext
+    big = syn.lmi_problem(K=1, n=80, m=6, branching=2, overlap=1, seed=2)
+    k = syn.build(KktContext, big, "lmi", device=0)
     assert k.L.cxk_device_mu_supported(k.h) == 0
-    p2 = syn.lmi_problem(K=12, n=12, m=6, branching=3, overlap=2, seed=4)   # order 12: the workgroup kernels
-    k2 = syn.build(KktContext, p2, "lmi", device=0)
-    assert k2.L.cxk_device_mu_supported(k2.h) == 0
 
 
 def test_conex_maximize_is_the_same_solve_with_mu_on_the_device_and_on_the_host(monkeypatch):
