@@ -39,15 +39,6 @@ inline bool LmiSparsePays(int n, int m, double nnz_a, bool lds_resident, bool fu
   return 0.5 * nnz_a * nnz_a * per_term <= dense;
 }
 
-__device__ __forceinline__ void PairFromIndex(long long t, int* i, int* j) {
-  // t = i (i + 1) / 2 + j, 0 <= j <= i
-  long long ii = (long long)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-  while (ii * (ii + 1) / 2 > t) ii--;
-  while ((ii + 1) * (ii + 2) / 2 <= t) ii++;
-  *i = (int)ii;
-  *j = (int)(t - ii * (ii + 1) / 2);
-}
-
 #ifdef CXK_DEBUG_STAMPS
 __device__ long long g_sparse_stamp[8];
 #define SPSTAMP(i) do { if (blockIdx.x == 500 && blockIdx.y == 0 && threadIdx.x == 0) g_sparse_stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -92,9 +83,33 @@ __global__ void __launch_bounds__(256) lmi_dense_c_scalars(LmiGroup g, const dou
 // every lane of the group receives the total.
 template <int LPP>
 __device__ __forceinline__ double GroupSum(double v) {
+  if constexpr (LPP == 4) {  // the same butterfly (xor 2, xor 1) on DPP quad permutations: no LDS crossbar
+    v += DppMove<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += DppMove<0xB1>(v);   // quad_perm [1,0,3,2]
+    return v;
+  } else if constexpr (LPP == 2) {
+    return v + DppMove<0xB1>(v);
+  } else {
 #pragma unroll
-  for (int d = LPP >> 1; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+    for (int d = LPP >> 1; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+  }
+}
+
+// x / d and x % d for small non-negative x (< 2^20) and d >= 1 without the integer-division sequence
+// (~40 instructions each, four per pair in the term walk below)
+__device__ __forceinline__ void DivModSmall(int x, int d, float rcp, int* q, int* r) {
+  int qq = (int)((float)x * rcp);
+  int rr = x - qq * d;
+  if (rr < 0) {
+    qq--;
+    rr += d;
+  } else if (rr >= d) {
+    qq++;
+    rr -= d;
+  }
+  *q = qq;
+  *r = rr;
 }
 
 // Sum of the ni x nj terms of one pair shared by LP consecutive lanes (lane `sub` of the group
@@ -106,8 +121,12 @@ __device__ __forceinline__ double PairSum(const int* erc, const double* eval, co
                                           int ni, int bj, int nj, int sub) {
   double s = 0;
   if (ni > 0 && nj > 0) {
-    int ei = bi + sub / nj, ej = bj + sub % nj;
-    const int di = LP / nj, dj = LP % nj, ei_end = bi + ni, ej_end = bj + nj;
+    const float rcp = 1.0f / (float)nj;
+    int q0, r0, di, dj;
+    DivModSmall(sub, nj, rcp, &q0, &r0);
+    DivModSmall(LP, nj, rcp, &di, &dj);
+    int ei = bi + q0, ej = bj + r0;
+    const int ei_end = bi + ni, ej_end = bj + nj;
     while (ei < ei_end) {
       int xi[4], xj[4];
       bool ok[4];
@@ -259,30 +278,23 @@ __global__ void __launch_bounds__(256) lmi_schur_sparse(LmiGroup g, Arena ar, Sp
     }
   }
   SPSTAMP(2);
-  // pair sums among the A_i: LPP lanes per pair, the pair range dealt to the chunks
+  // pair sums: LPP lanes per pair, the pair range dealt to the chunks; pair t -> (i, j) from the
+  // group's table.  Row m (a sparse C: at most 64 nonzeros) rides in the same loop:
+  // AQc(j) = G(C, A_j), <c,Qc> = G(C, C).
   double* G = ar.G + ar.g_off[id];
   {
-    const long long pairs = (long long)m * (m + 1) / 2;
+    const long long pairs = cdense ? (long long)m * (m + 1) / 2 : (long long)m1 * (m1 + 1) / 2;
     const long long per = (pairs + gridDim.y - 1) / gridDim.y;
     const long long t0 = per * blockIdx.y, t1 = (t0 + per < pairs) ? t0 + per : pairs;
     const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP, ngrp = blockDim.x / LPP;
     for (long long t = t0 + grp; t < t1; t += ngrp) {
-      int i, j;
-      PairFromIndex(t, &i, &j);
+      const int ij = g.sp_pairs[t], i = ij & 0xffff, j = ij >> 16;
       const int bi = s_ptr[i], bj = s_ptr[j];
       const double s = PairSum<LPP>(erc, eval, W, n, bi, s_ptr[i + 1] - bi, bj, s_ptr[j + 1] - bj, sub);
-      if (sub == 0) G[i + (size_t)j * m] = s * osc;
-    }
-  }
-  // row m (a sparse C, at most 64 nonzeros): AQc(j) = G(C, A_j), <c,Qc> = G(C, C) -- the longest
-  // lists of the constraint, a wavefront per pair
-  if (!cdense) {
-    const int bc = s_ptr[m], nc = s_ptr[m1] - bc;
-    for (int j = blockIdx.y * nwaves + wave; j <= m; j += gridDim.y * nwaves) {
-      const int bj = s_ptr[j];
-      const double s = PairSum<64>(erc, eval, W, n, bc, nc, bj, s_ptr[j + 1] - bj, lane);
-      if (lane == 0) {
-        if (j < m)
+      if (sub == 0) {
+        if (i < m)
+          G[i + (size_t)j * m] = s * osc;
+        else if (j < m)
           ar.AQcc[ar.r_off[id] + j] = s * osc;
         else
           ar.sc[2 * id + 1] = s * osc;

@@ -78,6 +78,7 @@ LmiGroup MakeLmi(Group& g) {
   d.herm_d = g.herm_d;
   d.sp_eptr = g.sparse ? g.sp_eptr.p : nullptr;
   d.sp_erc = g.sparse ? g.sp_erc.p : nullptr;
+  d.sp_pairs = g.sparse ? g.sp_pairs.p : nullptr;
   d.sp_eval = g.sparse ? g.sp_eval.p : nullptr;
   d.sp_pptr = g.sparse ? g.sp_pptr.p : nullptr;
   d.sp_pvar = g.sparse ? g.sp_pvar.p : nullptr;
@@ -335,6 +336,13 @@ int UploadSparseLmi(cxk_context* ctx, Group& g) {
   int chunks = (int)std::ceil(pairs / per_block);
   const int cap = (int)std::max<size_t>(1, 2048 / std::max<size_t>(cnt, 1));
   g.sp_chunks = std::max(1, std::min(chunks, cap));
+  {
+    std::vector<int> pr;
+    pr.reserve((size_t)m1 * (m1 + 1) / 2);
+    for (int i = 0; i < m1; i++)
+      for (int j = 0; j <= i; j++) pr.push_back(i | (j << 16));
+    CXK_TRY(g.sp_pairs.upload(pr));
+  }
   CXK_TRY(g.sp_eptr.upload(eptr));
   CXK_TRY(g.sp_erc.upload(erc));
   CXK_TRY(g.sp_eval.upload(eval));

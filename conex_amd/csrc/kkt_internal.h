@@ -111,7 +111,7 @@ struct Group {
   int sp_chunks = 1, sp_emax = 0;  // sp_emax: most nonzeros in one constraint
   bool sp_cdense = false;          // dense affine term: X = W C W instead of pair sums with C
   bool sp_small = false;           // W (and X) of a constraint fit in LDS
-  DevBuf<int> sp_eptr, sp_erc, sp_pptr, sp_pvar;
+  DevBuf<int> sp_eptr, sp_erc, sp_pptr, sp_pvar, sp_pairs;
   DevBuf<double> sp_eval, sp_pval;
 };
 

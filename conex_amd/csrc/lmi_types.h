@@ -33,6 +33,7 @@ struct LmiGroup {
   // [sp_pptr[mem*n*n+q], ...), variable index ascending.  All null for dense groups.
   const int* sp_eptr;
   const int* sp_erc;
+  const int* sp_pairs;  // pair number t = i (i + 1) / 2 + j -> i | j << 16, 0 <= j <= i <= m (row m: the list of C)
   const double* sp_eval;
   const int* sp_pptr;
   const int* sp_pvar;

@@ -16,7 +16,14 @@ if "--timers" in sys.argv:
 from conex_amd import capi as ca
 from conex_amd import synthetic as syn
 
-prob = syn.lmi_problem(K=1000, n=20, m=20, branching=8, overlap=5)
+def _opt(name, default):
+    return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default
+
+
+# --K / --n / --m: another shape of the same chordal program (orders other than 20 take the
+# workgroup LMI kernels: no tail workgroup, the selection of mu rides in the reduction launch)
+prob = syn.lmi_problem(K=_opt("--K", 1000), n=_opt("--n", 20), m=_opt("--m", 20), branching=8,
+                       overlap=min(5, _opt("--m", 20) - 1))
 L = ca.api()
 n = prob["n"]
 
