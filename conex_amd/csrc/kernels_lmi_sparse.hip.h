@@ -96,74 +96,54 @@ __device__ __forceinline__ double GroupSum(double v) {
   }
 }
 
-// x / d and x % d for small non-negative x (< 2^20) and d >= 1 without the integer-division sequence
-// (~40 instructions each, four per pair in the term walk below)
-__device__ __forceinline__ void DivModSmall(int x, int d, float rcp, int* q, int* r) {
-  int qq = (int)((float)x * rcp);
-  int rr = x - qq * d;
-  if (rr < 0) {
-    qq--;
-    rr += d;
-  } else if (rr >= d) {
-    qq++;
-    rr -= d;
-  }
-  *q = qq;
-  *r = rr;
-}
-
-// Sum of the ni x nj terms of one pair shared by LP consecutive lanes (lane `sub` of the group
-// takes terms sub, sub + LP, ...; q = (ei - bi) nj + (ej - bj)), four terms in flight per lane: a
-// term is two dependent hops (the entries, then the W elements they name).  Every lane of the
-// group returns the total (fixed order: bit-reproducible).
+// Sum of the ni x nj terms  a b W[c,p] W[q,r]  of one pair ((r,c,a) from the first list, (p,q,b)
+// from the second) shared by LP consecutive lanes.  The longer list goes across the lanes (lane
+// `sub` takes its entries sub, sub + LP, ..), every lane walks the whole shorter list, four entries
+// at a time: the lane's own entry fixes a column and a row of W (two base addresses), a term is
+// then one packed index, one value, two W elements and three multiply-adds -- ~13 instructions
+// where a term-by-term walk over the ni x nj rectangle took ~30 (the kernel is bound by instruction
+// issue at the sparse-C4 shape: DESIGN 4.8).  sum_i a_i (sum_j b_j w w): fixed order, bit-reproducible;
+// every lane of the group returns the total.
 template <int LP>
 __device__ __forceinline__ double PairSum(const int* erc, const double* eval, const double* W, int n, int bi,
                                           int ni, int bj, int nj, int sub) {
+  if (nj > ni) {  // (uniform over the group)
+    int t = bi;
+    bi = bj;
+    bj = t;
+    t = ni;
+    ni = nj;
+    nj = t;
+  }
   double s = 0;
-  if (ni > 0 && nj > 0) {
-    const float rcp = 1.0f / (float)nj;
-    int q0, r0, di, dj;
-    DivModSmall(sub, nj, rcp, &q0, &r0);
-    DivModSmall(LP, nj, rcp, &di, &dj);
-    int ei = bi + q0, ej = bj + r0;
-    const int ei_end = bi + ni, ej_end = bj + nj;
-    while (ei < ei_end) {
-      int xi[4], xj[4];
-      bool ok[4];
+  for (int ei = sub; ei < ni; ei += LP) {
+    const int rc = erc[bi + ei], r = rc & 0xffff, c = rc >> 16;
+    const double a = eval[bi + ei];
+    const double* Wc = W + c;              // W[c + p n]
+    const double* Wr = W + (size_t)r * n;  // W[q + r n]
+    double t = 0;
+    int ej = 0;
+    for (; ej + 4 <= nj; ej += 4) {
+      int pq[4];
+      double b[4], w0[4], w1[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        ok[u] = ei < ei_end;
-        xi[u] = ok[u] ? ei : bi;
-        xj[u] = ok[u] ? ej : bj;
-        ei += di;
-        ej += dj;
-        if (ej >= ej_end) {
-          ej -= nj;
-          ei++;
-        }
-      }
-      int rc[4], pq[4];
-      double a[4], b[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        rc[u] = erc[xi[u]];
-        pq[u] = erc[xj[u]];
-        a[u] = eval[xi[u]];
-        b[u] = eval[xj[u]];
-      }
-      double w0[4], w1[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int r = rc[u] & 0xffff, c = rc[u] >> 16, p = pq[u] & 0xffff, qq = pq[u] >> 16;
-        w0[u] = W[c + (size_t)p * n];
-        w1[u] = W[qq + (size_t)r * n];
+        pq[u] = erc[bj + ej + u];
+        b[u] = eval[bj + ej + u];
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const double term = (a[u] * b[u]) * (w0[u] * w1[u]);
-        s += ok[u] ? term : 0.0;
+        w0[u] = Wc[(size_t)(pq[u] & 0xffff) * n];
+        w1[u] = Wr[pq[u] >> 16];
       }
+#pragma unroll
+      for (int u = 0; u < 4; u++) t = fma(b[u], w0[u] * w1[u], t);
     }
+    for (; ej < nj; ej++) {
+      const int pq = erc[bj + ej];
+      t = fma(eval[bj + ej], Wc[(size_t)(pq & 0xffff) * n] * Wr[pq >> 16], t);
+    }
+    s = fma(a, t, s);
   }
   return GroupSum<LP>(s);
 }
@@ -287,8 +267,11 @@ __global__ void __launch_bounds__(256) lmi_schur_sparse(LmiGroup g, Arena ar, Sp
     const long long per = (pairs + gridDim.y - 1) / gridDim.y;
     const long long t0 = per * blockIdx.y, t1 = (t0 + per < pairs) ? t0 + per : pairs;
     const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP, ngrp = blockDim.x / LPP;
-    for (long long t = t0 + grp; t < t1; t += ngrp) {
-      const int ij = g.sp_pairs[t], i = ij & 0xffff, j = ij >> 16;
+    long long t = t0 + grp;
+    int ij_next = t < t1 ? g.sp_pairs[t] : 0;
+    for (; t < t1; t += ngrp) {
+      const int ij = ij_next, i = ij & 0xffff, j = ij >> 16;
+      ij_next = t + ngrp < t1 ? g.sp_pairs[t + ngrp] : 0;  // (asked for a pass ahead: off the chain)
       const int bi = s_ptr[i], bj = s_ptr[j];
       const double s = PairSum<LPP>(erc, eval, W, n, bi, s_ptr[i + 1] - bi, bj, s_ptr[j + 1] - bj, sub);
       if (sub == 0) {
