@@ -2805,7 +2805,7 @@ int cxk_device_mu_supported(cxk_context* ctx) {
 }
 int cxk_select_mu_async(cxk_context* ctx, double c_weight, double divergence_upper_bound, int rank, double prev,
                         double lb, double ub) {
-  if (!ctx || CheckReady(ctx)) return CXK_FAILURE;
+  CXK_ENTER_KEEP(ctx);  // (binds the context's device for the allocation below; the query itself enters again)
   CXK_DEMAND(DeviceMuOk(ctx), "cxk_select_mu_async: not supported by this program (cxk_device_mu_supported)");
   if (ctx->mu_dev.n != 1) CXK_TRY(ctx->mu_dev.alloc(1, true));
   MuRuleArgs r;
