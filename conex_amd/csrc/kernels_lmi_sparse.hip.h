@@ -119,8 +119,8 @@ __device__ __forceinline__ double PairSum(const int* erc, const double* eval, co
   for (int ei = sub; ei < ni; ei += LP) {
     const int rc = erc[bi + ei], r = rc & 0xffff, c = rc >> 16;
     const double a = eval[bi + ei];
-    const double* Wc = W + c;              // W[c + p n]
-    const double* Wr = W + (size_t)r * n;  // W[q + r n]
+    const double* Wc = W + c;                           // W[c + p n]
+    const double* Wr = W + __umul24((unsigned)r, (unsigned)n);  // W[q + r n]  (orders < 2^12: 24-bit products, full rate)
     double t = 0;
     int ej = 0;
     for (; ej + 4 <= nj; ej += 4) {
@@ -133,7 +133,7 @@ __device__ __forceinline__ double PairSum(const int* erc, const double* eval, co
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        w0[u] = Wc[(size_t)(pq[u] & 0xffff) * n];
+        w0[u] = Wc[__umul24((unsigned)(pq[u] & 0xffff), (unsigned)n)];
         w1[u] = Wr[pq[u] >> 16];
       }
 #pragma unroll
@@ -141,7 +141,7 @@ __device__ __forceinline__ double PairSum(const int* erc, const double* eval, co
     }
     for (; ej < nj; ej++) {
       const int pq = erc[bj + ej];
-      t = fma(eval[bj + ej], Wc[(size_t)(pq & 0xffff) * n] * Wr[pq >> 16], t);
+      t = fma(eval[bj + ej], Wc[__umul24((unsigned)(pq & 0xffff), (unsigned)n)] * Wr[pq >> 16], t);
     }
     s = fma(a, t, s);
   }
