@@ -284,8 +284,9 @@ __device__ __forceinline__ double LanczosMatVec(const double (&row)[NR], double 
 // AsymmetricLanczos (approximate_eigenvalues.cc:178-239) as in LanczosWave0, non-Hermitian rules.
 template <int N>
 __device__ __forceinline__ void LanczosRows(const double (&ws)[N], const double (&wst)[N], const double (&w)[N],
-                                            double rvec, int lane, int num_iter, double* ab, double* out) {
-  const bool act = lane < N;
+                                            double rvec, int lane, int num_iter, double* ab, double* out,
+                                            int n = N) {
+  const bool act = lane < n;
   double* alpha = ab;
   double* beta = ab + num_iter + 1;
   // V.col(1) = r ; V.col(0) = W r
@@ -326,7 +327,11 @@ __device__ __forceinline__ void LanczosRows(const double (&ws)[N], const double 
   TridiagMinMaxWave<N / 2 + 1>(cnt + 1, alpha, beta, &out[0], &out[1]);  // (at most num_iter = N / 2 steps)
 }
 
-template <int MODE, int N>
+// EXACT: the order is N (compile-time strides, the packed slack path).  Otherwise any EVEN order
+// n <= N at run time: the same code with the matrices n apart and the lanes / columns beyond n
+// holding zeros (an fma with a zero factor leaves a sum as it is: the same bits as the workgroup
+// kernel, which sums over n terms only).
+template <int MODE, int N, bool EXACT>
 __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa, StepTail tail) {
   static_assert(N > 16 && N <= 32 && (N * N) % 2 == 0, "two DPP rows; 16-byte chunks");
   constexpr int NN = N * N, HALF = NN / 2, CH = (HALF + 63) / 64, ITERS = N / 2;
@@ -342,13 +347,14 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
   const int mem = blockIdx.x * 4 + wave;
   if (mem >= g.count) return;  // wave-uniform; no workgroup barrier below
   const int id = g.ids[mem], m = g.m;
+  const int n = EXACT ? N : g.n, nn = n * n, half = nn / 2;
   const double c_weight = sa.cw_from ? sa.cw_from[0] * sa.cw_scale : sa.c_weight;
-  const double* Cm = g.C + (size_t)mem * NN;
-  const double* Wg = g.W + (size_t)mem * NN;
+  const double* Cm = g.C + (size_t)mem * nn;
+  const double* Wg = g.W + (size_t)mem * nn;
   double* M = sM[wave];
   // minus_s = sum_i y_i A_i - k C (dense_lmi_constraint.cc:8-27)
   const double yv = lane < m ? sa.y[sa.cl_perm[sa.cl_ptr[id] + lane]] : 0.0;
-  if (g.Apk) {
+  if (EXACT && g.Apk) {
     // from the packed lower triangles (exactly symmetric data: the mirrored entry is the same sum of
     // the same terms): 105 16-byte chunks per matrix instead of 200, lane l owns chunks l and l + 64,
     // twenty matrices per batch -- the whole constraint behind ONE round trip at m <= 20
@@ -414,14 +420,14 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
   constexpr int BATCH = 10;
   int eo[CH];
 #pragma unroll
-  for (int u = 0; u < CH; u++) eo[u] = lane + 64 * u < HALF ? lane + 64 * u : HALF - 1;
+  for (int u = 0; u < CH; u++) eo[u] = lane + 64 * u < half ? lane + 64 * u : half - 1;
   for (int i0 = 0; i0 < m; i0 += BATCH) {
     double2 v[BATCH][CH];
 #pragma unroll
     for (int b = 0; b < BATCH; b++) {
       const int i = i0 + b < m ? i0 + b : m - 1;
 #pragma unroll
-      for (int u = 0; u < CH; u++) v[b][u] = base[(size_t)i * HALF + eo[u]];
+      for (int u = 0; u < CH; u++) v[b][u] = base[(size_t)i * half + eo[u]];
     }
 #pragma unroll
     for (int b = 0; b < BATCH; b++) {
@@ -438,34 +444,37 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
 #pragma unroll
   for (int u = 0; u < CH; u++) {
     const int e = lane + 64 * u;
-    if (e < HALF) {
+    if (e < half) {
       M[2 * e] = acc[u].x - c_weight * Cm[2 * e];
       M[2 * e + 1] = acc[u].y - c_weight * Cm[2 * e + 1];
     }
   }
   }
   WaveSync();
-  const bool row = lane < N;
+  const bool row = lane < n;
   const int r = row ? lane : 0;
   double s[N], w[N], ws[N], wst[N];
 #pragma unroll
   for (int c = 0; c < N; c++) {
-    s[c] = row ? M[r + c * N] : 0.0;   // lane k: row k of minus_s
-    w[c] = row ? Wg[r + c * N] : 0.0;  // lane i: row i of W
+    const bool in = row && (EXACT || c < n);
+    const int at = in ? r + c * n : 0;
+    s[c] = in ? M[at] : 0.0;   // lane k: row k of minus_s
+    w[c] = in ? Wg[at] : 0.0;  // lane i: row i of W
   }
   RowTimesMatrix<N, 0>::run(w, s, ws);  // WS = W * minus_s, row per lane
   WaveSync();
   if (row) {
-    double* T1 = g.T1 + (size_t)mem * NN;
+    double* T1 = g.T1 + (size_t)mem * nn;
 #pragma unroll
-    for (int c = 0; c < N; c++) {
-      M[r + c * N] = ws[c];
-      if (MODE == 0) T1[r + c * N] = ws[c];
-    }
+    for (int c = 0; c < N; c++)
+      if (EXACT || c < n) {
+        M[r + c * n] = ws[c];
+        if (MODE == 0) T1[r + c * n] = ws[c];
+      }
   }
   WaveSync();
 #pragma unroll
-  for (int c = 0; c < N; c++) wst[c] = row ? M[c + r * N] : 0.0;  // row of WS^T
+  for (int c = 0; c < N; c++) wst[c] = (row && (EXACT || c < n)) ? M[c + r * n] : 0.0;  // row of WS^T
   // index of the first maximal diagonal entry of WS
   double dval = 0.0;
 #pragma unroll
@@ -477,7 +486,7 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
   double rvec = 0.0;
 #pragma unroll
   for (int c = 0; c < N; c++) rvec = (c == index) ? (MODE == 0 ? ws[c] : s[c]) : rvec;
-  LanczosRows<N>(ws, wst, w, rvec, lane, ITERS, sAB[wave], sOut[wave]);
+  LanczosRows<N>(ws, wst, w, rvec, lane, EXACT ? ITERS : n / 2, sAB[wave], sOut[wave], n);
   // tr(WS WS) and tr(WS) with the workgroup kernel's partition: virtual thread t = 64 v + lane
   // takes elements t and t + 256, the four wave sums are added in order
   double t2 = 0.0, t1 = 0.0;
@@ -487,9 +496,23 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const int q = 64 * v + lane + 256 * k;
-      if (q < NN) {
-        const int a = q % N, b = q / N;
-        p2 = fma(M[q], M[b + a * N], p2);
+      if (q < nn) {
+        int a, b;
+        if (EXACT) {
+          a = q % N;
+          b = q / N;
+        } else {  // (q < 1024, n <= 32: exact in single precision after one correction)
+          b = (int)(((float)q + 0.5f) * (1.0f / (float)n));
+          a = q - b * n;
+          if (a < 0) {
+            a += n;
+            b--;
+          } else if (a >= n) {
+            a -= n;
+            b++;
+          }
+        }
+        p2 = fma(M[q], M[b + a * n], p2);
         if (a == b) p1 += M[q];
       }
     }
@@ -499,10 +522,10 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
   WaveSync();
   if (lane == 0) {
     double mn = sOut[wave][0], mx = sOut[wave][1];
-    if (!sa.no_clamp) ClampToSpectrumBound(N, t1, t2, &mn, &mx);
+    if (!sa.no_clamp) ClampToSpectrumBound(n, t1, t2, &mn, &mx);
     if (MODE == 0) {
       const double l1 = fabs(sa.e_weight + mn), l2 = fabs(sa.e_weight + mx);
-      const double v0 = t2 + 2 * t1 + N, v1 = l1 < l2 ? l2 : l1;
+      const double v0 = t2 + 2 * t1 + n, v1 = l1 < l2 ? l2 : l1;
       sa.info[2 * id] = v0;
       sa.info[2 * id + 1] = v1;
       if (tail.slots) {
@@ -524,8 +547,10 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
   }
 }
 
+// order 20 exactly, or any even order below it on the same instance (odd orders would leave the
+// 16-byte chunks of a constraint's matrices misaligned)
 inline bool LmiPrepareRowsSupports(int n, int m, int herm_d, bool sparse) {
-  return n == 20 && m <= 64 && herm_d == 0 && !sparse;
+  return n >= 4 && n <= 20 && n % 2 == 0 && m <= 64 && herm_d == 0 && !sparse;
 }
 
 inline bool LmiTakeStepRowsSupports(int n) { return n <= 32; }

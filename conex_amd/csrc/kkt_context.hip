@@ -1396,7 +1396,8 @@ int cxk_create(int num_vars, int device, void* stream, cxk_context** out) {
   ctx->num_vars = num_vars;
   ctx->device = device;
   ctx->stream = static_cast<hipStream_t>(stream);
-  ctx->no_step_tail = getenv("CXK_NO_STEP_TAIL") != nullptr || getenv("CXK_PREPARE_LDS") != nullptr;
+  ctx->prepare_lds = getenv("CXK_PREPARE_LDS") != nullptr;
+  ctx->no_step_tail = getenv("CXK_NO_STEP_TAIL") != nullptr || ctx->prepare_lds;
   ctx->no_device_mu = getenv("CXK_NO_DEVICE_MU") != nullptr;
   if (device >= 0) {
     int count = 0;
@@ -1896,7 +1897,7 @@ static int FinalizeImpl(cxk_context* ctx) {
       }
       CXK_TRY(g.Aleft.upload(hl));
     }
-    if (g.type == CXK_LMI && !g.literal && !getenv("CXK_NO_PACKED_SLACK") &&
+    if (g.type == CXK_LMI && !g.literal && !getenv("CXK_NO_PACKED_SLACK") && g.n == 20 &&
         LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse)) {
       // the slack pass of PrepareStep / the eigenvalue query streams every A_i once more per call: a
       // packed copy of the lower triangles (the data is exactly symmetric) halves those bytes
@@ -2651,9 +2652,14 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
     if (g.type == CXK_LMI && g.large)
       CXK_TRY(LmiLargePrepare(MakeLmi(g), sa, MakeLargeWs(g), 0, ctx->stream));
     else if (g.type == CXK_LMI) {
-      static const bool lds_kernel = getenv("CXK_PREPARE_LDS") != nullptr;  // A/B switch (tests, timing)
+      const bool lds_kernel = ctx->prepare_lds;  // A/B switch (tests, timing): CXK_PREPARE_LDS at cxk_create
       if (!affine && !lds_kernel && !g.literal && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse))
-        lmi_prepare_rows<0, 20><<<(cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, 0, ctx->stream>>>(MakeLmi(g), sa, tail);
+      {
+        if (g.n == 20)
+          lmi_prepare_rows<0, 20, true><<<(cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, 0, ctx->stream>>>(MakeLmi(g), sa, tail);
+        else  // (an even order below 20 on the same instance)
+          lmi_prepare_rows<0, 20, false><<<(cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, 0, ctx->stream>>>(MakeLmi(g), sa, tail);
+      }
       else if (g.n == 20)
         lmi_prepare_generic<0, 20><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
       else
@@ -2766,9 +2772,14 @@ static int SlackEigenvaluesImpl(cxk_context* ctx, double c_weight, double* out, 
     if (g.type == CXK_LMI && g.large)
       CXK_TRY(LmiLargePrepare(MakeLmi(g), sa, MakeLargeWs(g), 1, ctx->stream));
     else if (g.type == CXK_LMI) {
-      static const bool lds_kernel = getenv("CXK_PREPARE_LDS") != nullptr;
+      const bool lds_kernel = ctx->prepare_lds;
       if (!lds_kernel && !g.literal && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse))
-        lmi_prepare_rows<1, 20><<<(cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, 0, ctx->stream>>>(MakeLmi(g), sa, tail);
+      {
+        if (g.n == 20)
+          lmi_prepare_rows<1, 20, true><<<(cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, 0, ctx->stream>>>(MakeLmi(g), sa, tail);
+        else  // (an even order below 20 on the same instance)
+          lmi_prepare_rows<1, 20, false><<<(cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, 0, ctx->stream>>>(MakeLmi(g), sa, tail);
+      }
       else if (g.n == 20)
         lmi_prepare_generic<1, 20><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
       else

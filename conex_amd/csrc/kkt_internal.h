@@ -323,6 +323,7 @@ struct cxk_context {
   bool scal_deferred = false;
   bool no_step_tail = false;  // CXK_NO_STEP_TAIL / CXK_PREPARE_LDS in the environment at cxk_create
   bool no_device_mu = false;  // CXK_NO_DEVICE_MU likewise
+  bool prepare_lds = false;   // CXK_PREPARE_LDS likewise: the workgroup PrepareStep kernels instead of the register ones
   DevBuf<double> tail_slots;  // two sets of 4 per constraint, armed with kTailSentinel, used in turn
   int tail_parity = 0;
   DevBuf<double> mu_dev;      // [1] inv_sqrt_mu as selected on the device (cxk_select_mu_async)

@@ -298,3 +298,38 @@ def test_conex_maximize_is_the_same_solve_with_mu_on_the_device_and_on_the_host(
     assert ok0 == ok1 == ok2 == 1 and len(mu0) > 5
     assert np.array_equal(mu0, mu1) and np.array_equal(mu0, mu2)
     assert np.array_equal(y0, y1) and np.array_equal(y0, y2)
+
+
+@pytest.mark.parametrize("n,m", [(4, 3), (8, 8), (12, 12), (16, 20), (18, 9), (20, 20)])
+def test_register_prepare_kernels_at_even_orders_up_to_20_match_the_workgroup_kernels_bit_for_bit(n, m, monkeypatch):
+    """lmi_prepare_rows<.., 20, EXACT = false> takes any even order n <= 20 at run time (matrices n apart,
+    lanes and columns beyond n holding zeros): PrepareStep, the eigenvalue query and the W that
+    TakeStep then produces must equal the workgroup kernels' (CXK_PREPARE_LDS=1 at context creation)
+    bit for bit -- zero factors leave every sum as it is -- and the oracle's to rounding."""
+    from conex_amd import KktContext
+    K = 24
+    prob = syn.lmi_problem(K=K, n=n, m=m, branching=3, overlap=min(2, m - 1), seed=100 + n)
+    a = syn.build(KktContext, prob, "lmi", device=0)
+    monkeypatch.setenv("CXK_PREPARE_LDS", "1")
+    b = syn.build(KktContext, prob, "lmi", device=0)
+    monkeypatch.delenv("CXK_PREPARE_LDS")
+    o = syn.build(ol.Program, prob, "lmi")
+    W = syn.scaling_points(K, n, seed=11)
+    for p in (a, b, o):
+        for i in range(K):
+            p.set_W(i, W[i])
+    oko, yo = o.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    assert oko == 1
+    for it in range(2):
+        ea, eb = a.weighted_slack_eigenvalues(yo, 0.8), b.weighted_slack_eigenvalues(yo, 0.8)
+        assert np.array_equal(ea, eb), (it, ea, eb)
+        assert np.allclose(ea, o.weighted_slack_eigenvalues(yo, 0.8), rtol=1e-8, atol=1e-10)
+        ia, ib = a.prepare_step(yo, 0.8, 1.0), b.prepare_step(yo, 0.8, 1.0)
+        assert np.array_equal(ia, ib), (it, ia, ib)
+        assert np.allclose(ia, o.prepare_step(yo, 0.8, 1.0), rtol=1e-8)
+        step = min(1.0, 2.0 / ia[1] ** 2)
+        for p in (a, b, o):
+            p.take_step(step, 1.0)
+        for i in (0, K - 1):
+            assert np.array_equal(np.asarray(a.get_W(i)), np.asarray(b.get_W(i)))
+            assert np.allclose(np.asarray(a.get_W(i)).ravel(), np.asarray(o.get_W(i)).ravel(), rtol=1e-8, atol=1e-10)
