@@ -327,7 +327,7 @@ __device__ __forceinline__ void LanczosRows(const double (&ws)[N], const double 
   TridiagMinMaxWave<N / 2 + 1>(cnt + 1, alpha, beta, &out[0], &out[1]);  // (at most num_iter = N / 2 steps)
 }
 
-// EXACT: the order is N (compile-time strides, the packed slack path).  Otherwise any EVEN order
+// EXACT: the order is N (compile-time strides, the packed slack path).  Otherwise any order
 // n <= N at run time: the same code with the matrices n apart and the lanes / columns beyond n
 // holding zeros (an fma with a zero factor leaves a sum as it is: the same bits as the workgroup
 // kernel, which sums over n terms only).
@@ -405,6 +405,40 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
           if (r != c) M[c + r * N] = a - c_weight * Cm[c + r * N];
         }
       }
+    }
+  } else if (!EXACT && (n & 1)) {
+    // an odd order: n^2 doubles per matrix leave every other matrix 8 bytes off a 16-byte boundary --
+    // element loads (lane l owns elements l, l + 64, ..), otherwise the loop below
+    constexpr int CE = (NN + 63) / 64, BATCH = 6;
+    double acc[CE];
+    int eo[CE];
+#pragma unroll
+    for (int u = 0; u < CE; u++) {
+      acc[u] = 0.0;
+      eo[u] = lane + 64 * u < nn ? lane + 64 * u : nn - 1;
+    }
+    const double* base = g.A + (size_t)mem * g.a_stride;
+    for (int i0 = 0; i0 < m; i0 += BATCH) {
+      double v[BATCH][CE];
+#pragma unroll
+      for (int b = 0; b < BATCH; b++) {
+        const int i = i0 + b < m ? i0 + b : m - 1;
+#pragma unroll
+        for (int u = 0; u < CE; u++) v[b][u] = base[(size_t)i * nn + eo[u]];
+      }
+#pragma unroll
+      for (int b = 0; b < BATCH; b++) {
+        if (i0 + b < m) {  // wave-uniform
+          const double yi = ReadLaneUniform(yv, i0 + b);
+#pragma unroll
+          for (int u = 0; u < CE; u++) acc[u] += yi * v[b][u];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CE; u++) {
+      const int e = lane + 64 * u;
+      if (e < nn) M[e] = acc[u] - c_weight * Cm[e];
     }
   } else {
   // lane l owns the 16-byte chunks l, l + 64, ..
@@ -547,10 +581,9 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
   }
 }
 
-// order 20 exactly, or any even order below it on the same instance (odd orders would leave the
-// 16-byte chunks of a constraint's matrices misaligned)
+// order 20 exactly, or any order from 3 below it on the same instance
 inline bool LmiPrepareRowsSupports(int n, int m, int herm_d, bool sparse) {
-  return n >= 4 && n <= 20 && n % 2 == 0 && m <= 64 && herm_d == 0 && !sparse;
+  return n >= 3 && n <= 20 && m <= 64 && herm_d == 0 && !sparse;
 }
 
 inline bool LmiTakeStepRowsSupports(int n) { return n <= 32; }

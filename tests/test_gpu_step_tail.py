@@ -300,9 +300,10 @@ def test_conex_maximize_is_the_same_solve_with_mu_on_the_device_and_on_the_host(
     assert np.array_equal(y0, y1) and np.array_equal(y0, y2)
 
 
-@pytest.mark.parametrize("n,m", [(4, 3), (8, 8), (12, 12), (16, 20), (18, 9), (20, 20)])
-def test_register_prepare_kernels_at_even_orders_up_to_20_match_the_workgroup_kernels_bit_for_bit(n, m, monkeypatch):
-    """lmi_prepare_rows<.., 20, EXACT = false> takes any even order n <= 20 at run time (matrices n apart,
+@pytest.mark.parametrize("n,m", [(3, 2), (4, 3), (5, 5), (8, 8), (9, 12), (12, 12), (15, 7), (16, 20), (18, 9), (19, 20),
+                                 (20, 20)])
+def test_register_prepare_kernels_at_orders_up_to_20_match_the_workgroup_kernels_bit_for_bit(n, m, monkeypatch):
+    """lmi_prepare_rows<.., 20, EXACT = false> takes any order 3 <= n <= 20 at run time (matrices n apart,
     lanes and columns beyond n holding zeros): PrepareStep, the eigenvalue query and the W that
     TakeStep then produces must equal the workgroup kernels' (CXK_PREPARE_LDS=1 at context creation)
     bit for bit -- zero factors leave every sum as it is -- and the oracle's to rounding."""
