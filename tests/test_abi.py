@@ -139,3 +139,73 @@ def test_numeric_path_fails_loudly_without_gpu():
     k.initialize()
     with pytest.raises(KktError):
         k.assemble()
+
+
+def _normalised_header(path):
+    """(prototypes, struct fields, #define constants) of a C header with comments, parameter
+    names and white space removed: `int CONEX_X(void* p, const double* A, int Ar)` becomes
+    ('CONEX_X', 'int', ('void*', 'const double*', 'int'))."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    defines = dict(re.findall(r"^\s*#define\s+(CONEX_[A-Z_0-9]+)\s+(\S+)\s*$", text, flags=re.M))
+    text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)
+    text = re.sub(r'extern\s+"C"\s*\{', " ", text)
+
+    def ctype(decl):
+        decl = re.sub(r"\s+", " ", decl.strip())
+        m = re.match(r"^(.*?[\s\*])([A-Za-z_][A-Za-z_0-9]*)$", decl)   # drop the parameter name
+        if m and m.group(1).strip() not in ("", "const", "unsigned", "long", "struct"):
+            decl = m.group(1)
+        return re.sub(r"\s*\*\s*", "*", decl.strip())
+
+    structs = {}
+    for body, name in re.findall(r"typedef\s+struct[^{]*\{(.*?)\}\s*([A-Za-z_0-9]+)\s*;", text, flags=re.S):
+        fields = []
+        for f in body.split(";"):
+            f = f.strip()
+            if f:
+                m = re.match(r"^(.*?[\s\*])([A-Za-z_][A-Za-z_0-9]*)$", re.sub(r"\s+", " ", f))
+                fields.append((re.sub(r"\s*\*\s*", "*", m.group(1).strip()), m.group(2)))
+        structs[name] = fields
+    text = re.sub(r"typedef\s+struct[^{]*\{.*?\}\s*[A-Za-z_0-9]+\s*;", " ", text, flags=re.S)
+    protos = {}
+    for ret, name, params in re.findall(r"([A-Za-z_][A-Za-z_0-9\s\*]*?)\s*\b(CONEX_[A-Za-z_0-9]+)\s*\(([^)]*)\)\s*;",
+                                        text, flags=re.S):
+        ret = re.sub(r"\b(CONEX_API|extern)\b", " ", ret)
+        ps = tuple(ctype(p) for p in params.split(",") if p.strip() and p.strip() != "void")
+        protos[name] = (re.sub(r"\s*\*\s*", "*", re.sub(r"\s+", " ", ret.strip())), ps)
+    return protos, structs, defines
+
+
+REFERENCE_HEADER = "/root/reference/interfaces/conex.h"
+
+
+@pytest.mark.skipif(not os.path.exists(REFERENCE_HEADER),
+                    reason="the reference tree is only present in the build container")
+def test_conex_h_equals_the_reference_header_prototype_by_prototype():
+    """interfaces/conex.h:7-99 against include/conex.h: return types, argument TYPES in order, the
+    field list (types, names, order) of CONEX_SolverConfiguration and the status constants.  The
+    symbol-name test above cannot see a swapped argument or a reordered field; this one does."""
+    ours = _normalised_header(os.path.join(ROOT, "include", "conex.h"))
+    ref = _normalised_header(REFERENCE_HEADER)
+    assert len(ref[0]) == 21 and "CONEX_SolverConfiguration" in ref[1]
+    assert sorted(ours[0]) == sorted(ref[0])
+    for name, sig in ref[0].items():
+        assert ours[0][name] == sig, f"{name}: {ours[0][name]} != reference {sig}"
+    assert ours[1]["CONEX_SolverConfiguration"] == ref[1]["CONEX_SolverConfiguration"]
+    assert len(ref[1]["CONEX_SolverConfiguration"]) == 19
+    for name, val in ref[2].items():
+        assert ours[2].get(name) == val, name
+
+
+def test_ctypes_configuration_mirror_has_the_header_field_order():
+    """tests/conex_api.py's ctypes mirror of CONEX_SolverConfiguration (what every C-ABI test passes
+    to CONEX_Maximize) lists the fields of include/conex.h in order and with matching C types."""
+    _, structs, _ = _normalised_header(os.path.join(ROOT, "include", "conex.h"))
+    fields = structs["CONEX_SolverConfiguration"]
+    mirror = ca.Config._fields_ if hasattr(ca, "Config") else ca.SolverConfiguration._fields_
+    assert [n for _, n in fields] == [n for n, _ in mirror]
+    want = {"int": C.c_int, "double": C.c_double}
+    for (ctype_, name), (_, py) in zip(fields, mirror):
+        assert want[ctype_] is py, name
