@@ -384,7 +384,11 @@ __global__ void __launch_bounds__(64) soc_prepare(VecGroup g, StepArgs sa) {
     SocQuadRep(len, wsqrt, ms, d);
     double nq = 0;
     if (MODE == 0) {
-      for (int k = 0; k < len; k++) W[k] = wsqrt[k];  // PrepareStep leaves w^{1/2} in W
+      // PrepareStep leaves w^{1/2} in W (soc_constraint.cc:259-261) -- unless it was enqueued behind a
+      // factorization that turns out to have failed: the reference returns before PrepareStep then,
+      // with W untouched (cone_program.cc:360-371)
+      if (!StepSkipped(sa))
+        for (int k = 0; k < len; k++) W[k] = wsqrt[k];
       d[0] += 1;
       double s = 0;
       for (int k = 0; k < len; k++) {

@@ -145,7 +145,9 @@ __global__ void __launch_bounds__(64) quad_prepare(QuadGroup g, StepArgs sa) {
   double d0;
   QuadRep(n, nsq, ip, w0, wsq, ms[0], ms + 1, &d0, d1);
   if (MODE == 0) {
-    W[0] = w0;  // (`wsqrt_q0` is *W0 itself)
+    // (`wsqrt_q0` is *W0 itself; not behind a failed factorization: the reference returns before
+    // PrepareStep then, cone_program.cc:360-371)
+    if (!StepSkipped(sa)) W[0] = w0;
     d0 += 1;
     D[0] = d0;
     for (int i = 0; i < n; i++) {

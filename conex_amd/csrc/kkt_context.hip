@@ -3,6 +3,7 @@
 // Host side = structure + launches only.  All fp64 state (A_i, C, W, Schur blocks, the
 // supernodal slab, right-hand sides) lives in HBM for the lifetime of the context; per
 // Newton step only scalars cross PCIe.
+#include <hip/hip_ext.h>
 #include "kkt_internal.h"
 #include "kernels_cone.hip.h"
 #include "kernels_gemm.hip.h"
@@ -412,6 +413,27 @@ hipError_t LaunchLmiSchurSparse(Group& g, const Arena& ar, hipStream_t st) {
   return LaunchLmiSparseKernel<false>(g, d, ar, X, st);
 }
 
+// A hipEvent pair for this launch of a clock slot's kernels, when it is one of the sampled ones.
+bool ClockSample(cxk_context* ctx, int slot, hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = *e1 = nullptr;
+  if (!ctx->timing || (ctx->timing_tick[slot]++ % ctx->timing_period) != 0) return false;
+  if (ctx->ev_used == ctx->ev_pool.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return false;
+    if (hipEventCreate(&b) != hipSuccess) {
+      (void)hipEventDestroy(a);
+      return false;
+    }
+    ctx->ev_pool.emplace_back(a, b);
+    ctx->ev_slot.push_back(slot);
+  }
+  *e0 = ctx->ev_pool[ctx->ev_used].first;
+  *e1 = ctx->ev_pool[ctx->ev_used].second;
+  ctx->ev_slot[ctx->ev_used] = slot;
+  ctx->ev_used++;
+  return true;
+}
+
 int LaunchSchur(cxk_context* ctx) {
   Arena ar = MakeArena(ctx);
   for (Group& g : ctx->groups) {
@@ -420,20 +442,9 @@ int LaunchSchur(cxk_context* ctx) {
     switch (g.type) {
       case CXK_LMI: {
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool sample = ctx->timing && (ctx->timing_tick++ % ctx->timing_period) == 0;
-        if (sample) {
-          if (ctx->ev_used == ctx->ev_pool.size()) {
-            hipEvent_t a, b;
-            CXK_TRY(hipEventCreate(&a));
-            CXK_TRY(hipEventCreate(&b));
-            ctx->ev_pool.emplace_back(a, b);
-          }
-          e0 = ctx->ev_pool[ctx->ev_used].first;
-          e1 = ctx->ev_pool[ctx->ev_used].second;
-          ctx->ev_used++;
-          // (lmi_schur_mfma carries the pair on its dispatch instead: no marker packets)
-          if (!(g.mfma && !g.sparse && !g.schur_gemm)) CXK_TRY(hipEventRecord(e0, ctx->stream));
-        }
+        const bool sample = ClockSample(ctx, CXK_CLOCK_ASSEMBLY, &e0, &e1);
+        // (lmi_schur_mfma carries the pair on its dispatch instead: no marker packets)
+        if (sample && !(g.mfma && !g.sparse && !g.schur_gemm)) CXK_TRY(hipEventRecord(e0, ctx->stream));
         if (g.sparse) {
           CXK_TRY(LaunchLmiSchurSparse(g, ar, ctx->stream));
         } else if (g.schur_gemm) {
@@ -842,7 +853,31 @@ int ShardedTree(cxk_context* ctx, int mode, bool with_rhs, bool backward);
 int QrFactor(cxk_context* ctx);
 int QrSolve(cxk_context* ctx);
 
+int LaunchTreeUntimed(cxk_context* ctx, int mode, bool with_rhs, bool backward);
+
+// (the kernel clocks CXK_CLOCK_TREE / CXK_CLOCK_SOLVE sit here: on the dispatch when the sweep is one
+// whole-tree launch, around the launches otherwise)
 int LaunchTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool solving = backward && (mode != 0 || with_rhs);
+  if (!ctx->timing || !solving || !ClockSample(ctx, mode == 0 ? CXK_CLOCK_TREE : CXK_CLOCK_SOLVE, &e0, &e1))
+    return LaunchTreeUntimed(ctx, mode, with_rhs, backward);
+  const bool one_launch =
+      ctx->world == 1 && ctx->refine_iters <= 0 && ctx->solver_mode != 2 && ctx->fused_tree && !ctx->fused_split &&
+      (mode == 0 ? (with_rhs && ctx->asm_pending.on && ctx->asm_pending.with_rhs != 0) : ctx->fused_sweep);
+  if (one_launch) {
+    ctx->clk_e0 = e0;
+    ctx->clk_e1 = e1;
+  } else {
+    CXK_TRY(hipEventRecord(e0, ctx->stream));
+  }
+  const int rc = LaunchTreeUntimed(ctx, mode, with_rhs, backward);
+  if (!one_launch) CXK_TRY(hipEventRecord(e1, ctx->stream));
+  ctx->clk_e0 = ctx->clk_e1 = nullptr;
+  return rc;
+}
+
+int LaunchTreeUntimed(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
   if (mode == 0) ctx->fail_clean = false;  // (whatever this factorization reports stays until the next gather)
   if (ctx->solver_mode == 2) {  // CONEX_QR_FACTORIZATION
     if (mode == 0 && QrFactor(ctx)) return CXK_FAILURE;
@@ -946,7 +981,12 @@ int MakeFusedTreeArgs(cxk_context* ctx, FusedTreeArgs* out) {
     memcpy(&sent, &bits, sizeof(sent));
     std::vector<double> ys(ctx->fx_ysig.n, sent);
     CXK_TRY(hipMemcpy(ctx->fx_ysig.p, ys.data(), sizeof(double) * ys.size(), hipMemcpyHostToDevice));
+    if (ctx->fx_done.p) {
+      CXK_TRY(hipMemset(ctx->fx_done.p, 0, sizeof(unsigned long long)));
+      ctx->fx_done_target = 0;
+    }
     *ctx->fx_flag = 0.0;
+    ctx->timeout_pending = true;  // (what cxk_sync / cxk_factor_status act on: FusedTimedOut)
   }
   FusedTreeArgs& a = *out;
   a.rec = ctx->fx_rec.p;
@@ -980,6 +1020,50 @@ int MakeFusedTreeArgs(cxk_context* ctx, FusedTreeArgs* out) {
   a.sys_sc = ctx->sys_sc.p;
   a.K = (int)ctx->cons.size();
   a.host_flag = ctx->fx_flag;
+  // sharded contexts (kFusedShardUp / kFusedShardTop)
+  a.count_up = ctx->fused_shard ? ctx->fused_up : a.count;
+  a.x = ctx->xbuf.p;
+  a.n_xs = ctx->n_xs;
+  a.n_xv = ctx->n_xv;
+  a.xg = ctx->fx_xg.p;
+  a.as_src = ctx->as_src.p;
+  a.xs_pt = ctx->xs_pt.p;
+  a.pt_ptr = ctx->pt_ptr.p;
+  a.pt_src = ctx->pt_src.p;
+  a.xr = ctx->fx_xr.p;
+  a.rs_src = ctx->rs_src.p;
+  a.pf_ptr = ctx->pf_ptr.p;
+  a.pf_src = ctx->pf_src.p;
+  a.done = ctx->fx_done.p;
+  a.done_target = 0;
+  return CXK_SUCCESS;
+}
+
+int ShardAllReduce(cxk_context* ctx, double* buf, size_t count, int op);
+long ExchangeCount(const cxk_context* ctx);
+
+// The factor-and-solve of a sharded context on the whole-tree kernels: own subtrees up with the pack of
+// the exchange buffer behind them (one launch), the sum all-reduce, the replicated top straight from
+// the buffer and the way back down the own subtrees (one launch).  Consumes the pending assembly.
+int LaunchFusedShard(cxk_context* ctx) {
+  const cxk_context::AsmPending ap = ctx->asm_pending;
+  ctx->asm_pending.on = false;
+  FusedTreeArgs a;
+  if (MakeFusedTreeArgs(ctx, &a)) return CXK_FAILURE;
+  ctx->asm_tag = ctx->asm_tag >= (1 << 30) ? 1 : ctx->asm_tag + 1;
+  a.tag = ctx->fail_tag = ctx->asm_tag;
+  a.k = ap.k;
+  a.bs = ap.bs;
+  a.cs = ap.cs;
+  a.cb = ap.cb;
+  a.cq = ap.cq;
+  a.cw = ap.cw;
+  a.comb = ap.with_rhs == 2;
+  ctx->fx_done_target += (unsigned long long)a.count_up;
+  a.done_target = ctx->fx_done_target;
+  CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedShardUp, ctx->stream));
+  if (ShardAllReduce(ctx, ctx->xbuf.p, (size_t)ExchangeCount(ctx), 0 /* kOpSum */)) return CXK_FAILURE;
+  CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedShardTop, ctx->stream));
   return CXK_SUCCESS;
 }
 
@@ -1003,7 +1087,14 @@ int LaunchFusedTreeSolve(cxk_context* ctx) {
     CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedUp, ctx->stream));
     CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedDown, ctx->stream));
   } else {
-    CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedFull, ctx->stream));
+    CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedFull, ctx->stream, ctx->clk_e0, ctx->clk_e1));
+  }
+  if (ctx->debug_timeout_at >= 0 && ctx->fused_launches++ == ctx->debug_timeout_at) {
+    // test hook (CXK_DEBUG_FUSED_TIMEOUT_AT=k at cxk_create): the k-th factor launch reports what a
+    // wait that ran out reports -- the tagged failure word on the device and the pinned host word
+    CXK_TRY(hipMemcpyAsync(ctx->d_fail.p + 1, &ctx->asm_tag, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    CXK_TRY(hipStreamSynchronize(ctx->stream));
+    *ctx->fx_flag = 1.0;
   }
   return CXK_SUCCESS;
 }
@@ -1026,8 +1117,45 @@ int LaunchFusedTreeSweep(cxk_context* ctx) {
     CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedForward, ctx->stream));
     CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedDown, ctx->stream));
   } else {
-    CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedSolve, ctx->stream));
+    CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedSolve, ctx->stream, ctx->clk_e0, ctx->clk_e1));
   }
+  return CXK_SUCCESS;
+}
+
+// A wait of a whole-tree launch ran out (the launch reports it as a failed factorization and through
+// the pinned word).  tree_fused is deadlock-free only while its whole grid is resident, i.e. while the
+// device is this context's alone; on a device shared with other streams / processes a wavefront can
+// wait for one that was never dispatched.  Nothing is wrong with the matrix then: the context gives
+// the whole-tree launch up and sweeps its tree level by level from here on (the CXK_NO_FUSED_TREE
+// path: kernel boundaries instead of in-kernel waits), and the caller redoes the sweep.
+bool FusedTimedOut(const cxk_context* ctx) { return ctx->timeout_pending || (ctx->fx_flag && *ctx->fx_flag != 0.0); }
+
+int DisableFusedTree(cxk_context* ctx) {
+  CXK_TRY(hipStreamSynchronize(ctx->stream));
+  *ctx->fx_flag = 0.0;
+  ctx->timeout_pending = false;
+  ctx->fused_tree = false;
+  ctx->fused_sweep = false;
+  ctx->fused_timeouts++;
+  fprintf(stderr, "conex_kkt_hip: a wait inside the whole-tree launch ran out (device shared with other work?); "
+                  "this context sweeps its elimination tree level by level from now on\n");
+  return CXK_SUCCESS;
+}
+
+// ... and the latest factor-and-solve again on the level kernels: the Schur blocks are still in the
+// arena, the right-hand side was cb b + cq AQc + cw AW with the coefficients of ctx->rhs_c.
+int RedoFactorSolveOnLevels(cxk_context* ctx) {
+  if (DisableFusedTree(ctx)) return CXK_FAILURE;
+  const int N = ctx->md.N;
+  ctx->asm_pending.on = false;
+  ctx->asm_deferred = false;
+  if (LaunchGather(ctx, false, 0, 0, 0)) return CXK_FAILURE;
+  CXK_TRY(hipMemsetAsync(ctx->d_fail.p, 0, 2 * sizeof(int), ctx->stream));
+  build_rhs_comb<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, ctx->rhs_c[0], ctx->rhs_c[1], ctx->rhs_c[2], ctx->b.p,
+                                                           ctx->AQc.p, ctx->AW.p, ctx->y.p, ctx->d_fail.p);
+  CXK_TRY(hipGetLastError());
+  if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;
+  ctx->factor_seq = ++ctx->seq;
   return CXK_SUCCESS;
 }
 
@@ -1269,6 +1397,9 @@ long ExchangeCount(const cxk_context* ctx) { return (long)(ctx->n_xs + 3 * (int6
 // then the top on every rank (bit-identical: same data, same kernels) and, when `backward`, the
 // back-substitution down this rank's subtrees.
 int ShardedTree(cxk_context* ctx, int mode, bool with_rhs, bool backward) {
+  if (mode == 0 && with_rhs && backward && ctx->fused_tree && ctx->fused_shard && ctx->asm_pending.on &&
+      ctx->asm_pending.with_rhs != 0)
+    return LaunchFusedShard(ctx);
   if (ctx->use_ldlt && mode == 0) CXK_TRY(hipMemsetAsync(ctx->d_reg.p, 0, sizeof(int), ctx->stream));
   const int nlev = ctx->nlev, cut = ctx->cut_level, top = ctx->top_level;
   const bool rhs = with_rhs || mode != 0;
@@ -1393,6 +1524,7 @@ extern "C" {
 int cxk_create(int num_vars, int device, void* stream, cxk_context** out) {
   if (!out || num_vars < 0) return CXK_FAILURE;
   cxk_context* ctx = new cxk_context();
+  if (const char* v = getenv("CXK_DEBUG_FUSED_TIMEOUT_AT")) ctx->debug_timeout_at = atoi(v);
   ctx->num_vars = num_vars;
   ctx->device = device;
   ctx->stream = static_cast<hipStream_t>(stream);
@@ -1741,8 +1873,9 @@ int cxk_finalize(cxk_context* ctx) {
 
 static int FinalizeImpl(cxk_context* ctx) {
   if (ctx->reference_identity < 0) {
+    // default: the reference as written; CXK_REFERENCE_QUIRKS=0 opts into the two corrections
     const char* quirks_env = getenv("CXK_REFERENCE_QUIRKS");
-    ctx->reference_identity = quirks_env && atoi(quirks_env) != 0;
+    ctx->reference_identity = !(quirks_env && atoi(quirks_env) == 0 && quirks_env[0] != '\0');
   }
   try {
     ctx->md = Analyze(ctx->cliques, ctx->dual_vars);
@@ -2297,7 +2430,17 @@ int cxk_factor_async(cxk_context* ctx) {
 int cxk_factor_status(cxk_context* ctx, int* ok) {
   CXK_ENTER(ctx);
   if (ctx->mb_seen < ctx->factor_seq && SyncMailbox(ctx)) return CXK_FAILURE;
-  if (ok) *ok = (ctx->mb ? (ctx->mbv[10] == 0.0) : 1) && !(ctx->fx_flag && *ctx->fx_flag != 0.0);
+  if (ok) *ok = (ctx->mb ? (ctx->mbv[10] == 0.0) : 1) && !FusedTimedOut(ctx);
+  if (FusedTimedOut(ctx) && ctx->world > 1) {
+    // (sharded: the ranks must keep issuing the same collectives -- reported as a failed
+    // factorization, the slots are rebuilt by the next whole-tree launch)
+    ctx->timeout_pending = false;
+  } else if (FusedTimedOut(ctx)) {
+    // not a property of the matrix: the caller learns it through cxk_fused_tree_timed_out and redoes
+    // its iteration, which then runs on the level kernels
+    if (DisableFusedTree(ctx)) return CXK_FAILURE;
+    ctx->timeout_unreported = true;
+  }
   return CXK_SUCCESS;
 }
 
@@ -2425,13 +2568,21 @@ int cxk_sync(cxk_context* ctx, int* factor_ok) {
   CXK_ENTER(ctx);
   if (SyncMailbox(ctx)) return CXK_FAILURE;
   CXK_TRY(hipStreamSynchronize(ctx->stream));  // the stream is idle: cheap, and later host-side copies rely on it
-  if (factor_ok) *factor_ok = ctx->mbv[10] == 0.0 && !(ctx->fx_flag && *ctx->fx_flag != 0.0);
+  bool timed_out = false;
+  if (FusedTimedOut(ctx) && ctx->world > 1) {
+    timed_out = true;
+    ctx->timeout_pending = false;
+  } else if (FusedTimedOut(ctx)) {  // redo the factor-and-solve level by level instead of reporting a failure
+    if (RedoFactorSolveOnLevels(ctx) || SyncMailbox(ctx)) return CXK_FAILURE;
+    CXK_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  if (factor_ok) *factor_ok = ctx->mbv[10] == 0.0 && !timed_out;
   // fold finished timing samples
   for (size_t k = 0; k < ctx->ev_used; k++) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev_pool[k].first, ctx->ev_pool[k].second) == hipSuccess) {
-      ctx->time_acc_ms += ms;
-      ctx->time_samples++;
+      ctx->time_acc_ms[ctx->ev_slot[k]] += ms;
+      ctx->time_samples[ctx->ev_slot[k]]++;
     }
   }
   ctx->ev_used = 0;
@@ -2634,6 +2785,39 @@ int cxk_prepare_take_step(cxk_context* ctx, double c_weight, double e_weight, do
   if (took) *took = 0;
   return PrepareStepImpl(ctx, 0, c_weight, e_weight, info, true, took);
 }
+}  // extern "C"
+namespace {
+// Kernel clocks of the step kernels (CXK_CLOCK_QUERY / _PREPARE / _TAKE): a program whose constraints
+// are ONE group on a register kernel carries the event pair on that dispatch; anything else is
+// bracketed by event records around its launches.
+struct StepClock {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool sample = false, on_dispatch = false;
+};
+StepClock BeginStepClock(cxk_context* ctx, int slot, bool one_register_kernel) {
+  StepClock c;
+  c.sample = ClockSample(ctx, slot, &c.e0, &c.e1);
+  c.on_dispatch = c.sample && one_register_kernel;
+  if (c.sample && !c.on_dispatch) (void)hipEventRecord(c.e0, ctx->stream);
+  return c;
+}
+void EndStepClock(cxk_context* ctx, const StepClock& c) {
+  if (c.sample && !c.on_dispatch) (void)hipEventRecord(c.e1, ctx->stream);
+}
+int NonEmptyGroups(const cxk_context* ctx) {
+  int n = 0;
+  for (const Group& g : ctx->groups) n += !g.ids.empty();
+  return n;
+}
+#define CXK_LAUNCH_CLOCKED(clk, kernel, grid, block, ...)                                                        \
+  do {                                                                                                           \
+    if ((clk).on_dispatch)                                                                                       \
+      hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, ctx->stream, (clk).e0, (clk).e1, 0, __VA_ARGS__); \
+    else                                                                                                         \
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, ctx->stream, __VA_ARGS__);                          \
+  } while (0)
+}  // namespace
+extern "C" {
 static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double e_weight, double* info, bool take,
                            int* took, const double* cw_from, double cw_scale) {
   CXK_ENTER_KEEP(ctx);
@@ -2642,10 +2826,20 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
   StepArgs sa = MakeStep(ctx, ctx->info2.p, affine, c_weight, e_weight, 1.0);
   sa.cw_from = cw_from;  // (CWeightOf in every PrepareStep kernel)
   sa.cw_scale = cw_scale;
+  // PrepareStep may be enqueued before the host has seen the factorization's outcome: the cones whose
+  // PrepareStep changes the scaling point itself (second-order and quadratic cones leave w^{1/2} in W)
+  // look at the flag and leave W as the reference does when Factor() failed
+  sa.skip_if = ctx->d_fail.p;
+  sa.skip_tag = ctx->fail_tag;
   StepTail tail;
   tail.slots = nullptr;
   if (with_tail && MakeStepTail(ctx, 0, &tail)) return CXK_FAILURE;
   ctx->lanczos_calls++;
+  bool rows_only = NonEmptyGroups(ctx) == 1 && !affine && !ctx->prepare_lds;
+  for (const Group& g : ctx->groups)
+    if (!g.ids.empty())
+      rows_only = rows_only && g.type == CXK_LMI && !g.large && !g.literal && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse);
+  const StepClock clk = BeginStepClock(ctx, CXK_CLOCK_PREPARE, rows_only);
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
     if (cnt == 0) continue;
@@ -2656,9 +2850,9 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
       if (!affine && !lds_kernel && !g.literal && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse))
       {
         if (g.n == 20)
-          lmi_prepare_rows<0, 20, true><<<(cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, 0, ctx->stream>>>(MakeLmi(g), sa, tail);
+          CXK_LAUNCH_CLOCKED(clk, (lmi_prepare_rows<0, 20, true>), (cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, MakeLmi(g), sa, tail);
         else  // (an even order below 20 on the same instance)
-          lmi_prepare_rows<0, 20, false><<<(cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, 0, ctx->stream>>>(MakeLmi(g), sa, tail);
+          CXK_LAUNCH_CLOCKED(clk, (lmi_prepare_rows<0, 20, false>), (cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, MakeLmi(g), sa, tail);
       }
       else if (g.n == 20)
         lmi_prepare_generic<0, 20><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
@@ -2675,6 +2869,7 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
     else if (g.type == CXK_OCT)
       oct_prepare<0><<<cnt, 64, sizeof(double) * (size_t)g.m, ctx->stream>>>(MakeOct(g), sa);
   }
+  EndStepClock(ctx, clk);
   CXK_TRY(hipGetLastError());
   if (ctx->use_ldlt) {  // lambda_ = y.tail(rows) (equality_constraint.cc:32-37)
     ctx->y_at_prepare.resize(ctx->md.N);
@@ -2711,25 +2906,30 @@ static int LaunchTakeStep(cxk_context* ctx, double e_weight, double step_size, c
     sa.skip_if = ctx->d_fail.p;
     sa.skip_tag = ctx->fail_tag;
   }
+  static const bool take_lds_kernel = getenv("CXK_TAKE_STEP_LDS") != nullptr;  // A/B switch (tests, timing)
+  bool rows_only = NonEmptyGroups(ctx) == 1 && !take_lds_kernel;
+  for (const Group& g : ctx->groups)
+    if (!g.ids.empty()) rows_only = rows_only && g.type == CXK_LMI && !g.large && !g.literal && LmiTakeStepRowsSupports(g.n);
+  const StepClock clk = BeginStepClock(ctx, CXK_CLOCK_TAKE, rows_only);
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
     if (cnt == 0) continue;
     if (g.type == CXK_LMI && g.large)
       CXK_TRY(LmiLargeTakeStep(MakeLmi(g), sa, MakeLargeWs(g), ctx->stream));
     else if (g.type == CXK_LMI) {
-      static const bool lds_kernel = getenv("CXK_TAKE_STEP_LDS") != nullptr;  // A/B switch (tests, timing)
+      const bool lds_kernel = take_lds_kernel;
       if (LmiTakeStepRowsSupports(g.n) && !lds_kernel && !g.literal) {
         const int blocks = (cnt + 3) / 4;
         if (g.herm_d == 0) {
           if (g.n <= 20)
-            lmi_take_step_rows<20><<<blocks, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+            CXK_LAUNCH_CLOCKED(clk, (lmi_take_step_rows<20>), blocks, 256, MakeLmi(g), sa);
           else
-            lmi_take_step_rows<32><<<blocks, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+            CXK_LAUNCH_CLOCKED(clk, (lmi_take_step_rows<32>), blocks, 256, MakeLmi(g), sa);
         } else {
           if (g.n <= 24)
-            lmi_take_step_rows_taylor<24><<<blocks, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+            CXK_LAUNCH_CLOCKED(clk, (lmi_take_step_rows_taylor<24>), blocks, 256, MakeLmi(g), sa);
           else
-            lmi_take_step_rows_taylor<32><<<blocks, 256, 0, ctx->stream>>>(MakeLmi(g), sa);
+            CXK_LAUNCH_CLOCKED(clk, (lmi_take_step_rows_taylor<32>), blocks, 256, MakeLmi(g), sa);
         }
       }
       else if (g.n == 20)
@@ -2746,6 +2946,7 @@ static int LaunchTakeStep(cxk_context* ctx, double e_weight, double step_size, c
     else if (g.type == CXK_OCT)
       oct_take_step<<<cnt, 64, 0, ctx->stream>>>(MakeOct(g), sa);
   }
+  EndStepClock(ctx, clk);
   CXK_TRY(hipGetLastError());
   return CXK_SUCCESS;
 }
@@ -2766,6 +2967,11 @@ static int SlackEigenvaluesImpl(cxk_context* ctx, double c_weight, double* out, 
   if (with_tail && MakeStepTail(ctx, 1, &tail)) return CXK_FAILURE;
   if (rule) tail.rule = *rule;
   ctx->lanczos_calls++;
+  bool rows_only = NonEmptyGroups(ctx) == 1 && !ctx->prepare_lds;
+  for (const Group& g : ctx->groups)
+    if (!g.ids.empty())
+      rows_only = rows_only && g.type == CXK_LMI && !g.large && !g.literal && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse);
+  const StepClock clk = BeginStepClock(ctx, CXK_CLOCK_QUERY, rows_only);
   for (Group& g : ctx->groups) {
     const int cnt = (int)g.ids.size();
     if (cnt == 0) continue;
@@ -2776,9 +2982,9 @@ static int SlackEigenvaluesImpl(cxk_context* ctx, double c_weight, double* out, 
       if (!lds_kernel && !g.literal && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse))
       {
         if (g.n == 20)
-          lmi_prepare_rows<1, 20, true><<<(cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, 0, ctx->stream>>>(MakeLmi(g), sa, tail);
+          CXK_LAUNCH_CLOCKED(clk, (lmi_prepare_rows<1, 20, true>), (cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, MakeLmi(g), sa, tail);
         else  // (an even order below 20 on the same instance)
-          lmi_prepare_rows<1, 20, false><<<(cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, 0, ctx->stream>>>(MakeLmi(g), sa, tail);
+          CXK_LAUNCH_CLOCKED(clk, (lmi_prepare_rows<1, 20, false>), (cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, MakeLmi(g), sa, tail);
       }
       else if (g.n == 20)
         lmi_prepare_generic<1, 20><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
@@ -2795,6 +3001,7 @@ static int SlackEigenvaluesImpl(cxk_context* ctx, double c_weight, double* out, 
     else if (g.type == CXK_OCT)
       oct_prepare<1><<<cnt, 64, sizeof(double) * (size_t)g.m, ctx->stream>>>(MakeOct(g), sa);
   }
+  EndStepClock(ctx, clk);
   CXK_TRY(hipGetLastError());
   if (ReduceStepInfoAndSync(ctx, 1, ctx->info4.p, nullptr, nullptr, with_tail, false, rule == nullptr, rule))
     return CXK_FAILURE;
@@ -3057,6 +3264,18 @@ int cxk_fused_assembly(const cxk_context* ctx) { return ctx && ctx->fused_asm ? 
 /* 1 when assembly, factorization and solve of a KKT solve run as one launch (tree_fused.hip) */
 int cxk_fused_tree(const cxk_context* ctx) { return ctx && ctx->fused_tree ? 1 : 0; }
 
+int cxk_fused_tree_timed_out(cxk_context* ctx) {
+  if (!ctx || !ctx->timeout_unreported) return 0;
+  ctx->timeout_unreported = false;
+  return 1;
+}
+
+int cxk_debug_force_fused_timeout(cxk_context* ctx) {
+  if (!ctx || !ctx->fx_flag || !ctx->fused_tree) return CXK_FAILURE;
+  *ctx->fx_flag = 1.0;
+  return CXK_SUCCESS;
+}
+
 int cxk_count_lmi_kernel(const cxk_context* ctx, int which) {
   if (!ctx || !ctx->device_ready) return -1;
   int k = 0;
@@ -3174,19 +3393,23 @@ int cxk_enable_timing(cxk_context* ctx, int on) {
   if (!ctx) return CXK_FAILURE;
   ctx->timing = on != 0;
   ctx->timing_period = on > 1 ? on : 1;
-  ctx->timing_tick = 0;
+  for (int k = 0; k < CXK_CLOCK_COUNT; k++) ctx->timing_tick[k] = 0;
   return CXK_SUCCESS;
 }
 
-int cxk_kernel_time(cxk_context* ctx, int reset, double* avg_ms) {
-  if (!ctx) return 0;
-  const int n = ctx->time_samples;
-  if (avg_ms) *avg_ms = n ? ctx->time_acc_ms / n : 0.0;
+int cxk_kernel_clock(cxk_context* ctx, int which, int reset, double* avg_ms) {
+  if (!ctx || which < 0 || which >= CXK_CLOCK_COUNT) return 0;
+  const int n = ctx->time_samples[which];
+  if (avg_ms) *avg_ms = n ? ctx->time_acc_ms[which] / n : 0.0;
   if (reset) {
-    ctx->time_acc_ms = 0;
-    ctx->time_samples = 0;
+    ctx->time_acc_ms[which] = 0;
+    ctx->time_samples[which] = 0;
   }
   return n;
+}
+
+int cxk_kernel_time(cxk_context* ctx, int reset, double* avg_ms) {
+  return cxk_kernel_clock(ctx, CXK_CLOCK_ASSEMBLY, reset, avg_ms);
 }
 
 }  // extern "C"

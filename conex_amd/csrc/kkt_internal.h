@@ -127,11 +127,11 @@ struct cxk_context {
   std::string err;
   std::vector<ConstraintRec> cons;
   IntLists cliques, dual_vars;
-  // Reference identity: reproduce the reference AS WRITTEN where this library deliberately departs
-  // from it -- (i) BindDiagonalBlock's unchecked direct_update placement on fill-in supernodes
-  // (supernodal_assembler.cc:72-91) instead of scatter-by-position, (ii) raw Lanczos Ritz values
-  // (approximate_eigenvalues.cc:178-239) instead of the Samuelson-clamped ones.  Set by
-  // cxk_set_reference_identity() or CXK_REFERENCE_QUIRKS=1 in the environment, before cxk_finalize.
+  // Reference identity (the default): the reference AS WRITTEN -- (i) BindDiagonalBlock's unchecked
+  // direct_update placement on fill-in supernodes (supernodal_assembler.cc:72-91), (ii) raw Lanczos
+  // Ritz values (approximate_eigenvalues.cc:178-239).  0 = the corrections (scatter by position,
+  // Samuelson clamp): cxk_set_reference_identity(ctx, 0) or CXK_REFERENCE_QUIRKS=0 in the
+  // environment, before cxk_finalize.
   int reference_identity = -1;  // -1: take the environment's word at finalize
   bool finalized = false;     // symbolic analysis done (getters)
   bool device_ready = false;  // device buffers and plans built: numeric entry points may run
@@ -238,6 +238,14 @@ struct cxk_context {
   bool fused_tree = false;
   bool fused_split = false;  // more supernodes than resident wavefronts: the way up and the way down are two launches
   bool fused_sweep = false;  // solve-only sweeps in one launch too (CXK_NO_FUSED_SWEEP=1 turns this part off)
+  // sharded contexts: own subtrees up (+ pack of the exchange buffer) and top + way down as two launches
+  // around the all-reduce; fused_up = positions below the cut; pack tables; the done counter of the up launch
+  bool fused_shard = false;
+  int fused_up = 0;
+  DevBuf<GatherRec> fx_xg;
+  DevBuf<ResidRec> fx_xr;
+  DevBuf<unsigned long long> fx_done;
+  unsigned long long fx_done_target = 0;
   int fused_sa = 0, fused_sb = 0;
   DevBuf<int> fx_rec, fx_xreg;
   DevBuf<long long> fx_xsrc, fx_rsrc;
@@ -247,6 +255,10 @@ struct cxk_context {
   long long fx_updb_base = 0;
   unsigned fused_gen = 0;
   double* fx_flag = nullptr;  // pinned host word the kernel sets when a wait ran out
+  int debug_timeout_at = -1, fused_launches = 0;  // CXK_DEBUG_FUSED_TIMEOUT_AT (test hook, LaunchFusedTreeSolve)
+  int fused_timeouts = 0;            // times that happened (the whole-tree launch is given up at the first)
+  bool timeout_pending = false;      // seen (and the slots rebuilt) by MakeFusedTreeArgs, not yet acted on
+  bool timeout_unreported = false;   // ... and cxk_fused_tree_timed_out has not told the caller yet
   bool asm_deferred = false;  // cxk_assemble ran the Schur kernels; the gather waits for the factorization that follows
   // solve-only sweeps whose every forward launch is a lean kernel form the right-hand side inside
   // those kernels (RhsIn) instead of in a launch of their own
@@ -282,13 +294,20 @@ struct cxk_context {
   DevBuf<unsigned char> d_count_mask;
   DevBuf<double> shard_tmp;        // N doubles: this rank's share of a vector / of the per-constraint pairs
   double rhs_c[3] = {0, 0, 0};     // right-hand side of the running factor-and-solve: cb b + cq AQc + cw AW
-  // timing of the dominant (dense-LMI Schur) kernel
+  // kernel clocks (bench.py's roofline entries): a hipEvent pair on every timing_period-th launch of
+  // the kernels of a slot (CXK_CLOCK_*: assembly, the tree launch of a KKT solve, solve-only sweep,
+  // eigenvalue query, PrepareStep, TakeStep) -- attached to the dispatch itself where the slot is ONE
+  // kernel (its own begin / end time stamps, the quantity rocprofv3 reports), recorded around the
+  // launches otherwise (which adds their boundaries)
   bool timing = false;
-  int timing_period = 1, timing_tick = 0;  // hipEvents bracket every timing_period-th launch
+  int timing_period = 1;
+  int timing_tick[CXK_CLOCK_COUNT] = {0, 0, 0, 0, 0, 0};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  std::vector<int> ev_slot;
   size_t ev_used = 0;
-  double time_acc_ms = 0;
-  int time_samples = 0;
+  hipEvent_t clk_e0 = nullptr, clk_e1 = nullptr;  // the pair the next whole-tree launch carries on its dispatch
+  double time_acc_ms[CXK_CLOCK_COUNT] = {0, 0, 0, 0, 0, 0};
+  int time_samples[CXK_CLOCK_COUNT] = {0, 0, 0, 0, 0, 0};
   // kkt_solver = CONEX_QR_FACTORIZATION (kkt_solver.cc:172-231): the reference factors the DENSE
   // N x N KKT matrix with a column-pivoted Householder QR (Eigen::ColPivHouseholderQR) and solves
   // with it -- a debugging mode for rank-deficient systems, O(N^2) memory and O(N^3) work on one

@@ -186,8 +186,8 @@ int BuildPlans(cxk_context* ctx) {
     // The reference's direct_update test (BindDiagonalBlock, supernodal_assembler.cc:72-91) passes
     // on a supernode whose positions are -1, 0, .., m-2 (a fill-in variable in front) and then
     // writes G one row/column off and drops the separator terms -- a defect.
-    // By default blocks are scattered by position; CXK_REFERENCE_QUIRKS=1 reproduces the
-    // reference as written for callers that need its trajectories.
+    // Reproduced as written by default (reference identity); cxk_set_reference_identity(ctx, 0) /
+    // CXK_REFERENCE_QUIRKS=0 scatters every block by position instead.
     bool misplaced = false;
     if (quirks && nse > 0 && m == nse && r[0] != 0) {
       misplaced = true;
@@ -441,12 +441,15 @@ int BuildPlans(cxk_context* ctx) {
   CXK_TRY(ctx->updb.alloc((size_t)slotsb + 2 + kPullPad, true));  // + dump slot + a slot that stays 0.0
 
   // ---- exchange layout: [T slab entries | AW_T | AQc_T | fwd_T | <w,c> <c,Qc> fail]
+  std::vector<int64_t> xs, xs_base(K, -1);  // (xs_base / xv_base: where a top supernode's entries / variables start)
+  std::vector<int> xv, xv_base(K, -1);
   if (sharded) {
-    std::vector<int64_t> xs;
-    std::vector<int> xv, pf_ptr, pf_src;
+    std::vector<int> pf_ptr, pf_src;
     pf_ptr.push_back(0);
     for (int e = 0; e < K; e++) {
       if (!ctx->sn_top[e]) continue;
+      xs_base[e] = (int64_t)xs.size();
+      xv_base[e] = (int)xv.size();
       for (int j = 0; j < ns[e]; j++)
         for (int i2 = j; i2 < ns[e]; i2++) xs.push_back(L.diag_off[e] + (int64_t)j * ns[e] + i2);
       for (int64_t q = 0; q < (int64_t)ns[e] * nsep[e]; q++) xs.push_back(L.offd_off[e] + q);
@@ -878,8 +881,13 @@ int BuildPlans(cxk_context* ctx) {
   // is resident at once (the way back down waits for HIGHER positions).
   ctx->fused_tree = false;
   ctx->fused_sweep = false;
-  if (!sharded && !ctx->use_ldlt && !ctx->no_lean && !getenv("CXK_NO_FUSED_TREE") && nlev >= 1 && N < (1 << 26)) {
+  ctx->fused_shard = false;
+  // (sharded contexts: the own subtrees up to the cut and, behind the exchange, the replicated top and
+  // the way back down -- two launches, tree_fused.h; CXK_NO_FUSED_SHARD=1 keeps the level kernels there)
+  if ((!sharded || (!getenv("CXK_NO_FUSED_SHARD") && ctx->cut_level >= 1 && ctx->cut_level < nlev)) && !ctx->use_ldlt &&
+      !ctx->no_lean && !getenv("CXK_NO_FUSED_TREE") && nlev >= 1 && N < (1 << 26)) {
     const int cnt_all = (int)ctx->level_sn.size();
+    const int cnt_up = sharded ? ctx->level_ptr[ctx->cut_level] : cnt_all;  // positions below the cut
     bool ok = cnt_all > 0 && cnt_all == ctx->level_ptr[nlev];
     const char* why = ok ? nullptr : "a supernode without columns / beyond LDS";
     auto note = [&](const char* msg) {
@@ -888,7 +896,7 @@ int BuildPlans(cxk_context* ctx) {
     int sa = 0, sb = 0;
     // a program that is ONE dense supernode of 33 .. 64 columns (BASELINE config 2: 50): the wide
     // instances of the same launch (tree_fused.hip, ElimWide)
-    const bool wide_single = ok && cnt_all == 1 && K >= 1 && ns[ctx->level_sn[0]] > 32 && ns[ctx->level_sn[0]] <= 64 &&
+    const bool wide_single = ok && !sharded && cnt_all == 1 && K >= 1 && ns[ctx->level_sn[0]] > 32 && ns[ctx->level_sn[0]] <= 64 &&
                              nsep[ctx->level_sn[0]] == 0 && !getenv("CXK_NO_FUSED_WIDE");
     if (wide_single) {
       sa = sb = ((ns[ctx->level_sn[0]] + 7) / 8 * 8) << 8;
@@ -897,6 +905,7 @@ int BuildPlans(cxk_context* ctx) {
       // the tree has one (same rows per lane: the pull locations tg_reg are the same)
       std::vector<int> shapes;
       for (int l = 0; l < nlev && ok; l++) {
+        if (ctx->level_ptr[l + 1] == ctx->level_ptr[l]) continue;  // (a level this rank has no supernode on)
         ok = ctx->level_lean[l] && !ctx->level_big[l] && ctx->level_nh[l] == ctx->level_ptr[l + 1] - ctx->level_ptr[l];
         for (auto& sg : ctx->level_segs[l])
           if (std::find(shapes.begin(), shapes.end(), sg.shape) == shapes.end()) shapes.push_back(sg.shape);
@@ -933,10 +942,22 @@ int BuildPlans(cxk_context* ctx) {
       const IntList& sp = md.separators_pos[e];
       const int nse = (int)r.size(), nsp = (int)sp.size();
       const int nsm = wide_single ? sa >> 8 : RegisterShape(ns[e], nsep[e]) >> 8;
+      int* w = recs.data() + (size_t)pos * kFusedRecWords;
+      if (pos >= cnt_up) {
+        // the replicated top of a sharded context: the panel comes from the exchange buffer
+        ok = ctx->sn_top[e] && nsm > 0 && xs_base[e] >= 0 && ctx->n_xs < (int64_t)INT32_MAX;
+        note("a top supernode without a register kernel");
+        if (!ok) break;
+        memcpy(w, &h_recs[pos], sizeof(SnRec));
+        w[32] = (int)(xs_base[e] & 0xffffffffll);
+        w[33] = (int)(xs_base[e] >> 32);
+        w[34] = xv_base[e];
+        w[63] = ctx->t_level[e];
+        continue;
+      }
       ok = nse == ns[e] && nsp == nsep[e] && nse + nsp <= 72 && m <= 255 && ctx->owned[i] && nsm > 0;
       note("a supernode that is not its constraint's own block");
       if (!ok) break;
-      int* w = recs.data() + (size_t)pos * kFusedRecWords;
       memcpy(w, &h_recs[pos], sizeof(SnRec));
       AsmRec ar;
       memset(&ar, 0, sizeof(ar));
@@ -1038,10 +1059,34 @@ int BuildPlans(cxk_context* ctx) {
       // residency: every workgroup (one wavefront each, one more for the scalars) at once, with a
       // CU's worth of margin per slot count the occupancy query may overstate; a larger tree takes
       // the way up and the way down as two launches (tree_fused.h, FusedTreeMode)
-      const int occ = FusedTreeOccupancy(sa, sb);
+      const int occ = FusedTreeOccupancy(sa, sb, sharded);
       ok = occ >= 2;
       note("occupancy query failed");
       split = (int64_t)cnt_all + 1 > (int64_t)(occ - 1) * ctx->cus || getenv("CXK_FUSED_SPLIT") != nullptr;
+      if (sharded) {
+        // only the top has to be resident at once (tree_fused.h, kFusedShardTop)
+        ok = ok && (int64_t)(cnt_all - cnt_up) + 1 <= (int64_t)(occ - 1) * ctx->cus;
+        note("the replicated top exceeds the resident wavefronts");
+        split = false;
+      }
+    }
+    if (ok && sharded) {
+      // pack tables: per exchange entry / top variable the record of its own-rank sources
+      std::vector<GatherRec> xg(xs.size() + 1, GatherRec{0, -1, 0, 0});
+      for (size_t t = 0; t < xs.size() && ok; t++) {
+        const int et = entry_of[xs[t]];
+        ok = et >= 0;
+        if (ok) xg[t] = h_as_rec[et];
+      }
+      note("a top entry without a gather record");
+      std::vector<ResidRec> xr(xv.size() + 1, ResidRec{-1, 0, 0});
+      for (size_t j = 0; j < xv.size(); j++) xr[j] = h_rs_rec[xv[j]];
+      if (ok) {
+        CXK_TRY(ctx->fx_xg.upload(xg));
+        CXK_TRY(ctx->fx_xr.upload(xr));
+        CXK_TRY(ctx->fx_done.alloc(1, true));
+        ctx->fx_done_target = 0;
+      }
     }
     if (ok) {
       xreg.resize(xreg.size() + kPullPad, 0);
@@ -1078,10 +1123,13 @@ int BuildPlans(cxk_context* ctx) {
       ctx->fused_gen = 0;
       ctx->fused_tree = true;
       ctx->fused_split = split;
-      ctx->fused_sweep = getenv("CXK_NO_FUSED_SWEEP") == nullptr;
+      ctx->fused_shard = sharded;
+      ctx->fused_up = cnt_up;
+      // (solve-only sweeps of a sharded context keep the level kernels and their own small exchange)
+      ctx->fused_sweep = !sharded && getenv("CXK_NO_FUSED_SWEEP") == nullptr;
       if (getenv("CXK_DEBUG_LEVELS"))
         fprintf(stderr, "whole tree in %s: %d supernodes, shapes <%d,%d> <%d,%d>, %zu entries / %zu variables with further sources\n",
-                split ? "two launches (up, down)" : "one launch", cnt_all, sa >> 8, sa & 255, sb >> 8, sb & 255,
+                sharded ? "two launches around the exchange (own subtrees up + pack, top + down)" : split ? "two launches (up, down)" : "one launch", cnt_all, sa >> 8, sa & 255, sb >> 8, sb & 255,
                 xreg.size() - kPullPad, rsrc.size());
     } else if (getenv("CXK_DEBUG_LEVELS")) {
       fprintf(stderr, "whole-tree launch not taken: %s\n", why ? why : "(unnamed check)");

@@ -71,8 +71,9 @@ struct StepArgs {
   const int* skip_if;
   int skip_tag;
   unsigned long long call;  // index of this PrepareStep / eigenvalue query (Hermitian start vectors)
-  // reference identity (cxk_set_reference_identity / CXK_REFERENCE_QUIRKS=1): the Ritz values go
-  // out exactly as approximate_eigenvalues.cc:178-239 produces them, without the Samuelson clamp
+  // reference identity (the default; off: cxk_set_reference_identity(ctx, 0) / CXK_REFERENCE_QUIRKS=0):
+  // the Ritz values go out exactly as approximate_eigenvalues.cc:178-239 produces them, without the
+  // Samuelson clamp
   int no_clamp;
 };
 

@@ -366,6 +366,21 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
   }
 
   for (int i = 0; i < cfg.max_iterations; i++) {
+    // (state an iteration changes before it knows its factorization's outcome: restored by a redo)
+    const double redo_mu = inv_sqrt_mu, redo_mu_max = inv_sqrt_mu_max, redo_bs = b_scaling, redo_cs = c_scaling;
+    const int redo_centering = centering_steps;
+    const bool redo_aborted = warmstart_aborted;
+#define REDO_ITERATION()                  \
+  {                                       \
+    inv_sqrt_mu = redo_mu;                \
+    inv_sqrt_mu_max = redo_mu_max;        \
+    b_scaling = redo_bs;                  \
+    c_scaling = redo_cs;                  \
+    centering_steps = redo_centering;     \
+    warmstart_aborted = redo_aborted;     \
+    i--;                                  \
+    continue;                             \
+  }
     if (i >= initial_centering_steps) initial_centering = 0;
     if (Verbose()) printf(i < 10 ? "i:  %d, " : "i: %d, ", i);
     const bool final_centering = (inv_sqrt_mu >= inv_sqrt_mu_max) ||
@@ -394,7 +409,9 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     }
     // solver->Factor() :360.  The LLT flag travels back with the next host round trip of this
     // iteration (mu selection or PrepareStep); everything enqueued in between only overwrites
-    // scratch state (y, the step temporaries), so acting on the flag there is equivalent.
+    // scratch state (y, the step temporaries) -- the PrepareStep kernels of the cones that keep
+    // w^{1/2} in W (second-order, quadratic) and every TakeStep kernel read the flag on the device
+    // and leave W alone when it is set -- so acting on the flag there is equivalent.
     // One upward pass serves the factorization and the first solve of the iteration: the
     // right-hand side of the mu selection (ComputeMuFromDivergence) when mu is updated without a
     // line search, the Newton direction itself when mu stays (its value is final before Factor()).
@@ -412,11 +429,15 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     } else {
       if (TIMED(1, cxk_factor_async(ctx))) return 0;
     }
-    enum { kOk, kRetry, kFailed };
+    enum { kOk, kRetry, kFailed, kRedo };
     auto factor_outcome = [&]() -> int {
       int ok = 0;
       if (TIMED(3, cxk_factor_status(ctx, &ok))) return kFailed;
       if (ok) return kOk;
+      // a wait inside the whole-tree launch ran out (shared device): nothing wrong with the matrix,
+      // the context has switched to its level kernels -- the same iteration again (W is untouched:
+      // every kernel that would have changed it looked at the failure flag first)
+      if (cxk_fused_tree_timed_out(ctx) == 1) return kRedo;
       if (i == 0 && cfg.initialization_mode == 1) {
         PRINTSTATUS("Aborting warmstart...");
         cxk_set_identity(ctx);
@@ -455,6 +476,7 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
       }
       {
         const int fo = factor_outcome();  // free: the mu selection above has waited for the stream
+        if (fo == kRedo) REDO_ITERATION();
         if (fo == kRetry) continue;
         if (fo == kFailed) return 0;
       }
@@ -487,6 +509,7 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
         return 0;
       c_weight = inv_sqrt_mu * c_scaling;
       const int fo = factor_outcome();
+      if (fo == kRedo) REDO_ITERATION();
       if (fo == kRetry) continue;
       if (fo == kFailed) return 0;
     } else if (step_on_device) {
@@ -496,6 +519,7 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     }
     if (!update_mu) {
       const int fo = factor_outcome();
+      if (fo == kRedo) REDO_ITERATION();
       if (fo == kRetry) continue;
       if (fo == kFailed) return 0;
     }
@@ -1101,8 +1125,24 @@ int CONEX_HIP_GetPhaseTimes(void* x, double* us5) {
   return cxk_phase_read(p->ctx, us5, 0) == CXK_SUCCESS ? CONEX_SUCCESS : CONEX_FAILURE;
 }
 
-/* not part of conex.h: 1 = reproduce the reference as written where this library deliberately
- * departs from it (conex_kkt_hip.h, cxk_set_reference_identity); default: CXK_REFERENCE_QUIRKS */
+/* not part of conex.h (bench.py's `newton_step`): hipEvent clocks on the kernels of the program's
+ * device context (cxk_enable_timing / cxk_kernel_clock); the context must exist (after a first solve) */
+int CONEX_HIP_KernelClocks(void* x, int period) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || !p->ctx) return CONEX_FAILURE;
+  return cxk_enable_timing(p->ctx, period) == CXK_SUCCESS ? CONEX_SUCCESS : CONEX_FAILURE;
+}
+/* avg_ms[CXK_CLOCK_COUNT], samples[CXK_CLOCK_COUNT] since the last call (the slots are reset) */
+int CONEX_HIP_ReadKernelClocks(void* x, double* avg_ms, int* samples) {
+  Program* p = static_cast<Program*>(x);
+  if (!p || !p->ctx || !avg_ms || !samples) return CONEX_FAILURE;
+  if (cxk_sync(p->ctx, nullptr) != CXK_SUCCESS) return CONEX_FAILURE;  // folds the finished event pairs
+  for (int k = 0; k < CXK_CLOCK_COUNT; k++) samples[k] = cxk_kernel_clock(p->ctx, k, 1, &avg_ms[k]);
+  return CONEX_SUCCESS;
+}
+
+/* not part of conex.h: 1 (the default) = the reference as written, 0 = with the two corrections of
+ * conex_kkt_hip.h (cxk_set_reference_identity); unset: CXK_REFERENCE_QUIRKS in the environment */
 int CONEX_HIP_SetReferenceIdentity(void* x, int on) {
   Program* p = static_cast<Program*>(x);
   if (!p) return CONEX_FAILURE;

@@ -24,12 +24,17 @@ constexpr int kFusedExtraMax = 64;       // ... at most (longer lists: the level
 // Words of a record (position = dependency order: a supernode only waits for lower positions):
 //   [0, 32)   SnRec (kernels_kkt.hip.h); its spare word 23: pub_beg
 //   [32, 56)  AsmRec: the Schur block of the supernode's own constraint and the position of every
-//             panel row in it
+//             panel row in it.  A supernode of the replicated top of a sharded context (its panel
+//             comes from the exchange buffer): 32,33 xs_base, 34 xv_base -- where its slab entries
+//             and its variables start in the buffer
 //   56 xt_beg  57 nxt  58 mx   panel entries with further sources: image location xreg[xt_beg + t],
 //   61,62 xbase                sources xsrc[xbase + t * mx + i] (index into G, -1 none), gather order
 //   59 rbase   60 mr           variables shared with other constraints: ALL their sources in gather
 //                              order rsrc[rbase + row * mr + i] (index into AWc / AQcc, -1 none); a
 //                              row whose list is empty has its own constraint as the one source
+struct GatherRec;
+struct ResidRec;
+
 struct FusedTreeArgs {
   const int* rec;
   int count;  // supernodes = workgroups (one more workgroup sums the two scalars)
@@ -62,6 +67,31 @@ struct FusedTreeArgs {
   double* sys_sc;
   int K;
   double* host_flag;  // pinned host word: set to 1.0 when a wait ran out (the sets are then rebuilt)
+  // ---- sharded contexts (kFusedShardUp / kFusedShardTop).  Positions [0, count_up) are
+  // this rank's own subtrees, [count_up, count) the replicated top of the tree.  The exchange buffer
+  // x = [T slab entries (n_xs) | AW_T | AQc_T | fwd_T (n_xv each) | <w,c> <c,Qc> fail pad] is what ONE
+  // sum all-reduce carries between the two launches (layout of exchange_pack, kernels_kkt.hip.h).
+  int count_up;
+  double* x;
+  long long n_xs;
+  int n_xv;
+  // pack (workgroups behind the supernodes of kFusedShardUp): per exchange entry its own-rank sources
+  // in G (assemble_gather's record over as_src) and the published Schur updates of this rank's
+  // subtrees into it (xs_pt -> pt_ptr / pt_src, hand-off slots); per top variable its own-rank
+  // sources of AW / AQc (xr over rs_src) and the published forward values (pf_ptr / pf_src)
+  const GatherRec* xg;
+  const int64_t* as_src;
+  const int* xs_pt;
+  const int* pt_ptr;
+  const int64_t* pt_src;
+  const ResidRec* xr;
+  const int64_t* rs_src;
+  const int* pf_ptr;
+  const int* pf_src;
+  // every supernode of the up launch counts itself here at its end; the workgroup that writes the
+  // buffer's tail (scalars, failure flag) waits for done_target
+  unsigned long long* done;
+  unsigned long long done_target;
 };
 
 // What a launch does.  A tree whose supernodes are all resident at once takes kFusedFull (assembly,
@@ -69,13 +99,22 @@ struct FusedTreeArgs {
 // substitution on the stored factor); a larger one the same work as two launches each -- kFusedUp
 // then kFusedDown, kFusedForward then kFusedDown -- because a wavefront that waits for its
 // ANCESTORS while it holds a slot could keep them from ever starting.
-enum FusedTreeMode { kFusedFull = 0, kFusedSolve = 1, kFusedUp = 2, kFusedForward = 3, kFusedDown = 4 };
+// Sharded contexts: kFusedShardUp = assembly + factorization + forward substitution of the rank's own
+// subtrees with the PACK of the exchange buffer riding behind them (extra workgroups that wait for the
+// published values); after the all-reduce kFusedShardTop = the replicated top straight from the
+// buffer (the unpack is the top supernodes' load phase), factored and solved, and the back
+// substitution down the own subtrees -- top workgroups first, then the subtrees root side first, so
+// only the top has to be resident at once.
+enum FusedTreeMode { kFusedFull = 0, kFusedSolve = 1, kFusedUp = 2, kFusedForward = 3, kFusedDown = 4,
+                     kFusedShardUp = 5, kFusedShardTop = 6 };
 
 // Register shapes (NSMAX << 8 | SMAX) of the tree's supernodes: at most two (shape_b == shape_a for
 // one).  False when no instance is compiled for the pair.
 bool FusedTreeCompiled(int shape_a, int shape_b);
-// Workgroups per CU the hardware can hold of the instance (0 on error).
-int FusedTreeOccupancy(int shape_a, int shape_b);
-hipError_t LaunchFusedTree(const FusedTreeArgs& a, int shape_a, int shape_b, int mode, hipStream_t stream);
+// Workgroups per CU the hardware can hold of the instance (0 on error); sharded: of kFusedShardTop.
+int FusedTreeOccupancy(int shape_a, int shape_b, bool sharded = false);
+// ev_start / ev_stop (both or neither): a hipEvent pair carried by the dispatch itself (its begin / end time stamps)
+hipError_t LaunchFusedTree(const FusedTreeArgs& a, int shape_a, int shape_b, int mode, hipStream_t stream,
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 
 }  // namespace cxk

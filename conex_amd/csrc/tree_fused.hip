@@ -35,6 +35,7 @@
 // order): the factor, the direction and AW / AQc / <w,c> / <c,Qc> are the bits the level kernels
 // with the separate gather produce.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <type_traits>
 
@@ -94,7 +95,10 @@ __device__ __forceinline__ void ReportTimeout(const FusedTreeArgs& A) {
 // supernode that waited for its ANCESTORS' solution while holding its slot could keep them from ever
 // starting): stops after publishing, leaves the factor and the forward-solved right-hand side in
 // memory; the back substitution is tree_fused_down's.
-template <int NSMAX, int SMAX, bool UP_ONLY = false>
+// FROM_X: a supernode of the replicated top of a sharded context.  Its panel, AW / AQc and the
+// forward values of the subtrees below come from the all-reduced exchange buffer (what
+// exchange_unpack would have put into the slab and y: the unpack is this load phase), nothing from G.
+template <int NSMAX, int SMAX, bool UP_ONLY = false, bool FROM_X = false>
 __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int w, double* __restrict__ my) {
   static_assert(NSMAX + SMAX <= 64, "one lane per panel row");
   constexpr int RB = NSMAX + SMAX, MMAX = kFastSlots, MFMAX = kFastSlots, XMAX = kFusedExtraSlots;
@@ -124,13 +128,26 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   const int npairs = s * (s + 1) / 2, nv = npairs + s;
 
   // ---- load phase, first trip: everything whose address follows from the record
-  const double* Gk = A.G + Join64(f(0), f(1));
-  const int64_t roff = Join64(f(2), f(3));
+  const double* Gk = A.G + (FROM_X ? 0 : Join64(f(0), f(1)));
+  const int64_t roff = FROM_X ? 0 : Join64(f(2), f(3));
   const int M = f(4);
   const int q = is_row ? lane : (is_sep ? ns + sc : 0);
   const int myp = (__builtin_amdgcn_ds_bpermute(4 * (32 + 6 + (q >> 2)), w) >> (8 * (q & 3))) & 255;
   double a[NSMAX + SMAX + 1];
-  {
+  double fwx = 0.0;  // FROM_X: what this rank's ... every rank's subtrees subtract from the right-hand side
+  if constexpr (FROM_X) {
+    // entry (row, j) of the diagonal block sits at xs_base + j ns - j (j - 1) / 2 + (row - j) (lower
+    // triangle, column by column), entry (j, c) of the off block behind the triangle at c ns + j
+    const int64_t xsb = Join64(f(0), f(1));
+    const double* xd = A.x + xsb;
+    const unsigned tri = (unsigned)(ns * (ns + 1) / 2);
+#pragma unroll
+    for (int j = 0; j < NSMAX; j++) {
+      const unsigned dj = (unsigned)(j * ns - j * (j - 1) / 2);
+      const unsigned idx = is_row ? dj + (unsigned)(lane - j) : tri + (unsigned)(sc * ns + j);
+      a[j] = xd[(j < lim) ? idx : 0u];
+    }
+  } else {
     // entry (row, j) of the panel is G(max(p_row, p_j), min(..)) of the own block (lower triangle,
     // column-major).  EVERY lane / column pair gives an address inside the block (positions of
     // padding rows and columns read as 0), so no load needs a predicate or a clamp -- the entries
@@ -146,8 +163,16 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     }
   }
   const int pr = is_row ? myp : (f(6) & 255);
-  double awv = A.AWc[roff + pr];
-  double aqv = A.AQcc[roff + pr];
+  double awv, aqv;
+  if constexpr (FROM_X) {
+    const int64_t xv = A.n_xs + f(2) + (is_row ? lane : 0);
+    awv = A.x[xv];
+    aqv = A.x[xv + A.n_xv];
+    fwx = A.x[xv + 2 * (int64_t)A.n_xv];
+  } else {
+    awv = A.AWc[roff + pr];
+    aqv = A.AQcc[roff + pr];
+  }
   double rb = A.b[R.start + (is_row ? lane : 0)];
   // where this supernode's values go: lane t of round r publishes value number t + 64 r (the
   // s (s + 1) / 2 Schur updates in the reference's S_S enumeration, then the s forward values)
@@ -174,7 +199,7 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     ploc0 = A.tg_reg[R.tg_beg + (lane < ntg ? lane : 0)];
     if (ntg > 64) ploc1 = A.tg_reg[R.tg_beg + (lane + 64 < ntg ? lane + 64 : 0)];
   }
-  const int xt_beg = f(24), nxt = f(25), mx = f(26), rbase = f(27), mr = f(28);
+  const int xt_beg = f(24), nxt = FROM_X ? 0 : f(25), mx = f(26), rbase = f(27), mr = FROM_X ? 0 : f(28);
   const int64_t xbase = Join64(f(29), f(30));
   // ---- entries with further sources (descendants' separator blocks) and shared variables: the
   // lists, then the values (two more trips, while the descendants are still at work)
@@ -259,6 +284,7 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     rb = A.cb * rb + A.cq * aqv + A.cw * awv;
   else
     rb = A.k * (rb * A.bs + aqv * A.cs) - 2 * awv;
+  if constexpr (FROM_X) rb -= fwx;  // (exchange_unpack: y = .. - the forward values of all ranks' subtrees)
 #pragma unroll
   for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? a[j] : 0.0;
 #pragma unroll
@@ -806,6 +832,152 @@ __global__ void __launch_bounds__(64) tree_fused(FusedTreeArgs A) {
   }
 }
 
+// ---- sharded contexts ---------------------------------------------------------------------
+// A value published by one of this rank's supernodes, waited for like every hand-off value.
+__device__ __forceinline__ double WaitValue(const FusedTreeArgs& A, const double* p) {
+  double v = LoadAgent(p);
+  for (int spin = 0; IsSentinel(v); spin++) {
+    if (spin >= kFusedSpinLimit) {
+      atomicExch(A.fail + 1, A.tag);
+      __hip_atomic_store(A.host_flag, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    v = LoadAgent(p);
+  }
+  return v;
+}
+
+// exchange_pack (kernels_kkt.hip.h) riding in the up launch, one lane per buffer entry: the partial
+// assembled value of a top entry -- own-rank sources in the gather's order, what assemble_gather
+// would have left in the slab -- minus the Schur updates this rank's subtrees publish into it (summed
+// in slot order, then subtracted); per top variable the partial AW / AQc and the sum of the
+// published forward values.
+__device__ __forceinline__ void ShardPackItem(const FusedTreeArgs& A, int64_t item) {
+  const double* handG = A.hand + (int64_t)A.gen * A.hand_stride;
+  if (item < A.n_xs) {
+    const GatherRec g = A.xg[item];
+    double s = 0;
+    if (g.first >= 0) s += A.G[g.first];
+    for (int k = g.beg; k < g.beg + g.extra; k++) {
+      const int64_t q = A.as_src[k];
+      if (q >= 0) s += A.G[q];
+    }
+    const int t = A.xs_pt[item];
+    if (t >= 0) {
+      double u = 0;
+      for (int q = A.pt_ptr[t]; q < A.pt_ptr[t + 1]; q++) u += WaitValue(A, handG + A.pt_src[q]);
+      s -= u;
+    }
+    A.x[item] = s;
+  } else if (item < A.n_xs + A.n_xv) {
+    const int64_t j = item - A.n_xs;
+    const ResidRec r = A.xr[j];
+    double aw = 0, aq = 0;
+    if (r.first >= 0) {
+      aw += A.AWc[r.first];
+      aq += A.AQcc[r.first];
+    }
+    for (int k = r.beg; k < r.beg + r.extra; k++) {
+      aw += A.AWc[A.rs_src[k]];
+      aq += A.AQcc[A.rs_src[k]];
+    }
+    double fw = 0;
+    for (int q = A.pf_ptr[j]; q < A.pf_ptr[j + 1]; q++) fw += WaitValue(A, handG + A.updb_base + A.pf_src[q]);
+    A.x[A.n_xs + j] = aw;
+    A.x[A.n_xs + A.n_xv + j] = aq;
+    A.x[A.n_xs + 2 * (int64_t)A.n_xv + j] = fw;
+  }
+}
+
+// The buffer's tail: this rank's part of <w,c> and <c,Qc> (FusedScalars' sums; constraints of other
+// ranks hold zeros) and the failure flag -- read once every supernode of the launch has counted
+// itself done, so that a failed pivot anywhere in this rank's subtrees travels with the exchange.
+__device__ __forceinline__ void ShardPackTail(const FusedTreeArgs& A) {
+  FusedScalars(A);
+  const int lane = threadIdx.x & 63;
+  if (lane == 0) {
+    for (int spin = 0; __hip_atomic_load(A.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < A.done_target; spin++) {
+      if (spin >= kFusedSpinLimit) {
+        atomicExch(A.fail + 1, A.tag);
+        __hip_atomic_store(A.host_flag, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const int64_t o = A.n_xs + 3 * (int64_t)A.n_xv;
+    const int f0 = __hip_atomic_load(A.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int f1 = __hip_atomic_load(A.fail + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    A.x[o] = A.sys_sc[0];
+    A.x[o + 1] = A.sys_sc[1];
+    A.x[o + 2] = (f0 != 0 || (A.tag != 0 && f1 == A.tag)) ? 1.0 : 0.0;
+    A.x[o + 3] = 0;
+  }
+}
+
+// kFusedShardUp: workgroups [0, count_up) the rank's own subtrees (UP_ONLY: factor, forward-solved
+// right-hand side and AW / AQc go to memory), then the pack of the exchange buffer (64 entries per
+// workgroup), then its tail.
+template <int NA, int SA, int NB, int SB>
+__global__ void __launch_bounds__(64) tree_fused_shard_up(FusedTreeArgs A) {
+  extern __shared__ double lds[];
+  const int pos = blockIdx.x;
+  if (pos < A.count_up) {
+    const int w = A.rec[(size_t)pos * kFusedRecWords + (threadIdx.x & 63)];
+    const int ns = __builtin_amdgcn_readlane(w, 1), s = __builtin_amdgcn_readlane(w, 2);
+    if (NA == NB && SA == SB) {
+      FusedSupernode<NA, SA, true>(A, w, lds);
+    } else if (RegisterShape(ns, s) == (NA << 8 | SA)) {
+      FusedSupernode<NA, SA, true>(A, w, lds);
+    } else {
+      FusedSupernode<NB, SB, true>(A, w, lds);
+    }
+    // (behind this wavefront's stores and its failure report, if any)
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(A.done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  const int64_t items = A.n_xs + A.n_xv;
+  const int64_t first = (int64_t)(pos - A.count_up) * 64;
+  if (first < items) {
+    ShardPackItem(A, first + (threadIdx.x & 63));
+    return;
+  }
+  ShardPackTail(A);
+}
+
+// kFusedShardTop: the top supernodes first (all resident: they wait for each other in both
+// directions), then this rank's subtrees root side first (a supernode waits for its ancestors only),
+// then the buffer's tail (scalars, failure flag).
+template <int NA, int SA, int NB, int SB>
+__global__ void __launch_bounds__(64) tree_fused_shard_top(FusedTreeArgs A) {
+  extern __shared__ double lds[];
+  const int b = blockIdx.x, ntop = A.count - A.count_up;
+  if (b >= A.count) {
+    if ((threadIdx.x & 63) == 0) {
+      const int64_t o = A.n_xs + 3 * (int64_t)A.n_xv;
+      A.sys_sc[0] = A.x[o];
+      A.sys_sc[1] = A.x[o + 1];
+      if (A.x[o + 2] > 0.0) *A.fail = 1;
+    }
+    return;
+  }
+  const int pos = b < ntop ? A.count_up + b : A.count - 1 - b;
+  const int w = A.rec[(size_t)pos * kFusedRecWords + (threadIdx.x & 63)];
+  const int ns = __builtin_amdgcn_readlane(w, 1), s = __builtin_amdgcn_readlane(w, 2);
+  const bool isA = (NA == NB && SA == SB) || RegisterShape(ns, s) == (NA << 8 | SA);
+  if (b < ntop) {
+    if (isA)
+      FusedSupernode<NA, SA, false, true>(A, w, lds);
+    else
+      FusedSupernode<NB, SB, false, true>(A, w, lds);
+  } else {
+    if (isA)
+      FusedSolveSupernode<NA, SA, 2>(A, w);
+    else
+      FusedSolveSupernode<NB, SB, 2>(A, w);
+  }
+}
+
 // PHASE 0: forward + back substitution in one launch; 1: forward only; 2: back substitution only,
 // workgroups in REVERSE position order (the root first: a supernode waits for its ancestors)
 template <int NA, int SA, int NB, int SB, int PHASE>
@@ -827,7 +999,7 @@ namespace {
 constexpr int FusedImage(int nsmax, int smax) { return 65 * nsmax > 64 * (smax + 1) ? 65 * nsmax : 64 * (smax + 1); }
 
 struct FusedKernels {
-  const void* k[5];  // FusedTreeMode order
+  const void* k[7];  // FusedTreeMode order
   int image;         // doubles of LDS of the factor sweeps
 };
 
@@ -839,6 +1011,12 @@ FusedKernels KernelsOf() {
   f.k[kFusedUp] = reinterpret_cast<const void*>(&tree_fused<NA, SA, NB, SB, 1>);
   f.k[kFusedForward] = reinterpret_cast<const void*>(&tree_fused_solve<NA, SA, NB, SB, 1>);
   f.k[kFusedDown] = reinterpret_cast<const void*>(&tree_fused_solve<NA, SA, NB, SB, 2>);
+  f.k[kFusedShardUp] = nullptr;
+  f.k[kFusedShardTop] = nullptr;
+  if constexpr (NA <= 32 && NB <= 32) {  // (the wide single-supernode instances are single-GPU)
+    f.k[kFusedShardUp] = reinterpret_cast<const void*>(&tree_fused_shard_up<NA, SA, NB, SB>);
+    f.k[kFusedShardTop] = reinterpret_cast<const void*>(&tree_fused_shard_top<NA, SA, NB, SB>);
+  }
   f.image = FusedImage(NA, SA) > FusedImage(NB, SB) ? FusedImage(NA, SA) : FusedImage(NB, SB);
   return f;
 }
@@ -875,24 +1053,35 @@ bool ForPair(int sa, int sb, FusedKernels* out) {
 
 bool FusedTreeCompiled(int sa, int sb) { return ForPair(sa, sb, nullptr); }
 
-int FusedTreeOccupancy(int sa, int sb) {
+int FusedTreeOccupancy(int sa, int sb, bool sharded) {
   FusedKernels f;
   if (!ForPair(sa, sb, &f)) return 0;
   int nb = 0, nbs = 0;
+  if (sharded) {
+    if (!f.k[kFusedShardTop]) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f.k[kFusedShardTop], 64, sizeof(double) * (size_t)f.image) != hipSuccess) return 0;
+    return nb;
+  }
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f.k[kFusedFull], 64, sizeof(double) * (size_t)f.image) != hipSuccess) return 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, f.k[kFusedSolve], 64, 0) != hipSuccess) return 0;
   return nb < nbs ? nb : nbs;
 }
 
-hipError_t LaunchFusedTree(const FusedTreeArgs& a, int sa, int sb, int mode, hipStream_t stream) {
+hipError_t LaunchFusedTree(const FusedTreeArgs& a, int sa, int sb, int mode, hipStream_t stream, hipEvent_t ev_start,
+                           hipEvent_t ev_stop) {
   FusedKernels f;
-  if (mode < 0 || mode > kFusedDown || !ForPair(sa, sb, &f)) return hipErrorInvalidValue;
-  const bool factor = mode == kFusedFull || mode == kFusedUp;
+  if (mode < 0 || mode > kFusedShardTop || !ForPair(sa, sb, &f) || !f.k[mode]) return hipErrorInvalidValue;
+  const bool factor = mode == kFusedFull || mode == kFusedUp || mode == kFusedShardUp || mode == kFusedShardTop;
   FusedTreeArgs args = a;
   void* params[] = {&args};
-  // (the factor sweeps' extra workgroup sums the two scalars)
-  return hipLaunchKernel(f.k[mode], dim3(a.count + (factor ? 1 : 0)), dim3(64), params,
-                         factor ? sizeof(double) * (size_t)f.image : 0, stream);
+  // (the factor sweeps' extra workgroup sums the two scalars; the sharded up launch carries the pack of
+  // the exchange buffer -- 64 entries per workgroup -- and its tail behind the supernodes)
+  int nwg = a.count + (factor ? 1 : 0);
+  if (mode == kFusedShardUp) nwg = a.count_up + (int)((a.n_xs + a.n_xv + 63) / 64) + 1;
+  const dim3 grid(nwg);
+  const size_t lds = factor ? sizeof(double) * (size_t)f.image : 0;
+  if (ev_start && ev_stop) return hipExtLaunchKernel(f.k[mode], grid, dim3(64), params, lds, stream, ev_start, ev_stop, 0);
+  return hipLaunchKernel(f.k[mode], grid, dim3(64), params, lds, stream);
 }
 
 }  // namespace cxk

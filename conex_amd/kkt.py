@@ -117,6 +117,9 @@ _SIGNATURES = {
                                                   C.POINTER(C.c_int), c_double_p]),
     "cxk_kernel_time": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     "cxk_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "cxk_kernel_clock": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p]),
+    "cxk_fused_tree_timed_out": (C.c_int, [C.c_void_p]),
+    "cxk_debug_force_fused_timeout": (C.c_int, [C.c_void_p]),
     "cxk_set_iterative_refinement": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
@@ -630,6 +633,21 @@ class KktContext:
         ms = C.c_double()
         n = self.L.cxk_kernel_time(self.h, int(reset), C.byref(ms))
         return n, ms.value
+
+    CLOCKS = {"assembly": 0, "tree": 1, "solve": 2, "query": 3, "prepare": 4, "take": 5}
+
+    def kernel_clock(self, which, reset=True):
+        """(samples, average ms) of a kernel clock slot (cxk_kernel_clock; names in CLOCKS)."""
+        ms = C.c_double()
+        n = self.L.cxk_kernel_clock(self.h, self.CLOCKS[which] if isinstance(which, str) else int(which),
+                                    int(reset), C.byref(ms))
+        return n, ms.value
+
+    def fused_tree_timed_out(self):
+        return bool(self.L.cxk_fused_tree_timed_out(self.h))
+
+    def debug_force_fused_timeout(self):
+        self._check(self.L.cxk_debug_force_fused_timeout(self.h), "cxk_debug_force_fused_timeout")
 
 
 def gemm_f64(A, B, C=None, ta=False, tb=False, alpha=1.0, beta=0.0, lower_only=False, splits=1,

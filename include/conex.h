@@ -19,15 +19,15 @@
  * (interfaces/conex.cc:143-223), outputs are caller-allocated, matrices are column-major, a
  * program handle is not thread-safe, separate handles are independent.
  *
- * Default behaviour vs the reference as written: results equal the reference algorithm's to
- * rounding, with two deliberate exceptions that are ON by default -- a constraint's Schur block is
- * always scattered by variable position (the reference misplaces it on rare fill-in structures,
+ * Default behaviour: the reference algorithm as written, results equal to rounding.  Two
+ * corrections of the reference are available and OFF by default -- a constraint's Schur block
+ * scattered by variable position also where the reference misplaces it (rare fill-in structures,
  * supernodal_assembler.cc:72-91), and the Lanczos eigenvalue estimates that set the step length
- * are clamped to a bound that provably contains the spectrum (psd_constraint.cc:45-84,
- * approximate_eigenvalues.cc:178-239 return them unclamped).  CXK_REFERENCE_QUIRKS=1 in the
- * environment (or the extra symbol CONEX_HIP_SetReferenceIdentity(program, 1)) switches both
- * off: CONEX_Maximize then reproduces the reference algorithm's mu sequence iteration for
- * iteration.
+ * clamped to a bound that provably contains the spectrum (psd_constraint.cc:45-84,
+ * approximate_eigenvalues.cc:178-239 return them unclamped).  CXK_REFERENCE_QUIRKS=0 in the
+ * environment (or the extra symbol CONEX_HIP_SetReferenceIdentity(program, 0)) switches both
+ * on; without them CONEX_Maximize reproduces the reference algorithm's mu sequence iteration
+ * for iteration.
  */
 #ifndef CONEX_API_H
 #define CONEX_API_H

@@ -93,25 +93,25 @@ int cxk_num_constraints(const cxk_context* ctx);
  * exchange slab that the caller sum-reduces across ranks (RCCL all-reduce). */
 int cxk_set_shard(cxk_context* ctx, int rank, int world_size);
 
-/* Reference identity (one switch for every place where this library deliberately departs from the
- * reference as written; must precede cxk_finalize; default off, or CXK_REFERENCE_QUIRKS=1 in the
- * environment):
- *   (i)  a constraint's Schur block lands where BindDiagonalBlock's unchecked direct_update test
- *        puts it on fill-in supernodes (supernodal_assembler.cc:72-91) instead of being scattered
- *        by position (a defect of the reference on rare structures);
- *   (ii) PrepareStep / GetWeightedSlackEigenvalues return the Lanczos Ritz values exactly as
- *        approximate_eigenvalues.cc:178-239 produces them; by default they are clamped to
- *        Samuelson's bound on the spectrum of W S (a noise-dominated Lanczos run near convergence
- *        otherwise yields an eigenvalue far outside the spectrum and a needlessly small step).
- * With the switch on, CONEX_Maximize reproduces the iteration count and mu sequence of the
- * reference algorithm (tests/test_gpu_solver.py::test_reference_identity_reproduces_the_oracle_trajectory). */
+/* Reference identity: ON by default -- the library computes what the reference as written computes.
+ * cxk_set_reference_identity(ctx, 0) (before cxk_finalize; or CXK_REFERENCE_QUIRKS=0 in the
+ * environment) opts into two corrections of the reference:
+ *   (i)  a constraint's Schur block is scattered by variable position also on fill-in supernodes,
+ *        where BindDiagonalBlock's unchecked direct_update test (supernodal_assembler.cc:72-91)
+ *        puts it one row and column off (a defect on rare structures);
+ *   (ii) the Lanczos Ritz values of PrepareStep / GetWeightedSlackEigenvalues
+ *        (approximate_eigenvalues.cc:178-239) are clamped to Samuelson's bound on the spectrum of
+ *        W S (a noise-dominated Lanczos run near convergence otherwise yields an eigenvalue far
+ *        outside the spectrum and a needlessly small step).
+ * With identity on, CONEX_Maximize reproduces the iteration count and mu sequence of the reference
+ * algorithm (tests/test_gpu_solver.py::test_reference_identity_reproduces_the_oracle_trajectory). */
 int cxk_set_reference_identity(cxk_context* ctx, int on);
 
 /* Initialize(): symbolic analysis (SupernodalKKTSolver ctor kkt_solver.cc:104-116),
  * Bind (kkt_solver.h:26-33), workspace carve + SetIdentity (cone_program.cc:78-112),
  * upload of constant data, construction of device index tables and level schedule.
  * Environment read here: CXK_SPARSE_LMI=0/1 (force the dense / sparse LMI evaluation),
- * CXK_REFERENCE_QUIRKS=1 (= cxk_set_reference_identity(ctx, 1) unless that was called). */
+ * CXK_REFERENCE_QUIRKS=0 (= cxk_set_reference_identity(ctx, 0) unless that was called). */
 int cxk_finalize(cxk_context* ctx);
 
 /* ---- symbolic results (MatrixData supernodal_solver.h:18-29; bit-exact vs reference) */
@@ -369,6 +369,17 @@ int cxk_fused_assembly(const cxk_context* ctx);
 /* 1 when a KKT solve (assembly gather + factorization + solve) runs as ONE launch over the whole
  * elimination tree (tree_fused.hip); CXK_NO_FUSED_TREE=1 in the environment turns it off */
 int cxk_fused_tree(const cxk_context* ctx);
+/* The whole-tree launch keeps every supernode's wavefront resident and lets it wait, inside the
+ * kernel, for its descendants' values: deadlock-free while the launch has the device to itself
+ * (grid <= resident slots, workgroups dispatched in index order), every wait bounded.  On a device
+ * shared with other streams or processes a wait can run out.  That is not a failed factorization:
+ * the context then gives the whole-tree launch up for good and sweeps level by level (kernel
+ * boundaries instead of in-kernel waits).  cxk_sync redoes the pending factor-and-solve that way
+ * itself; cxk_factor_status reports failure and this function returns 1 ONCE, so that an
+ * interior-point loop (program.cc) redoes its iteration instead of giving up. */
+int cxk_fused_tree_timed_out(cxk_context* ctx);
+/* test hook: pretend the latest whole-tree launch reported a wait that ran out */
+int cxk_debug_force_fused_timeout(cxk_context* ctx);
 
 /* ---- timing / roofline accounting -------------------------------------- */
 /* algorithmic bytes and flops of one dense-LMI assembly launch (SURVEY 8d formulas) */
@@ -376,6 +387,15 @@ int cxk_assembly_work(const cxk_context* ctx, double* bytes, double* flops);
 /* average device time (ms) of the dominant assembly kernel since the last reset, measured
  * with hipEvents on the context's stream; returns number of samples */
 int cxk_kernel_time(cxk_context* ctx, int reset, double* avg_ms);
+/* the same for the other kernels of a Newton step (bench.py's `roofline_tree` and `newton_step`):
+ * which = CXK_CLOCK_ASSEMBLY (what cxk_kernel_time reads), _TREE the tree launch(es) of a
+ * factor-and-solve, _SOLVE a solve-only sweep, _QUERY the eigenvalue query, _PREPARE, _TAKE.  A slot
+ * that is one kernel carries the event pair on its dispatch (the kernel's own begin / end time
+ * stamps); a slot of several launches is bracketed and includes their boundaries
+ * (DESIGN.md section 6 lists which slot is which at every configuration). */
+enum { CXK_CLOCK_ASSEMBLY = 0, CXK_CLOCK_TREE = 1, CXK_CLOCK_SOLVE = 2, CXK_CLOCK_QUERY = 3,
+       CXK_CLOCK_PREPARE = 4, CXK_CLOCK_TAKE = 5, CXK_CLOCK_COUNT = 6 };
+int cxk_kernel_clock(cxk_context* ctx, int which, int reset, double* avg_ms);
 /* on = 0: off; on = 1: bracket every launch of that kernel with a hipEvent pair; on = P > 1:
  * every P-th launch (an event pair costs a few us of stream time, sampling keeps the timed
  * region representative) */

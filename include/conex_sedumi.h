@@ -24,6 +24,15 @@
  * components of that support, each completed to a dense diagonal block.  A block-diagonal SDP given
  * as one large (arbitrarily permuted) LMI thus becomes several small LMIs, each over the variables
  * that touch it -- which is what feeds the clique path of the solver.
+ *
+ * One documented divergence from conex.m: options.blkdiag = 1 with a SINGLE PSD block.  conex.m
+ * preprocesses the problem and then, in its length(K.s) == 1 branch (conex.m:45-49), hands the
+ * ORIGINAL matrices to AddDenseLinearMatrixInequality reshaped with the REDUCED block's order --
+ * a reshape error (or a wrong program) whenever the preprocessing changed anything.  This front end
+ * gives the solver the preprocessed blocks in that case as in every other (the single block is
+ * split into its connected components; tests/test_sedumi_frontend.py pins it).  With the default
+ * (blkdiag = -1: off for one block) and with blkdiag = 0 a single block is solved as one dense LMI
+ * over the cleaned rows, exactly as conex.m does.
  */
 #ifndef CONEX_SEDUMI_H
 #define CONEX_SEDUMI_H

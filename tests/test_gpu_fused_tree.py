@@ -169,3 +169,93 @@ def test_fused_tree_on_the_mixed_program_shapes():
             k.kkt_solve_async(mu, 0.9, 0.8)
             assert k.sync()
         assert_same(snapshot(fused), snapshot(levels))
+
+
+def test_a_timed_out_wait_falls_back_to_the_level_kernels():
+    """A wait inside the whole-tree launch that runs out (a device shared with other work) is not a
+    failed factorization: cxk_sync redoes the factor-and-solve on the level kernels, reports success,
+    and the context stays on them (include/conex_kkt_hip.h, cxk_fused_tree_timed_out)."""
+    prob = syn.lmi_problem(K=60, n=20, m=20, branching=4, overlap=5, seed=41)
+    W = syn.scaling_points(60, 20, seed=42)
+    k = syn.build(KktContext, prob, "lmi", device=0)
+    o = syn.build(ol.Program, prob, "lmi")
+    for i in range(k.K):
+        k.set_W(i, W[i])
+        o.set_W(i, W[i])
+    k.set_cost(prob["b"])
+    assert k.fused_tree()
+    k.kkt_solve_async(0.7, 0.9, 0.8)
+    assert k.sync() == 1
+    y_fused = k.get_y().copy()
+    k.kkt_solve_async(0.7, 0.9, 0.8)
+    k.debug_force_fused_timeout()          # as if that launch had reported a wait that ran out
+    assert k.sync() == 1                   # redone level by level, not reported as a failure
+    assert not k.fused_tree()
+    oko, yo = o.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    assert oko == 1
+    assert np.linalg.norm(k.get_y() - yo) <= 1e-10 * np.linalg.norm(yo)
+    assert np.linalg.norm(k.get_y() - y_fused) <= 1e-12 * np.linalg.norm(y_fused)
+    k.kkt_solve_async(0.7, 0.9, 0.8)       # and the context keeps working on the level kernels
+    assert k.sync() == 1
+    assert np.linalg.norm(k.get_y() - yo) <= 1e-10 * np.linalg.norm(yo)
+
+
+def test_a_timed_out_wait_inside_conex_maximize_redoes_the_iteration(monkeypatch):
+    """program.cc: a time-out reported by cxk_factor_status makes the interior-point loop redo the
+    iteration (W is untouched: TakeStep looked at the flag) instead of ending with 'Factorization
+    failed'.  The hook arms the time-out through the environment for the second iteration."""
+    import ctypes as C
+    import conex_api as ca
+    prob = syn.lmi_problem(K=40, n=20, m=20, branching=3, overlap=5, seed=43)
+    L = ca.api()
+
+    def solve(force_at):
+        if force_at is None:
+            monkeypatch.delenv("CXK_DEBUG_FUSED_TIMEOUT_AT", raising=False)
+        else:
+            monkeypatch.setenv("CXK_DEBUG_FUSED_TIMEOUT_AT", str(force_at))
+        p = L.CONEX_CreateConeProgram()
+        assert L.CONEX_SetNumberOfVariables(p, prob["num_vars"]) == 0
+        for c, cl in enumerate(prob["cliques"]):
+            a, cm = ca.colmajor(prob["A"][c]), ca.colmajor(prob["C"][c])
+            v = np.ascontiguousarray(cl, dtype=np.int64)
+            assert L.CONEX_AddSparseLMIConstraint(p, ca.dp(a), 20, 20, 20, ca.dp(cm), 20, 20,
+                                                  v.ctypes.data_as(C.POINTER(C.c_long)), 20) == c
+        cfg = ca.default_config()
+        b = np.ascontiguousarray(prob["b"])
+        y = np.zeros(len(b))
+        ok = L.CONEX_Maximize(p, ca.dp(b), len(b), C.byref(cfg), ca.dp(y), len(b))
+        st = ca.IterationStats()
+        L.CONEX_GetIterationStats(p, C.byref(st), -1)
+        L.CONEX_DeleteConeProgram(p)
+        return ok, y, st.iteration_number + 1
+
+    ok0, y0, it0 = solve(None)
+    ok1, y1, it1 = solve(2)
+    assert ok0 == 1 and ok1 == 1          # (without the redo: "Factorization failed", ok1 == 0)
+    # from the redone iteration on the sweeps are the level kernels' (direction equal to 1e-15, not bit for
+    # bit), and the raw Lanczos estimates amplify that near convergence: same optimum, +- an iteration
+    assert abs(it1 - it0) <= 2
+    assert abs(prob["b"] @ y1 - prob["b"] @ y0) <= 1e-6 * abs(prob["b"] @ y0)
+    assert np.linalg.norm(y1 - y0) <= 1e-3 * np.linalg.norm(y0)
+
+
+def test_kernel_clocks_report_the_launches_of_a_step():
+    prob = syn.lmi_problem(K=100, n=20, m=20, branching=8, overlap=5, seed=31)
+    W = syn.scaling_points(100, 20, seed=32)
+    k = syn.build(KktContext, prob, "lmi", device=0)
+    for i in range(k.K):
+        k.set_W(i, W[i])
+    k.set_cost(prob["b"])
+    k.kkt_solve_async(0.7, 0.9, 0.8)
+    assert k.sync() == 1
+    k.enable_timing(1)
+    for _ in range(5):
+        k.kkt_solve_async(0.7, 0.9, 0.8)
+    assert k.sync() == 1
+    k.enable_timing(False)
+    na, ta = k.kernel_clock("assembly")
+    nt, tt = k.kernel_clock("tree")
+    assert na == 5 and nt == 5
+    assert 1e-3 < ta < 1.0 and 1e-3 < tt < 1.0     # milliseconds: a few microseconds up to a millisecond
+    assert k.kernel_clock("prepare")[0] == 0

@@ -1,4 +1,5 @@
-"""A defect of the reference's assembly that the HIP path does not reproduce.
+"""A defect of the reference's assembly: reproduced by default (reference identity), corrected
+behind cxk_set_reference_identity(ctx, 0) / CXK_REFERENCE_QUIRKS=0.
 
 BindDiagonalBlock (supernodal_assembler.cc:72-91) aliases a constraint's Schur block G onto its
 supernode's diagonal block ("direct_update") when the supernode has as many variables as the
@@ -10,7 +11,8 @@ last variable, which sits in the separator, never reaches its place.  The assemb
 not sum_c P_c^T G_c P_c.
 
 The oracle restates the reference as written (so it has the defect) and offers the corrected test
-behind cxo_set_strict_direct_update(1).  The HIP path always scatters by position.  Found by the
+behind cxo_set_strict_direct_update(1).  The HIP path does the same behind its own switch: as
+written by default, every block scattered by position with reference identity off.  Found by the
 randomised structure sweep (seed 1657 of tests/test_gpu_random_structures.py: 54 mixed cones,
 N = 715; the first such case in 700 random programs).
 """
@@ -82,8 +84,9 @@ def test_corrected_test_restores_the_sum_of_blocks(strict):
 
 
 @pytest.mark.gpu
-def test_hip_path_equals_the_corrected_reference(strict):
+def test_hip_path_with_the_correction_equals_the_corrected_reference(strict, monkeypatch):
     from conex_amd import KktContext
+    monkeypatch.setenv("CXK_REFERENCE_QUIRKS", "0")
     prob = random_program(SEED)
     o, k = build(ol.Program, prob), build(KktContext, prob, device=0)
     o.assemble()
@@ -99,23 +102,24 @@ def test_hip_path_equals_the_corrected_reference(strict):
 
 
 @pytest.mark.gpu
-def test_hip_path_differs_from_the_reference_as_written_here():
+def test_corrected_hip_path_differs_from_the_reference_as_written_here(monkeypatch):
     from conex_amd import KktContext
+    monkeypatch.setenv("CXK_REFERENCE_QUIRKS", "0")
     prob = random_program(SEED)
     o, k = build(ol.Program, prob), build(KktContext, prob, device=0)
     ok_o, yo = o.kkt_solve(prob["b"], 0.3, 0.9, 0.8)
     k.set_cost(prob["b"])
     k.kkt_solve_async(0.3, 0.9, 0.8)
     assert ok_o == 1 and k.sync()
-    assert rel(k.get_y(), yo) > 1e-4      # documented deviation: the reference's direction is off here
+    assert rel(k.get_y(), yo) > 1e-4      # what the correction is for: the reference's direction is off here
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [SEED, 2585])
-def test_reference_quirks_mode_reproduces_the_reference_as_written(monkeypatch, seed):
-    """CXK_REFERENCE_QUIRKS=1: the HIP path places the block where the reference does."""
+def test_default_mode_reproduces_the_reference_as_written(monkeypatch, seed):
+    """Reference identity (the default): the HIP path places the block where the reference does."""
     from conex_amd import KktContext
-    monkeypatch.setenv("CXK_REFERENCE_QUIRKS", "1")
+    monkeypatch.delenv("CXK_REFERENCE_QUIRKS", raising=False)
     prob = random_program(seed)
     o, k = build(ol.Program, prob), build(KktContext, prob, device=0)
     o.assemble()

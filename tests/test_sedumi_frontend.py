@@ -118,6 +118,20 @@ def test_block_splitting_equals_the_matlab_restatement(seed, big, parts, m):
     same_preprocessing(sedumi.preprocess(A2, b, c, {"s": Ks}, blkdiag=1), oracle.preprocess(A2, b, c, Ks, blkdiag=True))
 
 
+def test_single_psd_block_with_blkdiag_is_split_not_handed_over_whole():
+    """The documented divergence from conex.m (include/conex_sedumi.h): with pars.blkdiag = 1 and ONE
+    PSD block, conex.m:45-49 passes the unreduced matrices with the reduced order (a reshape error
+    whenever the preprocessing did anything); this front end hands the solver the preprocessed
+    blocks.  With conex.m's default (blkdiag off for a single block) the block stays whole."""
+    A, b, c, Ks, _ = hidden_blocks(11, [8], [[3, 5]], 6)
+    assert len(Ks) == 1
+    split = sedumi.preprocess(A, b, c, {"s": Ks}, blkdiag=1)
+    assert sorted(blk["order"] for blk in split["blocks"]) == [3, 5]
+    for mode in (-1, 0):
+        whole = sedumi.preprocess(A, b, c, {"s": Ks}, blkdiag=mode)
+        assert [blk["order"] for blk in whole["blocks"]] == [8]
+
+
 def test_triplets_add_up_and_bad_input_is_refused():
     import scipy.sparse as sp
     A, b, c, Ks, _ = hidden_blocks(7, [5], [[2, 3]], 4)

@@ -194,8 +194,17 @@ def _newton_iteration(k, prob, W, owned_only):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,world", [("lmi", 2), ("lmi", 3), ("c4", 4), ("mixed", 2), ("mixed", 5)])
-def test_sharded_newton_iteration_through_the_library_collectives(kind, world):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("kind,world", [("lmi", 2), ("lmi", 3), ("c4", 4), ("c4", 8), ("mixed", 2), ("mixed", 5)])
+def test_sharded_newton_iteration_through_the_library_collectives(monkeypatch, kind, world, fused):
+    """fused: the factor-and-solve of a rank runs on the whole-tree kernels -- own subtrees up with the
+    pack of the exchange buffer behind them, all-reduce, top straight from the buffer and the way back
+    down: two launches (tree_fused.h, kFusedShardUp / kFusedShardTop); CXK_NO_FUSED_SHARD=1 keeps the
+    level kernels with the separate pack / unpack launches.  Both must reproduce the single context."""
+    if fused:
+        monkeypatch.delenv("CXK_NO_FUSED_SHARD", raising=False)
+    else:
+        monkeypatch.setenv("CXK_NO_FUSED_SHARD", "1")
     prob, W = _program(kind, 11)
     build_kind = "mixed" if kind == "mixed" else "lmi"
     ref = _newton_iteration(syn.build(KktContext, prob, build_kind, device=0), prob, W, False)
@@ -213,9 +222,12 @@ def test_sharded_newton_iteration_through_the_library_collectives(kind, world):
         k.initialize()
         k.comm_set_allreduce(allreduce)
         k.set_cost(prob["b"])
-        return _newton_iteration(k, prob, W, True)
+        out = _newton_iteration(k, prob, W, True)
+        out["fused_tree"] = k.fused_tree()
+        return out
 
     for out in ThreadRanks(world).run(body):
+        assert out["fused_tree"] == fused
         for key in ("y", "y2", "y3"):
             assert np.linalg.norm(out[key] - ref[key]) <= 1e-10 * np.linalg.norm(ref[key]), key
         assert np.allclose(out["eig"], ref["eig"], rtol=1e-9, atol=0)
