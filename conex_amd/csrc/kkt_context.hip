@@ -1849,6 +1849,13 @@ int cxk_comm_set_allreduce(cxk_context* ctx, cxk_allreduce_fn fn, void* user) {
   return CXK_SUCCESS;
 }
 
+int cxk_set_chain_segments(cxk_context* ctx, int segments) {
+  if (!ctx || ctx->finalized || segments < 0) return CXK_FAILURE;
+  ctx->chain_segments = segments;
+  return CXK_SUCCESS;
+}
+int cxk_chain_segments(const cxk_context* ctx) { return ctx && ctx->finalized ? ctx->segments : 0; }
+
 int cxk_set_reference_identity(cxk_context* ctx, int on) {
   if (!ctx || ctx->finalized) return CXK_FAILURE;
   ctx->reference_identity = on != 0;
@@ -1880,6 +1887,29 @@ static int FinalizeImpl(cxk_context* ctx) {
   try {
     ctx->md = Analyze(ctx->cliques, ctx->dual_vars);
     ctx->lay = BuildLayout(ctx->md);
+    // what the library REPORTS (cxk_get_order / _permutation / _list / _block_offsets ...) is always the
+    // reference's structure; the factorization of a long chain-shaped tree runs in a segment-parallel
+    // order of its own (symbolic.h, SegmentChain): CXK_CHAIN_SEGMENTS=0 keeps the reference's order,
+    // =P asks for P segments, unset = automatic for chains of at least kAutoChainSteps steps
+    ctx->md_ref = ctx->md;
+    ctx->lay_ref = ctx->lay;
+    ctx->segments = 0;
+    constexpr int kAutoChainSteps = 256;
+    int want = ctx->chain_segments;
+    if (want < 0)
+      if (const char* v = getenv("CXK_CHAIN_SEGMENTS")) want = atoi(v);
+    if (want != 0 && ctx->md.K >= (want > 0 ? 4 : kAutoChainSteps) && IsChain(ctx->md)) {
+      // the deferred variables end up in ONE root supernode: beyond LDS on one GPU (the blocked
+      // big-supernode path), inside LDS on a sharded context (which has no such path)
+      int P = want > 1 ? want : (ctx->world > 1 ? 48 : 128);
+      P = std::min(P, ctx->md.K / 4);
+      MatrixData seg;
+      if (P >= 2 && SegmentChain(ctx->md, ctx->cliques, ctx->dual_vars, P, &seg)) {
+        ctx->md = seg;
+        ctx->lay = BuildLayout(ctx->md);
+        ctx->segments = P;
+      }
+    }
   } catch (const std::exception& e) {
     return Fail(ctx, e.what());
   }
@@ -2149,19 +2179,28 @@ int cxk_get_order(const cxk_context* ctx, int* order) {
 }
 int cxk_get_permutation(const cxk_context* ctx, int* perm, int* perm_inv) {
   if (!ctx || !ctx->finalized) return 0;
-  std::copy(ctx->md.permutation.begin(), ctx->md.permutation.end(), perm);
-  std::copy(ctx->md.permutation_inverse.begin(), ctx->md.permutation_inverse.end(), perm_inv);
-  return ctx->md.num_vars;
+  std::copy(ctx->md_ref.permutation.begin(), ctx->md_ref.permutation.end(), perm);
+  std::copy(ctx->md_ref.permutation_inverse.begin(), ctx->md_ref.permutation_inverse.end(), perm_inv);
+  return ctx->md_ref.num_vars;
 }
 int cxk_get_list(const cxk_context* ctx, int which, int e, int* out) {
-  if (!ctx || !ctx->finalized || e < 0 || e >= ctx->md.K) return -1;
+  if (!ctx || !ctx->finalized || e < 0 || e >= ctx->md_ref.K) return -1;
   const IntList* v = nullptr;
   switch (which) {
-    case 0: v = &ctx->md.cliques[e]; break;
-    case 1: v = &ctx->md.supernodes_orig[e]; break;
-    case 2: v = &ctx->md.separators_orig[e]; break;
-    case 3: v = &ctx->md.supernodes_pos[e]; break;
-    case 4: v = &ctx->md.separators_pos[e]; break;
+    case 0: v = &ctx->md_ref.cliques[e]; break;
+    case 1: v = &ctx->md_ref.supernodes_orig[e]; break;
+    case 2: v = &ctx->md_ref.separators_orig[e]; break;
+    case 3: v = &ctx->md_ref.supernodes_pos[e]; break;
+    case 4: v = &ctx->md_ref.separators_pos[e]; break;
+    // (10 ..: the structure the factorization runs on -- the same unless cxk_chain_segments(ctx) != 0;
+    // 20 / 21 ignore e: its supernode sizes / its permutation, original variable -> eliminated position)
+    case 10: v = &ctx->md.cliques[e]; break;
+    case 11: v = &ctx->md.supernodes_orig[e]; break;
+    case 12: v = &ctx->md.separators_orig[e]; break;
+    case 13: v = &ctx->md.supernodes_pos[e]; break;
+    case 14: v = &ctx->md.separators_pos[e]; break;
+    case 20: v = &ctx->md.supernode_size; break;
+    case 21: v = &ctx->md.permutation; break;
     default: return -1;
   }
   if (out) std::copy(v->begin(), v->end(), out);
@@ -2169,21 +2208,21 @@ int cxk_get_list(const cxk_context* ctx, int which, int e, int* out) {
 }
 int cxk_get_supernode_sizes(const cxk_context* ctx, int* out) {
   if (!ctx || !ctx->finalized) return 0;
-  std::copy(ctx->md.supernode_size.begin(), ctx->md.supernode_size.end(), out);
-  return ctx->md.K;
+  std::copy(ctx->md_ref.supernode_size.begin(), ctx->md_ref.supernode_size.end(), out);
+  return ctx->md_ref.K;
 }
 long cxk_slab_size(const cxk_context* ctx) { return ctx && ctx->finalized ? (long)ctx->lay.slab_size : 0; }
 int cxk_get_block_offsets(const cxk_context* ctx, long* diag_off, long* offd_off) {
   if (!ctx || !ctx->finalized) return 0;
-  for (int e = 0; e < ctx->md.K; e++) {
-    diag_off[e] = (long)ctx->lay.diag_off[e];
-    offd_off[e] = (long)ctx->lay.offd_off[e];
+  for (int e = 0; e < ctx->md_ref.K; e++) {
+    diag_off[e] = (long)ctx->lay_ref.diag_off[e];
+    offd_off[e] = (long)ctx->lay_ref.offd_off[e];
   }
-  return ctx->md.K;
+  return ctx->md_ref.K;
 }
 int cxk_get_ss_index(const cxk_context* ctx, int e, long* out) {
-  if (!ctx || !ctx->finalized || e < 0 || e >= ctx->md.K) return -1;
-  const auto& v = ctx->lay.ss_index[e];
+  if (!ctx || !ctx->finalized || e < 0 || e >= ctx->md_ref.K) return -1;
+  const auto& v = ctx->lay_ref.ss_index[e];
   if (out)
     for (size_t i = 0; i < v.size(); i++) out[i] = (long)v[i];
   return (int)v.size();
@@ -3063,6 +3102,8 @@ int cxk_prepare_take_step_device_mu(cxk_context* ctx, double c_scaling, double e
 // ------------------------------------------------------------- inspection
 int cxk_get_slab(cxk_context* ctx, double* out) {
   CXK_ENTER(ctx);
+  CXK_DEMAND(ctx->segments == 0, "the factor of this chain-shaped program is stored in its segment-parallel order, not in the "
+                                 "reference's block layout: set CXK_CHAIN_SEGMENTS=0 (or cxk_set_chain_segments(ctx, 0)) to inspect it");
   CXK_TRY(hipStreamSynchronize(ctx->stream));
   CXK_TRY(hipMemcpy(out, ctx->slab.p, sizeof(double) * (size_t)ctx->lay.slab_size,
                     hipMemcpyDeviceToHost));
@@ -3070,6 +3111,7 @@ int cxk_get_slab(cxk_context* ctx, double* out) {
 }
 int cxk_set_slab(cxk_context* ctx, const double* in) {
   CXK_ENTER(ctx);
+  CXK_DEMAND(ctx->segments == 0, "cxk_set_slab needs the reference's block layout: CXK_CHAIN_SEGMENTS=0");
   CXK_TRY(hipStreamSynchronize(ctx->stream));
   CXK_TRY(hipMemcpy(ctx->slab.p, in, sizeof(double) * (size_t)ctx->lay.slab_size,
                     hipMemcpyHostToDevice));

@@ -138,6 +138,12 @@ struct cxk_context {
   int rank = 0, world = 1;
   MatrixData md;
   Layout lay;
+  // the reference's structure (what the getters report); md / lay differ from it only when a long
+  // chain-shaped tree is factored in a segment-parallel order (symbolic.h, SegmentChain)
+  MatrixData md_ref;
+  Layout lay_ref;
+  int chain_segments = -1;  // cxk_set_chain_segments: -1 automatic / environment, 0 off, P segments
+  int segments = 0;         // segments in use (0: the reference's order)
   std::vector<Group> groups;
   std::vector<int64_t> g_off, r_off;
   std::vector<unsigned char> owned;      // constraint i assembled/updated by this rank

@@ -275,6 +275,138 @@ MatrixData Analyze(const IntLists& cliques, const IntLists& dual_vars_in) {
   return d;
 }
 
+// ---- chain-shaped trees: segment-parallel elimination order (symbolic.h)
+bool IsChain(const MatrixData& ref) {
+  const int K = ref.K;
+  if (K < 2) return false;
+  std::vector<int> step_of(ref.N, -1);
+  for (int k = 0; k < K; k++) {
+    if (ref.supernode_size[k] <= 0) return false;
+    for (int i = 0; i < ref.supernode_size[k]; i++) step_of[ref.cliques[k][i]] = k;
+  }
+  for (int k = 0; k + 1 < K; k++) {
+    const IntList& c = ref.cliques[k];
+    if ((int)c.size() == ref.supernode_size[k]) return false;  // a second root: not one chain
+    int parent = K;
+    for (size_t i = ref.supernode_size[k]; i < c.size(); i++) parent = std::min(parent, step_of[c[i]]);
+    if (parent != k + 1) return false;
+  }
+  return true;
+}
+
+bool SegmentChain(const MatrixData& ref, const IntLists& cliques, const IntLists& dual_vars, int segments,
+                  MatrixData* out) {
+  const int K = ref.K;
+  if (segments < 2 || K < 2 * segments || !IsChain(ref)) return false;
+  for (const IntList& dv : dual_vars)
+    if (!dv.empty()) return false;  // (the LDLT path pivots inside the reference's blocks: left alone)
+  const int nv = ref.num_vars;
+  // step of every variable in the reference order; the deferred variables move to the last step
+  std::vector<int> step_of(nv, -1);
+  for (int k = 0; k < K; k++)
+    for (int v : ref.supernodes_orig[k]) step_of[v] = k;
+  std::vector<char> deferred(nv, 0);
+  std::vector<int> deferred_list;
+  for (int p = 1; p < segments; p++) {
+    const int a = (int)((int64_t)p * K / segments);  // the cut lies between steps a - 1 and a
+    if (a <= 0 || a >= K - 1) continue;
+    // every variable the step before the cut updates; a step must keep at least one variable of its own
+    std::vector<int> cand;
+    for (int v : ref.separators_orig[a - 1])
+      if (!deferred[v] && step_of[v] != K - 1) cand.push_back(v);
+    std::vector<int> left(K, 0);
+    bool fits = true;
+    for (int v : cand) left[step_of[v]]++;
+    for (int v : cand) {
+      int kept = 0;
+      for (int u : ref.supernodes_orig[step_of[v]]) kept += !deferred[u];
+      if (kept - left[step_of[v]] < 1) fits = false;
+    }
+    if (!fits) continue;
+    for (int v : cand) {
+      deferred[v] = 1;
+      deferred_list.push_back(v);
+    }
+  }
+  if (deferred_list.empty()) return false;
+  for (int v : deferred_list) step_of[v] = K - 1;
+  // supernodes: the reference's without the deferred variables; the root's own, then the deferred
+  // ones in the reference's elimination order
+  IntLists sn(K), sep(K);
+  for (int k = 0; k < K; k++)
+    for (int v : ref.supernodes_orig[k])
+      if (!deferred[v]) sn[k].push_back(v);
+  std::sort(deferred_list.begin(), deferred_list.end(), [&](int x, int y) { return ref.permutation[x] < ref.permutation[y]; });
+  for (int v : deferred_list) sn[K - 1].push_back(v);
+  // separators by symbolic elimination: a step's structure is its constraint's variables and the
+  // separators of the steps whose first update lands in it, minus what it eliminates itself
+  std::vector<std::vector<int>> children(K);
+  std::vector<char> mark(nv, 0);
+  for (int k = 0; k < K; k++) {
+    std::vector<int> st;
+    auto add = [&](int v) {
+      if (!mark[v]) {
+        mark[v] = 1;
+        st.push_back(v);
+      }
+    };
+    const int con = ref.clique_order[k];
+    for (int v : cliques[con]) add(v);
+    for (int j : children[k])
+      for (int v : sep[j]) add(v);
+    int parent = K;
+    for (int v : st) {
+      mark[v] = 0;
+      if (step_of[v] == k) continue;
+      if (step_of[v] < k) return false;  // (cannot happen for a valid reference structure)
+      sep[k].push_back(v);
+      parent = std::min(parent, step_of[v]);
+    }
+    if (parent < K) children[parent].push_back(k);
+  }
+  // MatrixData as Analyze builds it (SupernodesToData + RelabelCliques) for the new order
+  MatrixData d;
+  d.K = K;
+  d.num_vars = nv;
+  d.clique_order = ref.clique_order;
+  d.permutation.assign(nv, 0);
+  d.permutation_inverse.assign(nv, 0);
+  int pos = 0;
+  for (int k = 0; k < K; k++)
+    for (int v : sn[k]) {
+      d.permutation_inverse[pos] = v;
+      d.permutation[v] = pos;
+      pos++;
+    }
+  if (pos != ref.N) return false;
+  d.N = ref.N;
+  d.supernode_size.resize(K);
+  d.cliques.resize(K);
+  d.supernodes_orig.resize(K);
+  d.separators_orig.resize(K);
+  d.supernodes_pos.resize(K);
+  d.separators_pos.resize(K);
+  for (int k = 0; k < K; k++) {
+    IntList temp;
+    for (int v : sep[k]) temp.push_back(d.permutation[v]);
+    std::sort(temp.begin(), temp.end());
+    d.supernodes_orig[k] = sn[k];
+    for (int t : temp) d.separators_orig[k].push_back(d.permutation_inverse[t]);
+    for (int v : sn[k]) d.cliques[k].push_back(d.permutation[v]);
+    for (int t : temp) d.cliques[k].push_back(t);
+    d.supernode_size[k] = (int)sn[k].size();
+    const IntList& labels = cliques[ref.clique_order[k]];
+    auto position = [&](int v) {
+      auto it = std::find(labels.begin(), labels.end(), v);
+      return it == labels.end() ? -1 : static_cast<int>(it - labels.begin());
+    };
+    for (int v : d.supernodes_orig[k]) d.supernodes_pos[k].push_back(position(v));
+    for (int v : d.separators_orig[k]) d.separators_pos[k].push_back(position(v));
+  }
+  *out = d;
+  return true;
+}
+
 namespace {
 int64_t Pad4(int64_t n) { return (n + 3) & ~int64_t(3); }
 }  // namespace

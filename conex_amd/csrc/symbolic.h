@@ -51,6 +51,22 @@ struct MatrixData {
 int GetRootNode(const IntLists& cliques, const IntLists& dual_vars);
 MatrixData Analyze(const IntLists& cliques, const IntLists& dual_vars);
 
+// A chain-shaped elimination tree (every step updates the next one only: BASELINE config 3 as the
+// reference's own tests arrange it, 5000 second-order cones, 10 000 strictly dependent block steps)
+// has no parallelism in the reference's order.  The order is part of the parity contract for what the
+// library REPORTS (order / supernodes / separators / permutation stay the reference's); the
+// factorization itself may run in any order that gives the same solution.  SegmentChain cuts the
+// chain into `segments` pieces: the variables that carry an update across a cut (the separator of the
+// step before it) are eliminated LAST, in the root's supernode, so that the pieces become independent
+// subtrees of equal depth (each step then carries those deferred variables as extra separator rows:
+// structural fill, the "spikes" of a partitioned tridiagonal solver) and the ordinary level-by-level
+// kernels sweep all pieces at once.  Same matrix, another elimination order: the Newton direction is
+// the same to rounding (tests: <= 1e-10 against the oracle, which eliminates in the reference's order).
+// Returns false (out untouched) when the structure is not a plain chain.
+bool IsChain(const MatrixData& ref);
+bool SegmentChain(const MatrixData& ref, const IntLists& cliques, const IntLists& dual_vars, int segments,
+                  MatrixData* out);
+
 // Block layout of the supernodal slab (triangular_matrix_workspace.cc).
 struct Layout {
   int K = 0;

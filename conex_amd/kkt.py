@@ -118,6 +118,8 @@ _SIGNATURES = {
     "cxk_kernel_time": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     "cxk_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "cxk_kernel_clock": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p]),
+    "cxk_set_chain_segments": (C.c_int, [C.c_void_p, C.c_int]),
+    "cxk_chain_segments": (C.c_int, [C.c_void_p]),
     "cxk_fused_tree_timed_out": (C.c_int, [C.c_void_p]),
     "cxk_debug_force_fused_timeout": (C.c_int, [C.c_void_p]),
     "cxk_set_iterative_refinement": (C.c_int, [C.c_void_p, C.c_int]),
@@ -642,6 +644,13 @@ class KktContext:
         n = self.L.cxk_kernel_clock(self.h, self.CLOCKS[which] if isinstance(which, str) else int(which),
                                     int(reset), C.byref(ms))
         return n, ms.value
+
+    def set_chain_segments(self, segments):
+        """0: the reference's elimination order; P >= 2: a chain-shaped tree in P segments (before initialize)."""
+        self._check(self.L.cxk_set_chain_segments(self.h, int(segments)), "cxk_set_chain_segments")
+
+    def chain_segments(self):
+        return self.L.cxk_chain_segments(self.h)
 
     def fused_tree_timed_out(self):
         return bool(self.L.cxk_fused_tree_timed_out(self.h))

@@ -93,6 +93,20 @@ int cxk_num_constraints(const cxk_context* ctx);
  * exchange slab that the caller sum-reduces across ranks (RCCL all-reduce). */
 int cxk_set_shard(cxk_context* ctx, int rank, int world_size);
 
+/* Chain-shaped elimination trees (every step updates the next one only: BASELINE config 3 as the
+ * reference's tests arrange it -- clique k = {8k .. 8k+9}, 5000 strictly dependent steps).  What the
+ * getters below report is always the reference's order, supernodes, separators and permutation
+ * (bit-identical: tests/test_symbolic_parity.py).  The FACTORIZATION of such a tree runs in a
+ * segment-parallel order: the chain is cut into P pieces, the variables that carry an update across
+ * a cut are eliminated last (in the root), the pieces become independent subtrees swept side by side
+ * (symbolic.h, SegmentChain).  Same matrix, another elimination order: every result -- direction,
+ * residuals, scaling points -- is the reference's to rounding (<= 1e-10 against the oracle); only the
+ * stored factor differs, which is why cxk_get_slab / cxk_set_slab refuse such a context.
+ * segments: 0 = the reference's order, P >= 2 = that many pieces; default (no call): the environment's
+ * CXK_CHAIN_SEGMENTS, else automatic for chains of 256 steps or more.  Before cxk_finalize. */
+int cxk_set_chain_segments(cxk_context* ctx, int segments);
+int cxk_chain_segments(const cxk_context* ctx);
+
 /* Reference identity: ON by default -- the library computes what the reference as written computes.
  * cxk_set_reference_identity(ctx, 0) (before cxk_finalize; or CXK_REFERENCE_QUIRKS=0 in the
  * environment) opts into two corrections of the reference:
