@@ -1899,10 +1899,10 @@ static int FinalizeImpl(cxk_context* ctx) {
     if (want < 0)
       if (const char* v = getenv("CXK_CHAIN_SEGMENTS")) want = atoi(v);
     if (want != 0 && ctx->md.K >= (want > 0 ? 4 : kAutoChainSteps) && IsChain(ctx->md)) {
-      // the deferred variables end up in ONE root supernode: beyond LDS on one GPU (the blocked
-      // big-supernode path), inside LDS on a sharded context (which has no such path)
-      int P = want > 1 ? want : (ctx->world > 1 ? 48 : 128);
-      P = std::min(P, ctx->md.K / 4);
+      // depth of the segmented tree = K / P + log2(P) levels: the shortest pieces (two steps each) are
+      // the fastest (measured on config 3: 128 / 500 / 1250 / 2500 pieces -> 2300 / 4680 / 6270 / 6600 solves/s)
+      int P = want > 1 ? want : ctx->md.K / 2;
+      P = std::min(P, ctx->md.K / 2);
       MatrixData seg;
       if (P >= 2 && SegmentChain(ctx->md, ctx->cliques, ctx->dual_vars, P, &seg)) {
         ctx->md = seg;
@@ -2174,8 +2174,8 @@ static int FinalizeImpl(cxk_context* ctx) {
 int cxk_system_size(const cxk_context* ctx) { return ctx && ctx->finalized ? ctx->md.N : 0; }
 int cxk_get_order(const cxk_context* ctx, int* order) {
   if (!ctx || !ctx->finalized) return 0;
-  std::copy(ctx->md.clique_order.begin(), ctx->md.clique_order.end(), order);
-  return ctx->md.K;
+  std::copy(ctx->md_ref.clique_order.begin(), ctx->md_ref.clique_order.end(), order);
+  return ctx->md_ref.K;
 }
 int cxk_get_permutation(const cxk_context* ctx, int* perm, int* perm_inv) {
   if (!ctx || !ctx->finalized) return 0;

@@ -906,9 +906,17 @@ int BuildPlans(cxk_context* ctx) {
       std::vector<int> shapes;
       for (int l = 0; l < nlev && ok; l++) {
         if (ctx->level_ptr[l + 1] == ctx->level_ptr[l]) continue;  // (a level this rank has no supernode on)
-        ok = ctx->level_lean[l] && !ctx->level_big[l] && ctx->level_nh[l] == ctx->level_ptr[l + 1] - ctx->level_ptr[l];
-        for (auto& sg : ctx->level_segs[l])
+        ok = !ctx->level_big[l] && ctx->level_nh[l] == ctx->level_ptr[l + 1] - ctx->level_ptr[l];
+        // (the whole-tree kernels take pull lists of any length up to kFusedMaxSlots, kFastSlots at a
+        // time: a level needs a register shape and inline separator lists, not the level kernels' "fast")
+        for (auto& sg : ctx->level_segs[l]) {
+          ok = ok && sg.shape != 0 && sg.inl;
           if (std::find(shapes.begin(), shapes.end(), sg.shape) == shapes.end()) shapes.push_back(sg.shape);
+        }
+        for (int pos = ctx->level_ptr[l]; pos < ctx->level_ptr[l + 1] && ok; pos++) {
+          const int e = ctx->level_sn[pos];
+          ok = h_tg_ptr[e + 1] - h_tg_ptr[e] <= kFastTargets && h_m[e] <= kFusedMaxSlots && h_mf[e] <= kFusedMaxSlots;
+        }
       }
       for (size_t i = 0; i < shapes.size(); i++)
         if ((shapes[i] & 255) == 0)
@@ -919,7 +927,7 @@ int BuildPlans(cxk_context* ctx) {
             }
       shapes.erase(std::remove(shapes.begin(), shapes.end(), -1), shapes.end());
       std::sort(shapes.begin(), shapes.end());
-      note("a level without lean kernels");
+      note("a level without a register shape, inline separator lists or within the slot limits");
       ok = ok && !shapes.empty() && shapes.size() <= 2;
       note("more than two register shapes");
       if (ok) {
@@ -955,7 +963,7 @@ int BuildPlans(cxk_context* ctx) {
         w[63] = ctx->t_level[e];
         continue;
       }
-      ok = nse == ns[e] && nsp == nsep[e] && nse + nsp <= 72 && m <= 255 && ctx->owned[i] && nsm > 0;
+      ok = nse == ns[e] && nsp == nsep[e] && nse + nsp <= 72 && m <= 254 && ctx->owned[i] && nsm > 0;
       note("a supernode that is not its constraint's own block");
       if (!ok) break;
       memcpy(w, &h_recs[pos], sizeof(SnRec));
@@ -968,11 +976,14 @@ int BuildPlans(cxk_context* ctx) {
         ok = r[a] >= 0 && r[a] < m;
         ar.pos[a] = (unsigned char)r[a];
       }
+      note("a fill-in variable among the supernode's own (position -1)");
+      // separator rows the constraint does not contain (structural fill: the deferred variables of a
+      // segmented chain): position 255, entries that start as zeros (AsmRec::pad_ flags the record)
       for (int a = 0; a < nsp && ok; a++) {
-        ok = sp[a] >= 0 && sp[a] < m;
-        ar.pos[nse + a] = (unsigned char)sp[a];
+        ok = sp[a] < m;
+        ar.pos[nse + a] = sp[a] < 0 ? (unsigned char)255 : (unsigned char)sp[a];
+        if (sp[a] < 0) ar.pad_ = 1;
       }
-      note("a fill-in row (position -1)");
       if (!ok) break;
       memcpy(w + 32, &ar, sizeof(AsmRec));
       // entries with further sources, in the order of the panel (columns of the diagonal block, then
@@ -983,7 +994,11 @@ int BuildPlans(cxk_context* ctx) {
         if (t < 0) return false;
         const GatherRec& g = h_as_rec[t];
         const int hi = std::max(pa, pb), lo = std::min(pa, pb);
-        if (g.first != ar.g_off + hi + (int64_t)lo * m) return false;
+        if (pa < 0 || pb < 0) {  // a fill-in row: no source in the own block
+          if (g.first >= 0) return false;
+        } else if (g.first != ar.g_off + hi + (int64_t)lo * m) {
+          return false;
+        }
         if (g.extra > 0) {
           extra.emplace_back(reg, std::vector<int64_t>(as_src.begin() + g.beg, as_src.begin() + g.beg + g.extra));
         }

@@ -301,43 +301,85 @@ bool SegmentChain(const MatrixData& ref, const IntLists& cliques, const IntLists
   for (const IntList& dv : dual_vars)
     if (!dv.empty()) return false;  // (the LDLT path pivots inside the reference's blocks: left alone)
   const int nv = ref.num_vars;
-  // step of every variable in the reference order; the deferred variables move to the last step
-  std::vector<int> step_of(nv, -1);
+  // owner (reference step) of every variable
+  std::vector<int> owner(nv, -1);
   for (int k = 0; k < K; k++)
-    for (int v : ref.supernodes_orig[k]) step_of[v] = k;
-  std::vector<char> deferred(nv, 0);
-  std::vector<int> deferred_list;
+    for (int v : ref.supernodes_orig[k]) owner[v] = k;
+  // Cuts.  The variables the step before a cut updates (its separator) are DEFERRED: they leave their
+  // supernode and are eliminated with the HOST of the cut -- the last step of the segment in front of
+  // it, whose own variables they are coupled to anyway -- after both neighbouring segments.  A step
+  // keeps at least one variable of its own, a host hosts one cut.
+  std::vector<char> deferred(nv, 0), is_host(K, 0);
+  std::vector<int> cut_host;            // per accepted cut: its host step
+  std::vector<IntList> cut_vars;        // ... and its deferred variables, in the reference's order
+  int prev_cut = 0;
   for (int p = 1; p < segments; p++) {
     const int a = (int)((int64_t)p * K / segments);  // the cut lies between steps a - 1 and a
-    if (a <= 0 || a >= K - 1) continue;
-    // every variable the step before the cut updates; a step must keep at least one variable of its own
-    std::vector<int> cand;
+    if (a - prev_cut < 2 || a > K - 2) continue;      // (segments of at least two steps)
+    IntList cand;
     for (int v : ref.separators_orig[a - 1])
-      if (!deferred[v] && step_of[v] != K - 1) cand.push_back(v);
-    std::vector<int> left(K, 0);
+      if (!deferred[v]) cand.push_back(v);
+    if (cand.empty()) continue;
     bool fits = true;
-    for (int v : cand) left[step_of[v]]++;
     for (int v : cand) {
-      int kept = 0;
-      for (int u : ref.supernodes_orig[step_of[v]]) kept += !deferred[u];
-      if (kept - left[step_of[v]] < 1) fits = false;
+      int kept = 0, leaving = 0;
+      for (int u : ref.supernodes_orig[owner[v]]) kept += !deferred[u];
+      for (int u : cand) leaving += owner[u] == owner[v];
+      if (kept - leaving < 1) fits = false;
     }
     if (!fits) continue;
-    for (int v : cand) {
-      deferred[v] = 1;
-      deferred_list.push_back(v);
+    std::sort(cand.begin(), cand.end(), [&](int x, int y) { return ref.permutation[x] < ref.permutation[y]; });
+    for (int v : cand) deferred[v] = 1;
+    cut_host.push_back(a - 1);
+    cut_vars.push_back(cand);
+    is_host[a - 1] = 1;
+    prev_cut = a;
+  }
+  const int C = (int)cut_host.size();
+  if (C == 0) return false;
+  // New order of the steps: every step that hosts nothing in the reference's order (the segments are
+  // independent of each other now), then the hosts in nested-dissection order over the cuts -- the cut
+  // in the middle of a range last, so that the interfaces merge pairwise, log2(segments) levels deep,
+  // instead of forming one dense block.
+  std::vector<int> seq;  // new position -> reference step
+  for (int k = 0; k < K; k++)
+    if (!is_host[k]) seq.push_back(k);
+  {
+    // post-order of the bisection tree over cuts [0, C), iteratively
+    struct Range { int lo, hi; bool emit; };
+    std::vector<Range> stack;
+    stack.push_back({0, C - 1, false});
+    while (!stack.empty()) {
+      const Range r = stack.back();
+      stack.pop_back();
+      if (r.lo > r.hi) continue;
+      const int mid = (r.lo + r.hi) / 2;
+      if (r.emit) {
+        seq.push_back(cut_host[mid]);
+        continue;
+      }
+      stack.push_back({r.lo, r.hi, true});
+      stack.push_back({mid + 1, r.hi, false});
+      stack.push_back({r.lo, mid - 1, false});
     }
   }
-  if (deferred_list.empty()) return false;
-  for (int v : deferred_list) step_of[v] = K - 1;
-  // supernodes: the reference's without the deferred variables; the root's own, then the deferred
-  // ones in the reference's elimination order
+  if ((int)seq.size() != K) return false;
+  std::vector<int> newpos(K, -1);
+  for (int k = 0; k < K; k++) newpos[seq[k]] = k;
+  std::vector<int> host_cut(K, -1);
+  for (int c = 0; c < C; c++) host_cut[cut_host[c]] = c;
+  // supernodes: a step's own variables without the deferred ones; a host's, then its cut's
   IntLists sn(K), sep(K);
-  for (int k = 0; k < K; k++)
-    for (int v : ref.supernodes_orig[k])
+  std::vector<int> step_of(nv, -1);
+  for (int k = 0; k < K; k++) {
+    const int r = seq[k];
+    for (int v : ref.supernodes_orig[r])
       if (!deferred[v]) sn[k].push_back(v);
-  std::sort(deferred_list.begin(), deferred_list.end(), [&](int x, int y) { return ref.permutation[x] < ref.permutation[y]; });
-  for (int v : deferred_list) sn[K - 1].push_back(v);
+    if (host_cut[r] >= 0)
+      for (int v : cut_vars[host_cut[r]]) sn[k].push_back(v);
+    if (sn[k].empty()) return false;
+    for (int v : sn[k]) step_of[v] = k;
+  }
   // separators by symbolic elimination: a step's structure is its constraint's variables and the
   // separators of the steps whose first update lands in it, minus what it eliminates itself
   std::vector<std::vector<int>> children(K);
@@ -350,25 +392,28 @@ bool SegmentChain(const MatrixData& ref, const IntLists& cliques, const IntLists
         st.push_back(v);
       }
     };
-    const int con = ref.clique_order[k];
+    const int con = ref.clique_order[seq[k]];
     for (int v : cliques[con]) add(v);
     for (int j : children[k])
       for (int v : sep[j]) add(v);
     int parent = K;
+    bool valid = true;
     for (int v : st) {
       mark[v] = 0;
       if (step_of[v] == k) continue;
-      if (step_of[v] < k) return false;  // (cannot happen for a valid reference structure)
+      if (step_of[v] < k) valid = false;  // (an order that eliminates a variable before its last update)
       sep[k].push_back(v);
       parent = std::min(parent, step_of[v]);
     }
+    if (!valid) return false;
     if (parent < K) children[parent].push_back(k);
   }
   // MatrixData as Analyze builds it (SupernodesToData + RelabelCliques) for the new order
   MatrixData d;
   d.K = K;
   d.num_vars = nv;
-  d.clique_order = ref.clique_order;
+  d.clique_order.resize(K);
+  for (int k = 0; k < K; k++) d.clique_order[k] = ref.clique_order[seq[k]];
   d.permutation.assign(nv, 0);
   d.permutation_inverse.assign(nv, 0);
   int pos = 0;
@@ -395,7 +440,7 @@ bool SegmentChain(const MatrixData& ref, const IntLists& cliques, const IntLists
     for (int v : sn[k]) d.cliques[k].push_back(d.permutation[v]);
     for (int t : temp) d.cliques[k].push_back(t);
     d.supernode_size[k] = (int)sn[k].size();
-    const IntList& labels = cliques[ref.clique_order[k]];
+    const IntList& labels = cliques[d.clique_order[k]];
     auto position = [&](int v) {
       auto it = std::find(labels.begin(), labels.end(), v);
       return it == labels.end() ? -1 : static_cast<int>(it - labels.begin());

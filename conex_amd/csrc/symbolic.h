@@ -57,11 +57,14 @@ MatrixData Analyze(const IntLists& cliques, const IntLists& dual_vars);
 // library REPORTS (order / supernodes / separators / permutation stay the reference's); the
 // factorization itself may run in any order that gives the same solution.  SegmentChain cuts the
 // chain into `segments` pieces: the variables that carry an update across a cut (the separator of the
-// step before it) are eliminated LAST, in the root's supernode, so that the pieces become independent
-// subtrees of equal depth (each step then carries those deferred variables as extra separator rows:
-// structural fill, the "spikes" of a partitioned tridiagonal solver) and the ordinary level-by-level
-// kernels sweep all pieces at once.  Same matrix, another elimination order: the Newton direction is
-// the same to rounding (tests: <= 1e-10 against the oracle, which eliminates in the reference's order).
+// step before it) are DEFERRED -- eliminated after both neighbouring pieces, together with the last
+// step of the piece in front of the cut -- so that the pieces become independent subtrees of equal
+// depth (each step then carries its piece's deferred variables as extra separator rows: structural
+// fill, the "spikes" of a partitioned tridiagonal solver), and the deferred sets themselves merge in
+// nested-dissection order, log2(segments) levels deep: K / segments + log2(segments) dependent levels
+// instead of K, every one of them swept for all pieces at once by the ordinary level kernels.  Same
+// matrix, another elimination order: the Newton direction is the same to rounding (tests: <= 1e-10
+// against the oracle, which eliminates in the reference's order).
 // Returns false (out untouched) when the structure is not a plain chain.
 bool IsChain(const MatrixData& ref);
 bool SegmentChain(const MatrixData& ref, const IntLists& cliques, const IntLists& dual_vars, int segments,

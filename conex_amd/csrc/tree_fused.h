@@ -20,6 +20,7 @@ constexpr int kFusedRecWords = 64;   // one record per supernode: 256 bytes, one
 constexpr int kFusedExtraTargets = 128;  // panel entries with more than one source (two per lane)
 constexpr int kFusedExtraSlots = 8;      // further sources per such entry / sources per shared variable fetched at once
 constexpr int kFusedExtraMax = 64;       // ... at most (longer lists: the level kernels)
+constexpr int kFusedMaxSlots = 4096;     // published values one entry / one row pulls, at most (taken kFastSlots at a time)
 
 // Words of a record (position = dependency order: a supernode only waits for lower positions):
 //   [0, 32)   SnRec (kernels_kkt.hip.h); its spare word 23: pub_beg

@@ -132,7 +132,11 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   const int64_t roff = FROM_X ? 0 : Join64(f(2), f(3));
   const int M = f(4);
   const int q = is_row ? lane : (is_sep ? ns + sc : 0);
-  const int myp = (__builtin_amdgcn_ds_bpermute(4 * (32 + 6 + (q >> 2)), w) >> (8 * (q & 3))) & 255;
+  // position 255 = a structural fill-in row (a separator variable the constraint does not contain: the
+  // deferred variables a segmented chain carries along, symbolic.h): its entries start as zeros
+  const int mypr = (__builtin_amdgcn_ds_bpermute(4 * (32 + 6 + (q >> 2)), w) >> (8 * (q & 3))) & 255;
+  const int myp = mypr == 255 ? 0 : mypr;
+  const int has_fill = FROM_X ? 0 : f(5);
   double a[NSMAX + SMAX + 1];
   double fwx = 0.0;  // FROM_X: what this rank's ... every rank's subtrees subtract from the right-hand side
   if constexpr (FROM_X) {
@@ -157,9 +161,17 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     const unsigned myp8 = 8u * (unsigned)myp;
 #pragma unroll
     for (int j = 0; j < NSMAX; j++) {
-      const unsigned pj8 = 8u * (unsigned)((f(6 + (j >> 2)) >> (8 * (j & 3))) & 255);  // wave-uniform
+      const unsigned pj = (unsigned)((f(6 + (j >> 2)) >> (8 * (j & 3))) & 255);  // wave-uniform
+      const unsigned pj8 = 8u * (pj == 255u ? 0u : pj);
       const unsigned hi8 = myp8 > pj8 ? myp8 : pj8, lo8 = myp8 > pj8 ? pj8 : myp8;
       a[j] = *reinterpret_cast<const double*>(gb + (__umul24(lo8, (unsigned)M) + hi8));
+    }
+    if (has_fill) {  // (wave-uniform; the loads above went to valid addresses either way)
+#pragma unroll
+      for (int j = 0; j < NSMAX; j++) {
+        const unsigned pj = (unsigned)((f(6 + (j >> 2)) >> (8 * (j & 3))) & 255);
+        a[j] = (mypr == 255 || pj == 255u) ? 0.0 : a[j];
+      }
     }
   }
   const int pr = is_row ? myp : (f(6) & 255);
@@ -343,6 +355,12 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     const double* src0 = handG + R.ubase + (int64_t)(lane < ntg ? lane : 0) * R.m;
     const double* src1 = handG + R.ubase + (int64_t)(lane + 64 < ntg ? lane + 64 : 0) * R.m;
     const double* srcb = handG + A.updb_base + R.fbase + (is_row ? lane : 0) * R.mf;
+    // Lists longer than the MMAX slots a round holds (the interfaces near the top of a segmented chain
+    // collect an update from every step that carried them: ~2 log2(segments)) are taken MMAX slots at
+    // a time, in slot order -- the order of the subtractions is the list's either way.
+    const int span = R.m > R.mf ? R.m : R.mf;
+    for (int sb0 = 0; sb0 < (span > 0 ? span : 1); sb0 += MMAX) {
+    const int mleft = R.m - sb0, fleft = R.mf - sb0;  // slots of this chunk in use: i < mleft / i < fleft
 #pragma unroll
     for (int i = 0; i < MMAX; i++) pv1[i] = 0.0;
     if (ntg <= 64) {
@@ -350,15 +368,15 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
       auto arrived = [&](const double (&v0)[MMAX], const double (&vb)[MFMAX]) {
         bool pending = false;
 #pragma unroll
-        for (int i = 0; i < MMAX; i++) pending = pending || (i < R.m && lane < ntg && IsSentinel(v0[i]));
+        for (int i = 0; i < MMAX; i++) pending = pending || (i < mleft && lane < ntg && IsSentinel(v0[i]));
 #pragma unroll
-        for (int i = 0; i < MFMAX; i++) pending = pending || (i < R.mf && is_row && IsSentinel(vb[i]));
+        for (int i = 0; i < MFMAX; i++) pending = pending || (i < fleft && is_row && IsSentinel(vb[i]));
         return __ballot(pending) == 0;
       };
 #define CXK_FUSED_ISSUE(V0, VB)                                                          \
   do {                                                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < MMAX; i_++) V0[i_] = LoadAgent(src0 + (i_ < R.m ? i_ : 0));   \
-    _Pragma("unroll") for (int i_ = 0; i_ < MFMAX; i_++) VB[i_] = LoadAgent(srcb + (i_ < R.mf ? i_ : 0)); \
+    _Pragma("unroll") for (int i_ = 0; i_ < MMAX; i_++) V0[i_] = LoadAgent(src0 + (i_ < mleft ? sb0 + i_ : 0));   \
+    _Pragma("unroll") for (int i_ = 0; i_ < MFMAX; i_++) VB[i_] = LoadAgent(srcb + (i_ < fleft ? sb0 + i_ : 0)); \
   } while (0)
       CXK_FUSED_ISSUE(pv0, pb);
       for (int spin = 0;; spin++) {
@@ -380,9 +398,9 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
       }
 #undef CXK_FUSED_ISSUE
 #pragma unroll
-      for (int i = 0; i < MMAX; i++) pv0[i] = i < R.m ? pv0[i] : 0.0;
+      for (int i = 0; i < MMAX; i++) pv0[i] = i < mleft ? pv0[i] : 0.0;
 #pragma unroll
-      for (int i = 0; i < MFMAX; i++) pb[i] = i < R.mf ? pb[i] : 0.0;
+      for (int i = 0; i < MFMAX; i++) pb[i] = i < fleft ? pb[i] : 0.0;
     } else {
       // (more than 64 pulled entries: one round at a time)
       for (int spin = 0;; spin++) {
@@ -393,13 +411,13 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
         for (int i = 0; i < MFMAX; i++) pb[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < MMAX; i++)
-          if (i < R.m) {
-            pv0[i] = LoadAgent(src0 + i);
-            pv1[i] = LoadAgent(src1 + i);
+          if (i < mleft) {
+            pv0[i] = LoadAgent(src0 + sb0 + i);
+            pv1[i] = LoadAgent(src1 + sb0 + i);
           }
 #pragma unroll
         for (int i = 0; i < MFMAX; i++)
-          if (i < R.mf) pb[i] = LoadAgent(srcb + i);
+          if (i < fleft) pb[i] = LoadAgent(srcb + sb0 + i);
 #pragma unroll
         for (int i = 0; i < MMAX; i++) {
           pending = pending || (lane < ntg && IsSentinel(pv0[i]));
@@ -435,6 +453,7 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     }
 #pragma unroll
     for (int i = 0; i < MFMAX; i++) a[RB] -= is_row ? pb[i] : 0.0;
+    }  // chunks of MMAX slots
   }
   if (nxt > 0 || ntg > 0) {
 #pragma unroll
@@ -678,43 +697,44 @@ __device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, cons
   }
   int pdb = 0;
   if constexpr (SMAX > 0) pdb = A.pub[pub_beg + npairs + (is_sep ? sc : 0)];
-  // ---- wait for the descendants' forward values (arrival words, then the values, as in the factor sweep)
-  double pb[MFMAX];
-#pragma unroll
-  for (int i = 0; i < MFMAX; i++) pb[i] = 0.0;
+  // ---- wait for the descendants' forward values (the values themselves are polled, as in the factor
+  // sweep; lists longer than MFMAX slots MFMAX at a time, in slot order) and subtract them
+  if constexpr (PHASE != 2) b = is_row ? b : 0.0;
   if (PHASE != 2 && R.mf > 0) {
     // (two rounds of loads in flight, every load unconditional: see the factor sweep)
     const double* srcb = handG + A.updb_base + R.fbase + (is_row ? lane : 0) * R.mf;
-    double qb[MFMAX];
-    auto arrived = [&](const double (&vb)[MFMAX]) {
-      bool pending = false;
+    for (int sb0 = 0; sb0 < R.mf; sb0 += MFMAX) {
+      const int fleft = R.mf - sb0;
+      double pb[MFMAX], qb[MFMAX];
+      auto arrived = [&](const double (&vb)[MFMAX]) {
+        bool pending = false;
 #pragma unroll
-      for (int i = 0; i < MFMAX; i++) pending = pending || (i < R.mf && is_row && IsSentinel(vb[i]));
-      return __ballot(pending) == 0;
-    };
+        for (int i = 0; i < MFMAX; i++) pending = pending || (i < fleft && is_row && IsSentinel(vb[i]));
+        return __ballot(pending) == 0;
+      };
 #define CXK_FUSED_ISSUE(VB) \
-  _Pragma("unroll") for (int i_ = 0; i_ < MFMAX; i_++) VB[i_] = LoadAgent(srcb + (i_ < R.mf ? i_ : 0))
-    CXK_FUSED_ISSUE(pb);
-    for (int spin = 0;; spin++) {
-      CXK_FUSED_ISSUE(qb);
-      if (arrived(pb)) break;
+  _Pragma("unroll") for (int i_ = 0; i_ < MFMAX; i_++) VB[i_] = LoadAgent(srcb + (i_ < fleft ? sb0 + i_ : 0))
       CXK_FUSED_ISSUE(pb);
-      if (arrived(qb) || 2 * spin >= kFusedSpinLimit) {
-        if (2 * spin >= kFusedSpinLimit) ReportTimeout(A);
+      for (int spin = 0;; spin++) {
+        CXK_FUSED_ISSUE(qb);
+        if (arrived(pb)) break;
+        CXK_FUSED_ISSUE(pb);
+        if (arrived(qb) || 2 * spin >= kFusedSpinLimit) {
+          if (2 * spin >= kFusedSpinLimit) ReportTimeout(A);
 #pragma unroll
-        for (int i = 0; i < MFMAX; i++) pb[i] = qb[i];
-        break;
+          for (int i = 0; i < MFMAX; i++) pb[i] = qb[i];
+          break;
+        }
       }
-    }
 #undef CXK_FUSED_ISSUE
+#pragma unroll
+      for (int i = 0; i < MFMAX; i++) b -= (is_row && i < fleft) ? pb[i] : 0.0;
+    }
   }
   // ---- forward substitution (ForwardSupernodeLean)
   if constexpr (PHASE != 2) {
 #pragma unroll
   for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? a[j] : 0.0;
-  b = is_row ? b : 0.0;
-#pragma unroll
-  for (int i = 0; i < MFMAX; i++) b -= (is_row && i < R.mf) ? pb[i] : 0.0;
   const double dinvf = is_row ? 1.0 / dg : 0.0;
   double dot = 0.0;
 #pragma unroll

@@ -62,8 +62,8 @@ def test_segmented_structure_factors_the_same_matrix(K, segments, overlap, m):
     sizes, paths, perm = internal_structure(k)
     N = prob["num_vars"]
     assert sorted(perm) == list(range(N)) and int(np.sum(sizes)) == N
-    # P independent pieces: a supernode's first separator variable names its parent; all but the root's
-    # children chains start at depth 0, so the tree has ~K / segments levels instead of K
+    # the pieces are independent subtrees of K / segments steps, the deferred sets merge pairwise above
+    # them: K / segments + log2(segments) dependent levels instead of K
     owner = np.zeros(N, dtype=int)
     start = np.concatenate([[0], np.cumsum(sizes)])
     for e in range(K):
@@ -72,7 +72,7 @@ def test_segmented_structure_factors_the_same_matrix(K, segments, overlap, m):
     for e in range(K):
         for v in paths[e][sizes[e]:]:
             level[owner[v]] = max(level[owner[v]], level[e] + 1)
-    assert level.max() + 1 <= -(-K // segments) + 2
+    assert level.max() + 1 <= -(-K // segments) + int(np.ceil(np.log2(segments))) + 1
     # a random SPD matrix with the program's sparsity: sum of P_c' G_c P_c, G_c = R R' + I
     M = np.zeros((N, N))
     for cl in prob["cliques"]:
@@ -121,7 +121,7 @@ def test_segmented_chain_newton_step_matches_the_oracle(K, segments):
     if segments:
         k.set_chain_segments(segments)
     k.initialize()
-    assert k.chain_segments() == (segments if segments else 128)
+    assert k.chain_segments() == (segments if segments else K // 2)
     o = syn.build(ol.Program, prob, "soc")
     for i in range(K):
         k.set_W(i, W[i])

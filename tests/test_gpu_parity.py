@@ -61,14 +61,19 @@ def check_newton_step(o, k, b, inv_sqrt_mu=0.7, bs=0.9, cs=0.8, check_update=Tru
         assert rel(np.tril(Gk), np.tril(Go)) <= TOL_SCHUR
         assert rel(AWk, AWo) <= TOL_SCHUR and rel(AQk, AQo) <= TOL_SCHUR
         assert rel(sck, sco) <= TOL_SCHUR
-    assert rel(blocks(k, k.slab()), blocks(o, o.slab())) <= TOL_SCHUR
+    # (a chain-shaped tree factored in its segment-parallel order keeps the factor in a layout of its
+    # own: the stage-by-stage slab comparison needs CXK_CHAIN_SEGMENTS=0, the reference's order)
+    segmented = k.chain_segments() != 0
+    if not segmented:
+        assert rel(blocks(k, k.slab()), blocks(o, o.slab())) <= TOL_SCHUR
     AWo, AQo, sco = o.residuals()
     AWk, AQk, sck = k.residuals()
     assert rel(AWk, AWo) <= TOL_SCHUR and rel(AQk, AQo) <= TOL_SCHUR and rel(sck, sco) <= 1e-12
 
     assert o.factor() == 1
     assert k.factor() == 1
-    assert rel(blocks(k, k.slab()), blocks(o, o.slab())) <= 1e-11
+    if not segmented:
+        assert rel(blocks(k, k.slab()), blocks(o, o.slab())) <= 1e-11
 
     N = o.N
     bb = np.zeros(N)
@@ -539,18 +544,25 @@ def test_c3_soc_newton_step():
 
 
 # --------------------------------------------------------------------- BASELINE configs 3 and 5 at FULL size
-@pytest.mark.parametrize("tree", [0, 8])
-def test_c3_full_size_5000_soc(tree):
+@pytest.mark.parametrize("tree,segments", [(0, "auto"), (0, "0"), (8, "auto")])
+def test_c3_full_size_5000_soc(monkeypatch, tree, segments):
     """BASELINE config 3 as named: 5000 second-order cones of dimension 10.  tree = 0 is the
     reference-style chain (clique k = {8k .. 8k+9}: 5000 elimination levels, N = 40002), tree = 8
     SURVEY 8d's clique-tree variant.  Schur blocks / slab <= 1e-13, direction <= 1e-10, updates
-    <= 1e-11 against the oracle, stage by stage."""
+    <= 1e-11 against the oracle, stage by stage.  The chain runs in both modes: the library's default
+    (the factorization in its segment-parallel order, symbolic.h: everything but the stored factor is
+    compared) and CXK_CHAIN_SEGMENTS=0 (the reference's order, the slab compared block by block)."""
+    if segments == "auto":
+        monkeypatch.delenv("CXK_CHAIN_SEGMENTS", raising=False)
+    else:
+        monkeypatch.setenv("CXK_CHAIN_SEGMENTS", segments)
     K = 5000
     prob = syn.soc_problem(K=K, dim=10, m=10, overlap=2, tree=tree)
     assert prob["num_vars"] == 40002
     W = syn.soc_scaling_points(K, 10)
     o, k = make_pair(prob, "soc", W)
     assert k.N == 40002
+    assert k.chain_segments() == (2500 if (tree == 0 and segments == "auto") else 0)
     check_newton_step(o, k, prob["b"])
 
 
