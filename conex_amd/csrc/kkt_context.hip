@@ -982,7 +982,7 @@ int MakeFusedTreeArgs(cxk_context* ctx, FusedTreeArgs* out) {
     std::vector<double> ys(ctx->fx_ysig.n, sent);
     CXK_TRY(hipMemcpy(ctx->fx_ysig.p, ys.data(), sizeof(double) * ys.size(), hipMemcpyHostToDevice));
     if (ctx->fx_done.p) {
-      CXK_TRY(hipMemset(ctx->fx_done.p, 0, sizeof(unsigned long long)));
+      CXK_TRY(hipMemset(ctx->fx_done.p, 0, sizeof(unsigned long long) * ctx->fx_done.n));
       ctx->fx_done_target = 0;
     }
     *ctx->fx_flag = 0.0;
@@ -1059,8 +1059,7 @@ int LaunchFusedShard(cxk_context* ctx) {
   a.cq = ap.cq;
   a.cw = ap.cw;
   a.comb = ap.with_rhs == 2;
-  ctx->fx_done_target += (unsigned long long)a.count_up;
-  a.done_target = ctx->fx_done_target;
+  a.done_target = ++ctx->fx_done_target;  // (up launches so far: kFusedShardUp's counters)
   CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedShardUp, ctx->stream));
   if (ShardAllReduce(ctx, ctx->xbuf.p, (size_t)ExchangeCount(ctx), 0 /* kOpSum */)) return CXK_FAILURE;
   CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedShardTop, ctx->stream));

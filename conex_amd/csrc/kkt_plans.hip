@@ -1099,7 +1099,7 @@ int BuildPlans(cxk_context* ctx) {
       if (ok) {
         CXK_TRY(ctx->fx_xg.upload(xg));
         CXK_TRY(ctx->fx_xr.upload(xr));
-        CXK_TRY(ctx->fx_done.alloc(1, true));
+        CXK_TRY(ctx->fx_done.alloc(64 * 16, true));  // 64 counters, 128 bytes apart
         ctx->fx_done_target = 0;
       }
     }

@@ -89,8 +89,9 @@ struct FusedTreeArgs {
   const int64_t* rs_src;
   const int* pf_ptr;
   const int* pf_src;
-  // every supernode of the up launch counts itself here at its end; the workgroup that writes the
-  // buffer's tail (scalars, failure flag) waits for done_target
+  // every supernode of the up launch counts itself at its end -- 64 counters, 128 bytes apart, position
+  // modulo 64 -- and the workgroup that writes the buffer's tail (scalars, failure flag) waits until
+  // each shows done_target (= up launches so far) times its share of the supernodes
   unsigned long long* done;
   unsigned long long done_target;
 };

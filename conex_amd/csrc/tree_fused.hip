@@ -916,15 +916,24 @@ __device__ __forceinline__ void ShardPackItem(const FusedTreeArgs& A, int64_t it
 __device__ __forceinline__ void ShardPackTail(const FusedTreeArgs& A) {
   FusedScalars(A);
   const int lane = threadIdx.x & 63;
-  if (lane == 0) {
-    for (int spin = 0; __hip_atomic_load(A.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < A.done_target; spin++) {
+  {
+    // lane l waits for counter l: done_target launches x the supernodes at positions l (mod 64)
+    const unsigned long long mine = lane < A.count_up ? (unsigned long long)((A.count_up - lane + 63) / 64) : 0ull;
+    const unsigned long long want = A.done_target * mine;
+    for (int spin = 0;; spin++) {
+      const unsigned long long have = __hip_atomic_load(A.done + 16 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__ballot(have < want) == 0) break;
       if (spin >= kFusedSpinLimit) {
-        atomicExch(A.fail + 1, A.tag);
-        __hip_atomic_store(A.host_flag, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0) {
+          atomicExch(A.fail + 1, A.tag);
+          __hip_atomic_store(A.host_flag, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         break;
       }
       __builtin_amdgcn_s_sleep(2);
     }
+  }
+  if (lane == 0) {
     const int64_t o = A.n_xs + 3 * (int64_t)A.n_xv;
     const int f0 = __hip_atomic_load(A.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int f1 = __hip_atomic_load(A.fail + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -952,8 +961,14 @@ __global__ void __launch_bounds__(64) tree_fused_shard_up(FusedTreeArgs A) {
     } else {
       FusedSupernode<NB, SB, true>(A, w, lds);
     }
-    // (behind this wavefront's stores and its failure report, if any)
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(A.done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // Behind this wavefront's failure report, if any (an atomic too: the wait orders the two).  64
+    // counters on lines of their own, position modulo 64: one counter would serialise its adders at
+    // ~12 ns each (2300 supernodes of a rank of config 5: 28 us behind the last elimination), and an
+    // agent-scope RELEASE here would write the XCD's L2 back once per wavefront.
+    if ((threadIdx.x & 63) == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __hip_atomic_fetch_add(A.done + 16 * (pos & 63), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return;
   }
   const int64_t items = A.n_xs + A.n_xv;

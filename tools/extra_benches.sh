@@ -2,7 +2,7 @@
 # The other BASELINE configurations and side workloads, one bench.py line each (run on the GPU box):
 #   tools/extra_benches.sh r02      -> gpurun_out/<round>/extra/bench_<workload and flags>.json
 # Copy what should be judged into profiles/<round>/extra/.
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$ROUND/extra
 mkdir -p "$OUT"

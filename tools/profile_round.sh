@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python3 "$ROOT/bench.py" > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-# (the driver's command line: 5 + 20 steps behind the untimed preheat)
+# (the driver's command line)
 python3 "$ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_settings.json" 2> "$OUT/bench_driver_settings.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- \
   python3 "$ROOT/bench.py" --no-cpu > "$OUT/bench_default_under_rocprof.log" 2>&1
@@ -28,6 +28,18 @@ python3 "$ROOT/tools/fused_tree_stamps.py" 1 200 50 > "$OUT/fused_tree_stamps_c2
 python3 "$ROOT/tools/big_chol_stamps.py" 500 > "$OUT/big_chol_stamps.txt" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_maxcut500" -o bench -- \
   python3 "$ROOT/bench.py" --workload maxcut --maxcut-n 500 --no-cpu --steps 100 > "$OUT/bench_maxcut500_under_rocprof.log" 2>&1
+# sharding, rehearsed on the one GPU (rank 0 of a virtual world, one-rank RCCL communicator standing in for
+# the exchange): the sharded step on the whole-tree kernels and on the level kernels, C4 and C5
+: > "$OUT/shard_rehearsal.jsonl"
+for W in 2 4 8; do
+  for WL in c4 c5; do
+    python3 "$ROOT/bench.py" --workload $WL --shard-path --shard-world $W --no-cpu 2>/dev/null | tail -1 >> "$OUT/shard_rehearsal.jsonl"
+    CXK_NO_FUSED_SHARD=1 python3 "$ROOT/bench.py" --workload $WL --shard-path --shard-world $W --no-cpu 2>/dev/null | tail -1 >> "$OUT/shard_rehearsal.jsonl"
+  done
+done
+# isolated rates of the fp64 MFMA GEMM at the supernode shapes of SURVEY 8(d)
+python3 "$ROOT/tools/gemm_profile.py" > "$OUT/gemm_rates.jsonl" 2> "$OUT/gemm_rates.err"
+"$ROOT/tools/extra_benches.sh" "$ROUND" > "$OUT/extra_benches.txt" 2>&1
 python3 "$ROOT/tools/ipm_iteration.py" --timers > "$OUT/ipm_iteration.txt" 2>&1
 # (the timed run takes the path with a host round trip per phase; this one is the product's)
 python3 "$ROOT/tools/ipm_iteration.py" > "$OUT/ipm_iteration_wall.txt" 2>&1
