@@ -1020,6 +1020,7 @@ int MakeFusedTreeArgs(cxk_context* ctx, FusedTreeArgs* out) {
   a.sys_sc = ctx->sys_sc.p;
   a.K = (int)ctx->cons.size();
   a.host_flag = ctx->fx_flag;
+  a.up_sleep = 30;  // units of 64 cycles a level takes at least (tree_fused.h)
   // sharded contexts (kFusedShardUp / kFusedShardTop)
   a.count_up = ctx->fused_shard ? ctx->fused_up : a.count;
   a.x = ctx->xbuf.p;

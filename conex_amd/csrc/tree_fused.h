@@ -68,6 +68,11 @@ struct FusedTreeArgs {
   double* sys_sc;
   int K;
   double* host_flag;  // pinned host word: set to 1.0 when a wait ran out (the sets are then rebuilt)
+  // A wavefront whose values cannot be there yet SLEEPS before it starts to poll (it shares a SIMD with
+  // wavefronts that are eliminating, which are bound by instruction issue): word 63 of its record is its
+  // level, a level of the tree takes at least up_sleep units of 64 cycles.  (Measured on C4, same box:
+  // 30.3 -> 29.8 us at 20 .. 40 units, back to 30.1 at 60, 31.7 at 100; the same on the way down: nothing.)
+  int up_sleep;
   // ---- sharded contexts (kFusedShardUp / kFusedShardTop).  Positions [0, count_up) are
   // this rank's own subtrees, [count_up, count) the replicated top of the tree.  The exchange buffer
   // x = [T slab entries (n_xs) | AW_T | AQc_T | fwd_T (n_xv each) | <w,c> <c,Qc> fail pad] is what ONE

@@ -83,6 +83,12 @@ __device__ __forceinline__ bool IsSentinel(double v) {
 __device__ __forceinline__ double SentinelValue() { return __longlong_as_double((long long)kFusedSentinel); }
 __device__ __forceinline__ int64_t Join64(int lo, int hi) { return ((int64_t)hi << 32) | (uint32_t)lo; }
 
+// `units` x 64 cycles without issuing anything (s_sleep takes a constant of at most 127)
+__device__ __forceinline__ void SleepUnits(int units) {
+  for (; units >= 32; units -= 32) __builtin_amdgcn_s_sleep(32);
+  for (; units >= 4; units -= 4) __builtin_amdgcn_s_sleep(4);
+}
+
 __device__ __forceinline__ void ReportTimeout(const FusedTreeArgs& A) {
   if ((threadIdx.x & 63) == 0) {
     atomicExch(A.fail + 1, A.tag);
@@ -359,48 +365,62 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     // collect an update from every step that carried them: ~2 log2(segments)) are taken MMAX slots at
     // a time, in slot order -- the order of the subtractions is the list's either way.
     const int span = R.m > R.mf ? R.m : R.mf;
+    SleepUnits(f(31) * A.up_sleep);  // (level x the least a level below can take: nothing to poll for before)
     for (int sb0 = 0; sb0 < (span > 0 ? span : 1); sb0 += MMAX) {
     const int mleft = R.m - sb0, fleft = R.mf - sb0;  // slots of this chunk in use: i < mleft / i < fleft
 #pragma unroll
     for (int i = 0; i < MMAX; i++) pv1[i] = 0.0;
     if (ntg <= 64) {
-      double q0[MMAX], qb[MFMAX];  // the second round in flight (the first one lands in pv0 / pb)
-      auto arrived = [&](const double (&v0)[MMAX], const double (&vb)[MFMAX]) {
-        bool pending = false;
+      // a round asks for MM slots per entry and row: four where no list of this chunk is longer (C4: three
+      // children share a parent's variable), the eight of MMAX otherwise -- half the loads per round
+      auto poll = [&](auto mmc) {
+        constexpr int MM = decltype(mmc)::value;
+        double p0[MM], pf[MM], q0[MM], qb[MM];  // two rounds in flight
+        auto arrived = [&](const double (&v0)[MM], const double (&vb)[MM]) {
+          bool pending = false;
 #pragma unroll
-        for (int i = 0; i < MMAX; i++) pending = pending || (i < mleft && lane < ntg && IsSentinel(v0[i]));
+          for (int i = 0; i < MM; i++) pending = pending || (i < mleft && lane < ntg && IsSentinel(v0[i]));
 #pragma unroll
-        for (int i = 0; i < MFMAX; i++) pending = pending || (i < fleft && is_row && IsSentinel(vb[i]));
-        return __ballot(pending) == 0;
-      };
+          for (int i = 0; i < MM; i++) pending = pending || (i < fleft && is_row && IsSentinel(vb[i]));
+          return __ballot(pending) == 0;
+        };
 #define CXK_FUSED_ISSUE(V0, VB)                                                          \
   do {                                                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < MMAX; i_++) V0[i_] = LoadAgent(src0 + (i_ < mleft ? sb0 + i_ : 0));   \
-    _Pragma("unroll") for (int i_ = 0; i_ < MFMAX; i_++) VB[i_] = LoadAgent(srcb + (i_ < fleft ? sb0 + i_ : 0)); \
+    _Pragma("unroll") for (int i_ = 0; i_ < MM; i_++) V0[i_] = LoadAgent(src0 + (i_ < mleft ? sb0 + i_ : 0));   \
+    _Pragma("unroll") for (int i_ = 0; i_ < MM; i_++) VB[i_] = LoadAgent(srcb + (i_ < fleft ? sb0 + i_ : 0)); \
   } while (0)
-      CXK_FUSED_ISSUE(pv0, pb);
-      for (int spin = 0;; spin++) {
-        CXK_FUSED_ISSUE(q0, qb);
-        if (arrived(pv0, pb)) {
-          FT_COUNT(12, 2 * spin);
-          break;
-        }
-        CXK_FUSED_ISSUE(pv0, pb);
-        if (arrived(q0, qb) || 2 * spin >= kFusedSpinLimit) {
-          if (2 * spin >= kFusedSpinLimit) ReportTimeout(A);
+        CXK_FUSED_ISSUE(p0, pf);
+        for (int spin = 0;; spin++) {
+          CXK_FUSED_ISSUE(q0, qb);
+          if (arrived(p0, pf)) {
+            FT_COUNT(12, 2 * spin);
+            break;
+          }
+          CXK_FUSED_ISSUE(p0, pf);
+          if (arrived(q0, qb) || 2 * spin >= kFusedSpinLimit) {
+            if (2 * spin >= kFusedSpinLimit) ReportTimeout(A);
 #pragma unroll
-          for (int i = 0; i < MMAX; i++) pv0[i] = q0[i];
+            for (int i = 0; i < MM; i++) p0[i] = q0[i];
 #pragma unroll
-          for (int i = 0; i < MFMAX; i++) pb[i] = qb[i];
-          FT_COUNT(12, 2 * spin + 1);
-          break;
+            for (int i = 0; i < MM; i++) pf[i] = qb[i];
+            FT_COUNT(12, 2 * spin + 1);
+            break;
+          }
         }
-      }
 #undef CXK_FUSED_ISSUE
 #pragma unroll
-      for (int i = 0; i < MMAX; i++) pv0[i] = i < mleft ? pv0[i] : 0.0;
+        for (int i = 0; i < MMAX; i++) pv0[i] = 0.0;
 #pragma unroll
-      for (int i = 0; i < MFMAX; i++) pb[i] = i < fleft ? pb[i] : 0.0;
+        for (int i = 0; i < MFMAX; i++) pb[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < MM; i++) pv0[i] = i < mleft ? p0[i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < MM; i++) pb[i] = i < fleft ? pf[i] : 0.0;
+      };
+      if (mleft <= 4 && fleft <= 4)
+        poll(std::integral_constant<int, 4>{});
+      else
+        poll(std::integral_constant<int, MMAX>{});
     } else {
       // (more than 64 pulled entries: one round at a time)
       for (int spin = 0;; spin++) {
