@@ -98,6 +98,7 @@ struct MfmaCfg {
   static constexpr int PROD = 8, CONS = 4;    // producer / consumer wavefronts (two / one per SIMD)
   static constexpr int TPW = 4;               // tiles per producer wave (<= 32 tiles of 16 rows)
   static constexpr int YSLOTS = 1;            // tile slots a producer keeps for phase Y
+  static constexpr bool DRAIN_HELP = N <= 20; // the producers take epilogues off the consumers in the drain
   static constexpr int THREADS = 64 * (PROD + CONS);
   static_assert(N % CONS == 0, "stage-2 rows (N/4 k-steps each) are dealt evenly to the consumer waves");
   // offset of the B-side operand of k-step bi inside the row block of P_y (doubles): P_y[4 bi + kq][r],
@@ -401,6 +402,38 @@ __device__ __forceinline__ void Triangles(const double* __restrict__ Pb, double*
   }
 }
 
+// Epilogue of constraint c, one iteration after its contraction: the K-split partial tiles (sb) are
+// summed in a fixed order and written out; entry e of the lower triangle by thread t0 + k nt.
+template <int N, bool H>
+__device__ __forceinline__ void Epilogue(const double* __restrict__ sb, const int64_t* __restrict__ dest, const int* __restrict__ etab,
+                                         int c, const Arena& ar, int nout, bool two, bool three, double osc, int t0, int nt) {
+  const int id = (int)dest[3 * c];
+  double* G = ar.G + dest[3 * c + 1];
+  double* AQc = ar.AQcc + dest[3 * c + 2];
+  for (int e = t0; e < nout; e += nt) {
+    const int code = etab[e];
+    const int off = code & 1023, kind = (code >> 10) & 3, dst = code >> 12;
+    double sum;
+    if (three) {
+      sum = sb[off];
+      if (off >= 256 && off < 768) sum += sb[off + 256];  // T10: two K halves
+    } else {
+      if (two && off >= 768)
+        sum = sb[off] + sb[off + 4];
+      else
+        sum = (sb[off] + sb[off + 256]) + sb[off + 512];
+      if (!two) sum += sb[off + 768];
+    }
+    sum *= osc;
+    if (kind == 0)
+      G[dst] = sum;
+    else if (kind == 1)
+      AQc[dst] = sum;
+    else
+      ar.sc[2 * id + 1] = sum;
+  }
+}
+
 template <int N, bool H>
 // single != 0: ONE P image instead of two (more matrices than fit LDS twice): the producers then wait
 // at the top of an iteration until the consumers have contracted the image they are about to
@@ -497,7 +530,17 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
       LdsBarrier();
     }
     MSTAMP(1 + 4 * cnt);
-    LdsBarrier();  // the consumers contract the last constraint (and then write its results out)
+    // The drain: the consumers contract the last constraint.  Its predecessor's epilogue -- theirs in
+    // every other iteration, in the slack behind their contraction -- is taken off their hands here (the
+    // partial tiles of c_{cnt-2} were complete at the barrier just passed), and the last epilogue is
+    // shared by all twelve waves.
+    // (orders up to 20: the order-24 instances have no registers to spare for it -- they spilled)
+    if constexpr (Cfg::DRAIN_HELP) {
+      if (cnt >= 2) Epilogue<N, H>(scratch + ((cnt - 2) & 1) * SB, dest, etab, cnt - 2, ar, nout, two, three, osc, threadIdx.x, 64 * Cfg::PROD);
+    }
+    LdsBarrier();
+    if constexpr (Cfg::DRAIN_HELP)
+      Epilogue<N, H>(scratch + ((cnt - 1) & 1) * SB, dest, etab, cnt - 1, ar, nout, two, three, osc, threadIdx.x, Cfg::THREADS);
     return;
   }
 
@@ -578,35 +621,8 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
     else
       ar.sc[2 * dest[3 * c]] = sum;
   };
-  // Epilogue of constraint c, one iteration after its contraction: the K-split partial tiles are
-  // summed in a fixed order and written out.
   auto epilogue = [&](int c) {
-    const double* sb = scratch + (c & 1) * SB;
-    const int id = (int)dest[3 * c];
-    double* G = ar.G + dest[3 * c + 1];
-    double* AQc = ar.AQcc + dest[3 * c + 2];
-    for (int e = ct; e < nout; e += 64 * Cfg::CONS) {
-      const int code = etab[e];
-      const int off = code & 1023, kind = (code >> 10) & 3, dst = code >> 12;
-      double sum;
-      if (three) {
-        sum = sb[off];
-        if (off >= 256 && off < 768) sum += sb[off + 256];  // T10: two K halves
-      } else {
-        if (two && off >= 768)
-          sum = sb[off] + sb[off + 4];
-        else
-          sum = (sb[off] + sb[off + 256]) + sb[off + 512];
-        if (!two) sum += sb[off + 768];
-      }
-      sum *= osc;
-      if (kind == 0)
-        G[dst] = sum;
-      else if (kind == 1)
-        AQc[dst] = sum;
-      else
-        ar.sc[2 * id + 1] = sum;
-    }
+    Epilogue<N, H>(scratch + (c & 1) * SB, dest, etab, c, ar, nout, two, three, osc, ct, 64 * Cfg::CONS);
   };
   LdsBarrier();
   MSTAMP(0);
@@ -631,11 +647,14 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
     // leave in that slack.
     traces(it - 1);
     if (single && it < cnt) LdsBarrier();  // the image is free for the next constraint
-    if (it >= 2) epilogue(it - 2);
+    if (it >= 2 && (it < cnt || !Cfg::DRAIN_HELP)) epilogue(it - 2);  // (it == cnt: the producers, idle by then, take it)
     MSTAMP(4 + 4 * it);
     LdsBarrier();
   }
-  epilogue(cnt - 1);
+  if constexpr (Cfg::DRAIN_HELP)  // (with the producers: all twelve waves)
+    Epilogue<N, H>(scratch + ((cnt - 1) & 1) * SB, dest, etab, cnt - 1, ar, nout, two, three, osc, threadIdx.x, Cfg::THREADS);
+  else
+    epilogue(cnt - 1);
   MSTAMP(1 + 4 * (cnt + 1));
 }
 
