@@ -1953,6 +1953,11 @@ static int FinalizeImpl(cxk_context* ctx) {
                                  "the large-order kernels use tr(W A_i W A_j) = tr(P_i P_j), which needs A_i = A_i^T");
       }
     }
+    if (c.type == CXK_SOC)
+      // soc_schur keeps a cone's (n + 1) x (m + 2) image in LDS (CONEX_NewLorentzConeConstraint makes a
+      // cone's matrix as wide as its largest variable index: thousands of columns are possible there)
+      CXK_DEMAND(sizeof(double) * (size_t)(c.n + 1) * (size_t)(c.m + 2) <= kLdsLimit,
+                 "a second-order cone whose (dimension + 1) x (variables + 2) image exceeds LDS (160 KB) is not supported");
     auto key = std::make_tuple(c.type, c.n, c.m, c.herm_d + (c.sparse ? 16 : 0) + (c.type == CXK_LMI && !c.symmetric ? 32 : 0) +
                                                      (c.type == CXK_QUAD && !c.Q.empty() ? 64 : 0));
     auto it = gmap.find(key);

@@ -146,3 +146,67 @@ def test_segmented_chain_newton_step_matches_the_oracle(K, segments):
         assert rel(k.get_W(i), o.get_W(i)) <= 1e-11
     with pytest.raises(Exception):
         k.slab()                       # the stored factor is not in the reference's layout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,overlap", [(6, 8, 3), (20, 20, 5)])
+def test_segmented_lmi_chain_matches_the_oracle(n, m, overlap):
+    """A chain of matrix inequalities (branching 1: every clique shares `overlap` variables with the next):
+    deferred sets of `overlap` variables, supernodes of other shapes than config 3's."""
+    from test_gpu_parity import rel
+    K = 300
+    prob = syn.lmi_problem(K=K, n=n, m=m, branching=1, overlap=overlap, seed=5)
+    W = syn.scaling_points(K, n, seed=6)
+    k = syn.build(KktContext, prob, "lmi", device=0)
+    assert k.chain_segments() == K // 2
+    o = syn.build(ol.Program, prob, "lmi")
+    for i in range(K):
+        k.set_W(i, W[i])
+        o.set_W(i, W[i])
+    ok, y = k.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    oko, yo = o.kkt_solve(prob["b"], 0.7, 0.9, 0.8)
+    assert ok == 1 and oko == 1
+    assert rel(y, yo) <= 1e-10
+    k.newton_direction(0.9, 0.8, 0.7)             # a solve-only sweep on the stored factor
+    rhs = 0.9 * (np.concatenate([prob["b"], np.zeros(o.N - len(prob["b"]))]) * 0.8 + o.residuals()[1] * 0.7) - 2 * o.residuals()[0]
+    assert rel(k.get_y(), o.solve_inplace(rhs)) <= 1e-10
+
+
+@pytest.mark.gpu
+def test_conex_maximize_on_a_chain_in_both_orders(monkeypatch):
+    """The whole interior-point solve of a chain-shaped program through conex.h (matrix inequalities
+    added with their variable lists: CONEX_AddSparseLMIConstraint): the segment-parallel factorization and
+    the reference's order reach the same optimum, which is the oracle's."""
+    import ctypes as C
+    import conex_api as ca
+    K, n, m = 300, 6, 8
+    prob = syn.lmi_problem(K=K, n=n, m=m, branching=1, overlap=3, seed=9)
+    L = ca.api()
+
+    def solve(segments):
+        if segments is None:
+            monkeypatch.delenv("CXK_CHAIN_SEGMENTS", raising=False)
+        else:
+            monkeypatch.setenv("CXK_CHAIN_SEGMENTS", str(segments))
+        p = L.CONEX_CreateConeProgram()
+        assert L.CONEX_SetNumberOfVariables(p, prob["num_vars"]) == 0
+        for c, cl in enumerate(prob["cliques"]):
+            a, cm = ca.colmajor(prob["A"][c]), ca.colmajor(prob["C"][c])
+            v = np.ascontiguousarray(cl, dtype=np.int64)
+            assert L.CONEX_AddSparseLMIConstraint(p, ca.dp(a), n, n, m, ca.dp(cm), n, n,
+                                                  v.ctypes.data_as(C.POINTER(C.c_long)), m) == c
+        cfg = ca.default_config()
+        b = np.ascontiguousarray(prob["b"])
+        y = np.zeros(len(b))
+        ok = L.CONEX_Maximize(p, ca.dp(b), len(b), C.byref(cfg), ca.dp(y), len(b))
+        L.CONEX_DeleteConeProgram(p)
+        return ok, y
+
+    ok_seg, y_seg = solve(None)
+    ok_ref, y_ref = solve(0)
+    o = syn.build(ol.Program, prob, "lmi")
+    oko, yo = o.solve(prob["b"])
+    assert ok_seg == 1 and ok_ref == 1 and oko == 1
+    assert abs(prob["b"] @ y_seg - prob["b"] @ yo) <= 1e-6 * abs(prob["b"] @ yo)
+    assert np.linalg.norm(y_seg - y_ref) <= 1e-3 * np.linalg.norm(y_ref)
+    assert np.linalg.norm(y_seg - yo) <= 1e-3 * np.linalg.norm(yo)

@@ -165,6 +165,11 @@ def _program(kind, seed):
     elif kind == "mixed":
         prob = syn.mixed_problem(K=230, seed=seed)
         W = syn.mixed_scaling_points(prob, seed=32)
+    elif kind == "chain":
+        # config 3's arrangement: second-order cones in a chain, factored in its segment-parallel order
+        # (symbolic.h): the pieces are the subtrees the ranks share out
+        prob = syn.soc_problem(K=600, dim=10, m=10, overlap=2, seed=seed)
+        W = syn.soc_scaling_points(600, 10, seed=33)
     else:
         raise ValueError(kind)
     return prob, W
@@ -195,7 +200,7 @@ def _newton_iteration(k, prob, W, owned_only):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("kind,world", [("lmi", 2), ("lmi", 3), ("c4", 4), ("c4", 8), ("mixed", 2), ("mixed", 5)])
+@pytest.mark.parametrize("kind,world", [("lmi", 2), ("lmi", 3), ("c4", 4), ("c4", 8), ("mixed", 2), ("mixed", 5), ("chain", 4)])
 def test_sharded_newton_iteration_through_the_library_collectives(monkeypatch, kind, world, fused):
     """fused: the factor-and-solve of a rank runs on the whole-tree kernels -- own subtrees up with the
     pack of the exchange buffer behind them, all-reduce, top straight from the buffer and the way back
@@ -206,7 +211,7 @@ def test_sharded_newton_iteration_through_the_library_collectives(monkeypatch, k
     else:
         monkeypatch.setenv("CXK_NO_FUSED_SHARD", "1")
     prob, W = _program(kind, 11)
-    build_kind = "mixed" if kind == "mixed" else "lmi"
+    build_kind = {"mixed": "mixed", "chain": "soc"}.get(kind, "lmi")
     ref = _newton_iteration(syn.build(KktContext, prob, build_kind, device=0), prob, W, False)
 
     def body(rank, allreduce):
@@ -214,6 +219,8 @@ def test_sharded_newton_iteration_through_the_library_collectives(monkeypatch, k
         for c, cl in enumerate(prob["cliques"]):
             if build_kind == "lmi":
                 k.add_lmi(prob["A"][c], prob["C"][c], cl)
+            elif build_kind == "soc":
+                k.add_soc(prob["A"][c], prob["c"][c], cl)
             elif prob["kinds"][c] == "herm":
                 k.add_hermitian(prob["A"][c], prob["C"][c], cl)
             else:
