@@ -113,6 +113,8 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   const int lane = threadIdx.x & 63;
   FT_STAMP_DECL;
   FT_STAMP(0);
+  FT_COUNT(10, __builtin_amdgcn_s_getreg((31 << 11) | 4));   // HW_ID: wave, SIMD, CU, SH, SE (tools/fused_tree_stamps.py: placement)
+  FT_COUNT(11, __builtin_amdgcn_s_getreg((31 << 11) | 20));  // XCC_ID
   const SnRec R = DecodeRec(w);
   FT_STAMP(1);  // the record is here
   auto f = [&](int i) { return __builtin_amdgcn_readlane(w, 32 + i); };

@@ -45,5 +45,20 @@ for l in sorted(set(lev.tolist())):
     sel = us[lev == l]
     print("%5d %6d | " % (l, len(sel)) + " | ".join("%5.2f / %5.2f" % (np.median(sel[:, i]), sel[:, i].max()) for i in range(len(order))))
     print("             polls until the descendants' values were in: median %d max %d; until the separator's solution was in: median %d max %d"
-          % (np.median(s[lev == l, 13]), s[lev == l, 13].max(), np.median(s[lev == l, 14]), s[lev == l, 14].max()))
+          % (np.median(s[lev == l, 12]), s[lev == l, 12].max(), np.median(s[lev == l, 14]), s[lev == l, 14].max()))
 print("span %.2f us" % us[:, -1].max())
+
+# placement: how many wavefronts of the launch share a SIMD (HW_ID: SIMD bits 5:4, CU 11:8, SH 12, SE 15:13; XCC_ID 3:0)
+hw, xcc = s[:, 10], s[:, 11] & 15
+simd = ((xcc << 16) | (hw & 0xFF00) | ((hw >> 4) & 3)).astype(np.int64)
+cu = ((xcc << 16) | (hw & 0xFF00)).astype(np.int64)
+_, inv, cnt = np.unique(simd, return_inverse=True, return_counts=True)
+share = cnt[inv]
+print("wavefronts per occupied SIMD: " + ", ".join("%d x%d" % (c, (cnt == c).sum()) for c in sorted(set(cnt.tolist()))),
+      "; CUs occupied %d, XCDs %d" % (len(set(cu.tolist())), len(set(xcc.tolist()))))
+el = (s[:, 4] - s[:, 3]) / 100.0
+for l in sorted(set(lev.tolist()))[:2]:
+    for c in sorted(set(share[lev == l].tolist())):
+        sel = (lev == l) & (share == c)
+        print("  level %d, %d on the SIMD: %4d wavefronts, elimination median %.2f max %.2f us, eliminated at median %.2f max %.2f"
+              % (l, c, sel.sum(), np.median(el[sel]), el[sel].max(), np.median(us[sel, 4]), us[sel, 4].max()))
