@@ -379,11 +379,14 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
         constexpr int MM = decltype(mmc)::value;
         double p0[MM], pf[MM], q0[MM], qb[MM];  // two rounds in flight
         auto arrived = [&](const double (&v0)[MM], const double (&vb)[MM]) {
+          // (no short-circuit: a chain of || became a ladder of exec-mask branches, ~0.4 us of instruction
+          // issue per round on this lone wavefront)
+          const bool is_tg = lane < ntg;
           bool pending = false;
 #pragma unroll
-          for (int i = 0; i < MM; i++) pending = pending || (i < mleft && lane < ntg && IsSentinel(v0[i]));
+          for (int i = 0; i < MM; i++) pending |= (i < mleft) & is_tg & IsSentinel(v0[i]);
 #pragma unroll
-          for (int i = 0; i < MM; i++) pending = pending || (i < fleft && is_row && IsSentinel(vb[i]));
+          for (int i = 0; i < MM; i++) pending |= (i < fleft) & is_row & IsSentinel(vb[i]);
           return __ballot(pending) == 0;
         };
 #define CXK_FUSED_ISSUE(V0, VB)                                                          \
