@@ -20,6 +20,7 @@
 #include "kernels_gemm.hip.h"
 
 #include <algorithm>
+#include <type_traits>
 
 #include "device_utils.h"
 
@@ -495,6 +496,242 @@ __global__ void __launch_bounds__(256, BK == 16 ? 4 : 2) gemm_f64_dma(GemmArgs g
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA kernel with 128-row tiles: gemm_f64_dma128<TA, TB, NJ>
+// ------------------------------------------------------------------------------------------
+// The 64 x 64 tile of gemm_f64_dma moves 16 KB from L2 into LDS for 131 kflop (8 flop per byte: 4.7 TB/s
+// of L2 -> LDS traffic at half the MFMA peak, which is where that kernel stops), and a tile row that
+// holds 8 of its 64 rows (order 200 = 3.1 tiles) costs a workgroup whose time is all DMA latency.
+// Here a workgroup owns 128 x 128 (NJ = 4) or 128 x 64 (NJ = 2) of C: up to 4 x NJ MFMA tiles per
+// wavefront (16 flop per byte at NJ = 4), a stage of 16 k-values keeps a wavefront's matrix pipe busy
+// for ~4000 cycles -- longer than the DMA of the next stage takes -- and the 16-row sub-tiles that exist
+// in a ragged tile are dealt EVENLY to the 2 x 2 wavefronts (order 200: 128 + 72 rows = 8 + 5
+// sub-tiles, dealt 4 + 4 and 3 + 2), so no wavefront sits on an empty quadrant.  Operand images are
+// gemm_f64_dma's (one 64-row image per half of a tile side, same rotations: conflict-free operand
+// reads); results leave straight from the accumulators (a 128-byte line of C is completed by the four
+// stores of one MFMA tile; the transposed copy is written in 128-byte runs).
+template <bool TA, bool TB, int NJ>
+__global__ void __launch_bounds__(256, 2) gemm_f64_dma128(GemmArgs g) {
+  constexpr int BK = 16, kHalf = 64 * BK, NI = BK / 8;
+  constexpr int BM = 128, BN = 32 * NJ, NBH = BN / 64;  // B side: two 64-column images or one
+  constexpr int kStage = (2 + NBH) * kHalf;
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_m = (g.M + BM - 1) / BM;
+  int tile, split, bz;
+  {
+    // (workgroups are dealt round-robin over the 8 XCDs: relabelled so that the tiles of one matrix
+    // meet in one XCD's L2, as in gemm_f64_dma)
+    const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+    const unsigned orig = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    tile = id % gx;
+    split = (id / gx) % gy;
+    bz = id / (gx * gy);
+  }
+  const int tm = tile % tiles_m, tn = tile / tiles_m;
+  const int m_base = tm * BM, n_base = tn * BN;
+  if (g.lower_only && m_base + BM - 1 < n_base) return;  // uniform per workgroup
+  const int b1 = bz / g.inner, b2 = bz % g.inner;
+  const double* A = g.A + b1 * g.sA1 + b2 * g.sA2;
+  const double* B = g.B + b1 * g.sB1 + b2 * g.sB2;
+  const int ksteps = (g.K + kGemmBK - 1) / kGemmBK;
+  const int per = (ksteps + g.splits - 1) / g.splits;
+  const int k_lo = min(g.K, split * per * kGemmBK), k_hi = min(g.K, k_lo + per * kGemmBK);
+  const int nstage = (k_hi - k_lo + BK - 1) / BK;
+
+  constexpr bool AK = TA, BKM = !TB;
+  // halves of the tile sides that hold rows / columns of the matrix (wave-uniform)
+  const int rows_m = min(BM, g.M - m_base), cols_n = min(BN, g.N - n_base);
+  DmaLane da[2], db[NBH];
+  const char* a0[2];
+  const char* b0[NBH];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int rows = rows_m - 64 * h;
+    MakeDmaLane<AK, BK>(da[h], wave, lane, rows > 64 ? 64 : rows, g.lda);
+    const int64_t mb = m_base + 64 * h;
+    a0[h] = reinterpret_cast<const char*>(A + (AK ? mb * g.lda + k_lo : (int64_t)k_lo * g.lda + mb));
+  }
+#pragma unroll
+  for (int h = 0; h < NBH; h++) {
+    const int rows = cols_n - 64 * h;
+    MakeDmaLane<BKM, BK>(db[h], wave, lane, rows > 64 ? 64 : rows, g.ldb);
+    const int64_t nb = n_base + 64 * h;
+    b0[h] = reinterpret_cast<const char*>(B + (BKM ? nb * g.ldb + k_lo : (int64_t)k_lo * g.ldb + nb));
+  }
+  const int64_t a_step = (AK ? (int64_t)BK : (int64_t)BK * g.lda) * 8;
+  const int64_t b_step = (BKM ? (int64_t)BK : (int64_t)BK * g.ldb) * 8;
+  const char* zero = reinterpret_cast<const char*>(g_gemm_zero_page) + 16 * lane;
+
+  auto issue = [&](int s) {
+    double* st = lds + (s & 1) * kStage;
+    const int krem = k_hi - k_lo - s * BK;  // k-values of this stage that exist
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      if (rows_m > 64 * h) {  // (a half past the edge of the matrix is never read)
+        const char* as = a0[h] + (int64_t)s * a_step;
+#pragma unroll
+        for (int u = 0; u < NI; u++) {
+          const int i = wave + 4 * u;
+          const char* src = da[h].krel[u] < krem ? as + da[h].off[u] : zero;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                           (__attribute__((address_space(3))) void*)(st + h * kHalf + i * 128), 16, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NBH; h++) {
+      if (cols_n > 64 * h) {
+        const char* bs = b0[h] + (int64_t)s * b_step;
+#pragma unroll
+        for (int u = 0; u < NI; u++) {
+          const int i = wave + 4 * u;
+          const char* src = db[h].krel[u] < krem ? bs + db[h].off[u] : zero;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                           (__attribute__((address_space(3))) void*)(st + (2 + h) * kHalf + i * 128), 16, 0, 0);
+        }
+      }
+    }
+  };
+
+  // the 16-row / 16-column sub-tiles of this tile that exist, dealt evenly to the 2 x 2 wavefronts
+  const int R = (rows_m + 15) >> 4, Cn = (cols_n + 15) >> 4;
+  const int rh = (R + 1) >> 1, ch = (Cn + 1) >> 1;
+  const int wi = wave & 1, wj = wave >> 1;
+  const int r_lo = wi ? rh : 0, c_lo = wj ? ch : 0;
+  int nr = wi ? R - rh : rh, nc = wj ? Cn - ch : ch;
+  // (a share wholly above the diagonal of a lower-only call has nothing to write)
+  if (g.lower_only && m_base + 16 * (r_lo + nr) - 1 < n_base + 16 * c_lo) nr = 0;
+  if (nr == 0 || nc == 0) nr = nc = 0;
+  const int l15 = lane & 15, kq = lane >> 4;
+  gemm_d4 acc[4][NJ];
+  // operand rows of this lane inside the images (sub-tiles past the wavefront's share re-read its first)
+  int ar[4], br[NJ];
+#pragma unroll
+  for (int i = 0; i < 4; i++) ar[i] = 16 * (r_lo + (i < nr ? i : 0)) + l15;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) br[j] = 16 * (c_lo + (j < nc ? j : 0)) + l15;
+  int ao[4], bo[NJ];  // m-major images: offset at k-sub-step 0 (256 doubles further per sub-step)
+#pragma unroll
+  for (int i = 0; i < 4; i++) ao[i] = (ar[i] >> 6) * kHalf + ImageOffset<false, BK>(ar[i] & 63, kq);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) bo[j] = (2 + (br[j] >> 6)) * kHalf + ImageOffset<false, BK>(br[j] & 63, kq);
+
+  double* C = g.C + b1 * g.sC1 + b2 * g.sC2 + (g.splits > 1 ? split * g.sCs : 0);
+  const bool partial = g.splits > 1;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < NJ; j++) acc[i][j] = gemm_d4{0.0, 0.0, 0.0, 0.0};
+
+  // The K loop, compiled once per size of a share (NR x NC sub-tiles): guards inside the loop -- one per
+  // MFMA, or one per 2 x 2 group -- either moved the MFMAs out of line or made a share of 3 x 3 cost 4 x 4.
+  auto stages = [&](auto nrc, auto ncc) {
+    constexpr int NR = decltype(nrc)::value, NC = decltype(ncc)::value;
+    if (nstage > 0) issue(0);
+    for (int s = 0; s < nstage; s++) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage s has landed
+      GemmBarrier();                                     // ... everybody's; and stage s-1 is no longer read
+      if (s + 1 < nstage) issue(s + 1);                  // in flight during the MFMAs below
+      if constexpr (NR > 0 && NC > 0) {
+        const double* st = lds + (s & 1) * kStage;
+        double a[2][NR], b[2][NC];
+        auto fetch = [&](int buf, int sub) {
+#pragma unroll
+          for (int i = 0; i < NR; i++) {
+            if (AK)
+              a[buf][i] = st[(ar[i] >> 6) * kHalf + ImageOffset<true, BK>(ar[i] & 63, 4 * sub + kq)];
+            else
+              a[buf][i] = st[ao[i] + 256 * sub];
+          }
+#pragma unroll
+          for (int j = 0; j < NC; j++) {
+            if (BKM)
+              b[buf][j] = st[(2 + (br[j] >> 6)) * kHalf + ImageOffset<true, BK>(br[j] & 63, 4 * sub + kq)];
+            else
+              b[buf][j] = st[bo[j] + 256 * sub];
+          }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int sub = 0; sub < BK / 4; sub++) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (sub + 1 < BK / 4) fetch((sub + 1) & 1, sub + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < NR; i++)
+#pragma unroll
+            for (int j = 0; j < NC; j++)
+              acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sub & 1][i], b[sub & 1][j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  };
+  auto with_rows = [&](auto nrc) {
+    if constexpr (NJ == 4) {
+      if (nc == 4) return stages(nrc, std::integral_constant<int, 4>{});
+      if (nc == 3) return stages(nrc, std::integral_constant<int, 3>{});
+    }
+    if (nc == 2) return stages(nrc, std::integral_constant<int, 2>{});
+    return stages(nrc, std::integral_constant<int, 1>{});
+  };
+  switch (nr) {
+    case 4: with_rows(std::integral_constant<int, 4>{}); break;
+    case 3: with_rows(std::integral_constant<int, 3>{}); break;
+    case 2: with_rows(std::integral_constant<int, 2>{}); break;
+    case 1: with_rows(std::integral_constant<int, 1>{}); break;
+    default: stages(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); break;
+  }
+  // Results: element e of a lane is (row (lane >> 4) + 4 e, column lane & 15) of its MFMA tile.  They leave
+  // through LDS, 32 rows of the tile at a time (column c of the strip at 33 c): C is then read (an
+  // accumulating call) and written in runs of 32 rows = 256 bytes per column, the transposed copy in runs
+  // of BN columns -- written straight from the accumulators (32-byte pieces) the SYRK shapes ran at half
+  // the 64 x 64 kernel's rate.
+  double* Ct = (g.Ct && !partial) ? g.Ct + b1 * g.sT1 + b2 * g.sT2 : nullptr;
+  constexpr int LDP = 33;
+  static_assert(BN * LDP <= 2 * kStage, "the strip fits the operand stages");
+  for (int p = 0; p < (rows_m + 31) / 32; p++) {
+    __syncthreads();  // the operand images / the strip before this one are no longer read
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int st = r_lo + i;  // sub-tile row of the tile
+      if (i < nr && (st >> 1) == p) {  // (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+          if (j < nc) {
+            const int c = 16 * (c_lo + j) + l15;
+#pragma unroll
+            for (int e = 0; e < 4; e++) lds[c * LDP + 16 * (st & 1) + kq + 4 * e] = acc[i][j][e];
+          }
+      }
+    }
+    __syncthreads();
+    {
+      const int row = tid & 31, m = m_base + 32 * p + row;
+#pragma unroll
+      for (int q = 0; q < BN / 8; q++) {
+        const int c = (tid >> 5) + 8 * q, n = n_base + c;
+        if (m < g.M && n < g.N && (!g.lower_only || m >= n)) {
+          const double v = lds[c * LDP + row];
+          C[m + (int64_t)n * g.ldc] = partial ? v : g.alpha * v;  // (beta == 0 here: ChooseTile)
+        }
+      }
+    }
+    if (Ct) {
+      const int c = tid % BN, n = n_base + c;
+#pragma unroll
+      for (int q = 0; q < 32 * BN / 256; q++) {
+        const int row = tid / BN + (256 / BN) * q, m = m_base + 32 * p + row;
+        if (m < g.M && n < g.N)
+          Ct[n + (int64_t)m * g.ldct + (g.ctb > 0 ? (int64_t)(n / g.ctb) * g.sTb : 0)] = g.alpha * lds[c * LDP + row];
+      }
+    }
+  }
+}
+
 namespace {
 
 bool Aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -527,6 +764,54 @@ hipError_t LaunchDmaBK(const GemmArgs& g, dim3 grid, hipStream_t stream) {
   return hipGetLastError();
 }
 
+template <bool TA, bool TB, int NJ>
+hipError_t LaunchDma128T(const GemmArgs& g, int batch, hipStream_t stream) {
+  constexpr size_t lds = sizeof(double) * 2 * (2 + NJ / 2) * 64 * 16;
+  static PerDeviceOnce once;
+  const hipError_t ec = once.run([] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_dma128<TA, TB, NJ>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  if (ec != hipSuccess) return ec;
+  const dim3 grid(((g.M + 127) / 128) * ((g.N + 32 * NJ - 1) / (32 * NJ)), g.splits > 1 ? g.splits : 1, batch);
+  gemm_f64_dma128<TA, TB, NJ><<<grid, 256, lds, stream>>>(g);
+  return hipGetLastError();
+}
+
+template <bool TA, bool TB>
+hipError_t LaunchDma128(const GemmArgs& g, int nj, int batch, hipStream_t stream) {
+  return nj == 4 ? LaunchDma128T<TA, TB, 4>(g, batch, stream) : LaunchDma128T<TA, TB, 2>(g, batch, stream);
+}
+
+// Which tile a DMA-eligible product takes: 0 = the 64 x 64 kernel, 4 = 128 x 128, 2 = 128 x 64.  The big
+// tiles need enough workgroups to fill the chip (two per CU are resident) and more than one 64-row tile
+// of rows to be worth it; CXK_GEMM_TILE=64 | 128 | 12864 forces the choice (comparison runs).
+int ChooseTile(const GemmArgs& g, int batch) {
+  static const int forced = [] {
+    const char* e = getenv("CXK_GEMM_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 64) return 0;
+  if (g.M <= 32 && g.N <= 32) return 0;  // (the Gram products share one quadrant: gemm_f64_dma)
+  if (g.beta != 0.0 && g.splits <= 1) return 0;  // (accumulating calls: the 64 x 64 kernel fetches the old values before its K loop)
+  if (forced == 128) return 4;
+  if (forced == 12864) return 2;
+  if (g.M <= 64) return 0;
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  // (a ragged last tile of 1 .. 6 sub-tiles a side leaves the four workgroups of an order-200 matrix with
+  // shares of 16 / 12 / 12 / 9 MFMA tiles: measured 0.377 against 0.391 of the MFMA peak for the 64 x 64 tiles)
+  auto clean = [](int n, int t) { return n % t == 0 || n % t > t - 16; };
+  if (!clean(g.M, 128)) return 0;
+  const int64_t reps = (int64_t)(g.splits > 1 ? g.splits : 1) * batch * ((g.M + 127) / 128);
+  if (g.N > 64 && clean(g.N, 128) && reps * ((g.N + 127) / 128) >= cus) return 4;
+  if (clean(g.N, 64) && reps * ((g.N + 63) / 64) >= 2 * cus) return 2;
+  return 0;
+}
+
 template <bool TA, bool TB>
 hipError_t LaunchDma(const GemmArgs& g, dim3 grid, hipStream_t stream) {
   const int ksteps = (g.K + kGemmBK - 1) / kGemmBK;
@@ -542,6 +827,12 @@ hipError_t LaunchGemm(const GemmArgs& g, bool ta, bool tb, int batch, hipStream_
   const int tiles = ((g.M + kGemmBM - 1) / kGemmBM) * ((g.N + kGemmBN - 1) / kGemmBN);
   dim3 grid(tiles, g.splits > 1 ? g.splits : 1, batch);
   if (DmaEligible(g, ta, tb)) {
+    if (const int nj = ChooseTile(g, batch)) {
+      if (!ta && !tb) return LaunchDma128<false, false>(g, nj, batch, stream);
+      if (ta && !tb) return LaunchDma128<true, false>(g, nj, batch, stream);
+      if (!ta && tb) return LaunchDma128<false, true>(g, nj, batch, stream);
+      return LaunchDma128<true, true>(g, nj, batch, stream);
+    }
     const int tiles_m = (g.M + kGemmBM - 1) / kGemmBM;
     if (g.lower_only && g.M == g.N) grid.x = tiles_m * (tiles_m + 1) / 2;  // lower tiles only
     if (!ta && !tb) return LaunchDma<false, false>(g, grid, stream);

@@ -78,6 +78,41 @@ def test_split_k_ordered_reduction(splits):
     assert np.array_equal(C1, C2)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("shape", [(128, 128, 40, 300), (120, 250, 50, 130), (256, 192, 64, 100), (128, 64, 24, 1100)])
+def test_big_tile_kernel_on_the_shapes_it_is_chosen_for(shape, ta, tb):
+    """gemm_f64_dma128 (128 x 128 / 128 x 64 tiles, gemm_mfma.hip ChooseTile): products without an old C,
+    sides that fill their last tile, enough workgroups for the chip."""
+    M, N, K, batch = shape
+    check(M, N, K, batch, ta, tb, seed=M + N + K)
+
+
+def test_big_tile_kernel_split_k_and_lower_only():
+    check(128, 128, 400, 100, True, False, splits=3)
+    check(128, 128, 48, 300, False, True, lower_only=True)
+    check(256, 256, 48, 100, False, True, lower_only=True)
+
+
+def test_big_tile_kernel_forced_onto_ragged_shapes():
+    """CXK_GEMM_TILE=128 / 12864 (read once per process): every layout on ragged shapes through the big-tile
+    kernel -- tiles with 1 .. 8 sub-tiles a side, dealt to the four wavefronts of a workgroup."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_gemm as t\n"
+        "for ta in (False, True):\n"
+        "    for tb in (False, True):\n"
+        "        for (M, N, K) in ((200, 200, 200), (130, 70, 258), (17, 33, 6), (65, 129, 40), (300, 90, 32), (128, 16, 20)):\n"
+        "            t.check(M, N, K, 3, ta, tb, seed=M + N)\n"
+        "t.check(200, 200, 64, 2, False, True, lower_only=True)\n"
+        "t.check(150, 150, 400, 2, True, False, splits=5)\n"
+        "print('ok')\n" % (root, os.path.join(root, "tests")))
+    for tile in ("128", "12864"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CXK_GEMM_TILE=tile), capture_output=True, text=True)
+        assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-3000:]
+
+
 RATE_FLOORS = [
     # (M, N, K, batch, ta, tb, alpha, beta, lower, floor in useful TFLOP/s)
     # measured on MI355X (profiles/r02/gemm_rates.jsonl): 39.1, 36.2, 45.6, 24.9, 23.5; floors leave ~20 %
