@@ -501,9 +501,10 @@ __device__ __forceinline__ double EvenRowsToOddRows(double v) {
 // (readlane, v_rsq_f64, two Goldschmidt steps: ~130 cycles on a lone wavefront) as soon as column J
 // has taken its own update, so that the chain overlaps the remaining column updates of step J-1
 // instead of following them.  Same operations on the same values: results are unchanged.
-template <int NSMAX, int SMAX, int J>
+// NRHS right-hand side columns a[RB ..] (1; 3 in the whole-tree launch with three right-hand sides).
+template <int NSMAX, int SMAX, int J, int NRHS = 1>
 struct ElimSteps {
-  static constexpr int LEN = NSMAX + SMAX + 1, RB = NSMAX + SMAX;
+  static constexpr int LEN = NSMAX + SMAX + NRHS, RB = NSMAX + SMAX;
   // ns = columns of the supernode (wave-uniform): the padding pivots ns .. NSMAX-1 are identity
   // steps (unit diagonal, zero column) and are skipped.
   static __device__ __forceinline__ void run(double (&a)[LEN], int lane, bool& bad, int ns) {
@@ -573,12 +574,15 @@ struct ElimSteps {
 #pragma unroll
         for (int c = J + 2; c < NSMAX + SMAX; c++) a[c] = fma(-ReadLane(a[J], c), a[J], a[c]);
       }
-      const double yj = ReadLane(a[RB], J) * inv;
-      if (lane > J)
-        a[RB] = fma(-yj, a[J], a[RB]);
-      else if (lane == J)
-        a[RB] = yj;
-      ElimSteps<NSMAX, SMAX, J + 1>::step(a, lane, bad, root1, inv1, ns);
+#pragma unroll
+      for (int q = 0; q < NRHS; q++) {
+        const double yj = ReadLane(a[RB + q], J) * inv;
+        if (lane > J)
+          a[RB + q] = fma(-yj, a[J], a[RB + q]);
+        else if (lane == J)
+          a[RB + q] = yj;
+      }
+      ElimSteps<NSMAX, SMAX, J + 1, NRHS>::step(a, lane, bad, root1, inv1, ns);
     }
   }
 };

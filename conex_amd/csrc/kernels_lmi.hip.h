@@ -183,16 +183,27 @@ __device__ __forceinline__ void TridiagMinMaxWave(int n, const double* d, const 
   }
   glo = -WaveMax(-glo);
   ghi = WaveMax(ghi);
-  const double pad = (ghi - glo) * 1e-12 + 1e-300;  // count(glo - pad) = 0, count(ghi + pad) = n
-  double a = glo - pad, b = ghi + pad;
+  // The matrix is mapped onto [0, 1] first -- T' = (T - glo) / width has the counts of T at the mapped shifts
+  // -- so that |d' - x| <= 1 and e'^2 <= 1/4 bound every minor by 1.25^n: the register form (MAXN > 0:
+  // n <= 17) then needs no rescaling test in its recurrence (a third of its instructions on this lone
+  // wavefront: the ten rounds took 8.5 of PrepareStep's 25 us chain); the memory form (any n) keeps the
+  // test, which multiplies by 1.0 at these sizes: the same bits.  The result is mapped back.
+  const double width = ghi - glo;
+  if (!(width > 1e-300)) {  // (wave-uniform: a multiple of the identity)
+    if (lane == 0) *mn = *mx = d[0];
+    return;
+  }
+  const double inv = 1.0 / width, org = glo;
+  const double pad = 1e-12;  // count(0 - pad) = 0, count(1 + pad) = n
+  double a = 0.0 - pad, b = 1.0 + pad;
   const int half = lane >> 5, sub = lane & 31;
   const int target = half == 0 ? 1 : n;
   double dd[MAXN > 0 ? MAXN : 1], e2[MAXN > 0 ? MAXN : 1];
   if constexpr (MAXN > 0) {
 #pragma unroll
     for (int i = 0; i < MAXN; i++) {
-      dd[i] = d[i < n ? i : 0];
-      const double ev = e[(i >= 1 && i < n) ? i - 1 : 0];
+      dd[i] = (d[i < n ? i : 0] - org) * inv;
+      const double ev = e[(i >= 1 && i < n) ? i - 1 : 0] * inv;
       e2[i] = ev * ev;
     }
   }
@@ -203,16 +214,22 @@ __device__ __forceinline__ void TridiagMinMaxWave(int n, const double* d, const 
     // p_{i+1} = (d_i - x) p_i - e_{i-1}^2 p_{i-1} (the pivot of the LDL^T recurrence is their ratio):
     // two dependent fmas per step where the pivot recurrence waits for a reciprocal and its Newton
     // step (~70 cycles a step on a lone wavefront; the ten rounds took 7 of PrepareStep's 24 us).
-    // Rescaled when it leaves [1e-150, 1e150]; an exact zero keeps the sign of its predecessor.
-    double pm = 1.0, p = (MAXN > 0 ? dd[0] : d[0]) - x;
+    // The memory form (any n) rescales when a minor leaves [1e-150, 1e150]; an exact zero keeps the sign
+    // of its predecessor.
+    double pm = 1.0, p = (MAXN > 0 ? dd[0] : (d[0] - org) * inv) - x;
     bool neg = p < 0.0;
     int c = neg;
     auto step = [&](double di, double ee) {
       double pn = fma(di - x, p, -(ee * pm));
-      const double mag = fabs(pn);
-      const double sc = mag > 1e150 ? 1e-150 : ((mag < 1e-150 && mag > 0.0) ? 1e150 : 1.0);
-      pm = p * sc;
-      p = pn * sc;
+      if constexpr (MAXN > 0) {
+        pm = p;
+        p = pn;
+      } else {
+        const double mag = fabs(pn);
+        const double sc = mag > 1e150 ? 1e-150 : ((mag < 1e-150 && mag > 0.0) ? 1e150 : 1.0);
+        pm = p * sc;
+        p = pn * sc;
+      }
       const bool ng = p < 0.0;
       c += (p != 0.0 && ng != neg);
       neg = p != 0.0 ? ng : neg;
@@ -223,7 +240,10 @@ __device__ __forceinline__ void TridiagMinMaxWave(int n, const double* d, const 
         if (i < n) step(dd[i], e2[i]);  // wave-uniform
     } else {
 #pragma unroll 4
-      for (int i = 1; i < n; i++) step(d[i], e[i - 1] * e[i - 1]);
+      for (int i = 1; i < n; i++) {
+        const double ev = e[i - 1] * inv;
+        step((d[i] - org) * inv, ev * ev);
+      }
     }
     const unsigned long long m = __ballot(c >= target);
     const unsigned int mh = half ? (unsigned int)(m >> 32) : (unsigned int)(m & 0xffffffffull);
@@ -233,7 +253,7 @@ __device__ __forceinline__ void TridiagMinMaxWave(int n, const double* d, const 
     a = na;
     b = nb;
   }
-  const double val = 0.5 * (a + b);
+  const double val = fma(0.5 * (a + b), width, org);
   if (lane == 0) *mn = val;
   if (lane == 32) *mx = val;
 }

@@ -1010,6 +1010,10 @@ int MakeFusedTreeArgs(cxk_context* ctx, FusedTreeArgs* out) {
   a.ysig = ctx->fx_ysig.p;
   a.ysig_stride = (long long)(ctx->fx_ysig.n / 2);
   a.gen = (int)(ctx->fused_gen++ & 1u);
+  a.tgen = (int)(ctx->fused_tgen & 1u);
+  a.fwd_stride = ctx->fx_fwd_stride;
+  a.y_stride = ctx->md.N;
+  a.y3 = ctx->y3.p;
   a.fail = ctx->d_fail.p;
   a.tag = ctx->fail_tag;
   a.k = a.bs = a.cs = a.cb = a.cq = a.cw = 0;
@@ -1083,7 +1087,10 @@ int LaunchFusedTreeSolve(cxk_context* ctx) {
   a.cq = ap.cq;
   a.cw = ap.cw;
   a.comb = ap.with_rhs == 2;
-  if (ctx->fused_split) {
+  if (ap.with_rhs == 3) {  // (cxk_factor_solve_triple_async: TripleOk has checked that the one-launch sweep applies)
+    ctx->fused_tgen++;
+    CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedTriple, ctx->stream, ctx->clk_e0, ctx->clk_e1));
+  } else if (ctx->fused_split) {
     CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedUp, ctx->stream));
     CXK_TRY(LaunchFusedTree(a, ctx->fused_sa, ctx->fused_sb, kFusedDown, ctx->stream));
   } else {
@@ -1136,6 +1143,7 @@ int DisableFusedTree(cxk_context* ctx) {
   ctx->timeout_pending = false;
   ctx->fused_tree = false;
   ctx->fused_sweep = false;
+  ctx->y3_valid = false;
   ctx->fused_timeouts++;
   fprintf(stderr, "conex_kkt_hip: a wait inside the whole-tree launch ran out (device shared with other work?); "
                   "this context sweeps its elimination tree level by level from now on\n");
@@ -1530,6 +1538,7 @@ int cxk_create(int num_vars, int device, void* stream, cxk_context** out) {
   ctx->stream = static_cast<hipStream_t>(stream);
   ctx->prepare_lds = getenv("CXK_PREPARE_LDS") != nullptr;
   ctx->no_step_tail = getenv("CXK_NO_STEP_TAIL") != nullptr || ctx->prepare_lds;
+  ctx->no_triple = getenv("CXK_NO_TRIPLE") != nullptr;
   ctx->no_device_mu = getenv("CXK_NO_DEVICE_MU") != nullptr;
   if (device >= 0) {
     int count = 0;
@@ -2317,6 +2326,7 @@ int cxk_set_W(cxk_context* ctx, int i, const double* in) {
 int cxk_assemble_local(cxk_context* ctx) {
   CXK_ENTER_KEEP(ctx);
   ctx->asm_deferred = false;  // a gather still pending would describe the previous Schur blocks
+  ctx->y3_valid = false;      // (so would three solutions nobody has combined: a redone iteration)
   if (LaunchSchur(ctx)) return CXK_FAILURE;
   if (FusedAssembly(ctx)) {
     ctx->asm_deferred = true;  // rides in the factorization that follows (or FlushDeferred)
@@ -2573,6 +2583,50 @@ int cxk_factor_solve_async(cxk_context* ctx, double cb, double cq, double cw) {
   if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;
   CXK_DEMAND(!ctx->asm_pending.on, "internal error: the folded assembly was not launched");
   ctx->factor_seq = ++ctx->seq;
+  return CXK_SUCCESS;
+}
+
+// The factorization with THREE right-hand sides in its one launch (tree_fused.h kFusedTriple): y <- K^-1 (-bs b +
+// cs AQc), the solve of the mu selection (cone_program.cc:181), and the three solutions K^-1 (bs b), K^-1 (cs AQc),
+// K^-1 AW from which the Newton direction for the mu the device selects is a linear combination -- formed on
+// the fly by the PrepareStep that follows (StepArgs::y3): cxk_newton_direction_device_mu then launches nothing,
+// the interior-point iteration is five launches instead of six.
+// y = k (K^-1 (bs b) + K^-1 (cs AQc)) - 2 K^-1 AW, k = the barrier parameter the device selected
+__global__ void newton_from_three(int n, const double* __restrict__ y3, long long st, const double* __restrict__ k_from,
+                                  double* __restrict__ y) {
+  const double k = k_from[0];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = k * (y3[i] + y3[st + i]) - 2.0 * y3[2 * st + i];
+}
+
+static bool DeviceMuOk(const cxk_context* ctx);
+static bool TripleOk(const cxk_context* ctx) {
+  return !ctx->no_triple && ctx->fused_tree && !ctx->fused_split && !ctx->fused_shard && ctx->world <= 1 && ctx->refine_iters <= 0 &&
+         ctx->solver_mode != 2 && !ctx->use_ldlt && ctx->y3.n == 3 * (size_t)ctx->md.N && StepTailOk(ctx, 0) && DeviceMuOk(ctx) &&
+         (ctx->fused_sa >> 8) <= 32 && (ctx->fused_sb >> 8) <= 32 &&
+         // (as things stand: the assembly just enqueued is still waiting to ride in the factorization -- not
+         // after a call that flushed it, e.g. the step scalars of the first iteration's rescaling)
+         ctx->asm_deferred && FusedAssembly(ctx);
+}
+int cxk_triple_supported(cxk_context* ctx) {
+  if (!ctx || CheckReady(ctx)) return 0;
+  return TripleOk(ctx) ? 1 : 0;
+}
+int cxk_factor_solve_triple_async(cxk_context* ctx, double bs, double cs) {
+  CXK_ENTER_KEEP(ctx);
+  CXK_DEMAND(TripleOk(ctx), "cxk_factor_solve_triple_async: not supported by this program, or not directly behind cxk_assemble (cxk_triple_supported)");
+  ctx->asm_deferred = false;
+  ctx->asm_pending.on = true;
+  ctx->asm_pending.with_rhs = 3;
+  ctx->asm_pending.bs = bs;
+  ctx->asm_pending.cs = cs;
+  ctx->rhs_c[0] = -bs;
+  ctx->rhs_c[1] = cs;
+  ctx->rhs_c[2] = 0.0;
+  if (LaunchTree(ctx, 0, true, true)) return CXK_FAILURE;
+  CXK_DEMAND(!ctx->asm_pending.on, "internal error: the folded assembly was not launched");
+  ctx->factor_seq = ++ctx->seq;
+  ctx->y3_valid = true;
   return CXK_SUCCESS;
 }
 
@@ -2870,6 +2924,7 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
   StepArgs sa = MakeStep(ctx, ctx->info2.p, affine, c_weight, e_weight, 1.0);
   sa.cw_from = cw_from;  // (CWeightOf in every PrepareStep kernel)
   sa.cw_scale = cw_scale;
+
   // PrepareStep may be enqueued before the host has seen the factorization's outcome: the cones whose
   // PrepareStep changes the scaling point itself (second-order and quadratic cones leave w^{1/2} in W)
   // look at the flag and leave W as the reference does when Factor() failed
@@ -3083,6 +3138,15 @@ int cxk_select_mu_async(cxk_context* ctx, double c_weight, double divergence_upp
 int cxk_newton_direction_device_mu(cxk_context* ctx, double bs, double cs) {
   CXK_ENTER(ctx);
   CXK_DEMAND(DeviceMuOk(ctx) && ctx->mu_dev.n == 1, "cxk_newton_direction_device_mu: no barrier parameter on the device");
+  // behind cxk_factor_solve_triple_async the direction is a combination of the three solutions at hand
+  // (cone_program.cc:409-411 by linearity): one elementwise launch instead of a sweep over the tree
+  if (ctx->y3_valid) {
+    ctx->y3_valid = false;
+    const int N = ctx->md.N;
+    newton_from_three<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, ctx->y3.p, (long long)N, ctx->mu_dev.p, ctx->y.p);
+    CXK_TRY(hipGetLastError());
+    return CXK_SUCCESS;
+  }
   RhsIn f{};
   f.form = 1;
   f.b = ctx->b.p;

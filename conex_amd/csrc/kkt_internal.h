@@ -259,6 +259,14 @@ struct cxk_context {
   DevBuf<double> fx_hand, fx_ysig;
   std::vector<double> fx_hand_init;
   long long fx_updb_base = 0;
+  // the whole-tree launch with three right-hand sides (tree_fused.h kFusedTriple): stride between the
+  // right-hand sides' forward slots, parity of the triple launches, their three solutions, and "y is to be
+  // formed from them by the PrepareStep that follows" (cxk_newton_direction_device_mu then launches nothing)
+  long long fx_fwd_stride = 0;
+  unsigned fused_tgen = 0;
+  DevBuf<double> y3;
+  bool y3_valid = false;
+  bool no_triple = false;  // CXK_NO_TRIPLE=1 at cxk_create: the mu selection's solve and the Newton direction as two sweeps
   unsigned fused_gen = 0;
   double* fx_flag = nullptr;  // pinned host word the kernel sets when a wait ran out
   int debug_timeout_at = -1, fused_launches = 0;  // CXK_DEBUG_FUSED_TIMEOUT_AT (test hook, LaunchFusedTreeSolve)

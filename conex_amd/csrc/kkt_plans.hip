@@ -1115,12 +1115,18 @@ int BuildPlans(cxk_context* ctx) {
         memcpy(&d, &bits, sizeof(d));
         return d;
       }();
-      const size_t hs = us + ubs + 8;
+      // (forward-value slots three times over: right-hand sides 1 and 2 of a launch with three, kFusedTriple)
+      const size_t hs = us + 3 * ubs + 8;
       ctx->fx_updb_base = (long long)us;
+      ctx->fx_fwd_stride = (long long)ubs;
       ctx->fx_hand_init.assign(2 * hs, 0.0);
       for (size_t t = 0; t + 64 < pub.size(); t++) {
         const int d = pub[t];
-        if (d != (int)slots && d != (int)us + slotsb) ctx->fx_hand_init[d] = ctx->fx_hand_init[hs + d] = sent;
+        if (d != (int)slots && d != (int)us + slotsb) {
+          ctx->fx_hand_init[d] = ctx->fx_hand_init[hs + d] = sent;
+          if ((size_t)d >= us)
+            for (size_t q = 1; q < 3; q++) ctx->fx_hand_init[d + q * ubs] = ctx->fx_hand_init[hs + d + q * ubs] = sent;
+        }
       }
       CXK_TRY(ctx->fx_rec.upload(recs));
       CXK_TRY(ctx->fx_xreg.upload(xreg));
@@ -1128,7 +1134,10 @@ int BuildPlans(cxk_context* ctx) {
       CXK_TRY(ctx->fx_rsrc.upload(rsrc));
       CXK_TRY(ctx->fx_pub.upload(pub));
       CXK_TRY(ctx->fx_hand.upload(ctx->fx_hand_init));
-      CXK_TRY(ctx->fx_ysig.upload(std::vector<double>(2 * (size_t)N, sent)));
+      CXK_TRY(ctx->fx_ysig.upload(std::vector<double>(6 * (size_t)N, sent)));  // two sets x three right-hand sides
+      CXK_TRY(ctx->y3.alloc(3 * (size_t)N, true));
+      ctx->fused_tgen = 0;
+      ctx->y3_valid = false;
       if (!ctx->fx_flag) {
         CXK_TRY(hipHostMalloc(reinterpret_cast<void**>(&ctx->fx_flag), 64, hipHostMallocDefault));
         *ctx->fx_flag = 0.0;

@@ -422,7 +422,13 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
       if (initial_centering == 0) centering_steps++;
       ApplyLimits(&inv_sqrt_mu, std::sqrt(1.0 / (1e-15 + cfg.maximum_mu)), inv_sqrt_mu_max);
     }
-    if (fuse_mu_solve) {
+    // (the barrier parameter selected on the device, below: known before the factorization is enqueued, so
+    // that it can carry the three right-hand sides the Newton direction for ANY mu is a combination of)
+    const bool mu_on_device = fuse_mu_solve && !p->contains_quadratic_costs && !timers &&
+                              !(i == 0 && cfg.initialization_mode == 1) && cxk_device_mu_supported(ctx) == 1;
+    if (fuse_mu_solve && mu_on_device && cxk_triple_supported(ctx) == 1) {
+      if (TIMED(1, cxk_factor_solve_triple_async(ctx, b_scaling, c_scaling))) return 0;
+    } else if (fuse_mu_solve) {
       if (TIMED(1, cxk_factor_solve_async(ctx, -b_scaling, c_scaling, 0.0))) return 0;
     } else if (fuse_direction) {
       if (TIMED(1, cxk_factor_direction_async(ctx, inv_sqrt_mu, b_scaling, c_scaling))) return 0;
@@ -451,8 +457,6 @@ int SolveProgram(Program* p, const Config& cfg, double* yout) {
     // The selection of mu on the device (cxk_select_mu_async): the eigenvalue query's launch evaluates
     // the rule below itself, the Newton direction and PrepareStep read inv_sqrt_mu from device memory,
     // and the host learns it, with everything else, from the one mailbox at the end of the iteration.
-    const bool mu_on_device = fuse_mu_solve && !p->contains_quadratic_costs && !timers &&
-                              !(i == 0 && cfg.initialization_mode == 1) && cxk_device_mu_supported(ctx) == 1;
     const double mu_lb = std::sqrt(1.0 / (1e-15 + cfg.maximum_mu));
     if (mu_on_device) {
       cxk_phase_mark(ctx, CXK_PHASE_OTHER);

@@ -57,6 +57,12 @@ struct FusedTreeArgs {
   double* ysig;
   long long ysig_stride;
   int gen;  // parity of this run
+  // kFusedTriple: right-hand sides 1 and 2 have hand-off slots of their own -- forward values fwd_stride
+  // and 2 fwd_stride behind those of right-hand side 0, solution entries y_stride and 2 y_stride behind --
+  // in sets that alternate with the triple launches only (tgen); their solutions go to y3 (3 x y_stride)
+  int tgen;
+  long long fwd_stride, y_stride;
+  double* y3;
   int* fail;
   int tag;  // a failed pivot writes fail[1] = tag
   double k, bs, cs;   // y = k (b bs + AQc cs) - 2 AW  (cone_program.cc:409-411)
@@ -112,8 +118,11 @@ struct FusedTreeArgs {
 // buffer (the unpack is the top supernodes' load phase), factored and solved, and the back
 // substitution down the own subtrees -- top workgroups first, then the subtrees root side first, so
 // only the top has to be resident at once.
+// kFusedTriple: kFusedFull with THREE right-hand sides -- bs b, cs AQc, AW -- whose solutions go to y3 (y_stride
+// apart) and y = K^-1 (-bs b + cs AQc): the mu selection's solve and, by linearity, the Newton direction
+// for any mu without another sweep (tree_fused.hip, FusedSupernode).
 enum FusedTreeMode { kFusedFull = 0, kFusedSolve = 1, kFusedUp = 2, kFusedForward = 3, kFusedDown = 4,
-                     kFusedShardUp = 5, kFusedShardTop = 6 };
+                     kFusedShardUp = 5, kFusedShardTop = 6, kFusedTriple = 7 };
 
 // Register shapes (NSMAX << 8 | SMAX) of the tree's supernodes: at most two (shape_b == shape_a for
 // one).  False when no instance is compiled for the pair.

@@ -104,11 +104,19 @@ __device__ __forceinline__ void ReportTimeout(const FusedTreeArgs& A) {
 // FROM_X: a supernode of the replicated top of a sharded context.  Its panel, AW / AQc and the
 // forward values of the subtrees below come from the all-reduced exchange buffer (what
 // exchange_unpack would have put into the slab and y: the unpack is this load phase), nothing from G.
-template <int NSMAX, int SMAX, bool UP_ONLY = false, bool FROM_X = false>
+// NRHS = 3 (kFusedTriple): three right-hand sides ride through the sweep -- bs b, cs AQc and AW -- so that the
+// right-hand side of the mu selection (-bs b + cs AQc, cone_program.cc:181) AND the Newton direction for
+// whatever mu comes out of it (k (bs b + cs AQc) - 2 AW, :409-411) are combinations of its three
+// solutions: the interior-point iteration needs no second sweep over the tree.  Right-hand side 0 uses the
+// hand-off slots of every other launch (set = run parity); 1 and 2 have slots of their own behind them
+// (fwd_stride / N apart), whose two sets alternate with the TRIPLE launches only (A.tgen).
+template <int NSMAX, int SMAX, bool UP_ONLY = false, bool FROM_X = false, int NRHS = 1>
 __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int w, double* __restrict__ my) {
   static_assert(NSMAX + SMAX <= 64, "one lane per panel row");
-  constexpr int RB = NSMAX + SMAX, MMAX = kFastSlots, MFMAX = kFastSlots, XMAX = kFusedExtraSlots;
-  constexpr int NVMAX = SMAX * (SMAX + 1) / 2 + SMAX;  // values a supernode publishes
+  static_assert(NRHS == 1 || (NRHS == 3 && !UP_ONLY && !FROM_X && NSMAX <= 32), "three right-hand sides: the one-launch sweep of a single GPU");
+  // (three right-hand sides: pull lists four slots at a time -- the registers of eight are spoken for)
+  constexpr int RB = NSMAX + SMAX, MMAX = NRHS > 1 ? 4 : kFastSlots, MFMAX = MMAX, XMAX = kFusedExtraSlots;
+  constexpr int NVMAX = SMAX * (SMAX + 1) / 2 + NRHS * SMAX;  // values a supernode publishes
   constexpr int PR = (NVMAX + 63) / 64;                // ... in this many store instructions
   const int lane = threadIdx.x & 63;
   FT_STAMP_DECL;
@@ -132,8 +140,13 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   double* handO = A.hand + (int64_t)(gen ^ 1) * A.hand_stride;  // the other one: re-armed at the end
   double* ysG = A.ysig + (int64_t)gen * A.ysig_stride;
   double* ysO = A.ysig + (int64_t)(gen ^ 1) * A.ysig_stride;
+  // (right-hand sides 1, 2: this run's set and the other one)
+  double* handT = A.hand + (int64_t)A.tgen * A.hand_stride;
+  double* handTO = A.hand + (int64_t)(A.tgen ^ 1) * A.hand_stride;
+  double* ysT = A.ysig + (int64_t)A.tgen * A.ysig_stride;
+  double* ysTO = A.ysig + (int64_t)(A.tgen ^ 1) * A.ysig_stride;
   const int pub_beg = __builtin_amdgcn_readlane(w, 23);
-  const int npairs = s * (s + 1) / 2, nv = npairs + s;
+  const int npairs = s * (s + 1) / 2, nv = npairs + NRHS * s;
 
   // ---- load phase, first trip: everything whose address follows from the record
   const double* Gk = A.G + (FROM_X ? 0 : Join64(f(0), f(1)));
@@ -145,7 +158,7 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   const int mypr = (__builtin_amdgcn_ds_bpermute(4 * (32 + 6 + (q >> 2)), w) >> (8 * (q & 3))) & 255;
   const int myp = mypr == 255 ? 0 : mypr;
   const int has_fill = FROM_X ? 0 : f(5);
-  double a[NSMAX + SMAX + 1];
+  double a[NSMAX + SMAX + NRHS];
   double fwx = 0.0;  // FROM_X: what this rank's ... every rank's subtrees subtract from the right-hand side
   if constexpr (FROM_X) {
     // entry (row, j) of the diagonal block sits at xs_base + j ns - j (j - 1) / 2 + (row - j) (lower
@@ -197,11 +210,17 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   // where this supernode's values go: lane t of round r publishes value number t + 64 r (the
   // s (s + 1) / 2 Schur updates in the reference's S_S enumeration, then the s forward values)
   int pd[PR > 0 ? PR : 1], prd[PR > 0 ? PR : 1];
+  bool pdt[PR > 0 ? PR : 1];  // value of right-hand side 1 or 2: its slot is in the TRIPLE launches' own sets
   pd[0] = prd[0] = 0;
+  pdt[0] = false;
 #pragma unroll
   for (int r = 0; r < PR; r++) {
     const int t = lane + 64 * r;
-    pd[r] = A.pub[pub_beg + (t < nv ? t : 0)];
+    // (right-hand side q of separator variable k: value npairs + q s + k, slot of value npairs + k, q fwd_stride on)
+    const int tq = (NRHS > 1 && t >= npairs + s && s > 0) ? (t - npairs) / s : 0;
+    const int tk = t - tq * s;  // the value of right-hand side 0 it sits behind
+    pdt[r] = tq > 0;
+    pd[r] = A.pub[pub_beg + (t < nv ? tk : 0)] + tq * (int)A.fwd_stride;
     // where value t will sit in the scratch image the separator lanes write after the elimination
     // (lane l's registers a[NSMAX ..] and its right-hand side at my[(SMAX + 1) l + c]): Schur update
     // t = (k, c) of the S_S enumeration, or forward value k
@@ -210,8 +229,8 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
       rem -= s - k;
       k++;
     }
-    const int kk = t < npairs ? k : t - npairs, cc = t < npairs ? k + rem : SMAX;
-    prd[r] = (SMAX + 1) * (NSMAX + (t < nv ? kk : 0)) + (t < nv ? cc : 0);
+    const int kk = t < npairs ? k : tk - npairs, cc = t < npairs ? k + rem : SMAX + tq;
+    prd[r] = (SMAX + NRHS) * (NSMAX + (t < nv ? kk : 0)) + (t < nv ? cc : 0);
   }
   const int ntg = R.tg_end - R.tg_beg;
   int ploc0 = 0, ploc1 = 0;
@@ -300,16 +319,22 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     }
   }
   // the expressions of build_rhs / build_rhs_comb, term for term
-  if (A.comb)
-    rb = A.cb * rb + A.cq * aqv + A.cw * awv;
-  else
-    rb = A.k * (rb * A.bs + aqv * A.cs) - 2 * awv;
+  if constexpr (NRHS == 1) {
+    if (A.comb)
+      rb = A.cb * rb + A.cq * aqv + A.cw * awv;
+    else
+      rb = A.k * (rb * A.bs + aqv * A.cs) - 2 * awv;
+  }
   if constexpr (FROM_X) rb -= fwx;  // (exchange_unpack: y = .. - the forward values of all ranks' subtrees)
 #pragma unroll
   for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? a[j] : 0.0;
 #pragma unroll
   for (int c = 0; c < SMAX; c++) a[NSMAX + c] = 0.0;
-  a[RB] = is_row ? rb : 0.0;
+  a[RB] = is_row ? (NRHS == 1 ? rb : rb * A.bs) : 0.0;
+  if constexpr (NRHS == 3) {
+    a[RB + 1] = is_row ? aqv * A.cs : 0.0;
+    a[RB + 2] = is_row ? awv : 0.0;
+  }
   FT_STAMP(2);  // panel and right-hand side assembled (own block; further sources still to add)
 
   const bool pulls = ntg > 0 || R.mf > 0;
@@ -360,6 +385,8 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     // memory latency after it became visible -- the earlier form (one arrival word per publisher
     // polled first, then the values) paid two dependent round trips behind every level of the tree.
     double pv0[MMAX], pv1[MMAX], pb[MFMAX];
+    double pbx[NRHS > 1 ? NRHS - 1 : 1][MFMAX];  // forward values of right-hand sides 1, 2
+    const double* srcx = handT + A.updb_base + A.fwd_stride + R.fbase + (is_row ? lane : 0) * R.mf;  // (2: fwd_stride further)
     const double* src0 = handG + R.ubase + (int64_t)(lane < ntg ? lane : 0) * R.m;
     const double* src1 = handG + R.ubase + (int64_t)(lane + 64 < ntg ? lane + 64 : 0) * R.m;
     const double* srcb = handG + A.updb_base + R.fbase + (is_row ? lane : 0) * R.mf;
@@ -378,7 +405,8 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
       auto poll = [&](auto mmc) {
         constexpr int MM = decltype(mmc)::value;
         double p0[MM], pf[MM], q0[MM], qb[MM];  // two rounds in flight
-        auto arrived = [&](const double (&v0)[MM], const double (&vb)[MM]) {
+        double pfx[NRHS > 1 ? NRHS - 1 : 1][MM], qbx[NRHS > 1 ? NRHS - 1 : 1][MM];
+        auto arrived = [&](const double (&v0)[MM], const double (&vb)[MM], const double (&vx)[NRHS > 1 ? NRHS - 1 : 1][MM]) {
           // (no short-circuit: a chain of || became a ladder of exec-mask branches, ~0.4 us of instruction
           // issue per round on this lone wavefront)
           const bool is_tg = lane < ntg;
@@ -387,27 +415,44 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
           for (int i = 0; i < MM; i++) pending |= (i < mleft) & is_tg & IsSentinel(v0[i]);
 #pragma unroll
           for (int i = 0; i < MM; i++) pending |= (i < fleft) & is_row & IsSentinel(vb[i]);
+          if constexpr (NRHS > 1) {
+#pragma unroll
+            for (int q = 0; q < NRHS - 1; q++)
+#pragma unroll
+              for (int i = 0; i < MM; i++) pending |= (i < fleft) & is_row & IsSentinel(vx[q][i]);
+          }
           return __ballot(pending) == 0;
         };
-#define CXK_FUSED_ISSUE(V0, VB)                                                          \
+#define CXK_FUSED_ISSUE(V0, VB, VX)                                                      \
   do {                                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < MM; i_++) V0[i_] = LoadAgent(src0 + (i_ < mleft ? sb0 + i_ : 0));   \
     _Pragma("unroll") for (int i_ = 0; i_ < MM; i_++) VB[i_] = LoadAgent(srcb + (i_ < fleft ? sb0 + i_ : 0)); \
+    if constexpr (NRHS > 1) {                                                            \
+      _Pragma("unroll") for (int q_ = 0; q_ < NRHS - 1; q_++)                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < MM; i_++)                                \
+          VX[q_][i_] = LoadAgent(srcx + q_ * A.fwd_stride + (i_ < fleft ? sb0 + i_ : 0)); \
+    }                                                                                    \
   } while (0)
-        CXK_FUSED_ISSUE(p0, pf);
+        CXK_FUSED_ISSUE(p0, pf, pfx);
         for (int spin = 0;; spin++) {
-          CXK_FUSED_ISSUE(q0, qb);
-          if (arrived(p0, pf)) {
+          CXK_FUSED_ISSUE(q0, qb, qbx);
+          if (arrived(p0, pf, pfx)) {
             FT_COUNT(12, 2 * spin);
             break;
           }
-          CXK_FUSED_ISSUE(p0, pf);
-          if (arrived(q0, qb) || 2 * spin >= kFusedSpinLimit) {
+          CXK_FUSED_ISSUE(p0, pf, pfx);
+          if (arrived(q0, qb, qbx) || 2 * spin >= kFusedSpinLimit) {
             if (2 * spin >= kFusedSpinLimit) ReportTimeout(A);
 #pragma unroll
             for (int i = 0; i < MM; i++) p0[i] = q0[i];
 #pragma unroll
             for (int i = 0; i < MM; i++) pf[i] = qb[i];
+            if constexpr (NRHS > 1) {
+#pragma unroll
+              for (int q = 0; q < NRHS - 1; q++)
+#pragma unroll
+                for (int i = 0; i < MM; i++) pfx[q][i] = qbx[q][i];
+            }
             FT_COUNT(12, 2 * spin + 1);
             break;
           }
@@ -421,6 +466,15 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
         for (int i = 0; i < MM; i++) pv0[i] = i < mleft ? p0[i] : 0.0;
 #pragma unroll
         for (int i = 0; i < MM; i++) pb[i] = i < fleft ? pf[i] : 0.0;
+        if constexpr (NRHS > 1) {
+#pragma unroll
+          for (int q = 0; q < NRHS - 1; q++) {
+#pragma unroll
+            for (int i = 0; i < MFMAX; i++) pbx[q][i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < MM; i++) pbx[q][i] = i < fleft ? pfx[q][i] : 0.0;
+          }
+        }
       };
       if (mleft <= 4 && fleft <= 4)
         poll(std::integral_constant<int, 4>{});
@@ -443,13 +497,22 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
 #pragma unroll
         for (int i = 0; i < MFMAX; i++)
           if (i < fleft) pb[i] = LoadAgent(srcb + sb0 + i);
+        if constexpr (NRHS > 1) {
 #pragma unroll
-        for (int i = 0; i < MMAX; i++) {
-          pending = pending || (lane < ntg && IsSentinel(pv0[i]));
-          pending = pending || (lane + 64 < ntg && IsSentinel(pv1[i]));
+          for (int q = 0; q < NRHS - 1; q++)
+#pragma unroll
+            for (int i = 0; i < MFMAX; i++) {
+              pbx[q][i] = i < fleft ? LoadAgent(srcx + q * A.fwd_stride + sb0 + i) : 0.0;
+              pending |= is_row & IsSentinel(pbx[q][i]);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < MFMAX; i++) pending = pending || (is_row && IsSentinel(pb[i]));
+        for (int i = 0; i < MMAX; i++) {
+          pending |= (lane < ntg) & IsSentinel(pv0[i]);
+          pending |= (lane + 64 < ntg) & IsSentinel(pv1[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < MFMAX; i++) pending |= is_row & IsSentinel(pb[i]);
         if (__ballot(pending) == 0) {
           FT_COUNT(12, spin);
           break;
@@ -478,6 +541,12 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     }
 #pragma unroll
     for (int i = 0; i < MFMAX; i++) a[RB] -= is_row ? pb[i] : 0.0;
+    if constexpr (NRHS > 1) {
+#pragma unroll
+      for (int q = 0; q < NRHS - 1; q++)
+#pragma unroll
+        for (int i = 0; i < MFMAX; i++) a[RB + 1 + q] -= is_row ? pbx[q][i] : 0.0;
+    }
     }  // chunks of MMAX slots
   }
   if (nxt > 0 || ntg > 0) {
@@ -502,7 +571,7 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
       my[65 * j + lane] = colj;
     });
   } else {
-    ElimSteps<NSMAX, SMAX, 0>::run(a, lane, bad, ns);
+    ElimSteps<NSMAX, SMAX, 0, NRHS>::run(a, lane, bad, ns);
   }
   FT_STAMP(4);  // eliminated
   if (bad && lane == 0) atomicExch(A.fail + 1, A.tag);  // (carries on: everybody above must still drain)
@@ -513,13 +582,14 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     if (s > 0) {
       // (every lane writes, no predicates: SMAX + 1 LDS stores, one read, one global store)
 #pragma unroll
-      for (int c = 0; c < SMAX; c++) my[(SMAX + 1) * lane + c] = a[NSMAX + c];
-      my[(SMAX + 1) * lane + SMAX] = a[RB];
+      for (int c = 0; c < SMAX; c++) my[(SMAX + NRHS) * lane + c] = a[NSMAX + c];
+#pragma unroll
+      for (int q = 0; q < NRHS; q++) my[(SMAX + NRHS) * lane + SMAX + q] = a[RB + q];
       WaveSync();
 #pragma unroll
       for (int r = 0; r < PR; r++) {
         const double v = -my[prd[r]];
-        if (lane + 64 * r < nv) StoreAgent(handG + pd[r], v);
+        if (lane + 64 * r < nv) StoreAgent((NRHS > 1 && pdt[r] ? handT : handG) + pd[r], v);
       }
       WaveSync();
     }
@@ -567,7 +637,9 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   FT_STAMP(9);  // columns of L back from the image
   constexpr int QN = SMAX < 8 ? SMAX : 8;
   double bv[QN > 0 ? QN : 1], yv[QN > 0 ? QN : 1], Mb[QN > 0 ? QN : 1];
+  double yvx[NRHS > 1 ? NRHS - 1 : 1][QN > 0 ? QN : 1];
   bv[0] = yv[0] = Mb[0] = 0.0;
+  yvx[0][0] = 0.0;
   if constexpr (QN > 0) {
 #pragma unroll
     for (int qq = 0; qq < QN; qq++) {
@@ -584,6 +656,12 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   for (int k = 0; k < NSMAX; k++) col[k] = (active && k > lane && k < ns) ? col[k] : 0.0;
   dg = active ? dg : 1.0;
   double ub = active ? a[RB] : 0.0;
+  double ubx[NRHS > 1 ? NRHS - 1 : 1];  // right-hand sides 1, 2
+  ubx[0] = 0.0;
+  if constexpr (NRHS > 1) {
+#pragma unroll
+    for (int q = 0; q < NRHS - 1; q++) ubx[q] = active ? a[RB + 1 + q] : 0.0;
+  }
   if constexpr (QN > 0) {
 #pragma unroll
     for (int qq = 0; qq < QN; qq++) Mb[qq] = (qq < cnt && active) ? bv[qq] : 0.0;
@@ -594,6 +672,13 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     for (int k = NSMAX - 1; k >= 0; k--) {
       if (lane == k) ub *= dinv;
       ub = fma(-col[k], ReadLane(ub, k), ub);  // col[k] is zero for lanes >= k
+      if constexpr (NRHS > 1) {
+#pragma unroll
+        for (int q = 0; q < NRHS - 1; q++) {
+          if (lane == k) ubx[q] *= dinv;
+          ubx[q] = fma(-col[k], ReadLane(ubx[q], k), ubx[q]);
+        }
+      }
       if constexpr (QN > 0) {
         if (cnt > 0) {
 #pragma unroll
@@ -609,11 +694,22 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     if (cnt > 0) {
       // lane qq < cnt polls the solution entry of separator variable qq
       const int sepw = __builtin_amdgcn_ds_bpermute(4 * (24 + (lane < 8 ? lane : 0)), w);
-      const double* src = ysG + (lane < cnt ? (sepw & 0x3ffffff) : (R.sep[0] & 0x3ffffff));
+      const int sidx = lane < cnt ? (sepw & 0x3ffffff) : (R.sep[0] & 0x3ffffff);
+      const double* src = ysG + sidx;
       double v;
+      double vx[NRHS > 1 ? NRHS - 1 : 1];
+      vx[0] = 0.0;
       for (int spin = 0;; spin++) {
         v = LoadAgent(src);
-        if (__ballot(lane < cnt && IsSentinel(v)) == 0) {
+        bool pending = (lane < cnt) & IsSentinel(v);
+        if constexpr (NRHS > 1) {
+#pragma unroll
+          for (int q = 0; q < NRHS - 1; q++) {
+            vx[q] = LoadAgent(ysT + (int64_t)(1 + q) * A.y_stride + sidx);
+            pending |= (lane < cnt) & IsSentinel(vx[q]);
+          }
+        }
+        if (__ballot(pending) == 0) {
           FT_COUNT(14, spin);
           break;
         }
@@ -625,20 +721,55 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
       }
 #pragma unroll
       for (int qq = 0; qq < QN; qq++) yv[qq] = ReadLane(v, qq);
+      if constexpr (NRHS > 1) {
+#pragma unroll
+        for (int q = 0; q < NRHS - 1; q++)
+#pragma unroll
+          for (int qq = 0; qq < QN; qq++) yvx[q][qq] = ReadLane(vx[q], qq);
+      }
     }
   }
   FT_STAMP(5);  // the separator's solution is in
+  double accx[NRHS > 1 ? NRHS - 1 : 1];
+  accx[0] = 0.0;
+  if constexpr (NRHS > 1 && QN > 0) {
+#pragma unroll
+    for (int q = 0; q < NRHS - 1; q++) {
+      accx[q] = ubx[q];
+#pragma unroll
+      for (int qq = 0; qq < QN; qq++) accx[q] = fma(-Mb[qq], qq < cnt ? yvx[q][qq] : 0.0, accx[q]);
+    }
+  } else if constexpr (NRHS > 1) {
+#pragma unroll
+    for (int q = 0; q < NRHS - 1; q++) accx[q] = ubx[q];
+  }
   double acc = ub;
   if constexpr (QN > 0) {
 #pragma unroll
     for (int qq = 0; qq < QN; qq++) acc = fma(-Mb[qq], qq < cnt ? yv[qq] : 0.0, acc);
   }
   if (active) StoreAgent(ysG + R.start + lane, acc);
+  if constexpr (NRHS > 1) {
+#pragma unroll
+    for (int q = 0; q < NRHS - 1; q++)
+      if (active) StoreAgent(ysT + (int64_t)(1 + q) * A.y_stride + R.start + lane, accx[q]);
+  }
   FT_STAMP(6);
   // ---- nobody waits for the rest: the solution and AW / AQc for the kernels that follow, the
   // root's factor, the re-armed slots of the other set
   if (active) {
-    A.y[R.start + lane] = acc;
+    if constexpr (NRHS == 3) {
+      // K^-1 (bs b), K^-1 (cs AQc), K^-1 AW for whoever forms the Newton direction, and y = -first + second:
+      // the solution for the right-hand side of the mu selection (-bs b + cs AQc)
+      A.y3[R.start + lane] = acc;
+      A.y3[A.y_stride + R.start + lane] = accx[0];
+      A.y3[2 * A.y_stride + R.start + lane] = accx[1];
+      A.y[R.start + lane] = accx[0] - acc;
+      StoreAgent(ysTO + A.y_stride + R.start + lane, SentinelValue());
+      StoreAgent(ysTO + 2 * A.y_stride + R.start + lane, SentinelValue());
+    } else {
+      A.y[R.start + lane] = acc;
+    }
     A.AW[R.start + lane] = awv;
     A.AQc[R.start + lane] = aqv;
     StoreAgent(ysO + R.start + lane, SentinelValue());
@@ -652,7 +783,7 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     if (s > 0) {
 #pragma unroll
       for (int r = 0; r < PR; r++)
-        if (lane + 64 * r < nv) StoreAgent(handO + pd[r], SentinelValue());
+        if (lane + 64 * r < nv) StoreAgent((NRHS > 1 && pdt[r] ? handTO : handO) + pd[r], SentinelValue());
     }
   }
   FT_STAMP_FLUSH(f(31));
@@ -734,7 +865,7 @@ __device__ __forceinline__ void FusedSolveSupernode(const FusedTreeArgs& A, cons
       auto arrived = [&](const double (&vb)[MFMAX]) {
         bool pending = false;
 #pragma unroll
-        for (int i = 0; i < MFMAX; i++) pending = pending || (i < fleft && is_row && IsSentinel(vb[i]));
+        for (int i = 0; i < MFMAX; i++) pending |= (i < fleft) & is_row & IsSentinel(vb[i]);  // (no short-circuit: FusedSupernode)
         return __ballot(pending) == 0;
       };
 #define CXK_FUSED_ISSUE(VB) \
@@ -857,9 +988,9 @@ __device__ __forceinline__ void FusedScalars(const FusedTreeArgs& A) {
 }
 
 // MODE 0: the whole sweep (assembly + factor + solve); 1: its upward half only (two launches: trees
-// too large to be resident at once)
+// too large to be resident at once); 2: the whole sweep with three right-hand sides (kFusedTriple)
 template <int NA, int SA, int NB, int SB, int MODE>
-__global__ void __launch_bounds__(64) tree_fused(FusedTreeArgs A) {
+__global__ void __launch_bounds__(64, 2) tree_fused(FusedTreeArgs A) {
   extern __shared__ double lds[];
   const int pos = blockIdx.x;
   if (pos >= A.count) {
@@ -868,12 +999,13 @@ __global__ void __launch_bounds__(64) tree_fused(FusedTreeArgs A) {
   }
   const int w = A.rec[(size_t)pos * kFusedRecWords + (threadIdx.x & 63)];
   const int ns = __builtin_amdgcn_readlane(w, 1), s = __builtin_amdgcn_readlane(w, 2);
+  constexpr int NRHS = MODE == 2 ? 3 : 1;
   if (NA == NB && SA == SB) {
-    FusedSupernode<NA, SA, MODE == 1>(A, w, lds);
+    FusedSupernode<NA, SA, MODE == 1, false, NRHS>(A, w, lds);
   } else if (RegisterShape(ns, s) == (NA << 8 | SA)) {
-    FusedSupernode<NA, SA, MODE == 1>(A, w, lds);
+    FusedSupernode<NA, SA, MODE == 1, false, NRHS>(A, w, lds);
   } else {
-    FusedSupernode<NB, SB, MODE == 1>(A, w, lds);
+    FusedSupernode<NB, SB, MODE == 1, false, NRHS>(A, w, lds);
   }
 }
 
@@ -1056,10 +1188,10 @@ __global__ void __launch_bounds__(64) tree_fused_solve(FusedTreeArgs A) {
 
 namespace {
 // doubles of LDS one wavefront needs: the transposed image of L (65 NSMAX) / the publish scratch (64 (SMAX + 1))
-constexpr int FusedImage(int nsmax, int smax) { return 65 * nsmax > 64 * (smax + 1) ? 65 * nsmax : 64 * (smax + 1); }
+constexpr int FusedImage(int nsmax, int smax) { return 65 * nsmax > 64 * (smax + 3) ? 65 * nsmax : 64 * (smax + 3); }  // (+ 3: kFusedTriple)
 
 struct FusedKernels {
-  const void* k[7];  // FusedTreeMode order
+  const void* k[8];  // FusedTreeMode order
   int image;         // doubles of LDS of the factor sweeps
 };
 
@@ -1073,6 +1205,8 @@ FusedKernels KernelsOf() {
   f.k[kFusedDown] = reinterpret_cast<const void*>(&tree_fused_solve<NA, SA, NB, SB, 2>);
   f.k[kFusedShardUp] = nullptr;
   f.k[kFusedShardTop] = nullptr;
+  f.k[kFusedTriple] = nullptr;
+  if constexpr (NA <= 32 && NB <= 32) f.k[kFusedTriple] = reinterpret_cast<const void*>(&tree_fused<NA, SA, NB, SB, 2>);
   if constexpr (NA <= 32 && NB <= 32) {  // (the wide single-supernode instances are single-GPU)
     f.k[kFusedShardUp] = reinterpret_cast<const void*>(&tree_fused_shard_up<NA, SA, NB, SB>);
     f.k[kFusedShardTop] = reinterpret_cast<const void*>(&tree_fused_shard_top<NA, SA, NB, SB>);
@@ -1130,8 +1264,8 @@ int FusedTreeOccupancy(int sa, int sb, bool sharded) {
 hipError_t LaunchFusedTree(const FusedTreeArgs& a, int sa, int sb, int mode, hipStream_t stream, hipEvent_t ev_start,
                            hipEvent_t ev_stop) {
   FusedKernels f;
-  if (mode < 0 || mode > kFusedShardTop || !ForPair(sa, sb, &f) || !f.k[mode]) return hipErrorInvalidValue;
-  const bool factor = mode == kFusedFull || mode == kFusedUp || mode == kFusedShardUp || mode == kFusedShardTop;
+  if (mode < 0 || mode > kFusedTriple || !ForPair(sa, sb, &f) || !f.k[mode]) return hipErrorInvalidValue;
+  const bool factor = mode == kFusedFull || mode == kFusedUp || mode == kFusedShardUp || mode == kFusedShardTop || mode == kFusedTriple;
   FusedTreeArgs args = a;
   void* params[] = {&args};
   // (the factor sweeps' extra workgroup sums the two scalars; the sharded up launch carries the pack of

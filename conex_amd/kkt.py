@@ -110,6 +110,8 @@ _SIGNATURES = {
     "cxk_factor_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "cxk_step_scalars_async": (C.c_int, [C.c_void_p]),
     "cxk_device_mu_supported": (C.c_int, [C.c_void_p]),
+    "cxk_triple_supported": (C.c_int, [C.c_void_p]),
+    "cxk_factor_solve_triple_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "cxk_select_mu_async": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
                                       C.c_double]),
     "cxk_newton_direction_device_mu": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),

@@ -235,6 +235,17 @@ int cxk_select_mu_async(cxk_context* ctx, double c_weight, double divergence_upp
                         double prev, double lb, double ub);
 /* cxk_newton_direction with k = the device's inv_sqrt_mu */
 int cxk_newton_direction_device_mu(cxk_context* ctx, double b_scaling, double c_scaling);
+/* The factorization carrying THREE right-hand sides through its one whole-tree launch -- bs b, cs AQc, AW --
+ * so that the solve of the mu selection (K^-1 (-bs b + cs AQc), cone_program.cc:181: left in y) and the Newton
+ * direction for the mu selected afterwards (K^-1 (k (bs b + cs AQc) - 2 AW), :409-411) are combinations of its
+ * three solutions: the cxk_newton_direction_device_mu that follows is one elementwise launch instead of a sweep
+ * over the tree.  Call order:
+ * cxk_assemble, cxk_factor_solve_triple_async, cxk_select_mu_async, cxk_newton_direction_device_mu,
+ * cxk_prepare_take_step_device_mu.  cxk_triple_supported: 1 where that applies (the tree in one launch on one
+ * GPU, every constraint on the register LMI kernels, the barrier parameter on the device, no refinement)
+ * AND the assembly just enqueued still waits to ride in the factorization (ask directly behind cxk_assemble). */
+int cxk_triple_supported(cxk_context* ctx);
+int cxk_factor_solve_triple_async(cxk_context* ctx, double b_scaling, double c_scaling);
 /* cxk_prepare_take_step with c_weight = the device's inv_sqrt_mu * c_scaling; waits, and returns
  * the selected inv_sqrt_mu as well */
 int cxk_prepare_take_step_device_mu(cxk_context* ctx, double c_scaling, double e_weight, double* info,

@@ -260,9 +260,11 @@ def test_device_mu_is_not_offered_where_the_host_is_needed():
 
 
 def test_conex_maximize_is_the_same_solve_with_mu_on_the_device_and_on_the_host(monkeypatch):
-    """CONEX_Maximize on a C4-shaped program three ways -- the one-round-trip iteration (default), the
-    host-side selection (CXK_NO_DEVICE_MU=1) and the separate reduction launches as well
-    (CXK_NO_STEP_TAIL=1): the same iterate, the same mu at every iteration, bit for bit."""
+    """CONEX_Maximize on a C4-shaped program three ways -- the one-round-trip iteration with the Newton
+    direction solved for as the reference does (CXK_NO_TRIPLE=1: a second sweep over the tree), the host-side
+    selection (CXK_NO_DEVICE_MU=1) and the separate reduction launches as well (CXK_NO_STEP_TAIL=1): the same
+    iterate, the same mu at every iteration, bit for bit.  (The default forms the direction from the three
+    solutions of ONE sweep -- equal to rounding, tests/test_gpu_triple.py.)"""
     import ctypes as C
     from conex_amd import capi as ca
     prob = syn.lmi_problem(K=120, n=20, m=20, branching=4, overlap=5, seed=41)
@@ -290,6 +292,7 @@ def test_conex_maximize_is_the_same_solve_with_mu_on_the_device_and_on_the_host(
         L.CONEX_DeleteConeProgram(p)
         return ok, y, np.array(mus)
 
+    monkeypatch.setenv("CXK_NO_TRIPLE", "1")
     ok0, y0, mu0 = solve()
     monkeypatch.setenv("CXK_NO_DEVICE_MU", "1")
     ok1, y1, mu1 = solve()
