@@ -51,8 +51,13 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "device_utils.h"
+
+#ifndef CXK_RELOAD_MODE
+#define CXK_RELOAD_MODE 3  // when a producer asks for the next constraint's operands (producer loop below): 0 late, 1 early, 3 early from the second iteration on
+#endif
 
 namespace cxk {
 namespace {
@@ -486,7 +491,7 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    for (int it = 0; it < cnt; it++) {
+    auto iteration = [&](int it, auto early_c) {
       // Every load below is unconditional (a tile slot past the last tile re-reads the last tile,
       // the last iteration re-reads its own constraint: cache hits that nothing waits for), so the
       // count of loads in flight is the same on every path and each wait can be exact.
@@ -502,25 +507,42 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
       double* Pb = P0 + (single ? 0 : (it & 1) * pbuf);
       if (single && it > 0) LdsBarrier();  // the consumers are done with the image
       TileAcc<N> res[2];
+      // When a producer asks for the next constraint's operands.  EARLY: right behind the MFMAs of the tile that
+      // held the registers (they read their operands at issue) -- a tile's pipe time, 800 - 2000 cycles of this
+      // wave's schedule, earlier than behind the NEXT tile's MFMAs, where the request sat until round 4.  The
+      // steady state is bound by WHEN the requests go out, not by how many bytes are in flight: C4 step
+      // 47.7 -> 46.7 us on one box (asking again k-step by k-step inside the tile: 48.1 -- more instructions
+      // between the MFMAs, two spilled registers).  The FIRST iteration keeps the late placement: its own
+      // operands are still on their way from every CU of the chip at once, and early requests for the second
+      // constraint lengthened that fill from 11.7 k to 13.9 k cycles.  (The first iteration is peeled off the
+      // loop, not a branch inside it: the compiler's load counting would merge the two placements at every tile
+      // and wait for the younger loads.)
+      constexpr bool EARLY = decltype(early_c)::value;
+      {
 #pragma unroll
-      for (int tt = 0; tt <= TPW; tt++) {
-        const bool cur_ok = tt < TPW && wave + Cfg::PROD * tt < nt1;
-        const bool prev_ok = tt > 0 && wave + Cfg::PROD * (tt - 1) < nt1;
-        if (it == 2) MSTAMP(48 + 2 * tt);
-        if (cur_ok) {
-          if (tt == 0)
-            FullStep<N, false>(res[0], a[0], w, res[1], Pb, gm, 0);
-          else
-            FullStep<N, true>(res[tt & 1], a[tt < TPW ? tt : 0], w, res[(tt & 1) ^ 1], Pb, gm, tt);
-        } else if (prev_ok) {
-          // the wave's last tile (possibly the ragged last tile of the constraint: masked stores)
+        for (int tt = 0; tt <= TPW; tt++) {
+          const bool cur_ok = tt < TPW && wave + Cfg::PROD * tt < nt1;
+          const bool prev_ok = tt > 0 && wave + Cfg::PROD * (tt - 1) < nt1;
+          if (it == 2) MSTAMP(48 + 2 * tt);
+          if (cur_ok) {
+            if (tt == 0)
+              FullStep<N, false>(res[0], a[0], w, res[1], Pb, gm, 0);
+            else
+              FullStep<N, true>(res[tt & 1], a[tt < TPW ? tt : 0], w, res[(tt & 1) ^ 1], Pb, gm, tt);
+          } else if (prev_ok) {
+            // the wave's last tile (possibly the ragged last tile of the constraint: masked stores)
 #pragma unroll
-          for (int e = 0; e < Cfg::PIECES; e++) StorePiece<N, true>(res[(tt & 1) ^ 1], e, Pb, gm, tt - 1);
+            for (int e = 0; e < Cfg::PIECES; e++) StorePiece<N, true>(res[(tt & 1) ^ 1], e, Pb, gm, tt - 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (it == 2) MSTAMP(49 + 2 * tt);
+          if constexpr (EARLY) {
+            if (tt < TPW) LoadTile<N>(a[tt], gm, tt, nx.block);
+          } else {
+            if (tt > 0) LoadTile<N>(a[tt - 1], gm, tt - 1, nx.block);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (it == 2) MSTAMP(49 + 2 * tt);
-        if (tt > 0) LoadTile<N>(a[tt - 1], gm, tt - 1, nx.block);
-        __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (N > 20) {
         LoadW<N>(wn, nx.Wg, lane, g.n);
@@ -528,6 +550,14 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
       }
       MSTAMP(2 + 4 * it);
       LdsBarrier();
+    };
+    if (CXK_RELOAD_MODE == 1) {
+      for (int it = 0; it < cnt; it++) iteration(it, std::true_type{});
+    } else if (CXK_RELOAD_MODE == 0) {
+      for (int it = 0; it < cnt; it++) iteration(it, std::false_type{});
+    } else {
+      iteration(0, std::false_type{});
+      for (int it = 1; it < cnt; it++) iteration(it, std::true_type{});
     }
     MSTAMP(1 + 4 * cnt);
     // The drain: the consumers contract the last constraint.  Its predecessor's epilogue -- theirs in
