@@ -328,6 +328,12 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   if constexpr (FROM_X) rb -= fwx;  // (exchange_unpack: y = .. - the forward values of all ranks' subtrees)
 #pragma unroll
   for (int j = 0; j < NSMAX; j++) a[j] = (j < lim) ? a[j] : 0.0;
+  // padding pivots: unit diagonal (set here, ahead of the wait for the descendants -- no pulled entry is a padding
+  // one, the LDS image below carries them along -- instead of behind it, where every instruction is on the
+  // tree's critical path)
+#pragma unroll
+  for (int j = 0; j < NSMAX; j++)
+    if (j >= ns && lane == j) a[j] = 1.0;
 #pragma unroll
   for (int c = 0; c < SMAX; c++) a[NSMAX + c] = 0.0;
   a[RB] = is_row ? (NRHS == 1 ? rb : rb * A.bs) : 0.0;
@@ -554,10 +560,6 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     for (int j = 0; j < NSMAX; j++) a[j] = my[64 * j + lane];
     WaveSync();  // (the image is reused below)
   }
-  // padding pivots: unit diagonal
-#pragma unroll
-  for (int j = 0; j < NSMAX; j++)
-    if (j >= ns && lane == j) a[j] = 1.0;
   FT_STAMP(3);  // descendants' values are in
   bool bad = false;
   if constexpr (NSMAX > 32) {
