@@ -107,6 +107,11 @@ struct FusedTreeArgs {
   unsigned long long done_target;
 };
 
+// The lane that takes the first right-hand side as a ROW of the panel in tree_fused's elimination (the next
+// ones follow it), or -1: shapes whose column updates reach a free lane -- <16, 8>: separator rows end at lane
+// 23, the updates cover DPP row 1; <24, 0>: rows end at lane 23, the updates cover DPP rows 0 and 1.
+constexpr int FusedRhsLane(int nsmax, int smax) { return (nsmax == 16 && smax == 8) || (nsmax == 24 && smax == 0) ? 24 : -1; }
+
 // What a launch does.  A tree whose supernodes are all resident at once takes kFusedFull (assembly,
 // factorization with the first right-hand side, back substitution) and kFusedSolve (forward + back
 // substitution on the stored factor); a larger one the same work as two launches each -- kFusedUp

@@ -116,6 +116,16 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   static_assert(NRHS == 1 || (NRHS == 3 && !UP_ONLY && !FROM_X && NSMAX <= 32), "three right-hand sides: the one-launch sweep of a single GPU");
   // (three right-hand sides: pull lists four slots at a time -- the registers of eight are spoken for)
   constexpr int RB = NSMAX + SMAX, MMAX = NRHS > 1 ? 4 : kFastSlots, MFMAX = MMAX, XMAX = kFusedExtraSlots;
+  // The right-hand sides ride through the elimination as ROWS of the panel where a free lane takes them
+  // (lanes RL .. of DPP row 1, FusedRhsLane): a row under the panel is forward-solved by the column updates
+  // every lane takes part in anyway -- y_j = (b_j - sum_k L[j][k] y_k) / L[j][j] in its entry j, -off[:,c] . y
+  // in its trailing entry c: the same fma chains, the same bits -- so the nine instructions per pivot and
+  // right-hand side of the column form (two v_readlane, a multiply, an fma, selects: 135 on the critical path
+  // of a 15-column supernode, 405 with three right-hand sides) become one transposition through LDS in front
+  // of the elimination; behind it the values sit where the image of L's rows puts them anyway.
+  constexpr int RL = FusedRhsLane(NSMAX, SMAX);
+  constexpr bool ROWRHS = RL >= 0 && !UP_ONLY && !FROM_X;
+  constexpr int NCOL = ROWRHS ? 0 : NRHS;  // right-hand side COLUMNS a[RB ..] of the elimination
   constexpr int NVMAX = SMAX * (SMAX + 1) / 2 + NRHS * SMAX;  // values a supernode publishes
   constexpr int PR = (NVMAX + 63) / 64;                // ... in this many store instructions
   const int lane = threadIdx.x & 63;
@@ -158,7 +168,8 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   const int mypr = (__builtin_amdgcn_ds_bpermute(4 * (32 + 6 + (q >> 2)), w) >> (8 * (q & 3))) & 255;
   const int myp = mypr == 255 ? 0 : mypr;
   const int has_fill = FROM_X ? 0 : f(5);
-  double a[NSMAX + SMAX + NRHS];
+  double a[NSMAX + SMAX + NCOL];
+  double rv[NRHS];  // this lane's entry of every right-hand side, until the elimination
   double fwx = 0.0;  // FROM_X: what this rank's ... every rank's subtrees subtract from the right-hand side
   if constexpr (FROM_X) {
     // entry (row, j) of the diagonal block sits at xs_base + j ns - j (j - 1) / 2 + (row - j) (lower
@@ -230,7 +241,10 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
       k++;
     }
     const int kk = t < npairs ? k : tk - npairs, cc = t < npairs ? k + rem : SMAX + tq;
-    prd[r] = (SMAX + NRHS) * (NSMAX + (t < nv ? kk : 0)) + (t < nv ? cc : 0);
+    if (ROWRHS && t >= npairs)  // (forward value k of right-hand side tq: trailing entry k of its row)
+      prd[r] = (SMAX + NRHS) * (RL + (t < nv ? tq : 0)) + (t < nv ? kk : 0);
+    else
+      prd[r] = (SMAX + NRHS) * (NSMAX + (t < nv ? kk : 0)) + (t < nv ? cc : 0);
   }
   const int ntg = R.tg_end - R.tg_beg;
   int ploc0 = 0, ploc1 = 0;
@@ -336,10 +350,10 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     if (j >= ns && lane == j) a[j] = 1.0;
 #pragma unroll
   for (int c = 0; c < SMAX; c++) a[NSMAX + c] = 0.0;
-  a[RB] = is_row ? (NRHS == 1 ? rb : rb * A.bs) : 0.0;
+  rv[0] = is_row ? (NRHS == 1 ? rb : rb * A.bs) : 0.0;
   if constexpr (NRHS == 3) {
-    a[RB + 1] = is_row ? aqv * A.cs : 0.0;
-    a[RB + 2] = is_row ? awv : 0.0;
+    rv[1] = is_row ? aqv * A.cs : 0.0;
+    rv[2] = is_row ? awv : 0.0;
   }
   FT_STAMP(2);  // panel and right-hand side assembled (own block; further sources still to add)
 
@@ -546,12 +560,12 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
       WaveSync();
     }
 #pragma unroll
-    for (int i = 0; i < MFMAX; i++) a[RB] -= is_row ? pb[i] : 0.0;
+    for (int i = 0; i < MFMAX; i++) rv[0] -= is_row ? pb[i] : 0.0;
     if constexpr (NRHS > 1) {
 #pragma unroll
       for (int q = 0; q < NRHS - 1; q++)
 #pragma unroll
-        for (int i = 0; i < MFMAX; i++) a[RB + 1 + q] -= is_row ? pbx[q][i] : 0.0;
+        for (int i = 0; i < MFMAX; i++) rv[1 + q] -= is_row ? pbx[q][i] : 0.0;
     }
     }  // chunks of MMAX slots
   }
@@ -559,6 +573,20 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
 #pragma unroll
     for (int j = 0; j < NSMAX; j++) a[j] = my[64 * j + lane];
     WaveSync();  // (the image is reused below)
+  }
+  if constexpr (ROWRHS) {
+    // right-hand side q becomes row RL + q of the panel: entry j = lane j's value (zero beyond the columns)
+#pragma unroll
+    for (int q = 0; q < NRHS; q++) my[64 * q + lane] = rv[q];
+    WaveSync();
+    if (lane >= RL && lane < RL + NRHS) {
+#pragma unroll
+      for (int j = 0; j < NSMAX; j++) a[j] = my[64 * (lane - RL) + j];
+    }
+    WaveSync();  // (the image is reused below)
+  } else {
+#pragma unroll
+    for (int q = 0; q < NRHS; q++) a[RB + q] = rv[q];
   }
   FT_STAMP(3);  // descendants' values are in
   bool bad = false;
@@ -573,7 +601,7 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
       my[65 * j + lane] = colj;
     });
   } else {
-    ElimSteps<NSMAX, SMAX, 0, NRHS>::run(a, lane, bad, ns);
+    ElimSteps<NSMAX, SMAX, 0, NCOL>::run(a, lane, bad, ns);
   }
   FT_STAMP(4);  // eliminated
   if (bad && lane == 0) atomicExch(A.fail + 1, A.tag);  // (carries on: everybody above must still drain)
@@ -586,7 +614,7 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
 #pragma unroll
       for (int c = 0; c < SMAX; c++) my[(SMAX + NRHS) * lane + c] = a[NSMAX + c];
 #pragma unroll
-      for (int q = 0; q < NRHS; q++) my[(SMAX + NRHS) * lane + SMAX + q] = a[RB + q];
+      for (int q = 0; q < NCOL; q++) my[(SMAX + NRHS) * lane + SMAX + q] = a[RB + q];
       WaveSync();
 #pragma unroll
       for (int r = 0; r < PR; r++) {
@@ -602,7 +630,7 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     for (int j = 0; j < NSMAX; j++)
       if (j < lim) base[o0 + j * st] = a[j];
     if (is_row) {
-      A.y[R.start + lane] = a[RB];
+      A.y[R.start + lane] = a[NCOL > 0 ? RB : 0];  // (UP_ONLY: the column form)
       A.AW[R.start + lane] = awv;
       A.AQc[R.start + lane] = aqv;
     }
@@ -657,12 +685,18 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
 #pragma unroll
   for (int k = 0; k < NSMAX; k++) col[k] = (active && k > lane && k < ns) ? col[k] : 0.0;
   dg = active ? dg : 1.0;
-  double ub = active ? a[RB] : 0.0;
-  double ubx[NRHS > 1 ? NRHS - 1 : 1];  // right-hand sides 1, 2
+  // the forward-solved right-hand side of this lane's row: in the column a[RB ..], or entry `lane` of row RL + q
+  // (the image holds a_l[j] at 65 j + l)
+  double ub, ubx[NRHS > 1 ? NRHS - 1 : 1];  // right-hand side 0; 1, 2
   ubx[0] = 0.0;
-  if constexpr (NRHS > 1) {
+  if constexpr (ROWRHS) {
+    ub = active ? my[65 * li + RL] : 0.0;
 #pragma unroll
-    for (int q = 0; q < NRHS - 1; q++) ubx[q] = active ? a[RB + 1 + q] : 0.0;
+    for (int q = 0; q < NRHS - 1; q++) ubx[q] = active ? my[65 * li + RL + 1 + q] : 0.0;
+  } else {
+    ub = active ? a[NCOL > 0 ? RB : 0] : 0.0;
+#pragma unroll
+    for (int q = 0; q < NCOL - 1; q++) ubx[q] = active ? a[RB + 1 + q] : 0.0;
   }
   if constexpr (QN > 0) {
 #pragma unroll
