@@ -502,7 +502,10 @@ __device__ __forceinline__ double EvenRowsToOddRows(double v) {
 // has taken its own update, so that the chain overlaps the remaining column updates of step J-1
 // instead of following them.  Same operations on the same values: results are unchanged.
 // NRHS right-hand side columns a[RB ..] (1; 3 in the whole-tree launch with three right-hand sides).
-template <int NSMAX, int SMAX, int J, int NRHS = 1>
+// CHECK = false: no test of the pivots (two instructions per pivot on a lone wavefront's critical path): a pivot
+// that is not positive leaves NaNs in its column and in everything eliminated behind it, and the caller looks
+// for them in what it produces at its end (tree_fused: the solution entries).
+template <int NSMAX, int SMAX, int J, int NRHS = 1, bool CHECK = true>
 struct ElimSteps {
   static constexpr int LEN = NSMAX + SMAX + NRHS, RB = NSMAX + SMAX;
   // ns = columns of the supernode (wave-uniform): the padding pivots ns .. NSMAX-1 are identity
@@ -510,7 +513,7 @@ struct ElimSteps {
   static __device__ __forceinline__ void run(double (&a)[LEN], int lane, bool& bad, int ns) {
     if constexpr (J == 0 && NSMAX > 0) {
       const double d = ReadLane(a[0], 0);
-      bad |= !(d > 0.0);
+      if constexpr (CHECK) bad |= !(d > 0.0);
       double root, inv;
       SqrtAndInverse(d, root, inv);
       step(a, lane, bad, root, inv, ns);
@@ -524,7 +527,7 @@ struct ElimSteps {
       auto next_pivot = [&]() {  // column J+1 is final for step J+1 once it has taken column J's term
         if constexpr (J + 1 < NSMAX) {
           const double d1 = ReadLane(a[J + 1], J + 1);
-          bad |= !(d1 > 0.0);
+          if constexpr (CHECK) bad |= !(d1 > 0.0);
           SqrtAndInverse(d1, root1, inv1);
         }
       };
@@ -582,7 +585,7 @@ struct ElimSteps {
         else if (lane == J)
           a[RB + q] = yj;
       }
-      ElimSteps<NSMAX, SMAX, J + 1, NRHS>::step(a, lane, bad, root1, inv1, ns);
+      ElimSteps<NSMAX, SMAX, J + 1, NRHS, CHECK>::step(a, lane, bad, root1, inv1, ns);
     }
   }
 };

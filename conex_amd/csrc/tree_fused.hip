@@ -601,7 +601,7 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
       my[65 * j + lane] = colj;
     });
   } else {
-    ElimSteps<NSMAX, SMAX, 0, NCOL>::run(a, lane, bad, ns);
+    ElimSteps<NSMAX, SMAX, 0, NCOL, !ROWRHS>::run(a, lane, bad, ns);  // (ROWRHS: the pivots are judged by the solution, below)
   }
   FT_STAMP(4);  // eliminated
   if (bad && lane == 0) atomicExch(A.fail + 1, A.tag);  // (carries on: everybody above must still drain)
@@ -785,6 +785,11 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     for (int qq = 0; qq < QN; qq++) acc = fma(-Mb[qq], qq < cnt ? yv[qq] : 0.0, acc);
   }
   if (active) StoreAgent(ysG + R.start + lane, acc);
+  if constexpr (ROWRHS) {
+    // a pivot that was not positive (here or in a descendant) has left NaNs in everything behind it: the test of
+    // the factorization, two instructions per pivot inside the elimination, is one comparison out here
+    if (__ballot(active && !(acc == acc)) != 0 && lane == 0) atomicExch(A.fail + 1, A.tag);
+  }
   if constexpr (NRHS > 1) {
 #pragma unroll
     for (int q = 0; q < NRHS - 1; q++)
