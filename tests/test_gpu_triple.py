@@ -99,6 +99,38 @@ def test_direction_from_three_solutions_against_the_oracle():
     assert np.linalg.norm(y - yb) <= 1e-10 * np.linalg.norm(yb)
 
 
+def test_direction_asked_for_before_prepare_step_is_materialised():
+    """Behind the triple launch the direction is normally formed inside PrepareStep; whoever reads y first gets
+    it from one elementwise launch instead (FlushDeferred) -- the same values."""
+    K = 40
+    prob = syn.lmi_problem(K=K, n=20, m=20, branching=4, overlap=5, seed=5)
+    a, b = _pair(prob)
+    W = syn.scaling_points(K, 20, seed=10)
+    bs, cs = 0.9, 0.8
+    for k in (a, b):
+        for i in range(K):
+            k.set_W(i, W[i])
+        k.set_cost(prob["b"])
+        k.assemble()
+    a._check(a.L.cxk_factor_solve_triple_async(a.h, bs, cs), "cxk_factor_solve_triple_async")
+    b.factor_solve_async(-bs, cs, 0.0)
+    for k in (a, b):
+        k._check(k.L.cxk_select_mu_async(k.h, cs, 1.0, 20 * K, 0.3, 1e-8, 1e9), "cxk_select_mu_async")
+        k._check(k.L.cxk_newton_direction_device_mu(k.h, bs, cs), "cxk_newton_direction_device_mu")
+    ya, yb = a.get_y(), b.get_y()          # (a: materialised here)
+    assert np.linalg.norm(ya - yb) <= 1e-9 * np.linalg.norm(yb)
+    # ... and PrepareStep then takes y as it finds it
+    res = []
+    for k in (a, b):
+        assert k.L.cxk_step_scalars_async(k.h) == 0
+        info, took, inv = np.zeros(2), C.c_int(0), C.c_double(0)
+        k._check(k.L.cxk_prepare_take_step_device_mu(k.h, cs, 1.0, ol.dp(info), C.byref(took), C.byref(inv)),
+                 "cxk_prepare_take_step_device_mu")
+        res.append((info.copy(), k.step_scalars()))
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-8, atol=1e-12)
+    assert np.allclose(res[0][1], res[1][1], rtol=1e-8, atol=1e-12)
+
+
 def test_not_offered_where_it_does_not_apply():
     prob, kind = syn.soc_problem(K=40, dim=6, m=5, overlap=2, tree=4), "soc"
     k = syn.build(KktContext, prob, kind, device=0)
