@@ -182,11 +182,8 @@ __global__ void __launch_bounds__(256) lmi_take_step_rows(LmiGroup g, StepArgs s
   GjSteps<N, 0>::run(aug, lane, n, done, mypiv, myk);
   // this lane now holds row myk of E = denominator^-1 numerator
   double e[N], w[N], ew[N];
-  // (one reciprocal and N products for the row's N quotients: a division is ~12 instructions of this lone
-  // wavefront; the row of E differs from the quotients' in the last bit, W stays within the 1e-11 of the parity tests)
-  const double rpiv = 1.0 / mypiv;
 #pragma unroll
-  for (int c = 0; c < N; c++) e[c] = aug[N + c] * rpiv;
+  for (int c = 0; c < N; c++) e[c] = aug[N + c] / mypiv;
 #pragma unroll
   for (int c = 0; c < N; c++) w[c] = (row && c < n) ? Wg[r + c * n] : 0.0;  // lane j: row j of W
   RowTimesMatrix<N, 0>::run(e, w, ew);  // row myk of E W
