@@ -105,6 +105,8 @@ struct MfmaCfg {
   static constexpr int YSLOTS = 1;            // tile slots a producer keeps for phase Y
   static constexpr bool DRAIN_HELP = N <= 20; // the producers take epilogues off the consumers in the drain
   static constexpr int THREADS = 64 * (PROD + CONS);
+  static constexpr int CUT_A = (3 * RPM + 2) / 4;  // three tiles: the 3/4 cut of the K range (rows of a matrix)
+  static constexpr int PARTS = THREE_TILES ? 6 : CONS;  // partial tiles of a contraction (three tiles: each in two K parts)
   static_assert(N % CONS == 0, "stage-2 rows (N/4 k-steps each) are dealt evenly to the consumer waves");
   // offset of the B-side operand of k-step bi inside the row block of P_y (doubles): P_y[4 bi + kq][r],
   // or for the second sum of the Hermitian form P_y[4 (bi - NK/2) + kq][N/2 + r]
@@ -417,11 +419,10 @@ __device__ __forceinline__ void Epilogue(const double* __restrict__ sb, const in
   double* AQc = ar.AQcc + dest[3 * c + 2];
   for (int e = t0; e < nout; e += nt) {
     const int code = etab[e];
-    const int off = code & 1023, kind = (code >> 10) & 3, dst = code >> 12;
+    const int off = code & 2047, kind = (code >> 11) & 3, dst = code >> 13;
     double sum;
     if (three) {
-      sum = sb[off];
-      if (off >= 256 && off < 768) sum += sb[off + 256];  // T10: two K halves
+      sum = sb[off] + sb[off + 256];  // (every tile in two K parts: the consumers' work split)
     } else {
       if (two && off >= 768)
         sum = sb[off] + sb[off + 4];
@@ -458,7 +459,7 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
   const bool two = M1 > 16 && M1 <= 24, three = Cfg::THREE_TILES && M1 > 24;
   double* P0 = lds;
   double* scratch = lds + (single ? 1 : 2) * (size_t)pbuf;  // 2 buffers x CONS partial tiles of 256 entries
-  constexpr int SB = Cfg::CONS * 256;
+  constexpr int SB = Cfg::PARTS * 256;
   // where this workgroup's constraints write (kDestSlots x {id, g_off, r_off}) and the epilogue
   // table, both filled by the consumers in iteration 0
   int64_t* dest = reinterpret_cast<int64_t*>(scratch + 2 * SB);
@@ -587,13 +588,23 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
   // leaves out.  M1 <= 16: the four waves take the K quarters of the single tile (rows past M1
   // alias M1 - 1).  25 <= M1 <= 32: three tiles -- T00 (matrices 0..15 squared) on wave 0, T10
   // (rows 16.., columns 0..15) in two K halves on waves 1 and 2, T11 (16.. squared) on wave 3.
+  // (Round 4: T00 and T11 whole on one wave each and T10 in halves gave the four waves 4 : 2 : 2 : 4 of the
+  // K range -- the contraction, not the producers, set the pace of config 5's folded Hermitian form.  Now every
+  // tile goes in two K parts, cut so that each wave takes 3/4 of a tile's range: wave 0 the first 3/4 of T00;
+  // wave 1 its last 1/4 and the first half of T10; wave 2 the second half of T10 and the first 1/4 of T11;
+  // wave 3 its last 3/4.  Six partial tiles, each result the sum of two.)
   int rr0, nrows, ra, ca;
+  int rr0b = 0, nrowsb = 0, rab = 0, cab = 0;  // three tiles: a wave's second piece (none on waves 0 and 3)
   if (three) {
-    const int hi = (16 + il < M1 ? 16 + il : M1 - 1) * MS;
-    ra = cw == 0 ? il * MS : hi;
-    ca = cw == 3 ? hi : il * MS;
-    rr0 = cw == 2 ? RPM / 2 : 0;
-    nrows = cw == 1 ? RPM / 2 : (cw == 2 ? RPM - RPM / 2 : RPM);
+    const int hi = (16 + il < M1 ? 16 + il : M1 - 1) * MS, lo = il * MS;
+    constexpr int QA = Cfg::CUT_A, QB = RPM / 2;
+    ra = cw <= 1 ? lo : hi;                 // first piece: T00 (waves 0, 1), T10 (wave 2), T11 (wave 3)
+    ca = cw == 3 ? hi : lo;
+    rr0 = cw == 0 ? 0 : (cw == 1 ? QA : (cw == 2 ? QB : RPM - QA));
+    nrows = cw == 0 ? QA : (cw == 1 ? RPM - QA : (cw == 2 ? RPM - QB : QA));
+    rab = hi;                               // second piece: T10 first half (wave 1), T11 first quarter (wave 2)
+    cab = cw == 1 ? lo : hi;
+    nrowsb = cw == 1 ? QB : (cw == 2 ? RPM - QA : 0);
   } else {
     const int parts = two ? Cfg::CONS - 1 : Cfg::CONS;
     const int part = cw < parts ? cw : 0;
@@ -627,13 +638,13 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
         off = 768 + 64 * u + 16 * (a & 3) + 8 * t + (b & 3);
       }
     } else if (three) {
-      off = ii < 16 ? ii * 16 + jj : (jj < 16 ? 256 + (ii - 16) * 16 + jj : 768 + (ii - 16) * 16 + (jj - 16));
+      off = ii < 16 ? ii * 16 + jj : (jj < 16 ? 512 + (ii - 16) * 16 + jj : 1024 + (ii - 16) * 16 + (jj - 16));
     } else {
       off = ii * 16 + jj;
     }
     const int kind = ii < M ? 0 : (jj < M ? 1 : 2);
     const int dst = ii < M ? ii + jj * M : (jj < M ? jj : 0);
-    etab[ii * (ii + 1) / 2 + jj] = off | kind << 10 | dst << 12;
+    etab[ii * (ii + 1) / 2 + jj] = off | kind << 11 | dst << 13;
   }
   // AW(i) = tr(P_i), <w,c> = tr(P_C) from the image being contracted: one lane per matrix.
   auto traces = [&](int c) {
@@ -667,10 +678,17 @@ __global__ void __launch_bounds__(MfmaCfg<N>::THREADS) lmi_schur_mfma(LmiGroup g
       else
         Triangles<N, false>(Pb, sb + 256 * (Cfg::CONS - 1), lane, M1);
     } else {
-      const d4_t acc = three ? Contract<N, RPM, H>(Pb, ra, ca, rr0, kq, nrows) : Contract<N, MAXROWS, H>(Pb, ra, ca, rr0, kq, nrows);
+      const d4_t acc = three ? Contract<N, Cfg::CUT_A, H>(Pb, ra, ca, rr0, kq, nrows) : Contract<N, MAXROWS, H>(Pb, ra, ca, rr0, kq, nrows);
+      // (three tiles: partial tiles T00a T00b T10a T10b T11a T11b; wave 0 -> 0, wave 1 -> 1 and 2, wave 2 -> 3 and 4, wave 3 -> 5)
+      const int slot = three ? (cw == 0 ? 0 : (cw == 1 ? 1 : (cw == 2 ? 3 : 5))) : cw;
 #pragma unroll
       for (int e = 0; e < 4; e++)  // C/D layout: column = lane & 15, row = (lane >> 4) + 4 e
-        sb[cw * 256 + (kq + 4 * e) * 16 + il] = acc[e];
+        sb[slot * 256 + (kq + 4 * e) * 16 + il] = acc[e];
+      if (three && nrowsb > 0) {  // (wave-uniform)
+        const d4_t accb = Contract<N, RPM / 2, H>(Pb, rab, cab, rr0b, kq, nrowsb);
+#pragma unroll
+        for (int e = 0; e < 4; e++) sb[(slot + 1) * 256 + (kq + 4 * e) * 16 + il] = accb[e];
+      }
     }
     MSTAMP(2 + 4 * it);
     // The consumers finish their contraction well before the producers their tiles: the results
@@ -692,7 +710,7 @@ template <int N, bool H>
 size_t MfmaLds(int m, int single = 0) {
   using Cfg = MfmaCfg<N, H>;
   const int m1 = m + 1;
-  return sizeof(double) * ((single ? 1 : 2) * (size_t)m1 * Cfg::MS + 2 * (size_t)Cfg::CONS * 256 + 3 * kDestSlots) +
+  return sizeof(double) * ((single ? 1 : 2) * (size_t)m1 * Cfg::MS + 2 * (size_t)Cfg::PARTS * 256 + 3 * kDestSlots) +
          sizeof(int) * (size_t)(m1 * (m1 + 1) / 2);
 }
 
