@@ -1128,6 +1128,50 @@ int BuildPlans(cxk_context* ctx) {
             for (size_t q = 1; q < 3; q++) ctx->fx_hand_init[d + q * ubs] = ctx->fx_hand_init[hs + d + q * ubs] = sent;
         }
       }
+      if (!split && !sharded && !getenv("CXK_FUSED_LEVEL_ORDER")) {
+        // Which workgroup takes which supernode.  Every wavefront of the launch is resident (no order is needed
+        // for progress) and the dispatcher deals workgroups round-robin over the 8 XCDs (workgroup b on XCD
+        // b mod 8: tools/xcc_placement_bench.hip -- a speed assumption only).  A hand-off between wavefronts of
+        // one XCD is 0.1 - 0.3 us shorter than one across the fabric (MI355X_MICROARCH.md, handoff-1to1), and
+        // the launch is nine hand-offs deep: the supernodes are dealt in depth-first order of the tree, an
+        // eighth of them per XCD, so that a supernode mostly sits with its children; within an XCD the level
+        // order stays (leaves first: they have the most to load).
+        std::vector<int> pos_of(K, -1), parent(cnt_all, -1);
+        for (int pos = 0; pos < cnt_all; pos++) pos_of[ctx->level_sn[pos]] = pos;
+        std::vector<std::vector<int>> kids(cnt_all);
+        std::vector<int> roots;
+        for (int pos = 0; pos < cnt_all; pos++) {
+          int par = INT32_MAX;
+          for (int v : L.separators[ctx->level_sn[pos]]) par = std::min(par, pos_of[L.var_to_sn[v]]);
+          if (par == INT32_MAX)
+            roots.push_back(pos);
+          else
+            kids[par].push_back(pos);
+        }
+        std::vector<int> dfs, stack(roots.rbegin(), roots.rend());
+        dfs.reserve(cnt_all);
+        while (!stack.empty()) {
+          const int u = stack.back();
+          stack.pop_back();
+          dfs.push_back(u);
+          for (auto it = kids[u].rbegin(); it != kids[u].rend(); ++it) stack.push_back(*it);
+        }
+        if ((int)dfs.size() == cnt_all) {
+          std::vector<int> perm(cnt_all, -1);  // workgroup -> position in level order
+          size_t at = 0;
+          for (int x = 0; x < 8; x++) {
+            const int n = (cnt_all - x + 7) / 8;  // workgroups x, x + 8, ... below cnt_all
+            std::vector<int> mine(dfs.begin() + at, dfs.begin() + at + n);
+            at += n;
+            std::sort(mine.begin(), mine.end());
+            for (int i = 0; i < n; i++) perm[8 * i + x] = mine[i];
+          }
+          std::vector<int> dealt(recs.size());
+          for (int b = 0; b < cnt_all; b++)
+            memcpy(dealt.data() + (size_t)b * kFusedRecWords, recs.data() + (size_t)perm[b] * kFusedRecWords, sizeof(int) * kFusedRecWords);
+          recs.swap(dealt);
+        }
+      }
       CXK_TRY(ctx->fx_rec.upload(recs));
       CXK_TRY(ctx->fx_xreg.upload(xreg));
       CXK_TRY(ctx->fx_xsrc.upload(xsrc));
