@@ -569,21 +569,33 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     }
     }  // chunks of MMAX slots
   }
-  if (nxt > 0 || ntg > 0) {
+  const bool imaged = nxt > 0 || ntg > 0;
+  if (imaged) {
+    if constexpr (ROWRHS) {
+      // right-hand side q becomes row RL + q of the panel, entry j = lane j's value (zero beyond the columns): lane j
+      // puts it where the image has that entry, and the read below hands the rows out with the panel's -- no pass of
+      // its own behind the descendants' values (NSMAX reads and two waits per level of the tree, ~0.3 us each)
+      if (lane < NSMAX) {
+#pragma unroll
+        for (int q = 0; q < NRHS; q++) my[64 * lane + RL + q] = rv[q];
+      }
+      WaveSync();
+    }
 #pragma unroll
     for (int j = 0; j < NSMAX; j++) a[j] = my[64 * j + lane];
     WaveSync();  // (the image is reused below)
   }
   if constexpr (ROWRHS) {
-    // right-hand side q becomes row RL + q of the panel: entry j = lane j's value (zero beyond the columns)
+    if (!imaged) {  // (a leaf: no image so far)
 #pragma unroll
-    for (int q = 0; q < NRHS; q++) my[64 * q + lane] = rv[q];
-    WaveSync();
-    if (lane >= RL && lane < RL + NRHS) {
+      for (int q = 0; q < NRHS; q++) my[64 * q + lane] = rv[q];
+      WaveSync();
+      if (lane >= RL && lane < RL + NRHS) {
 #pragma unroll
-      for (int j = 0; j < NSMAX; j++) a[j] = my[64 * (lane - RL) + j];
+        for (int j = 0; j < NSMAX; j++) a[j] = my[64 * (lane - RL) + j];
+      }
+      WaveSync();  // (the image is reused below)
     }
-    WaveSync();  // (the image is reused below)
   } else {
 #pragma unroll
     for (int q = 0; q < NRHS; q++) a[RB + q] = rv[q];
