@@ -693,6 +693,14 @@ struct StepTail {
   int scal, N;    // scal != 0: the step scalars as well
   const double *b, *AQc, *y, *sys_sc;
   double* scal_out;
+  // ny > 0: the Newton direction is still the three solutions of the triple factorization (StepArgs::y3).  The
+  // constraints' wavefronts combine the entries they need where they read them; ny further workgroups behind this
+  // one write all of y out (DirectionBlock), count themselves in y_done, and this workgroup forms its scalars when
+  // the count has reached y_target -- long before the constraints' results arrive.
+  int ny;
+  double* y_out;
+  unsigned long long* y_done;
+  unsigned long long y_target;
   MailboxArgs mbx;
   MuRuleArgs rule;  // mode 1: the selection of inv_sqrt_mu on the device
 };
@@ -706,7 +714,7 @@ __device__ __forceinline__ void AgentStore(double* p, double v) {
 // wave totals added in the same order: the same bits.
 __device__ inline void StepScalarsOn256(int N, const double* __restrict__ b, const double* __restrict__ AQc,
                                         const double* __restrict__ y, const double* __restrict__ sys_sc,
-                                        double* __restrict__ out, double* lds_out) {
+                                        double* __restrict__ out, double* lds_out, bool y_fresh = false) {
   __shared__ double red[4][16];
   double s[4][4];
 #pragma unroll
@@ -724,7 +732,8 @@ __device__ inline void StepScalarsOn256(int N, const double* __restrict__ b, con
         const bool on = p < N;
         vb[q][u] = on ? b[p] : 0.0;
         vq[q][u] = on ? AQc[p] : 0.0;
-        vy[q][u] = on ? y[p] : 0.0;
+        // (y_fresh: written by other workgroups of this launch -- past this XCD's L2)
+        vy[q][u] = on ? (y_fresh ? __hip_atomic_load(y + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : y[p]) : 0.0;
       }
 #pragma unroll
     for (int q = 0; q < 4; q++)
@@ -754,9 +763,34 @@ __device__ inline void StepScalarsOn256(int N, const double* __restrict__ b, con
   if (threadIdx.x == 5) out[5] = lds_out[5] = sys_sc[1];
 }
 
+// One of the ny workgroups that write the Newton direction out (newton_from_three riding in the launch that reads
+// it): write-through stores, then -- behind their completion -- one count per workgroup.
+__device__ inline void DirectionBlock(const StepTail& T, const StepArgs& sa, int b) {
+  const int i = b * 256 + (int)threadIdx.x;
+  if (i < T.N) AgentStore(T.y_out + i, YFromThree(sa.y3, sa.y3_stride, sa.y3_k[0], i));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(T.y_done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ inline void PrepareTailBlock(const StepTail& T) {
   __shared__ double s_scal[6];
-  if (T.scal) StepScalarsOn256(T.N, T.b, T.AQc, T.y, T.sys_sc, T.scal_out, s_scal);
+  bool y_ok = true;
+  if (T.ny > 0) {  // the direction's workgroups first (a few microseconds; nothing else to do before)
+    y_ok = false;
+    for (int spin = 0; spin < kTailSpin && !y_ok; spin++) {
+      y_ok = __hip_atomic_load(T.y_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= T.y_target;
+      if (!y_ok) __builtin_amdgcn_s_sleep(8);
+    }
+    y_ok = __syncthreads_and(y_ok) != 0;
+  }
+  if (T.scal) {
+    StepScalarsOn256(T.N, T.b, T.AQc, T.y, T.sys_sc, T.scal_out, s_scal, T.ny > 0);
+    if (!y_ok) {  // (the wait ran out: NaNs go out, the solve fails loudly)
+      __syncthreads();
+      if (threadIdx.x < 2) T.scal_out[threadIdx.x] = s_scal[threadIdx.x] = __longlong_as_double(0x7FF8000000000000ll);
+    }
+  }
   const int K = T.K, mode = T.mode, t = threadIdx.x;
   // what the mailbox carries besides this launch's results: final before the launch
   double pre = 0.0;

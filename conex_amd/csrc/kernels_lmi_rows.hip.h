@@ -339,8 +339,12 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
   __shared__ double sAB[4][2 * (ITERS + 2)];
   __shared__ double sOut[4][2];
   // with a tail the launch has one workgroup more: it reduces what the others produce and talks to the host
-  if (tail.slots && blockIdx.x == gridDim.x - 1) {
-    PrepareTailBlock(tail);
+  // (... and, behind it, tail.ny workgroups that write the Newton direction out while it is still in its three parts)
+  if (tail.slots && blockIdx.x + 1 + tail.ny >= gridDim.x) {
+    if (blockIdx.x + 1 + tail.ny == gridDim.x)
+      PrepareTailBlock(tail);
+    else
+      DirectionBlock(tail, sa, (int)(blockIdx.x + tail.ny - gridDim.x));
     return;
   }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -353,7 +357,7 @@ __global__ void __launch_bounds__(256) lmi_prepare_rows(LmiGroup g, StepArgs sa,
   const double* Wg = g.W + (size_t)mem * nn;
   double* M = sM[wave];
   // minus_s = sum_i y_i A_i - k C (dense_lmi_constraint.cc:8-27)
-  const double yv = lane < m ? sa.y[sa.cl_perm[sa.cl_ptr[id] + lane]] : 0.0;
+  const double yv = lane < m ? StepY(sa, sa.cl_perm[sa.cl_ptr[id] + lane]) : 0.0;
   if (EXACT && g.Apk) {
     // from the packed lower triangles (exactly symmetric data: the mirrored entry is the same sum of
     // the same terms): 105 16-byte chunks per matrix instead of 200, lane l owns chunks l and l + 64,

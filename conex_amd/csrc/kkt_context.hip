@@ -148,6 +148,9 @@ Arena MakeArena(cxk_context* ctx) {
 StepArgs MakeStep(cxk_context* ctx, double* info, int affine, double cw, double ew, double ss) {
   StepArgs s;
   s.y = ctx->y.p;
+  s.y3 = nullptr;
+  s.y3_stride = 0;
+  s.y3_k = nullptr;
   s.cl_ptr = ctx->cl_ptr.p;
   s.cl_perm = ctx->cl_perm.p;
   s.info = info;
@@ -1506,11 +1509,28 @@ int LaunchStepScalars(cxk_context* ctx) {
   return CXK_SUCCESS;
 }
 
-int FlushDeferred(cxk_context* ctx, bool keep_scalars = false) {
+// The Newton direction from the three solutions of cxk_factor_solve_triple_async and the barrier parameter the
+// device selected (cone_program.cc:409-411 by linearity).  YFromThree (lmi_types.h) is the one expression for it.
+__global__ void newton_from_three(int n, const double* __restrict__ y3, long long st, const double* __restrict__ k_from,
+                                  double* __restrict__ y) {
+  const double k = k_from[0];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = YFromThree(y3, st, k, i);
+}
+int FlushDirection(cxk_context* ctx) {
+  if (!ctx->y_deferred) return CXK_SUCCESS;
+  ctx->y_deferred = false;
+  const int N = ctx->md.N;
+  newton_from_three<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, ctx->y3.p, (long long)N, ctx->mu_dev.p, ctx->y.p);
+  CXK_TRY(hipGetLastError());
+  return CXK_SUCCESS;
+}
+int FlushDeferred(cxk_context* ctx, bool keep_scalars = false, bool keep_y = false) {
   if (ctx->asm_deferred) {
     ctx->asm_deferred = false;
     if (LaunchGather(ctx, false, 0, 0, 0)) return CXK_FAILURE;
   }
+  if (!keep_y && FlushDirection(ctx)) return CXK_FAILURE;  // (before the scalars: they read y)
   if (ctx->scal_deferred && !keep_scalars) {
     ctx->scal_deferred = false;
     if (LaunchStepScalars(ctx)) return CXK_FAILURE;
@@ -1539,6 +1559,7 @@ int cxk_create(int num_vars, int device, void* stream, cxk_context** out) {
   ctx->prepare_lds = getenv("CXK_PREPARE_LDS") != nullptr;
   ctx->no_step_tail = getenv("CXK_NO_STEP_TAIL") != nullptr || ctx->prepare_lds;
   ctx->no_triple = getenv("CXK_NO_TRIPLE") != nullptr;
+  ctx->no_y_deferral = getenv("CXK_NO_Y_DEFERRAL") != nullptr;
   ctx->no_device_mu = getenv("CXK_NO_DEVICE_MU") != nullptr;
   if (device >= 0) {
     int count = 0;
@@ -2325,6 +2346,7 @@ int cxk_set_W(cxk_context* ctx, int i, const double* in) {
 // ------------------------------------------------------------- Newton step
 int cxk_assemble_local(cxk_context* ctx) {
   CXK_ENTER_KEEP(ctx);
+  if (FlushDirection(ctx)) return CXK_FAILURE;  // (a direction nobody has read yet: before its three parts are overwritten)
   ctx->asm_deferred = false;  // a gather still pending would describe the previous Schur blocks
   ctx->y3_valid = false;      // (so would three solutions nobody has combined: a redone iteration)
   if (LaunchSchur(ctx)) return CXK_FAILURE;
@@ -2535,6 +2557,10 @@ int MakeStepTail(cxk_context* ctx, int mode, StepTail* t) {
   t->b = ctx->b.p;
   t->AQc = ctx->AQc.p;
   t->y = ctx->y.p;
+  t->ny = 0;
+  t->y_out = nullptr;
+  t->y_done = nullptr;
+  t->y_target = 0;
   t->sys_sc = ctx->sys_sc.p;
   t->scal_out = ctx->scal_out.p;
   t->rule.on = 0;
@@ -2549,7 +2575,8 @@ int MakeStepTail(cxk_context* ctx, int mode, StepTail* t) {
 extern "C" {
 
 int cxk_step_scalars_async(cxk_context* ctx) {
-  CXK_ENTER(ctx);
+  CXK_ENTER_KEEP(ctx);
+  if (FlushDeferred(ctx, false, StepTailOk(ctx, 0))) return CXK_FAILURE;
   if (StepTailOk(ctx, 0)) {
     ctx->scal_deferred = true;  // normally picked up by the PrepareStep that follows
     return CXK_SUCCESS;
@@ -2592,12 +2619,6 @@ int cxk_factor_solve_async(cxk_context* ctx, double cb, double cq, double cw) {
 // the fly by the PrepareStep that follows (StepArgs::y3): cxk_newton_direction_device_mu then launches nothing,
 // the interior-point iteration is five launches instead of six.
 // y = k (K^-1 (bs b) + K^-1 (cs AQc)) - 2 K^-1 AW, k = the barrier parameter the device selected
-__global__ void newton_from_three(int n, const double* __restrict__ y3, long long st, const double* __restrict__ k_from,
-                                  double* __restrict__ y) {
-  const double k = k_from[0];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) y[i] = k * (y3[i] + y3[st + i]) - 2.0 * y3[2 * st + i];
-}
 
 static bool DeviceMuOk(const cxk_context* ctx);
 static bool TripleOk(const cxk_context* ctx) {
@@ -2920,8 +2941,17 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
                            int* took, const double* cw_from, double cw_scale) {
   CXK_ENTER_KEEP(ctx);
   const bool with_tail = StepTailOk(ctx, affine);
-  if (FlushDeferred(ctx, with_tail)) return CXK_FAILURE;
+  // A direction still in its three parts is combined inside this launch: the constraints' wavefronts form the
+  // entries they read, a few workgroups more write y out, and the tail workgroup -- which needs all of y for the
+  // step scalars -- waits for their count (newton_from_three, 5 us and a kernel boundary, rides along)
+  const bool y_here = with_tail && ctx->y_deferred && !ctx->prepare_lds;
+  if (FlushDeferred(ctx, with_tail, y_here)) return CXK_FAILURE;
   StepArgs sa = MakeStep(ctx, ctx->info2.p, affine, c_weight, e_weight, 1.0);
+  if (y_here) {
+    sa.y3 = ctx->y3.p;
+    sa.y3_stride = ctx->md.N;
+    sa.y3_k = ctx->mu_dev.p;
+  }
   sa.cw_from = cw_from;  // (CWeightOf in every PrepareStep kernel)
   sa.cw_scale = cw_scale;
 
@@ -2933,6 +2963,19 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
   StepTail tail;
   tail.slots = nullptr;
   if (with_tail && MakeStepTail(ctx, 0, &tail)) return CXK_FAILURE;
+  if (y_here) {
+    CXK_DEMAND(tail.slots, "internal error: no tail workgroup in the launch that combines the direction");
+    if (ctx->y_done.n != 1) {
+      CXK_TRY(ctx->y_done.alloc(1, true));
+      ctx->y_done_target = 0;
+    }
+    tail.ny = (ctx->md.N + 255) / 256;
+    tail.y_out = ctx->y.p;
+    tail.y_done = ctx->y_done.p;
+    ctx->y_done_target += (unsigned long long)tail.ny;
+    tail.y_target = ctx->y_done_target;
+    ctx->y_deferred = false;
+  }
   ctx->lanczos_calls++;
   bool rows_only = NonEmptyGroups(ctx) == 1 && !affine && !ctx->prepare_lds;
   for (const Group& g : ctx->groups)
@@ -2949,9 +2992,9 @@ static int PrepareStepImpl(cxk_context* ctx, int affine, double c_weight, double
       if (!affine && !lds_kernel && !g.literal && LmiPrepareRowsSupports(g.n, g.m, g.herm_d, g.sparse))
       {
         if (g.n == 20)
-          CXK_LAUNCH_CLOCKED(clk, (lmi_prepare_rows<0, 20, true>), (cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, MakeLmi(g), sa, tail);
+          CXK_LAUNCH_CLOCKED(clk, (lmi_prepare_rows<0, 20, true>), (cnt + 3) / 4 + (tail.slots ? 1 + tail.ny : 0), 256, MakeLmi(g), sa, tail);
         else  // (an even order below 20 on the same instance)
-          CXK_LAUNCH_CLOCKED(clk, (lmi_prepare_rows<0, 20, false>), (cnt + 3) / 4 + (tail.slots ? 1 : 0), 256, MakeLmi(g), sa, tail);
+          CXK_LAUNCH_CLOCKED(clk, (lmi_prepare_rows<0, 20, false>), (cnt + 3) / 4 + (tail.slots ? 1 + tail.ny : 0), 256, MakeLmi(g), sa, tail);
       }
       else if (g.n == 20)
         lmi_prepare_generic<0, 20><<<cnt, 256, LmiPrepareLds(g.n, g.m), ctx->stream>>>(MakeLmi(g), sa);
@@ -3142,9 +3185,8 @@ int cxk_newton_direction_device_mu(cxk_context* ctx, double bs, double cs) {
   // (cone_program.cc:409-411 by linearity): one elementwise launch instead of a sweep over the tree
   if (ctx->y3_valid) {
     ctx->y3_valid = false;
-    const int N = ctx->md.N;
-    newton_from_three<<<GridFor(N, 256), 256, 0, ctx->stream>>>(N, ctx->y3.p, (long long)N, ctx->mu_dev.p, ctx->y.p);
-    CXK_TRY(hipGetLastError());
+    ctx->y_deferred = true;  // normally combined inside the PrepareStep launch that follows (PrepareStepImpl)
+    if (ctx->no_y_deferral && FlushDirection(ctx)) return CXK_FAILURE;
     return CXK_SUCCESS;
   }
   RhsIn f{};

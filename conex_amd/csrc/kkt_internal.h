@@ -266,6 +266,10 @@ struct cxk_context {
   unsigned fused_tgen = 0;
   DevBuf<double> y3;
   bool y3_valid = false;
+  bool y_deferred = false;  // the direction is still y3 and mu_dev: combined inside the PrepareStep launch that follows (or FlushDeferred)
+  bool no_y_deferral = false;  // CXK_NO_Y_DEFERRAL=1 at cxk_create: the direction in a launch of its own (newton_from_three)
+  DevBuf<unsigned long long> y_done;  // count of the direction's workgroups, all launches so far
+  unsigned long long y_done_target = 0;
   bool no_triple = false;  // CXK_NO_TRIPLE=1 at cxk_create: the mu selection's solve and the Newton direction as two sweeps
   unsigned fused_gen = 0;
   double* fx_flag = nullptr;  // pinned host word the kernel sets when a wait ran out

@@ -51,6 +51,12 @@ struct Arena {
 
 struct StepArgs {
   const double* y;        // permuted Newton direction (device)
+  // not null: the direction is still the three solutions of cxk_factor_solve_triple_async and is combined where it
+  // is read, y_i = k (y3[i] + y3[st + i]) - 2 y3[2 st + i] with k = y3_k[0] (StepY: the expression of
+  // newton_from_three, the same bits); extra workgroups of the launch write y out (StepTail::ny)
+  const double* y3;
+  long long y3_stride;
+  const double* y3_k;
   const int* cl_ptr;      // [K+1] clique pointer
   const int* cl_perm;     // permuted index of each clique variable
   double* info;           // per-constraint outputs (2 or 4 doubles each)
@@ -80,6 +86,12 @@ struct StepArgs {
 #ifdef __HIPCC__
 __device__ __forceinline__ bool StepSkipped(const StepArgs& sa) {
   return sa.skip_if && (sa.skip_if[0] != 0 || (sa.skip_tag != 0 && sa.skip_if[1] == sa.skip_tag));
+}
+__device__ __forceinline__ double YFromThree(const double* __restrict__ y3, long long st, double k, int i) {
+  return k * (y3[i] + y3[st + i]) - 2.0 * y3[2 * st + i];
+}
+__device__ __forceinline__ double StepY(const StepArgs& sa, int i) {
+  return sa.y3 ? YFromThree(sa.y3, sa.y3_stride, sa.y3_k[0], i) : sa.y[i];
 }
 __device__ __forceinline__ double CWeightOf(const StepArgs& sa) {
   return sa.cw_from ? sa.cw_from[0] * sa.cw_scale : sa.c_weight;

@@ -131,6 +131,44 @@ def test_direction_asked_for_before_prepare_step_is_materialised():
     assert np.allclose(res[0][1], res[1][1], rtol=1e-8, atol=1e-12)
 
 
+def test_direction_inside_prepare_step_equals_the_launch_of_its_own_bit_for_bit(monkeypatch):
+    """Behind the triple launch the direction is combined INSIDE the PrepareStep launch (the constraints' wavefronts
+    form the entries they read, extra workgroups write y out, the tail workgroup waits for them before it forms the
+    step scalars).  CXK_NO_Y_DEFERRAL=1 keeps newton_from_three as a launch of its own: the same expression, so the
+    direction, the step scalars, PrepareStep's norms and the W that TakeStep leaves are the same bits."""
+    K = 96
+    prob = syn.lmi_problem(K=K, n=20, m=20, branching=4, overlap=5, seed=12)
+    a = syn.build(KktContext, prob, "lmi", device=0)
+    monkeypatch.setenv("CXK_NO_Y_DEFERRAL", "1")
+    b = syn.build(KktContext, prob, "lmi", device=0)
+    monkeypatch.delenv("CXK_NO_Y_DEFERRAL")
+    W = syn.scaling_points(K, 20, seed=11)
+    bs, cs = 0.9, 0.8
+    for k in (a, b):
+        for i in range(K):
+            k.set_W(i, W[i])
+        k.set_cost(prob["b"])
+    for rep in range(3):
+        res = []
+        for k in (a, b):
+            k.assemble()
+            assert k.L.cxk_triple_supported(k.h) == 1
+            k._check(k.L.cxk_factor_solve_triple_async(k.h, bs, cs), "cxk_factor_solve_triple_async")
+            k._check(k.L.cxk_select_mu_async(k.h, cs, 1.0, 20 * K, 0.3 if rep else 0.0, 1e-8, 1e9), "cxk_select_mu_async")
+            k._check(k.L.cxk_newton_direction_device_mu(k.h, bs, cs), "cxk_newton_direction_device_mu")
+            assert k.L.cxk_step_scalars_async(k.h) == 0
+            info, took, inv = np.zeros(2), C.c_int(0), C.c_double(0)
+            k._check(k.L.cxk_prepare_take_step_device_mu(k.h, cs, 1.0, ol.dp(info), C.byref(took), C.byref(inv)),
+                     "cxk_prepare_take_step_device_mu")
+            res.append((info.copy(), took.value, inv.value, np.asarray(k.step_scalars()), k.get_y(),
+                        [np.asarray(k.get_W(i)) for i in (0, K // 2, K - 1)]))
+        (ia, ta, va, sa, ya, Wa), (ib, tb, vb, sb, yb, Wb) = res
+        assert ta == tb == 1 and va == vb
+        assert np.array_equal(ya, yb) and np.array_equal(ia, ib) and np.array_equal(sa, sb)
+        for x, y in zip(Wa, Wb):
+            assert np.array_equal(x, y)
+
+
 def test_not_offered_where_it_does_not_apply():
     prob, kind = syn.soc_problem(K=40, dim=6, m=5, overlap=2, tree=4), "soc"
     k = syn.build(KktContext, prob, kind, device=0)
