@@ -109,6 +109,35 @@ def test_fused_tree_as_two_launches_equals_level_kernels(K, n, branching, overla
         assert np.array_equal(fused.get_y(), levels.get_y())
 
 
+@pytest.mark.parametrize("K,branching", [(1000, 8), (300, 3), (64, 1)])
+def test_dealing_the_supernodes_per_xcd_changes_no_bit(K, branching, monkeypatch):
+    """Which workgroup takes which supernode is a matter of speed only (depth-first order, an eighth per XCD:
+    kkt_plans.hip; CXK_FUSED_LEVEL_ORDER=1 when the plans are built keeps the level order): direction, factor,
+    residuals and scalars are the same bits either way, over several launches (both slot sets in use)."""
+    prob = syn.lmi_problem(K=K, n=20, m=20, branching=branching, overlap=5, seed=7 + K)
+    W = syn.scaling_points(K, 20, seed=33)
+
+    def make():
+        k = syn.build(KktContext, prob, "lmi", device=0)
+        for i in range(k.K):
+            k.set_W(i, W[i])
+        k.set_cost(prob["b"])
+        return k
+
+    dealt = make()
+    monkeypatch.setenv("CXK_FUSED_LEVEL_ORDER", "1")
+    level = make()
+    monkeypatch.delenv("CXK_FUSED_LEVEL_ORDER")
+    assert dealt.fused_tree() and level.fused_tree()
+    for rep in range(3):
+        for k in (dealt, level):
+            k.kkt_solve_async(0.7 + 0.1 * rep, 0.9, 0.8)
+            assert k.sync()
+        a, b = snapshot(dealt), snapshot(level)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True)
+
+
 def test_fused_tree_against_the_oracle_and_two_runs_agree():
     prob = syn.lmi_problem(K=150, n=20, m=20, branching=8, overlap=5, seed=5)
     W = syn.scaling_points(150, 20, seed=6)

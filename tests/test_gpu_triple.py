@@ -1,7 +1,7 @@
 """The factorization with three right-hand sides in its one whole-tree launch (tree_fused.h kFusedTriple,
 cxk_factor_solve_triple_async): the solve of the mu selection and -- by linearity -- the Newton direction
 for the mu selected afterwards come out of ONE sweep over the tree (cone_program.cc:181, :409-411), the
-interior-point iteration is five launches instead of six.
+interior-point iteration is five launches instead of seven (the combination itself rides in PrepareStep's).
 
 Twin contexts on the same program: one runs the reference's sequence call for call (factorization with the
 mu selection's right-hand side, eigenvalue query, a second sweep with the Newton right-hand side,
