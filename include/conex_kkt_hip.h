@@ -238,8 +238,9 @@ int cxk_newton_direction_device_mu(cxk_context* ctx, double b_scaling, double c_
 /* The factorization carrying THREE right-hand sides through its one whole-tree launch -- bs b, cs AQc, AW --
  * so that the solve of the mu selection (K^-1 (-bs b + cs AQc), cone_program.cc:181: left in y) and the Newton
  * direction for the mu selected afterwards (K^-1 (k (bs b + cs AQc) - 2 AW), :409-411) are combinations of its
- * three solutions: the cxk_newton_direction_device_mu that follows is one elementwise launch instead of a sweep
- * over the tree.  Call order:
+ * three solutions: the cxk_newton_direction_device_mu that follows is 3 N multiply-adds instead of a sweep
+ * over the tree -- formed inside the PrepareStep launch that reads the direction, or by one elementwise launch
+ * for whoever reads y before that (cxk_get_y, cxk_step_scalars, ...): the same values.  Call order:
  * cxk_assemble, cxk_factor_solve_triple_async, cxk_select_mu_async, cxk_newton_direction_device_mu,
  * cxk_prepare_take_step_device_mu.  cxk_triple_supported: 1 where that applies (the tree in one launch on one
  * GPU, every constraint on the register LMI kernels, the barrier parameter on the device, no refinement)
