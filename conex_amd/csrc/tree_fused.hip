@@ -680,8 +680,15 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   constexpr int QN = SMAX < 8 ? SMAX : 8;
   double bv[QN > 0 ? QN : 1], yv[QN > 0 ? QN : 1], Mb[QN > 0 ? QN : 1];
   double yvx[NRHS > 1 ? NRHS - 1 : 1][QN > 0 ? QN : 1];
-  bv[0] = yv[0] = Mb[0] = 0.0;
-  yvx[0][0] = 0.0;
+  bv[0] = Mb[0] = 0.0;
+  // (the solution entries of the separator: zeros beyond its cnt variables, so that the combination below needs
+  // no select per term -- the lanes beyond cnt are cleared once, before the values are handed out)
+#pragma unroll
+  for (int qq = 0; qq < (QN > 0 ? QN : 1); qq++) {
+    yv[qq] = 0.0;
+#pragma unroll
+    for (int q = 0; q < (NRHS > 1 ? NRHS - 1 : 1); q++) yvx[q][qq] = 0.0;
+  }
   if constexpr (QN > 0) {
 #pragma unroll
     for (int qq = 0; qq < QN; qq++) {
@@ -767,6 +774,11 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
         }
         __builtin_amdgcn_s_sleep(1);
       }
+      v = lane < cnt ? v : 0.0;
+      if constexpr (NRHS > 1) {
+#pragma unroll
+        for (int q = 0; q < NRHS - 1; q++) vx[q] = lane < cnt ? vx[q] : 0.0;
+      }
 #pragma unroll
       for (int qq = 0; qq < QN; qq++) yv[qq] = ReadLane(v, qq);
       if constexpr (NRHS > 1) {
@@ -785,7 +797,7 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
     for (int q = 0; q < NRHS - 1; q++) {
       accx[q] = ubx[q];
 #pragma unroll
-      for (int qq = 0; qq < QN; qq++) accx[q] = fma(-Mb[qq], qq < cnt ? yvx[q][qq] : 0.0, accx[q]);
+      for (int qq = 0; qq < QN; qq++) accx[q] = fma(-Mb[qq], yvx[q][qq], accx[q]);
     }
   } else if constexpr (NRHS > 1) {
 #pragma unroll
@@ -794,20 +806,21 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
   double acc = ub;
   if constexpr (QN > 0) {
 #pragma unroll
-    for (int qq = 0; qq < QN; qq++) acc = fma(-Mb[qq], qq < cnt ? yv[qq] : 0.0, acc);
+    for (int qq = 0; qq < QN; qq++) acc = fma(-Mb[qq], yv[qq], acc);
   }
   if (active) StoreAgent(ysG + R.start + lane, acc);
-  if constexpr (ROWRHS) {
-    // a pivot that was not positive (here or in a descendant) has left NaNs in everything behind it: the test of
-    // the factorization, two instructions per pivot inside the elimination, is one comparison out here
-    if (__ballot(active && !(acc == acc)) != 0 && lane == 0) atomicExch(A.fail + 1, A.tag);
-  }
   if constexpr (NRHS > 1) {
 #pragma unroll
     for (int q = 0; q < NRHS - 1; q++)
       if (active) StoreAgent(ysT + (int64_t)(1 + q) * A.y_stride + R.start + lane, accx[q]);
   }
   FT_STAMP(6);
+  if constexpr (ROWRHS) {
+    // a pivot that was not positive (here or in a descendant) has left NaNs in everything behind it: the test of
+    // the factorization, two instructions per pivot inside the elimination, is one comparison out here (behind
+    // the stores the descendants wait for)
+    if (__ballot(active && !(acc == acc)) != 0 && lane == 0) atomicExch(A.fail + 1, A.tag);
+  }
   // ---- nobody waits for the rest: the solution and AW / AQc for the kernels that follow, the
   // root's factor, the re-armed slots of the other set
   if (active) {
