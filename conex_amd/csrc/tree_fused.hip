@@ -96,6 +96,13 @@ __device__ __forceinline__ void ReportTimeout(const FusedTreeArgs& A) {
   }
 }
 
+// acc += w[lane J of the own 16-lane DPP row] * v (the multiply-add of DppColumns, kernels_kkt.hip.h; operands
+// through DppOperandFence first)
+template <int J>
+__device__ __forceinline__ void FmacRowBcast(double& acc, double w, double v) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(v), "n"(J));
+}
+
 // One supernode: w = this lane's word of its record (kFusedRecWords dwords, one per lane).
 // UP_ONLY: the first of two launches (trees with more supernodes than the chip holds wavefronts: a
 // supernode that waited for its ANCESTORS' solution while holding its slot could keep them from ever
@@ -745,6 +752,20 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
       }
     }
   }
+  // (a supernode of at most 16 columns: its rows sit in DPP row 0, where the separator's solution -- entry qq in
+  // lane qq of the polled register -- reaches every row as the broadcast operand of the multiply-add itself;
+  // the negated columns of M wait in registers: two v_readlane per term less behind the arrival)
+  constexpr bool ROW0 = NSMAX <= 16 && QN > 0;
+  double vsep = 0.0, vsepx[NRHS > 1 ? NRHS - 1 : 1];
+#pragma unroll
+  for (int q = 0; q < (NRHS > 1 ? NRHS - 1 : 1); q++) vsepx[q] = 0.0;
+  if constexpr (ROW0) {
+#pragma unroll
+    for (int qq = 0; qq < QN; qq++) {
+      Mb[qq] = -Mb[qq];
+      asm volatile("" : "+v"(Mb[qq]));  // (negated here, ahead of the wait: not in front of each multiply-add)
+    }
+  }
   if constexpr (QN > 0) {
     if (cnt > 0) {
       // lane qq < cnt polls the solution entry of separator variable qq
@@ -779,34 +800,67 @@ __device__ __forceinline__ void FusedSupernode(const FusedTreeArgs& A, const int
 #pragma unroll
         for (int q = 0; q < NRHS - 1; q++) vx[q] = lane < cnt ? vx[q] : 0.0;
       }
+      if constexpr (ROW0) {
+        vsep = v;
+        if constexpr (NRHS > 1) {
 #pragma unroll
-      for (int qq = 0; qq < QN; qq++) yv[qq] = ReadLane(v, qq);
-      if constexpr (NRHS > 1) {
+          for (int q = 0; q < NRHS - 1; q++) vsepx[q] = vx[q];
+        }
+      } else {
 #pragma unroll
-        for (int q = 0; q < NRHS - 1; q++)
+        for (int qq = 0; qq < QN; qq++) yv[qq] = ReadLane(v, qq);
+        if constexpr (NRHS > 1) {
 #pragma unroll
-          for (int qq = 0; qq < QN; qq++) yvx[q][qq] = ReadLane(vx[q], qq);
+          for (int q = 0; q < NRHS - 1; q++)
+#pragma unroll
+            for (int qq = 0; qq < QN; qq++) yvx[q][qq] = ReadLane(vx[q], qq);
+        }
       }
     }
   }
   FT_STAMP(5);  // the separator's solution is in
   double accx[NRHS > 1 ? NRHS - 1 : 1];
   accx[0] = 0.0;
-  if constexpr (NRHS > 1 && QN > 0) {
-#pragma unroll
-    for (int q = 0; q < NRHS - 1; q++) {
-      accx[q] = ubx[q];
-#pragma unroll
-      for (int qq = 0; qq < QN; qq++) accx[q] = fma(-Mb[qq], yvx[q][qq], accx[q]);
-    }
-  } else if constexpr (NRHS > 1) {
-#pragma unroll
-    for (int q = 0; q < NRHS - 1; q++) accx[q] = ubx[q];
-  }
   double acc = ub;
-  if constexpr (QN > 0) {
+  if constexpr (ROW0) {
+    // acc = fma(y_sep[qq], -M[qq], acc), qq ascending: the products and the order of the sums of the other form
+    if constexpr (NRHS > 1) {
+      static_assert(NRHS == 3, "two further right-hand sides");
+      accx[0] = ubx[0];
+      accx[1] = ubx[1];
+      DppOperandFence(vsep, vsepx[0], vsepx[1]);
+    } else {
+      double d0 = 0.0, d1 = 0.0;
+      DppOperandFence(vsep, d0, d1);
+    }
+    auto chain = [&](auto self, auto qc) {
+      constexpr int qq = decltype(qc)::value;
+      if constexpr (qq < QN) {
+        FmacRowBcast<qq>(acc, vsep, Mb[qq]);
+        if constexpr (NRHS > 1) {
+          FmacRowBcast<qq>(accx[0], vsepx[0], Mb[qq]);
+          FmacRowBcast<qq>(accx[1], vsepx[1], Mb[qq]);
+        }
+        self(self, std::integral_constant<int, qq + 1>{});
+      }
+    };
+    chain(chain, std::integral_constant<int, 0>{});
+  } else {
+    if constexpr (NRHS > 1 && QN > 0) {
 #pragma unroll
-    for (int qq = 0; qq < QN; qq++) acc = fma(-Mb[qq], yv[qq], acc);
+      for (int q = 0; q < NRHS - 1; q++) {
+        accx[q] = ubx[q];
+#pragma unroll
+        for (int qq = 0; qq < QN; qq++) accx[q] = fma(-Mb[qq], yvx[q][qq], accx[q]);
+      }
+    } else if constexpr (NRHS > 1) {
+#pragma unroll
+      for (int q = 0; q < NRHS - 1; q++) accx[q] = ubx[q];
+    }
+    if constexpr (QN > 0) {
+#pragma unroll
+      for (int qq = 0; qq < QN; qq++) acc = fma(-Mb[qq], yv[qq], acc);
+    }
   }
   if (active) StoreAgent(ysG + R.start + lane, acc);
   if constexpr (NRHS > 1) {
